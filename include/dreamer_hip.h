@@ -1,0 +1,231 @@
+/*
+ * dreamer_hip.h — C-ABI of libdreamer_hip.so (MI355X / gfx950, HIP, fp32).
+ *
+ * This is the drop-in boundary of the DreamerV2 gradient-step hot path.  pydreamer itself has no FFI:
+ * everything below is what a `torch.autograd.Function` in a pydreamer-style `Dreamer.training_step`
+ * binds instead of the ATen ops the reference dispatches from its nn.Modules (file:line citations are
+ * into /root/reference).  See INTEGRATION.md for the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 (unless typed otherwise), owned by the caller
+ *    (torch tensors); the library never allocates or frees device memory and never synchronises;
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - every function returns 0 on success or a negative DM_E_* code; dm_last_error() gives the
+ *    thread-local message; nothing throws across the ABI;
+ *  - tensors are time-major: row index n = t*B + b for (T,B,...) tensors (reference layout,
+ *    pydreamer/data.py:188, rssm.py:21-78); matrices are row-major with explicit leading dimension
+ *    where a `ld*` argument is given;
+ *  - workspaces: `ws` is scratch (size from dm_workspace_bytes), `acts` holds activations saved by a
+ *    *_fwd call for the matching *_bwd call (size from dm_<op>_acts_floats); both are caller-allocated.
+ */
+#ifndef DREAMER_HIP_H
+#define DREAMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_OK 0
+#define DM_E_SHAPE (-1)       /* bad / unsupported shape or config */
+#define DM_E_WORKSPACE (-2)   /* workspace or acts buffer too small */
+#define DM_E_HIP (-3)         /* HIP runtime error (captured with hipGetLastError) */
+#define DM_E_DEVICE (-4)      /* not a gfx950 device */
+#define DM_E_NULL (-5)        /* required pointer is null */
+
+#define DM_MAX_MLP_LAYERS 8
+
+/* model / batch geometry: the config/defaults.yaml keys the hot path reads (dreamer.py:23-58,237-277) */
+typedef struct dm_shape {
+  int32_t T, B, I;          /* batch_length, batch_size, iwae_samples (I must be 1) */
+  int32_t H;                /* imag_horizon */
+  int32_t D, Hd;            /* deter_dim, hidden_dim */
+  int32_t S, C;             /* stoch_dim, stoch_discrete (Z = S*C) */
+  int32_t E;                /* embed dim = 32*cnn_depth (encoders.py:76) */
+  int32_t A;                /* action_dim */
+  int32_t mlp_hidden;       /* 400 (a2c.py:16, decoders.py:259,289) */
+  int32_t mlp_layers;       /* 4  (defaults.yaml:83,85; a2c.py:17) */
+  int32_t cnn_depth;        /* 48 */
+  int32_t img, img_ch;      /* 64, 3 */
+  int32_t flags;            /* reserved, 0 */
+} dm_shape;
+
+/* ---------------------------------------------------------------- library ---------------------- */
+int dm_version(void);                 /* ABI version, currently 1 */
+const char* dm_last_error(void);      /* thread-local message of the last failing call */
+int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
+size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
+
+/* ---------------------------------------------------------------- primitives ------------------- */
+/* C[m,n] (ldc) = epi( sum_k A(m,k) * B(n,k) ), fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * a_layout 0: A(m,k) = A[m*lda+k]   1: A(m,k) = A[k*lda+m]
+ * b_layout 0: B(n,k) = B[n*ldb+k]   1: B(n,k) = B[k*ldb+n]
+ * epi(v) = act( v + bias[n] + add[m*ldadd+n] + (flags&DM_GEMM_ACCUM ? C[m,n] : 0) ), act = ELU if DM_GEMM_ELU.
+ * Replaces torch.nn.functional.linear and its backward (common.py:37-65, rssm.py:138-146, rnn.py:48-49). */
+#define DM_GEMM_ACCUM 1
+#define DM_GEMM_ELU 2
+int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
+                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* add, int ldadd, int flags,
+                void* ws, size_t ws_bytes, void* stream);
+
+/* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
+int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                  float* y, int ldy, float* stats, void* stream);
+/* dx from dy; dgamma/dbeta overwritten (column sums over rows). */
+int dm_ln_elu_bwd(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                  const float* gamma, const float* dy, int lddy, float* dx, int lddx,
+                  float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum_r x[r*ld+c]  (bias gradients). */
+int dm_colsum(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.GRUCell gate math (rnn.py:48-49; torch GRUCell: r,z,n row blocks).  gi,gh: (rows,3D) incl. biases. */
+int dm_gru_gates_fwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                     float* h_out, int ldo, void* stream);
+/* dgi, dgh (rows,3D) overwritten; dh_in overwritten with the direct path dh_out*u (the gh path is added by the caller's GEMM). */
+int dm_gru_gates_bwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                     const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, void* stream);
+
+/* OneHotCategorical(StraightThrough) sample (rssm.py:147-148,195-201; dreamer.py:198-200):
+ * per group of C logits: p = softmax(logits); cdf = sequential fp32 cumsum(p);
+ * idx = #{k : cdf_k <= u*cdf_{C-1}} clamped to C-1 (the inverse-CDF rule the oracle patches into torch.multinomial);
+ * if forced_idx != NULL it is used instead of sampling.  onehot (rows, groups*C) with leading dim ldo. */
+int dm_sample_onehot(int rows, int groups, int C, const float* logits, int ldl, const float* u,
+                     const int32_t* forced_idx, float* onehot, int ldo, int32_t* idx, void* stream);
+
+/* KL(post||prior), entropies (dreamer.py:326-343,369-379; torch/distributions/kl.py:248-252). */
+int dm_kl_balance_fwd(int rows, int S, int C, const float* post, const float* prior,
+                      float* kl, float* ent_post, float* ent_prior, void* stream);
+/* dpost = scale_post * dKL/dpost, dprior = scale_prior * dKL/dprior (overwrite). */
+int dm_kl_balance_bwd(int rows, int S, int C, const float* post, const float* prior,
+                      float scale_post, float scale_prior, float* dpost, float* dprior, void* stream);
+/* straight-through backward: dlogits (+)= softmax-jacobian(logits)^T dz per group (accumulate if accum). */
+int dm_st_softmax_bwd(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
+                      float* dlogits, int lddl, int accum, void* stream);
+
+/* rows of h and z multiplied by (1-reset[r]) (rssm.py:41,134-135). */
+int dm_mask_rows(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, void* stream);
+
+/* stride-2 "valid" conv patch gather / scatter used by ConvEncoder and ConvDecoder (encoders.py:80-96, decoders.py:144-161).
+ * Small image (n, hs, ws) relates to big image (n, hb, wb) by y_big = 2*y_small + ky, ky in [0,k).
+ * im2col: col[(n,ys,xs)][(ky,kx,c)] = big[n, 2ys+ky, 2xs+kx, c]   (big NHWC, or NCHW if big_nchw: col order (c,ky,kx))
+ * col2im: big[n,y,x,c] = act( bias[c] + sum_{ky,kx valid} col[(n,ys,xs)][(ky,kx,c)] ) * (mul_elu_grad_of ? ELU'(ref) : 1) */
+int dm_im2col_s2(int n, int hb, int wb, int c, int k, const float* big, int big_nchw, float* col, void* stream);
+#define DM_C2I_ELU 1
+int dm_col2im_s2(int n, int hb, int wb, int c, int k, const float* col, const float* bias, int flags,
+                 const float* elu_ref, float* big, void* stream);
+
+/* ---------------------------------------------------------------- fused operators -------------- */
+/* MLP = [Linear, LayerNorm(eps 1e-3), ELU] x layers, Linear  (common.py:37-65). */
+typedef struct dm_mlp_params {
+  const float* w[DM_MAX_MLP_LAYERS + 1];   /* w[l]: (hidden,in_l) ; w[layers]: (out,hidden) */
+  const float* b[DM_MAX_MLP_LAYERS + 1];
+  const float* ln_g[DM_MAX_MLP_LAYERS];
+  const float* ln_b[DM_MAX_MLP_LAYERS];
+} dm_mlp_params;
+typedef struct dm_mlp_grads {
+  float* w[DM_MAX_MLP_LAYERS + 1];
+  float* b[DM_MAX_MLP_LAYERS + 1];
+  float* ln_g[DM_MAX_MLP_LAYERS];
+  float* ln_b[DM_MAX_MLP_LAYERS];
+} dm_mlp_grads;
+size_t dm_mlp_acts_floats(int rows, int hidden, int layers);
+int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim,
+                    const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
+                    void* ws, size_t ws_bytes, void* stream);
+/* dout (rows,out_dim); grads overwritten; dx (rows,in_dim; ld lddx) written if non-null (accumulated if dx_accum). */
+int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim,
+                    const float* x, int ldx, const dm_mlp_params* p, const float* acts, const float* dout,
+                    const dm_mlp_grads* g, float* dx, int lddx, int dx_accum,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* loss epilogues of the dense heads: kind 0 = reward, 0.5*(mu-y)^2 + c (decoders.py:302-304); 1 = terminal,
+ * BCE-with-logits (decoders.py:263-269).  loss[r]; dout[r] = scale * dloss/dout; mean_out[r] = mu or sigmoid(logit). */
+int dm_head_loss(int kind, int rows, const float* out, const float* target, float scale, float loss_const,
+                 float* loss, float* dout, float* mean_out, void* stream);
+
+/* ConvEncoder (encoders.py:72-96): 4 x (Conv2d k4 s2 + ELU), Flatten.  w[i]: (Cout,Cin,4,4) torch layout. */
+typedef struct dm_conv_params { const float* w[5]; const float* b[5]; } dm_conv_params;
+typedef struct dm_conv_grads { float* w[5]; float* b[5]; } dm_conv_grads;
+size_t dm_conv_encoder_acts_floats(const dm_shape* shp);
+int dm_conv_encoder_fwd(const dm_shape* shp, const float* image /* (N,ch,64,64) */, const dm_conv_params* p,
+                        float* acts, float* embed /* (N,E) torch (c,y,x) order */, void* ws, size_t ws_bytes, void* stream);
+int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_params* p, const float* acts,
+                        const float* dembed, const dm_conv_grads* g, void* ws, size_t ws_bytes, void* stream);
+
+/* ConvDecoder + MSE (decoders.py:111-180): Linear F->32d, 4 x ConvTranspose2d (k 5,5,6,6; s2), ELU x3.
+ * w[0],b[0] = Linear; w[1..4]: (Cin,Cout,k,k) torch layout.  loss_image[n] = 0.5*sum (pred-target)^2. */
+size_t dm_conv_decoder_acts_floats(const dm_shape* shp);
+int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                            const dm_conv_params* p, float* acts, float* loss_image, float* image_rec /* nullable, NCHW */,
+                            void* ws, size_t ws_bytes, void* stream);
+/* dfeat (N,F) accumulated (+=) ; scale = image_weight / (T*B). */
+int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                            const dm_conv_params* p, const float* acts, float scale,
+                            const dm_conv_grads* g, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream);
+
+/* RSSM posterior sequence (rssm.py:21-78,125-153,186-193; rnn.py:40-67). Parameter order of dm_rssm_params.p[]: */
+enum {
+  DM_RSSM_Z_W = 0, DM_RSSM_Z_B, DM_RSSM_A_W, DM_RSSM_IN_G, DM_RSSM_IN_B,
+  DM_RSSM_GRU_WIH, DM_RSSM_GRU_WHH, DM_RSSM_GRU_BIH, DM_RSSM_GRU_BHH,
+  DM_RSSM_PRIOR_H_W, DM_RSSM_PRIOR_H_B, DM_RSSM_PRIOR_G, DM_RSSM_PRIOR_B, DM_RSSM_PRIOR_W, DM_RSSM_PRIOR_OB,
+  DM_RSSM_POST_H_W, DM_RSSM_POST_H_B, DM_RSSM_POST_E_W, DM_RSSM_POST_G, DM_RSSM_POST_B, DM_RSSM_POST_W, DM_RSSM_POST_OB,
+  DM_RSSM_NPARAMS
+};
+typedef struct dm_rssm_params { const float* p[DM_RSSM_NPARAMS]; } dm_rssm_params;
+typedef struct dm_rssm_grads { float* p[DM_RSSM_NPARAMS]; } dm_rssm_grads;
+size_t dm_rssm_acts_floats(const dm_shape* shp);
+/* feat (N,F): [h | z]; post, prior (N,Z) logits; idx (N,S).  u (N,S) uniforms; forced_idx nullable. */
+int dm_rssm_sequence_fwd(const dm_shape* shp, const float* embed, const float* action, const uint8_t* reset,
+                         const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
+                         const dm_rssm_params* p, float* acts, float* feat, float* post, float* prior, int32_t* idx,
+                         void* ws, size_t ws_bytes, void* stream);
+/* dfeat (N,F) from decoders/heads (consumed, overwritten as scratch), dpost/dprior (N,Z) from the KL term.
+ * Produces parameter grads and dembed (N,E). */
+int dm_rssm_sequence_bwd(const dm_shape* shp, const float* embed, const float* action, const uint8_t* reset,
+                         const dm_rssm_params* p, const float* acts, const float* feat, const float* post,
+                         float* dfeat, float* dpost, float* dprior,
+                         const dm_rssm_grads* g, float* dembed, void* ws, size_t ws_bytes, void* stream);
+
+/* Imagination rollout (dreamer.py:188-216, rssm.py:155-184, a2c.py:43-55), no autograd graph (actor_grad=reinforce).
+ * start (M,F) = [h|z] rows; feats (H+1,M,F); actions one-hot (H,M,A); act_idx (H,M); u_act (H,M); u_prior (H,M,S). */
+int dm_dream_rollout(const dm_shape* shp, int M, const float* start, const dm_rssm_params* cell,
+                     const dm_mlp_params* actor, const float* u_act, const float* u_prior,
+                     float* feats, float* actions, int32_t* act_idx, void* ws, size_t ws_bytes, void* stream);
+
+/* GAE + reality weight (a2c.py:81-108). All (J,M)/(H,M) row-major with J=H+1. */
+int dm_gae_losses(int H, int M, float gamma, float lambda, const float* reward, const float* terminal,
+                  const float* value_t, float* advantage, float* advantage_gae, float* value_target, float* weight,
+                  void* stream);
+/* actor (reinforce, onehot) loss rows (a2c.py:119-130): loss[r] = (-logpi(a)*adv - ent_w*H[pi])*w;
+ * dlogits = scale * dloss/dlogits. */
+int dm_actor_loss(int rows, int A, const float* logits, const int32_t* act_idx, const float* adv_gae,
+                  const float* weight, float ent_w, float scale, float* loss, float* entropy, float* dlogits, void* stream);
+/* critic loss rows (a2c.py:112-115): loss[r] = 0.5*(vt-v)^2*w ; dvalue = scale * -(vt-v)*w. */
+int dm_critic_loss(int rows, const float* value, const float* value_target, const float* weight, float scale,
+                   float* loss, float* dvalue, void* stream);
+
+/* out[i] = scale[i] * sum(x_i[0..n_i)) for up to 32 arrays in one launch (losses / metrics, dreamer.py:362-379, a2c.py:133-147). */
+typedef struct dm_reduce_item { const float* x; int64_t n; float scale; } dm_reduce_item;
+int dm_multi_sum(int count, const dm_reduce_item* items /* host array */, float* out, void* stream);
+
+/* Optimizer (dreamer.py:60-87; torch.optim.AdamW defaults, clip_grad_norm_). */
+/* norm_out[0] = ||g||_2 ; norm_out[1] = min(1, max_norm/(norm+1e-6)). */
+int dm_multi_tensor_norm_clip(const float* grad, int64_t n, float max_norm, float* norm_out,
+                              void* ws, size_t ws_bytes, void* stream);
+/* x *= coef[0] (device scalar): the in-place gradient scaling of clip_grad_norm_. */
+int dm_scale_inplace(float* x, int64_t n, const float* coef, void* stream);
+/* AdamW step with the clip coefficient read from device memory (clip_coef may be NULL = 1). */
+int dm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  const float* clip_coef, void* stream);
+int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* critic_target <- critic, a2c.py:151-152 */
+/* y = a*x + b*y */
+int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREAMER_HIP_H */

@@ -1,0 +1,114 @@
+// Shared host/device helpers for libdreamer_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "dreamer_hip.h"
+
+int dm_fail(int code, const char* fmt, ...);
+
+#define DM_LAUNCH_CHECK()                                                                      \
+  do {                                                                                         \
+    hipError_t e__ = hipGetLastError();                                                        \
+    if (e__ != hipSuccess) return dm_fail(DM_E_HIP, "%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+  } while (0)
+
+#define DM_TRY(expr)                 \
+  do {                               \
+    int rc__ = (expr);               \
+    if (rc__ != DM_OK) return rc__;  \
+  } while (0)
+
+#define DM_REQUIRE(cond, code, ...)                     \
+  do {                                                  \
+    if (!(cond)) return dm_fail(code, __VA_ARGS__);     \
+  } while (0)
+
+static inline int dm_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t dm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided float buffer (acts / workspace carving).
+struct DmArena {
+  float* base;
+  size_t cap;    // floats
+  size_t off;    // floats
+  bool ok;
+  DmArena(void* p, size_t bytes) : base((float*)p), cap(bytes / sizeof(float)), off(0), ok(true) {}
+  float* take(size_t nfloats) {
+    size_t n = dm_align_up(nfloats, 64);   // 256-byte granules keep every carve 16B-aligned for float4 access
+    if (base == nullptr || off + n > cap) { ok = false; off += n; return nullptr; }
+    float* r = base + off;
+    off += n;
+    return r;
+  }
+};
+
+// ---- internal (C++) entry points shared between translation units -------------------------------
+struct DmGemm {
+  int a_layout = 0, b_layout = 0;
+  int M = 0, N = 0, K = 0;
+  const float* A = nullptr; int lda = 0;
+  const float* B = nullptr; int ldb = 0;
+  float* C = nullptr; int ldc = 0;
+  const float* bias = nullptr;
+  const float* add = nullptr; int ldadd = 0;
+  const float* mulref = nullptr; int ldmul = 0;   // v *= ELU'(mulref[m,n]) (mulref holds ELU outputs), applied last
+  const uint8_t* row_zero = nullptr;              // rows with row_zero[m] != 0 contribute 0 (reset masks), applied first
+  int flags = 0;
+};
+int dm_gemm_launch(const DmGemm& g, void* ws, size_t ws_bytes, hipStream_t stream);
+
+// element-wise / row-wise launchers (elementwise.hip)
+int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                         float* y, int ldy, float* stats, hipStream_t st);
+int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                            const float* gamma, const float* dy, int lddy, float* dx, int lddx, hipStream_t st);
+int dm_ln_elu_bwd_params_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                                const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                hipStream_t st);
+int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
+                            int ldo, hipStream_t st);
+// dh_in (+)= row_mask * dh_out*u  (accum: add into dh_in; row_zero: rows whose flag is set contribute 0)
+int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                            const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,
+                            const uint8_t* row_zero, hipStream_t st);
+int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
+                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, hipStream_t st);
+int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* prior, float* kl, float* ep, float* eq,
+                     hipStream_t st);
+int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* prior, float sp, float sq, float* dpost,
+                     float* dprior, hipStream_t st);
+int dm_st_softmax_bwd_launch(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
+                             float* dlogits, int lddl, int accum, hipStream_t st);
+int dm_mask_rows_launch(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, hipStream_t st);
+int dm_mul_elu_grad_launch(size_t n, const float* dy, const float* yact, float* out, hipStream_t st);
+
+// conv helpers (conv.hip)
+int dm_im2col_s2_launch(int n, int hb, int wb, int c, int k, const float* big, int big_nchw, float* col, hipStream_t st);
+int dm_col2im_s2_launch(int n, int hb, int wb, int c, int k, const float* col, const float* bias, int flags,
+                        const float* elu_ref, float* big, hipStream_t st);
+int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                       hipStream_t st);
+
+// fused MLP (mlp.hip)
+int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                      const dm_mlp_params* p, float* acts, float* out, int ldout, void* ws, size_t ws_bytes, hipStream_t st);
+
+// split-K partial region carved at the front of every operator workspace
+static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;
+
+__device__ __forceinline__ float dm_elu(float v) { return v > 0.f ? v : expm1f(v); }
+// ELU'(x) expressed through y = ELU(x):  1 for x>0, exp(x) = y+1 otherwise.
+__device__ __forceinline__ float dm_elu_grad_from_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ float dm_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float dm_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}

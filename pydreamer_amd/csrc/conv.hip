@@ -1,0 +1,533 @@
+// ConvEncoder (encoders.py:72-96) and ConvDecoder + MSE (decoders.py:111-180) as GEMMs over stride-2 patch
+// matrices.  Internal activations are NHWC so that a patch row (ky,kx,c) is contiguous in c and every
+// gather/scatter kernel below moves 16-byte vectors; weights are re-laid once per call from the torch
+// layouts (O,I,kh,kw) / (I,O,kh,kw) to (O,kh,kw,I) / (I,kh,kw,O) and gradients are permuted back.
+//
+//   conv   k4 s2 : Y[(n,ys,xs)][o]          = ELU( im2col(X)[(n,ys,xs)][(ky,kx,i)] . Wr[o][(ky,kx,i)] + b[o] )
+//   convT  k  s2 : Ycol[(n,ys,xs)][(ky,kx,o)] = X[(n,ys,xs)][i] . Wr[i][(ky,kx,o)] ;  out = col2im(Ycol) + b (+ELU)
+// The backward passes are the same two gathers with the roles swapped (convT backward-data is a conv).
+// All kernels here are HBM-streaming; the contractions run in gemm.hip on the matrix cores.
+#include "common.h"
+
+// ---------------------------------------------------------------- patch gather ------------------
+// col[(i,ys,xs)][(ky,kx,cc)] = big[i, 2ys+ky, 2xs+kx, cc]      (NHWC, VEC floats of c per thread)
+template <int VEC>
+__global__ void __launch_bounds__(256) im2col_s2_nhwc_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
+                                                             const float* __restrict__ big, float* __restrict__ col) {
+  const int cv = c / VEC;
+  const size_t total = (size_t)n * hs * ws * k * k * cv;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int c4 = (int)(t % cv); t /= cv;
+    const int kx = (int)(t % k); t /= k;
+    const int ky = (int)(t % k); t /= k;
+    const int xs = (int)(t % ws); t /= ws;
+    const int ys = (int)(t % hs); t /= hs;
+    const int i = (int)t;
+    const size_t src = (((size_t)i * hb + (2 * ys + ky)) * wb + (2 * xs + kx)) * c + (size_t)c4 * VEC;
+    if constexpr (VEC == 4) {
+      reinterpret_cast<float4*>(col)[e] = *reinterpret_cast<const float4*>(big + src);
+    } else {
+      col[e] = big[src];
+    }
+  }
+}
+
+// layer-1 variant reading the (T,B,C,H,W) batch directly: col[(i,ys,xs)][(cc,ky,kx)] = big[i, cc, 2ys+ky, 2xs+kx]
+__global__ void __launch_bounds__(256) im2col_s2_nchw_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
+                                                             const float* __restrict__ big, float* __restrict__ col) {
+  const size_t total = (size_t)n * hs * ws * c * k * k;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int kx = (int)(t % k); t /= k;
+    const int ky = (int)(t % k); t /= k;
+    const int cc = (int)(t % c); t /= c;
+    const int xs = (int)(t % ws); t /= ws;
+    const int ys = (int)(t % hs); t /= hs;
+    const int i = (int)t;
+    col[e] = big[(((size_t)i * c + cc) * hb + (2 * ys + ky)) * wb + (2 * xs + kx)];
+  }
+}
+
+// big[i,y,x,cc] = epi( bias[cc] + sum_{ky,kx : (y-ky),(x-kx) even, in range} col[(i,(y-ky)/2,(x-kx)/2)][(ky,kx,cc)] )
+template <int VEC>
+__global__ void __launch_bounds__(256) col2im_s2_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
+                                                        const float* __restrict__ col, const float* __restrict__ bias,
+                                                        int flags, const float* __restrict__ elu_ref,
+                                                        float* __restrict__ big) {
+  const int cv = c / VEC;
+  const size_t total = (size_t)n * hb * wb * cv;
+  const size_t rowlen = (size_t)k * k * c;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int c4 = (int)(t % cv); t /= cv;
+    const int x = (int)(t % wb); t /= wb;
+    const int y = (int)(t % hb); t /= hb;
+    const int i = (int)t;
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = bias ? bias[c4 * VEC + q] : 0.f;
+    for (int ky = y & 1; ky < k && ky <= y; ky += 2) {
+      const int ys = (y - ky) >> 1;
+      if (ys >= hs) continue;
+      for (int kx = x & 1; kx < k && kx <= x; kx += 2) {
+        const int xs = (x - kx) >> 1;
+        if (xs >= ws) continue;
+        const float* p = col + (((size_t)i * hs + ys) * ws + xs) * rowlen + (size_t)(ky * k + kx) * c + (size_t)c4 * VEC;
+        if constexpr (VEC == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        } else {
+          acc[0] += p[0];
+        }
+      }
+    }
+    const size_t dst = e * VEC;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float v = acc[q];
+      if (flags & DM_C2I_ELU) v = dm_elu(v);
+      if (elu_ref) v *= dm_elu_grad_from_y(elu_ref[dst + q]);
+      big[dst + q] = v;
+    }
+  }
+}
+
+static inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int dm_im2col_s2_launch(int n, int hb, int wb, int c, int k, const float* big, int big_nchw, float* col, hipStream_t st) {
+  DM_REQUIRE(hb >= k && wb >= k && ((hb - k) % 2) == 0 && ((wb - k) % 2) == 0, DM_E_SHAPE,
+             "im2col_s2: big %dx%d incompatible with k=%d stride 2", hb, wb, k);
+  const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
+  const size_t total = (size_t)n * hs * ws * k * k * c;
+  if (total == 0) return DM_OK;
+  if (big_nchw) {
+    hipLaunchKernelGGL(im2col_s2_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, big, col);
+  } else if ((c & 3) == 0 && (((uintptr_t)big | (uintptr_t)col) & 15) == 0) {
+    hipLaunchKernelGGL((im2col_s2_nhwc_kernel<4>), dim3(grid_for(total / 4)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws,
+                       big, col);
+  } else {
+    hipLaunchKernelGGL((im2col_s2_nhwc_kernel<1>), dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, big,
+                       col);
+  }
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+int dm_col2im_s2_launch(int n, int hb, int wb, int c, int k, const float* col, const float* bias, int flags,
+                        const float* elu_ref, float* big, hipStream_t st) {
+  DM_REQUIRE(hb >= k && wb >= k && ((hb - k) % 2) == 0 && ((wb - k) % 2) == 0, DM_E_SHAPE,
+             "col2im_s2: big %dx%d incompatible with k=%d stride 2", hb, wb, k);
+  const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
+  const size_t total = (size_t)n * hb * wb * c;
+  if (total == 0) return DM_OK;
+  if ((c & 3) == 0 && (((uintptr_t)big | (uintptr_t)col) & 15) == 0) {
+    hipLaunchKernelGGL((col2im_s2_kernel<4>), dim3(grid_for(total / 4)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, col,
+                       bias, flags, elu_ref, big);
+  } else {
+    hipLaunchKernelGGL((col2im_s2_kernel<1>), dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, col, bias,
+                       flags, elu_ref, big);
+  }
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_im2col_s2(int n, int hb, int wb, int c, int k, const float* big, int big_nchw, float* col, void* stream) {
+  DM_REQUIRE(big && col, DM_E_NULL, "im2col_s2: null pointer");
+  return dm_im2col_s2_launch(n, hb, wb, c, k, big, big_nchw, col, (hipStream_t)stream);
+}
+extern "C" int dm_col2im_s2(int n, int hb, int wb, int c, int k, const float* col, const float* bias, int flags,
+                            const float* elu_ref, float* big, void* stream) {
+  DM_REQUIRE(big && col, DM_E_NULL, "col2im_s2: null pointer");
+  return dm_col2im_s2_launch(n, hb, wb, c, k, col, bias, flags, elu_ref, big, (hipStream_t)stream);
+}
+
+// dst[j0,j1,j2,j3] = src[i0,i1,i2,i3] with j_a = i_{p_a}  (dst dims = (d[p0],d[p1],d[p2],d[p3]))
+__global__ void __launch_bounds__(256) permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0,
+                                                       int d1, int d2, int d3, int p0, int p1, int p2, int p3) {
+  const int d[4] = {d0, d1, d2, d3};
+  const int p[4] = {p0, p1, p2, p3};
+  const size_t total = (size_t)d0 * d1 * d2 * d3;
+  const size_t sstride[4] = {(size_t)d1 * d2 * d3, (size_t)d2 * d3, (size_t)d3, 1};
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    size_t s = 0;
+#pragma unroll
+    for (int a = 3; a >= 0; --a) {
+      const int dim = d[p[a]];
+      const int j = (int)(t % dim);
+      t /= dim;
+      s += (size_t)j * sstride[p[a]];
+    }
+    dst[e] = src[s];
+  }
+}
+int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                       hipStream_t st) {
+  const size_t total = (size_t)d0 * d1 * d2 * d3;
+  if (total == 0) return DM_OK;
+  hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total)), dim3(256), 0, st, src, dst, d0, d1, d2, d3, p0, p1, p2, p3);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ---------------------------------------------------------------- MSE (decoders.py:163-167) -----
+// pred NHWC (n,hw,c), target NCHW (n,c,hw).  loss[n] = 0.5*sum (pred-target)^2 ; dpred = scale*(pred-target) (NHWC);
+// rec = pred in NCHW.  One block per frame, fixed reduction order.
+__global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const float* __restrict__ pred,
+                                                        const float* __restrict__ target, float scale,
+                                                        float* __restrict__ loss, float* __restrict__ dpred,
+                                                        float* __restrict__ rec) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  const int per = hw * c;
+  const float* pr = pred + (size_t)i * per;
+  const float* tg = target + (size_t)i * per;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < per; e += 256) {
+    const int pix = e / c, cc = e % c;
+    const float pv = pr[e];
+    const float d = pv - tg[(size_t)cc * hw + pix];
+    s += d * d;
+    if (dpred) dpred[(size_t)i * per + e] = scale * d;
+    if (rec) rec[(size_t)i * per + (size_t)cc * hw + pix] = pv;
+  }
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) loss[i] = 0.5f * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------- geometry ----------------------
+struct EncGeom {
+  int N, ch, d;
+  int hb[4], hs[4], cin[4], cout[4];
+  size_t rows[4], kdim[4];
+  explicit EncGeom(const dm_shape* s) {
+    N = s->T * s->B * (s->I > 0 ? s->I : 1);
+    ch = s->img_ch; d = s->cnn_depth;
+    int h = s->img;
+    const int ci[4] = {ch, d, 2 * d, 4 * d};
+    const int co[4] = {d, 2 * d, 4 * d, 8 * d};
+    for (int l = 0; l < 4; ++l) {
+      hb[l] = h;
+      hs[l] = (h - 4) / 2 + 1;
+      cin[l] = ci[l]; cout[l] = co[l];
+      rows[l] = (size_t)N * hs[l] * hs[l];
+      kdim[l] = (size_t)16 * ci[l];
+      h = hs[l];
+    }
+  }
+  bool valid(const dm_shape* s) const {
+    return s->img == 64 && hs[3] == 2 && s->E == 8 * d * 4 && ch >= 1 && d >= 1;
+  }
+};
+
+struct DecGeom {
+  int N, ch, d, F;
+  int k[5], hsm[5], hbg[5], cin[5], cout[5];   // index 1..4
+  size_t rows_s[5], rows_b[5];
+  explicit DecGeom(const dm_shape* s) {
+    N = s->T * s->B * (s->I > 0 ? s->I : 1);
+    ch = s->img_ch; d = s->cnn_depth;
+    F = s->D + s->S * s->C;
+    const int kk[5] = {0, 5, 5, 6, 6};
+    const int ci[5] = {0, 32 * d, 4 * d, 2 * d, d};
+    const int co[5] = {0, 4 * d, 2 * d, d, ch};
+    int h = 1;
+    for (int l = 1; l <= 4; ++l) {
+      k[l] = kk[l]; cin[l] = ci[l]; cout[l] = co[l];
+      hsm[l] = h;
+      hbg[l] = 2 * (h - 1) + kk[l];
+      rows_s[l] = (size_t)N * h * h;
+      rows_b[l] = (size_t)N * hbg[l] * hbg[l];
+      h = hbg[l];
+    }
+  }
+  bool valid(const dm_shape* s) const { return hbg[4] == s->img && s->img == 64; }
+};
+
+// ---------------------------------------------------------------- encoder -----------------------
+struct EncActs {
+  float* wr[4];    // repacked weights (l>=1)
+  float* xcol[4];
+  float* y[4];     // post-ELU NHWC outputs
+};
+static size_t enc_carve(const EncGeom& g, float* base, size_t cap_floats, EncActs* a) {
+  DmArena ar(base, cap_floats * sizeof(float));
+  for (int l = 0; l < 4; ++l) {
+    float* w = ar.take(l == 0 ? 0 : (size_t)g.cout[l] * g.kdim[l]);
+    float* xc = ar.take(g.rows[l] * g.kdim[l]);
+    float* yy = ar.take(g.rows[l] * g.cout[l]);
+    if (a) { a->wr[l] = w; a->xcol[l] = xc; a->y[l] = yy; }
+  }
+  return ar.off;
+}
+extern "C" size_t dm_conv_encoder_acts_floats(const dm_shape* shp) {
+  if (!shp) return 0;
+  EncGeom g(shp);
+  return enc_carve(g, nullptr, 0, nullptr);
+}
+
+// NHWC (n, hw, c) <-> torch flatten order (n, c*hw + pix)
+__global__ void __launch_bounds__(256) nhwc_to_chw_flat_kernel(size_t n, int hw, int c, const float* __restrict__ src,
+                                                               float* __restrict__ dst, int to_chw) {
+  const size_t total = n * hw * c;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t i = e / ((size_t)hw * c);
+    const int rem = (int)(e % ((size_t)hw * c));
+    const int pix = rem / c, cc = rem % c;        // e indexes the NHWC side
+    const size_t o = i * hw * c + (size_t)cc * hw + pix;
+    if (to_chw) dst[o] = src[e];
+    else dst[e] = src[o];
+  }
+}
+
+extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, const dm_conv_params* p, float* acts,
+                                   float* embed, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp && image && p && acts && embed && ws, DM_E_NULL, "conv_encoder_fwd: null pointer");
+  EncGeom g(shp);
+  DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry (img=%d, E=%d, depth=%d)", shp->img, shp->E,
+             shp->cnn_depth);
+  hipStream_t st = (hipStream_t)stream;
+  EncActs a;
+  enc_carve(g, acts, (size_t)1 << 60, &a);
+  DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small");
+  for (int l = 0; l < 4; ++l) {
+    const float* src = l == 0 ? image : a.y[l - 1];
+    DM_TRY(dm_im2col_s2_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, src, l == 0, a.xcol[l], st));
+    const float* w = p->w[l];
+    if (l > 0) {
+      DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cout[l], g.cin[l], 4, 4, 0, 2, 3, 1, st));
+      w = a.wr[l];
+    }
+    DmGemm q;
+    q.a_layout = 0; q.b_layout = 0;
+    q.M = (int)g.rows[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
+    q.A = a.xcol[l]; q.lda = q.K;
+    q.B = w; q.ldb = q.K;
+    q.C = a.y[l]; q.ldc = q.N;
+    q.bias = p->b[l];
+    q.flags = DM_GEMM_ELU;
+    DM_TRY(dm_gemm_launch(q, ws, DM_SPLITK_FLOATS * sizeof(float), st));
+  }
+  const size_t tot = (size_t)g.N * 4 * g.cout[3];
+  hipLaunchKernelGGL(nhwc_to_chw_flat_kernel, dim3(grid_for(tot)), dim3(256), 0, st, (size_t)g.N, 4, g.cout[3], a.y[3],
+                     embed, 1);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_params* p, const float* acts,
+                                   const float* dembed, const dm_conv_grads* gr, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp && p && acts && dembed && gr && ws, DM_E_NULL, "conv_encoder_bwd: null pointer");
+  (void)image;
+  EncGeom g(shp);
+  DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry");
+  hipStream_t st = (hipStream_t)stream;
+  EncActs a;
+  enc_carve(g, const_cast<float*>(acts), (size_t)1 << 60, &a);
+  DmArena ar(ws, ws_bytes);
+  float* splitk = ar.take(DM_SPLITK_FLOATS);
+  const size_t gmax = g.rows[0] * g.cout[0];
+  float* ga = ar.take(gmax);
+  float* gb = ar.take(g.rows[1] * g.cout[1]);
+  float* dwr = ar.take((size_t)g.cout[3] * g.kdim[3]);
+  size_t xcmax = 0;
+  for (int l = 1; l < 4; ++l) if (g.rows[l] * g.kdim[l] > xcmax) xcmax = g.rows[l] * g.kdim[l];
+  float* dxcol = ar.take(xcmax);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_encoder_bwd: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  // dY3 (NHWC) = permute(dembed) ; G = dY3 * ELU'(Y3)
+  float* G = gb;      // layer-3 grads are small; ping-pong between ga / gb going down
+  const size_t tot3 = (size_t)g.N * 4 * g.cout[3];
+  hipLaunchKernelGGL(nhwc_to_chw_flat_kernel, dim3(grid_for(tot3)), dim3(256), 0, st, (size_t)g.N, 4, g.cout[3], dembed, G,
+                     0);
+  DM_LAUNCH_CHECK();
+  DM_TRY(dm_mul_elu_grad_launch(tot3, G, a.y[3], G, st));
+  for (int l = 3; l >= 0; --l) {
+    const int rows = (int)g.rows[l], co = g.cout[l], kd = (int)g.kdim[l];
+    DM_TRY(dm_colsum_launch(rows, co, G, co, gr->b[l], splitk, skb, st));
+    DmGemm q;   // dWr[o][kidx] = sum_rows G[row][o] * Xcol[row][kidx]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = co; q.N = kd; q.K = rows;
+    q.A = G; q.lda = co;
+    q.B = a.xcol[l]; q.ldb = kd;
+    q.C = (l == 0) ? gr->w[0] : dwr; q.ldc = kd;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    if (l > 0) {
+      DM_TRY(dm_permute4_launch(dwr, gr->w[l], co, 4, 4, g.cin[l], 0, 3, 1, 2, st));
+      DmGemm d;   // dXcol[row][kidx] = sum_o G[row][o] * Wr[o][kidx]
+      d.a_layout = 0; d.b_layout = 1;
+      d.M = rows; d.N = kd; d.K = co;
+      d.A = G; d.lda = co;
+      d.B = a.wr[l]; d.ldb = kd;
+      d.C = dxcol; d.ldc = kd;
+      DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+      float* Gn = (G == ga) ? gb : ga;
+      if (l == 1) Gn = ga;   // layer-0 output grads are the largest buffer
+      DM_TRY(dm_col2im_s2_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, dxcol, nullptr, 0, a.y[l - 1], Gn, st));
+      G = Gn;
+    }
+  }
+  return DM_OK;
+}
+
+// ---------------------------------------------------------------- decoder -----------------------
+struct DecActs {
+  float* wr[5];
+  float* x[5];     // x[0] = fc output (N,32d); x[l] = NHWC activations after layer l (x[4] = prediction)
+};
+static size_t dec_carve(const DecGeom& g, float* base, size_t cap_floats, DecActs* a) {
+  DmArena ar(base, cap_floats * sizeof(float));
+  float* x0 = ar.take((size_t)g.N * g.cin[1]);
+  if (a) a->x[0] = x0;
+  for (int l = 1; l <= 4; ++l) {
+    float* w = ar.take((size_t)g.cin[l] * g.k[l] * g.k[l] * g.cout[l]);
+    float* xx = ar.take(g.rows_b[l] * g.cout[l]);
+    if (a) { a->wr[l] = w; a->x[l] = xx; }
+  }
+  return ar.off;
+}
+extern "C" size_t dm_conv_decoder_acts_floats(const dm_shape* shp) {
+  if (!shp) return 0;
+  DecGeom g(shp);
+  return dec_carve(g, nullptr, 0, nullptr);
+}
+
+extern "C" int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                       const dm_conv_params* p, float* acts, float* loss_image, float* image_rec,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp && feat && target && p && acts && ws, DM_E_NULL, "conv_decoder_fwd: null pointer");
+  DecGeom g(shp);
+  DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry (img=%d)", shp->img);
+  hipStream_t st = (hipStream_t)stream;
+  DecActs a;
+  dec_carve(g, acts, (size_t)1 << 60, &a);
+  DmArena ar(ws, ws_bytes);
+  float* splitk = ar.take(DM_SPLITK_FLOATS);
+  size_t colmax = 0;
+  for (int l = 1; l <= 4; ++l) {
+    const size_t c = g.rows_s[l] * g.k[l] * g.k[l] * g.cout[l];
+    if (c > colmax) colmax = c;
+  }
+  float* ycol = ar.take(colmax);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_fwd: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  {
+    DmGemm q;   // x0 = feat W^T + b
+    q.M = g.N; q.N = g.cin[1]; q.K = g.F;
+    q.A = feat; q.lda = ldf;
+    q.B = p->w[0]; q.ldb = g.F;
+    q.C = a.x[0]; q.ldc = q.N;
+    q.bias = p->b[0];
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+  }
+  for (int l = 1; l <= 4; ++l) {
+    const int kk = g.k[l] * g.k[l];
+    DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cin[l], g.cout[l], g.k[l], g.k[l], 0, 2, 3, 1, st));
+    DmGemm q;   // Ycol[(n,ys,xs)][(ky,kx,o)] = X[(n,ys,xs)][i] * Wr[i][(ky,kx,o)]
+    q.a_layout = 0; q.b_layout = 1;
+    q.M = (int)g.rows_s[l]; q.N = kk * g.cout[l]; q.K = g.cin[l];
+    q.A = a.x[l - 1]; q.lda = q.K;
+    q.B = a.wr[l]; q.ldb = q.N;
+    q.C = ycol; q.ldc = q.N;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    DM_TRY(dm_col2im_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], ycol, p->b[l], l < 4 ? DM_C2I_ELU : 0, nullptr,
+                               a.x[l], st));
+  }
+  if (loss_image || image_rec) {
+    hipLaunchKernelGGL(mse_image_kernel, dim3(g.N), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4], target, 0.f,
+                       loss_image, nullptr, image_rec);
+    DM_LAUNCH_CHECK();
+  }
+  return DM_OK;
+}
+
+extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                       const dm_conv_params* p, const float* acts, float scale, const dm_conv_grads* gr,
+                                       float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp && feat && target && p && acts && gr && ws, DM_E_NULL, "conv_decoder_bwd: null pointer");
+  DecGeom g(shp);
+  DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry");
+  hipStream_t st = (hipStream_t)stream;
+  DecActs a;
+  dec_carve(g, const_cast<float*>(acts), (size_t)1 << 60, &a);
+  DmArena ar(ws, ws_bytes);
+  float* splitk = ar.take(DM_SPLITK_FLOATS);
+  size_t colmax = 0, gmax = 0, wmax = 0;
+  for (int l = 1; l <= 4; ++l) {
+    const size_t c = g.rows_s[l] * g.k[l] * g.k[l] * g.cout[l];
+    if (c > colmax) colmax = c;
+    if (g.rows_b[l] * g.cout[l] > gmax) gmax = g.rows_b[l] * g.cout[l];
+    const size_t w = (size_t)g.cin[l] * g.k[l] * g.k[l] * g.cout[l];
+    if (w > wmax) wmax = w;
+  }
+  if ((size_t)g.N * g.cin[1] > gmax) gmax = (size_t)g.N * g.cin[1];
+  float* dycol = ar.take(colmax);
+  float* ga = ar.take(gmax);
+  float* gb = ar.take(gmax);
+  float* dwr = ar.take(wmax);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  // G4 = scale * (pred - target), NHWC
+  float* G = ga;
+  hipLaunchKernelGGL(mse_image_kernel, dim3(g.N), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4], target, scale,
+                     nullptr, G, nullptr);
+  DM_LAUNCH_CHECK();
+  for (int l = 4; l >= 1; --l) {
+    const int kk = g.k[l] * g.k[l];
+    const int ncol = kk * g.cout[l];
+    const int rows_s = (int)g.rows_s[l];
+    DM_TRY(dm_colsum_launch((int)g.rows_b[l], g.cout[l], G, g.cout[l], gr->b[l], splitk, skb, st));
+    DM_TRY(dm_im2col_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], G, 0, dycol, st));
+    DmGemm q;   // dWr[i][(ky,kx,o)] = sum_rows X[row][i] * dYcol[row][(ky,kx,o)]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = g.cin[l]; q.N = ncol; q.K = rows_s;
+    q.A = a.x[l - 1]; q.lda = g.cin[l];
+    q.B = dycol; q.ldb = ncol;
+    q.C = dwr; q.ldc = ncol;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, st));
+    float* Gn = (G == ga) ? gb : ga;
+    DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
+    d.a_layout = 0; d.b_layout = 0;
+    d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
+    d.A = dycol; d.lda = ncol;
+    d.B = a.wr[l]; d.ldb = ncol;
+    d.C = Gn; d.ldc = g.cin[l];
+    if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }
+    DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+    G = Gn;
+  }
+  // fc: x0 = feat W^T + b
+  const int O = g.cin[1];
+  DM_TRY(dm_colsum_launch(g.N, O, G, O, gr->b[0], splitk, skb, st));
+  {
+    DmGemm q;   // dW[o][f] = sum_n G[n][o] feat[n][f]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = O; q.N = g.F; q.K = g.N;
+    q.A = G; q.lda = O;
+    q.B = feat; q.ldb = ldf;
+    q.C = gr->w[0]; q.ldc = g.F;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+  }
+  if (dfeat) {
+    DmGemm d;   // dfeat[n][f] += sum_o G[n][o] W[o][f]
+    d.a_layout = 0; d.b_layout = 1;
+    d.M = g.N; d.N = g.F; d.K = O;
+    d.A = G; d.lda = O;
+    d.B = p->w[0]; d.ldb = g.F;
+    d.C = dfeat; d.ldc = lddf;
+    d.flags = DM_GEMM_ACCUM;
+    DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+  }
+  return DM_OK;
+}

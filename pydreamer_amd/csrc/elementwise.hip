@@ -1,0 +1,676 @@
+// Row-wise / element-wise kernels of the DreamerV2 step (HBM- or latency-bound; no MFMA here):
+// LayerNorm+ELU, column sums, GRU gate math, categorical sampler, KL, straight-through backward, masks,
+// head losses, GAE, actor / critic losses, multi-array reductions.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm(eps) + ELU, one wave per row (common.py:44-49; rssm.py:105-115; torch LayerNorm: biased variance)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ y, int ldy, float* __restrict__ stats) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < n; c += 64) s += xr[c];
+  const float mean = dm_wave_sum(s) / (float)n;
+  float v = 0.f;
+  for (int c = lane; c < n; c += 64) {
+    const float d = xr[c] - mean;
+    v += d * d;
+  }
+  const float var = dm_wave_sum(v) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float* yr = y + (size_t)row * ldy;
+  for (int c = lane; c < n; c += 64) {
+    const float t = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    yr[c] = dm_elu(t);
+  }
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * ELU'(y) * gamma
+__global__ void __launch_bounds__(256) ln_elu_bwd_dx_kernel(int rows, int n, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, int lddy,
+                                                            float* __restrict__ dx, int lddx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  const float* xr = x + (size_t)row * ldx;
+  const float* yr = y + (size_t)row * ldy;
+  const float* dyr = dy + (size_t)row * lddy;
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane; c < n; c += 64) {
+    const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
+    const float xh = (xr[c] - mean) * rstd;
+    sg += g;
+    sgx += g * xh;
+  }
+  sg = dm_wave_sum(sg) / (float)n;
+  sgx = dm_wave_sum(sgx) / (float)n;
+  float* dxr = dx + (size_t)row * lddx;
+  for (int c = lane; c < n; c += 64) {
+    const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
+    const float xh = (xr[c] - mean) * rstd;
+    dxr[c] = rstd * (g - sg - xh * sgx);
+  }
+}
+
+// Column partial sums over row chunks.  MODE 0: sum x.  MODE 1: LayerNorm dgamma/dbeta.
+// Block = 64 columns x 4 row lanes; partial[(chunk*nq + q)*n + col].
+template <int MODE>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(int rows, int n, int rows_per_chunk,
+                                                             const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ y, int ldy,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ dy, int lddy,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int chunk = blockIdx.y;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  float a0 = 0.f, a1 = 0.f;
+  if (col < n) {
+    for (int r = r0 + ry; r < r1; r += 4) {
+      if (MODE == 0) {
+        a0 += x[(size_t)r * ldx + col];
+      } else {
+        const float dl = dy[(size_t)r * lddy + col] * dm_elu_grad_from_y(y[(size_t)r * ldy + col]);
+        const float xh = (x[(size_t)r * ldx + col] - stats[2 * r]) * stats[2 * r + 1];
+        a0 += dl * xh;   // dgamma
+        a1 += dl;        // dbeta
+      }
+    }
+  }
+  red[0][ry][cx] = a0;
+  red[1][ry][cx] = a1;
+  __syncthreads();
+  if (ry == 0 && col < n) {
+    const int nq = (MODE == 0) ? 1 : 2;
+    float s0 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+    partial[((size_t)chunk * nq + 0) * n + col] = s0;
+    if (MODE == 1) {
+      float s1 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+      partial[((size_t)chunk * nq + 1) * n + col] = s1;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) colsum_final_kernel(int n, int chunks, int nq, const float* __restrict__ partial,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  for (int q = 0; q < nq; ++q) {
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[((size_t)c * nq + q) * n + col];
+    (q == 0 ? out0 : out1)[col] = s;
+  }
+}
+
+static int colsum_plan(int rows, int* rows_per_chunk) {
+  int chunks = dm_cdiv(rows, 32);
+  if (chunks > 256) chunks = 256;
+  if (chunks < 1) chunks = 1;
+  *rows_per_chunk = dm_cdiv(rows, chunks);
+  return dm_cdiv(rows, *rows_per_chunk);
+}
+
+int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (n <= 0) return DM_OK;
+  int rpc;
+  const int chunks = rows > 0 ? colsum_plan(rows, &rpc) : 0;
+  if (chunks == 0) {
+    (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st);
+    return DM_OK;
+  }
+  DM_REQUIRE(ws && (size_t)chunks * n * sizeof(float) <= ws_bytes, DM_E_WORKSPACE, "colsum: workspace too small");
+  hipLaunchKernelGGL((colsum_partial_kernel<0>), dim3(dm_cdiv(n, 64), chunks), dim3(256), 0, st, rows, n, rpc, x, ld,
+                     nullptr, 0, nullptr, nullptr, 0, (float*)ws);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 256)), dim3(256), 0, st, n, chunks, 1, (const float*)ws, out,
+                     nullptr);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                         float* y, int ldy, float* stats, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(ln_elu_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta, eps, y,
+                     ldy, stats);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dx only (row kernel)
+int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                            const float* gamma, const float* dy, int lddy, float* dx, int lddx, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(ln_elu_bwd_dx_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, y, ldy, stats,
+                     gamma, dy, lddy, dx, lddx);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dgamma / dbeta only (column kernel)
+int dm_ln_elu_bwd_params_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                                const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                hipStream_t st) {
+  int rpc;
+  const int chunks = colsum_plan(rows, &rpc);
+  DM_REQUIRE(ws && (size_t)chunks * 2 * n * sizeof(float) <= ws_bytes, DM_E_WORKSPACE, "ln_bwd: workspace too small");
+  hipLaunchKernelGGL((colsum_partial_kernel<1>), dim3(dm_cdiv(n, 64), chunks), dim3(256), 0, st, rows, n, rpc, x, ldx, y,
+                     ldy, stats, dy, lddy, (float*)ws);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 256)), dim3(256), 0, st, n, chunks, 2, (const float*)ws, dgamma,
+                     dbeta);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                             float* y, int ldy, float* stats, void* stream) {
+  DM_REQUIRE(x && gamma && beta && y && stats, DM_E_NULL, "ln_elu_fwd: null pointer");
+  return dm_ln_elu_fwd_launch(rows, n, x, ldx, gamma, beta, eps, y, ldy, stats, (hipStream_t)stream);
+}
+
+extern "C" int dm_ln_elu_bwd(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                             const float* gamma, const float* dy, int lddy, float* dx, int lddx, float* dgamma,
+                             float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && y && stats && gamma && dy && dx && dgamma && dbeta, DM_E_NULL, "ln_elu_bwd: null pointer");
+  DM_TRY(dm_ln_elu_bwd_dx_launch(rows, n, x, ldx, y, ldy, stats, gamma, dy, lddy, dx, lddx, (hipStream_t)stream));
+  return dm_ln_elu_bwd_params_launch(rows, n, x, ldx, y, ldy, stats, dy, lddy, dgamma, dbeta, ws, ws_bytes,
+                                     (hipStream_t)stream);
+}
+
+extern "C" int dm_colsum(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && out, DM_E_NULL, "colsum: null pointer");
+  return dm_colsum_launch(rows, n, x, ld, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn.GRUCell gate math (rnn.py:48-49).  Row blocks of gi/gh: [r | z(update) | n].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dm_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, const float* __restrict__ gi,
+                                                            const float* __restrict__ gh, const float* __restrict__ h_in,
+                                                            int ldh, float* __restrict__ h_out, int ldo) {
+  const size_t total = (size_t)rows * D;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / D), d = (int)(i % D);
+    const float* gir = gi + (size_t)r * 3 * D;
+    const float* ghr = gh + (size_t)r * 3 * D;
+    const float rg = dm_sigmoid(gir[d] + ghr[d]);
+    const float ug = dm_sigmoid(gir[D + d] + ghr[D + d]);
+    const float ng = tanhf(gir[2 * D + d] + rg * ghr[2 * D + d]);
+    const float h = h_in[(size_t)r * ldh + d];
+    h_out[(size_t)r * ldo + d] = (h - ng) * ug + ng;
+  }
+}
+
+__global__ void __launch_bounds__(256) gru_gates_bwd_kernel(int rows, int D, const float* __restrict__ gi,
+                                                            const float* __restrict__ gh, const float* __restrict__ h_in,
+                                                            int ldh, const float* __restrict__ dh_out, int lddh,
+                                                            float* __restrict__ dgi, float* __restrict__ dgh,
+                                                            float* __restrict__ dh_in, int lddi, int accum,
+                                                            const uint8_t* __restrict__ row_zero) {
+  const size_t total = (size_t)rows * D;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / D), d = (int)(i % D);
+    const size_t g0 = (size_t)r * 3 * D;
+    const float ghn = gh[g0 + 2 * D + d];
+    const float rg = dm_sigmoid(gi[g0 + d] + gh[g0 + d]);
+    const float ug = dm_sigmoid(gi[g0 + D + d] + gh[g0 + D + d]);
+    const float ng = tanhf(gi[g0 + 2 * D + d] + rg * ghn);
+    const float h = h_in[(size_t)r * ldh + d];
+    const float dh = dh_out[(size_t)r * lddh + d];
+    const float dn = dh * (1.f - ug);
+    const float du = dh * (h - ng);
+    const float dpn = dn * (1.f - ng * ng);
+    const float dpr = dpn * ghn * rg * (1.f - rg);
+    const float dpu = du * ug * (1.f - ug);
+    dgi[g0 + d] = dpr;
+    dgi[g0 + D + d] = dpu;
+    dgi[g0 + 2 * D + d] = dpn;
+    dgh[g0 + d] = dpr;
+    dgh[g0 + D + d] = dpu;
+    dgh[g0 + 2 * D + d] = dpn * rg;
+    if (dh_in) {
+      const float v = (row_zero && row_zero[r]) ? 0.f : dh * ug;
+      float* o = dh_in + (size_t)r * lddi + d;
+      *o = accum ? *o + v : v;
+    }
+  }
+}
+
+static inline int ew_blocks(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
+                            int ldo, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
+                     ldh, h_out, ldo);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                            const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,
+                            const uint8_t* row_zero, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
+                     ldh, dh_out, lddh, dgi, dgh, dh_in, lddi, accum, row_zero);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_gru_gates_fwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                                float* h_out, int ldo, void* stream) {
+  DM_REQUIRE(gi && gh && h_in && h_out, DM_E_NULL, "gru_gates_fwd: null pointer");
+  return dm_gru_gates_fwd_launch(rows, D, gi, gh, h_in, ldh, h_out, ldo, (hipStream_t)stream);
+}
+extern "C" int dm_gru_gates_bwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                                const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi,
+                                void* stream) {
+  DM_REQUIRE(gi && gh && h_in && dh_out && dgi && dgh && dh_in, DM_E_NULL, "gru_gates_bwd: null pointer");
+  return dm_gru_gates_bwd_launch(rows, D, gi, gh, h_in, ldh, dh_out, lddh, dgi, dgh, dh_in, lddi, 0, nullptr,
+                                 (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Categorical sampler under the shared inverse-CDF rule (rssm.py:147-148,195-201; dreamer.py:198-200).
+// One thread per (row, group).  p = exp(x-max)/sum (sequential fp32 sum), cdf = sequential cumsum,
+// idx = #{k : cdf_k <= u*cdf_last}, clamped to C-1.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sample_onehot_kernel(int rows, int groups, int C, const float* __restrict__ logits,
+                                                            int ldl, const float* __restrict__ u,
+                                                            const int32_t* __restrict__ forced, float* __restrict__ onehot,
+                                                            int ldo, int32_t* __restrict__ idx_out) {
+  const int total = rows * groups;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / groups, gq = i % groups;
+    const float* x = logits + (size_t)r * ldl + (size_t)gq * C;
+    int idx;
+    if (forced) {
+      idx = forced[i];
+    } else {
+      float mx = x[0];
+      for (int k = 1; k < C; ++k) mx = fmaxf(mx, x[k]);
+      float sum = 0.f;
+      for (int k = 0; k < C; ++k) sum += expf(x[k] - mx);
+      float total_p = 0.f;
+      for (int k = 0; k < C; ++k) total_p += expf(x[k] - mx) / sum;
+      const float target = u[i] * total_p;
+      float cdf = 0.f;
+      idx = 0;
+      for (int k = 0; k < C; ++k) {
+        cdf += expf(x[k] - mx) / sum;
+        idx += (cdf <= target) ? 1 : 0;
+      }
+      if (idx > C - 1) idx = C - 1;
+    }
+    float* o = onehot + (size_t)r * ldo + (size_t)gq * C;
+    for (int k = 0; k < C; ++k) o[k] = (k == idx) ? 1.f : 0.f;
+    if (idx_out) idx_out[i] = idx;
+  }
+}
+
+int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
+                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(sample_onehot_kernel, dim3(ew_blocks((size_t)rows * groups)), dim3(256), 0, st, rows, groups, C,
+                     logits, ldl, u, forced, onehot, ldo, idx);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_sample_onehot(int rows, int groups, int C, const float* logits, int ldl, const float* u,
+                                const int32_t* forced_idx, float* onehot, int ldo, int32_t* idx, void* stream) {
+  DM_REQUIRE(logits && onehot && (u || forced_idx), DM_E_NULL, "sample_onehot: null pointer");
+  DM_REQUIRE(C >= 1 && groups >= 1, DM_E_SHAPE, "sample_onehot: bad groups/C");
+  return dm_sample_onehot_launch(rows, groups, C, logits, ldl, u, forced_idx, onehot, ldo, idx, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// KL(post || prior) and entropies, summed over the S groups of each row (dreamer.py:326-343,369-379).
+// One wave per row; lanes stride over groups.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dm_group_lse(const float* x, int C) {
+  float mx = x[0];
+  for (int k = 1; k < C; ++k) mx = fmaxf(mx, x[k]);
+  float s = 0.f;
+  for (int k = 0; k < C; ++k) s += expf(x[k] - mx);
+  return mx + logf(s);
+}
+
+__global__ void __launch_bounds__(256) kl_fwd_kernel(int rows, int S, int C, const float* __restrict__ post,
+                                                     const float* __restrict__ prior, float* __restrict__ kl,
+                                                     float* __restrict__ ent_post, float* __restrict__ ent_prior) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float akl = 0.f, aep = 0.f, aeq = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float* a = post + ((size_t)row * S + s) * C;
+    const float* b = prior + ((size_t)row * S + s) * C;
+    const float la = dm_group_lse(a, C), lb = dm_group_lse(b, C);
+    float gk = 0.f, ep = 0.f, eq = 0.f;
+    for (int k = 0; k < C; ++k) {
+      const float lp = a[k] - la, lq = b[k] - lb;
+      const float p = expf(lp), q = expf(lq);
+      gk += p * (lp - lq);
+      ep -= p * lp;
+      eq -= q * lq;
+    }
+    akl += gk; aep += ep; aeq += eq;
+  }
+  akl = dm_wave_sum(akl); aep = dm_wave_sum(aep); aeq = dm_wave_sum(aeq);
+  if (lane == 0) {
+    kl[row] = akl;
+    if (ent_post) ent_post[row] = aep;
+    if (ent_prior) ent_prior[row] = aeq;
+  }
+}
+
+// dKL/dpost_k = p_k ((lp_k - lq_k) - KL_g) ; dKL/dprior_k = q_k - p_k
+__global__ void __launch_bounds__(256) kl_bwd_kernel(int rows, int S, int C, const float* __restrict__ post,
+                                                     const float* __restrict__ prior, float sp, float sq,
+                                                     float* __restrict__ dpost, float* __restrict__ dprior) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const float* a = post + (size_t)i * C;
+    const float* b = prior + (size_t)i * C;
+    const float la = dm_group_lse(a, C), lb = dm_group_lse(b, C);
+    float gk = 0.f;
+    for (int k = 0; k < C; ++k) {
+      const float lp = a[k] - la, lq = b[k] - lb;
+      gk += expf(lp) * (lp - lq);
+    }
+    for (int k = 0; k < C; ++k) {
+      const float lp = a[k] - la, lq = b[k] - lb;
+      const float p = expf(lp), q = expf(lq);
+      dpost[(size_t)i * C + k] = sp * p * ((lp - lq) - gk);
+      dprior[(size_t)i * C + k] = sq * (q - p);
+    }
+  }
+}
+
+// straight-through: sample = onehot + (p - sg(p)) => dlogits_k = p_k (g_k - sum_j p_j g_j)
+__global__ void __launch_bounds__(256) st_softmax_bwd_kernel(int rows, int groups, int C, const float* __restrict__ logits,
+                                                             int ldl, const float* __restrict__ dz, int lddz,
+                                                             float* __restrict__ dlogits, int lddl, int accum) {
+  const int total = rows * groups;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / groups, gq = i % groups;
+    const float* x = logits + (size_t)r * ldl + (size_t)gq * C;
+    const float* g = dz + (size_t)r * lddz + (size_t)gq * C;
+    float* o = dlogits + (size_t)r * lddl + (size_t)gq * C;
+    const float l = dm_group_lse(x, C);
+    float dot = 0.f;
+    for (int k = 0; k < C; ++k) dot += expf(x[k] - l) * g[k];
+    for (int k = 0; k < C; ++k) {
+      const float v = expf(x[k] - l) * (g[k] - dot);
+      o[k] = accum ? o[k] + v : v;
+    }
+  }
+}
+
+int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* prior, float* kl, float* ep, float* eq,
+                     hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, S, C, post, prior, kl, ep, eq);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* prior, float sp, float sq, float* dpost,
+                     float* dprior, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(ew_blocks((size_t)rows * S)), dim3(256), 0, st, rows, S, C, post, prior, sp, sq,
+                     dpost, dprior);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_st_softmax_bwd_launch(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
+                             float* dlogits, int lddl, int accum, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(st_softmax_bwd_kernel, dim3(ew_blocks((size_t)rows * groups)), dim3(256), 0, st, rows, groups, C,
+                     logits, ldl, dz, lddz, dlogits, lddl, accum);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_kl_balance_fwd(int rows, int S, int C, const float* post, const float* prior, float* kl,
+                                 float* ent_post, float* ent_prior, void* stream) {
+  DM_REQUIRE(post && prior && kl, DM_E_NULL, "kl_fwd: null pointer");
+  return dm_kl_fwd_launch(rows, S, C, post, prior, kl, ent_post, ent_prior, (hipStream_t)stream);
+}
+extern "C" int dm_kl_balance_bwd(int rows, int S, int C, const float* post, const float* prior, float scale_post,
+                                 float scale_prior, float* dpost, float* dprior, void* stream) {
+  DM_REQUIRE(post && prior && dpost && dprior, DM_E_NULL, "kl_bwd: null pointer");
+  return dm_kl_bwd_launch(rows, S, C, post, prior, scale_post, scale_prior, dpost, dprior, (hipStream_t)stream);
+}
+extern "C" int dm_st_softmax_bwd(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
+                                 float* dlogits, int lddl, int accum, void* stream) {
+  DM_REQUIRE(logits && dz && dlogits, DM_E_NULL, "st_softmax_bwd: null pointer");
+  return dm_st_softmax_bwd_launch(rows, groups, C, logits, ldl, dz, lddz, dlogits, lddl, accum, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset masks (rssm.py:41,134-135)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mask_rows_kernel(int rows, int n, const float* __restrict__ x, int ldx,
+                                                        const uint8_t* __restrict__ reset, float* __restrict__ y, int ldy) {
+  const size_t total = (size_t)rows * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    const float m = reset[r] ? 0.f : 1.f;
+    y[(size_t)r * ldy + c] = x[(size_t)r * ldx + c] * m;
+  }
+}
+int dm_mask_rows_launch(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, hipStream_t st) {
+  if (rows <= 0 || n <= 0) return DM_OK;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_blocks((size_t)rows * n)), dim3(256), 0, st, rows, n, x, ldx, reset, y, ldy);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_mask_rows(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy,
+                            void* stream) {
+  DM_REQUIRE(x && reset && y, DM_E_NULL, "mask_rows: null pointer");
+  return dm_mask_rows_launch(rows, n, x, ldx, reset, y, ldy, (hipStream_t)stream);
+}
+
+// y = dy * ELU'(yact)
+__global__ void __launch_bounds__(256) mul_elu_grad_kernel(size_t n, const float* __restrict__ dy,
+                                                           const float* __restrict__ yact, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = dy[i] * dm_elu_grad_from_y(yact[i]);
+}
+int dm_mul_elu_grad_launch(size_t n, const float* dy, const float* yact, float* out, hipStream_t st) {
+  if (n == 0) return DM_OK;
+  hipLaunchKernelGGL(mul_elu_grad_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, n, dy, yact, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense-head loss epilogues (decoders.py:257-319)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_loss_kernel(int kind, int rows, const float* __restrict__ out,
+                                                        const float* __restrict__ target, float scale, float loss_const,
+                                                        float* __restrict__ loss, float* __restrict__ dout,
+                                                        float* __restrict__ mean_out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const float o = out[i];
+    const float y = target ? target[i] : 0.f;
+    if (kind == 0) {
+      const float d = o - y;
+      if (loss) loss[i] = 0.5f * d * d + loss_const;
+      if (dout) dout[i] = scale * d;
+      if (mean_out) mean_out[i] = o;
+    } else {
+      // -Bernoulli(logits=o).log_prob(y) = max(o,0) - o*y + log1p(exp(-|o|))
+      const float sg = dm_sigmoid(o);
+      if (loss) loss[i] = fmaxf(o, 0.f) - o * y + log1pf(expf(-fabsf(o)));
+      if (dout) dout[i] = scale * (sg - y);
+      if (mean_out) mean_out[i] = sg;
+    }
+  }
+}
+extern "C" int dm_head_loss(int kind, int rows, const float* out, const float* target, float scale, float loss_const,
+                            float* loss, float* dout, float* mean_out, void* stream) {
+  DM_REQUIRE(out, DM_E_NULL, "head_loss: null pointer");
+  DM_REQUIRE(kind == 0 || kind == 1, DM_E_SHAPE, "head_loss: kind %d", kind);
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(head_loss_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, kind, rows, out, target,
+                     scale, loss_const, loss, dout, mean_out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GAE reverse scan + reality weight, one thread per dream column (a2c.py:81-108)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gae_kernel(int H, int M, float gamma, float lambda, const float* __restrict__ reward,
+                                                  const float* __restrict__ terminal, const float* __restrict__ value_t,
+                                                  float* __restrict__ advantage, float* __restrict__ advantage_gae,
+                                                  float* __restrict__ value_target, float* __restrict__ weight) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float agae = 0.f;
+  for (int t = H - 1; t >= 0; --t) {
+    const float v0 = value_t[(size_t)t * M + m];
+    const float v1 = value_t[(size_t)(t + 1) * M + m];
+    const float r1 = reward[(size_t)(t + 1) * M + m];
+    const float nt1 = 1.0f - terminal[(size_t)(t + 1) * M + m];
+    const float adv = -v0 + r1 + gamma * nt1 * v1;
+    agae = (t == H - 1) ? adv : adv + lambda * gamma * nt1 * agae;
+    advantage[(size_t)t * M + m] = adv;
+    advantage_gae[(size_t)t * M + m] = agae;
+    value_target[(size_t)t * M + m] = agae + v0;
+  }
+  float cs = 0.f;
+  for (int t = 0; t < H; ++t) {
+    cs += logf(1.0f - terminal[(size_t)t * M + m]);
+    weight[(size_t)t * M + m] = expf(cs);
+  }
+}
+extern "C" int dm_gae_losses(int H, int M, float gamma, float lambda, const float* reward, const float* terminal,
+                             const float* value_t, float* advantage, float* advantage_gae, float* value_target,
+                             float* weight, void* stream) {
+  DM_REQUIRE(reward && terminal && value_t && advantage && advantage_gae && value_target && weight, DM_E_NULL,
+             "gae: null pointer");
+  DM_REQUIRE(H >= 1 && M >= 1, DM_E_SHAPE, "gae: H=%d M=%d", H, M);
+  hipLaunchKernelGGL(gae_kernel, dim3(dm_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, H, M, gamma, lambda, reward,
+                     terminal, value_t, advantage, advantage_gae, value_target, weight);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// actor (reinforce, OneHotCategorical) rows (a2c.py:119-130)
+__global__ void __launch_bounds__(256) actor_loss_kernel(int rows, int A, const float* __restrict__ logits,
+                                                         const int32_t* __restrict__ act_idx,
+                                                         const float* __restrict__ adv, const float* __restrict__ weight,
+                                                         float ent_w, float scale, float* __restrict__ loss,
+                                                         float* __restrict__ entropy, float* __restrict__ dlogits) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const float* x = logits + (size_t)i * A;
+    const float l = dm_group_lse(x, A);
+    float ent = 0.f;
+    for (int k = 0; k < A; ++k) {
+      const float lp = x[k] - l;
+      ent -= expf(lp) * lp;
+    }
+    const int a = act_idx[i];
+    const float lpa = x[a] - l;
+    const float w = weight[i], ad = adv[i];
+    if (loss) loss[i] = (-lpa * ad - ent_w * ent) * w;
+    if (entropy) entropy[i] = ent;
+    if (dlogits) {
+      const float sw = scale * w;
+      for (int k = 0; k < A; ++k) {
+        const float lp = x[k] - l;
+        const float p = expf(lp);
+        const float dpol = -ad * ((k == a ? 1.f : 0.f) - p);
+        const float dent = ent_w * p * (lp + ent);
+        dlogits[(size_t)i * A + k] = sw * (dpol + dent);
+      }
+    }
+  }
+}
+extern "C" int dm_actor_loss(int rows, int A, const float* logits, const int32_t* act_idx, const float* adv_gae,
+                             const float* weight, float ent_w, float scale, float* loss, float* entropy, float* dlogits,
+                             void* stream) {
+  DM_REQUIRE(logits && act_idx && adv_gae && weight, DM_E_NULL, "actor_loss: null pointer");
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, rows, A, logits,
+                     act_idx, adv_gae, weight, ent_w, scale, loss, entropy, dlogits);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+__global__ void __launch_bounds__(256) critic_loss_kernel(int rows, const float* __restrict__ value,
+                                                          const float* __restrict__ vt, const float* __restrict__ weight,
+                                                          float scale, float* __restrict__ loss, float* __restrict__ dvalue) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const float d = vt[i] - value[i];
+    const float w = weight[i];
+    if (loss) loss[i] = 0.5f * d * d * w;
+    if (dvalue) dvalue[i] = -scale * d * w;
+  }
+}
+extern "C" int dm_critic_loss(int rows, const float* value, const float* value_target, const float* weight, float scale,
+                              float* loss, float* dvalue, void* stream) {
+  DM_REQUIRE(value && value_target && weight, DM_E_NULL, "critic_loss: null pointer");
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, rows, value,
+                     value_target, weight, scale, loss, dvalue);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-array sums: one block per array, deterministic order
+// ------------------------------------------------------------------------------------------------
+struct MultiSumArgs {
+  const float* x[32];
+  long long n[32];
+  float scale[32];
+};
+__global__ void __launch_bounds__(256) multi_sum_kernel(const MultiSumArgs a, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int item = blockIdx.x;
+  const float* x = a.x[item];
+  const long long n = a.n[item];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[item] = (red[0] + red[1] + red[2] + red[3]) * a.scale[item];
+}
+extern "C" int dm_multi_sum(int count, const dm_reduce_item* items, float* out, void* stream) {
+  DM_REQUIRE(items && out, DM_E_NULL, "multi_sum: null pointer");
+  DM_REQUIRE(count >= 1 && count <= 32, DM_E_SHAPE, "multi_sum: count %d not in [1,32]", count);
+  MultiSumArgs a;
+  for (int i = 0; i < count; ++i) {
+    DM_REQUIRE(items[i].x || items[i].n == 0, DM_E_NULL, "multi_sum: item %d null", i);
+    a.x[i] = items[i].x;
+    a.n[i] = items[i].n;
+    a.scale[i] = items[i].scale;
+  }
+  hipLaunchKernelGGL(multi_sum_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, a, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

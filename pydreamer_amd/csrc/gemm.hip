@@ -1,0 +1,313 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, 256-thread workgroups.
+//
+//   C[m,n] = epi( sum_k A(m,k) * B(n,k) )
+//
+// One kernel template serves every dense contraction of the DreamerV2 step:
+//   Linear forward            y = x W^T      (A k-contiguous, B k-contiguous)   reference: common.py:37-65, rssm.py:138-146
+//   Linear backward (data)    dx = dy W      (A k-contiguous, B n-contiguous)
+//   Linear backward (weight)  dW = dy^T x    (A m-contiguous, B n-contiguous, split-K over the row dimension)
+//   conv / conv-transpose as GEMM over im2col matrices (encoders.py:80-96, decoders.py:144-161)
+//
+// fp32-input MFMA is an exact k-ordered fmaf chain (no TF32/xf32 on gfx950), so results stay fp32-class.
+//
+// Tiling: BMxBNx32 block tile, 4 waves in a 2x2 grid, each wave (BM/2)x(BN/2) as 32x32 MFMA blocks.
+// LDS image per operand is chosen by the SOURCE layout so that both the global->LDS stores and the
+// LDS->fragment reads stay conflict-free:
+//   k-contiguous source: LDS [row][k] (row stride 36 floats), fragment = one ds_read_b128 per lane holding 4 k's
+//   row-contiguous source: LDS [k][row], fragment = ds_read_b32 per k (lanes read consecutive floats)
+// The k -> (mfma step, lane half) mapping is identical in both images: within a group of 8 k's, lanes 0-31
+// feed k = 8g + j and lanes 32-63 feed k = 8g + 4 + j at step j (0..3); A and B therefore always agree.
+// Global loads of tile t+1 are issued into registers before the MFMAs of tile t (register prefetch).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmKArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* add;
+  const float* mulref;
+  const uint8_t* row_zero;
+  float* partial;
+  int M, N, K;
+  int lda, ldb, ldc, ldadd, ldmul;
+  int flags;
+  int k_per_split;
+  int nsplit;
+  int tiles_m;
+  int a_vec, b_vec;
+};
+
+// Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).
+template <int ROWS, int LAYOUT, int NF4>
+__device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __restrict__ P, int ld, int row0,
+                                               int nrows, int k0, int kend, int vec, int tid) {
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int f = tid + i * 256;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LAYOUT == 0) {
+      const int row = f >> 3;
+      const int gk = k0 + ((f & 7) << 2);
+      const int grow = row0 + row;
+      if (grow < nrows && gk < kend) {
+        const float* p = P + (size_t)grow * ld + gk;
+        if (vec && gk + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (gk + 1 < kend) v.y = p[1];
+          if (gk + 2 < kend) v.z = p[2];
+          if (gk + 3 < kend) v.w = p[3];
+        }
+      }
+    } else {
+      constexpr int F4_PER_K = ROWS / 4;
+      const int kr = f / F4_PER_K;
+      const int r4 = (f % F4_PER_K) << 2;
+      const int gk = k0 + kr;
+      const int grow = row0 + r4;
+      if (gk < kend && grow < nrows) {
+        const float* p = P + (size_t)gk * ld + grow;
+        if (vec && grow + 3 < nrows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (grow + 1 < nrows) v.y = p[1];
+          if (grow + 2 < nrows) v.z = p[2];
+          if (grow + 3 < nrows) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+
+template <int ROWS, int LAYOUT, int NF4>
+__device__ __forceinline__ void gemm_store_tile(const float4 (&r)[NF4], float* S, int tid) {
+  constexpr int LDK = 36;
+  constexpr int LDM = ROWS + 4;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int f = tid + i * 256;
+    if (LAYOUT == 0) {
+      const int row = f >> 3;
+      const int kq = (f & 7) << 2;
+      *reinterpret_cast<float4*>(&S[row * LDK + kq]) = r[i];
+    } else {
+      constexpr int F4_PER_K = ROWS / 4;
+      const int kr = f / F4_PER_K;
+      const int r4 = (f % F4_PER_K) << 2;
+      *reinterpret_cast<float4*>(&S[kr * LDM + r4]) = r[i];
+    }
+  }
+}
+
+template <int BM, int BN, int AL, int BL>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
+  constexpr int BK = 32;
+  constexpr int LDK = 36;
+  constexpr int LDMA = BM + 4, LDMB = BN + 4;
+  constexpr int A_FLOATS = (AL == 0) ? BM * LDK : BK * LDMA;
+  constexpr int B_FLOATS = (BL == 0) ? BN * LDK : BK * LDMB;
+  constexpr int MB = BM / 64, NB = BN / 64;
+  constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+  float* As = smem;
+  float* Bs = smem + A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int bid = blockIdx.x;
+  const int m0 = (bid % g.tiles_m) * BM;
+  const int n0 = (bid / g.tiles_m) * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_F4], rb[B_F4];
+  if (nkt > 0) {
+    gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec, tid);
+    gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.b_vec, tid);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
+    gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, m0, g.M, k0, kend, g.a_vec, tid);
+      gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, n0, g.N, k0, kend, g.b_vec, tid);
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      float a[MB][4], b[NB][4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int row = wm * (BM / 2) + mb * 32 + l31;
+        if (AL == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
+          a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[mb][j] = As[(kg * 8 + half * 4 + j) * LDMA + row];
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int row = wn * (BN / 2) + nb * 32 + l31;
+        if (BL == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
+          b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[nb][j] = Bs[(kg * 8 + half * 4 + j) * LDMB + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + wn * (BN / 2) + nb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M && col < g.N) {
+          float v = acc[mb][nb][r];
+          if (g.nsplit > 1) {
+            g.partial[((size_t)split * g.M + row) * g.N + col] = v;
+          } else {
+            if (g.row_zero && g.row_zero[row]) v = 0.f;
+            if (g.bias) v += g.bias[col];
+            if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+            float* c = g.C + (size_t)row * g.ldc + col;
+            if (g.flags & DM_GEMM_ACCUM) v += *c;
+            if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
+            if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
+            *c = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs g) {
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / g.N);
+    const int col = (int)(i % g.N);
+    float v = 0.f;
+    for (int s = 0; s < g.nsplit; ++s) v += g.partial[(size_t)s * total + i];
+    if (g.row_zero && g.row_zero[row]) v = 0.f;
+    if (g.bias) v += g.bias[col];
+    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+    float* c = g.C + (size_t)row * g.ldc + col;
+    if (g.flags & DM_GEMM_ACCUM) v += *c;
+    if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
+    if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
+    *c = v;
+  }
+}
+
+template <int BM, int BN>
+static void gemm_dispatch(const GemmKArgs& a, int al, int bl, dim3 grid, hipStream_t stream) {
+  if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, stream, a);
+}
+
+int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
+  DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 0, DM_E_SHAPE, "gemm: negative dims %d %d %d", q.M, q.N, q.K);
+  if (q.M == 0 || q.N == 0) return DM_OK;
+  DM_REQUIRE(q.A && q.B && q.C, DM_E_NULL, "gemm: null operand");
+  DM_REQUIRE((unsigned)q.a_layout < 2 && (unsigned)q.b_layout < 2, DM_E_SHAPE, "gemm: bad layout");
+  DM_REQUIRE(q.lda >= (q.a_layout == 0 ? q.K : q.M), DM_E_SHAPE, "gemm: lda %d too small", q.lda);
+  DM_REQUIRE(q.ldb >= (q.b_layout == 0 ? q.K : q.N), DM_E_SHAPE, "gemm: ldb %d too small", q.ldb);
+  DM_REQUIRE(q.ldc >= q.N, DM_E_SHAPE, "gemm: ldc %d < N %d", q.ldc, q.N);
+  DM_REQUIRE(!q.add || q.ldadd >= q.N, DM_E_SHAPE, "gemm: ldadd %d < N %d", q.ldadd, q.N);
+
+  GemmKArgs a;
+  a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.mulref = q.mulref; a.row_zero = q.row_zero; a.partial = nullptr;
+  a.M = q.M; a.N = q.N; a.K = q.K;
+  a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
+  a.flags = q.flags;
+  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.lda & 3) == 0) ? 1 : 0;
+  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.ldb & 3) == 0) ? 1 : 0;
+
+  const int64_t t128 = (int64_t)dm_cdiv(q.M, 128) * dm_cdiv(q.N, 128);
+  const bool big = t128 >= 192;
+  const int BM = big ? 128 : 64, BN = BM;
+  const int tiles_m = dm_cdiv(q.M, BM), tiles_n = dm_cdiv(q.N, BN);
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  const int ktiles = dm_cdiv(q.K, 32);
+  int nsplit = 1;
+  if (tiles < 256 && ktiles >= 8) {
+    int want = dm_cdiv(512, tiles);
+    nsplit = want < ktiles / 4 ? want : ktiles / 4;
+    if (nsplit > 64) nsplit = 64;
+    const size_t per = (size_t)q.M * q.N * sizeof(float);
+    if (ws == nullptr || per == 0) nsplit = 1;
+    else if ((size_t)nsplit * per > ws_bytes) nsplit = (int)(ws_bytes / per);
+    if (nsplit < 2) nsplit = 1;
+  }
+  int k_per_split = dm_cdiv(ktiles > 0 ? ktiles : 1, nsplit) * 32;
+  nsplit = q.K > 0 ? dm_cdiv(q.K, k_per_split) : 1;
+  a.k_per_split = k_per_split;
+  a.nsplit = nsplit;
+  a.tiles_m = tiles_m;
+  a.partial = nsplit > 1 ? (float*)ws : nullptr;
+
+  dim3 grid((unsigned)tiles, (unsigned)nsplit);
+  if (big) gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, grid, stream);
+  else gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, grid, stream);
+  DM_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    const size_t total = (size_t)q.M * q.N;
+    int blocks = dm_cdiv(total, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+  }
+  return DM_OK;
+}
+
+extern "C" int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda,
+                           const float* B, int ldb, float* C, int ldc, const float* bias, const float* add,
+                           int ldadd, int flags, void* ws, size_t ws_bytes, void* stream) {
+  DmGemm g;
+  g.a_layout = a_layout; g.b_layout = b_layout;
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.add = add; g.ldadd = ldadd; g.flags = flags;
+  return dm_gemm_launch(g, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,125 @@
+// pydreamer MLP (common.py:37-65): [Linear -> LayerNorm(eps 1e-3) -> ELU] x L, Linear.
+// Used by the reward / terminal decoders (decoders.py:257-319) and actor / critic / critic_target (a2c.py:37-39).
+// Contractions run on gemm.hip (MFMA); LayerNorm+ELU and the bias / gamma / beta column sums are row kernels.
+#include "common.h"
+
+struct MlpActs {
+  float* xpre[DM_MAX_MLP_LAYERS];
+  float* stats[DM_MAX_MLP_LAYERS];
+  float* y[DM_MAX_MLP_LAYERS];
+};
+static size_t mlp_carve(int rows, int hidden, int layers, float* base, MlpActs* a) {
+  DmArena ar(base, (size_t)1 << 62);
+  for (int l = 0; l < layers; ++l) {
+    float* xp = ar.take((size_t)rows * hidden);
+    float* st = ar.take((size_t)rows * 2);
+    float* yy = ar.take((size_t)rows * hidden);
+    if (a) { a->xpre[l] = xp; a->stats[l] = st; a->y[l] = yy; }
+  }
+  return ar.off;
+}
+extern "C" size_t dm_mlp_acts_floats(int rows, int hidden, int layers) {
+  if (rows < 0 || hidden < 0 || layers < 0 || layers > DM_MAX_MLP_LAYERS) return 0;
+  return mlp_carve(rows, hidden, layers, nullptr, nullptr);
+}
+
+int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                      const dm_mlp_params* p, float* acts, float* out, int ldout, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
+  DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
+  DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
+  MlpActs a;
+  mlp_carve(rows, hidden, layers, acts, &a);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  const float* in = x;
+  int ldin = ldx, kin = in_dim;
+  for (int l = 0; l < layers; ++l) {
+    DmGemm q;
+    q.M = rows; q.N = hidden; q.K = kin;
+    q.A = in; q.lda = ldin;
+    q.B = p->w[l]; q.ldb = kin;
+    q.C = a.xpre[l]; q.ldc = hidden;
+    q.bias = p->b[l];
+    DM_TRY(dm_gemm_launch(q, ws, skb, st));
+    DM_TRY(dm_ln_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, p->ln_g[l], p->ln_b[l], 1e-3f, a.y[l], hidden,
+                                a.stats[l], st));
+    in = a.y[l]; ldin = hidden; kin = hidden;
+  }
+  DmGemm q;
+  q.M = rows; q.N = out_dim; q.K = hidden;
+  q.A = in; q.lda = hidden;
+  q.B = p->w[layers]; q.ldb = hidden;
+  q.C = out; q.ldc = ldout;
+  q.bias = p->b[layers];
+  return dm_gemm_launch(q, ws, skb, st);
+}
+
+extern "C" int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                               const dm_mlp_params* p, float* acts, float* out, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && p && acts && out && ws, DM_E_NULL, "mlp_head_fwd: null pointer");
+  return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, out, out_dim, ws, ws_bytes,
+                           (hipStream_t)stream);
+}
+
+extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                               const dm_mlp_params* p, const float* acts, const float* dout, const dm_mlp_grads* g,
+                               float* dx, int lddx, int dx_accum, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && p && acts && dout && g && ws, DM_E_NULL, "mlp_head_bwd: null pointer");
+  DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
+  hipStream_t st = (hipStream_t)stream;
+  MlpActs a;
+  mlp_carve(rows, hidden, layers, const_cast<float*>(acts), &a);
+  DmArena ar(ws, ws_bytes);
+  float* splitk = ar.take(DM_SPLITK_FLOATS);
+  float* dy = ar.take((size_t)rows * hidden);
+  float* dxp = ar.take((size_t)rows * hidden);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "mlp_head_bwd: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  // output layer
+  {
+    DmGemm q;   // dW_L[o][h] = sum_r dout[r][o] y[r][h]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = out_dim; q.N = hidden; q.K = rows;
+    q.A = dout; q.lda = out_dim;
+    q.B = a.y[layers - 1]; q.ldb = hidden;
+    q.C = g->w[layers]; q.ldc = hidden;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    DM_TRY(dm_colsum_launch(rows, out_dim, dout, out_dim, g->b[layers], splitk, skb, st));
+    DmGemm d;   // dy[r][h] = sum_o dout[r][o] W_L[o][h]
+    d.a_layout = 0; d.b_layout = 1;
+    d.M = rows; d.N = hidden; d.K = out_dim;
+    d.A = dout; d.lda = out_dim;
+    d.B = p->w[layers]; d.ldb = hidden;
+    d.C = dy; d.ldc = hidden;
+    DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+  }
+  for (int l = layers - 1; l >= 0; --l) {
+    const float* in = l == 0 ? x : a.y[l - 1];
+    const int ldin = l == 0 ? ldx : hidden;
+    const int kin = l == 0 ? in_dim : hidden;
+    DM_TRY(dm_ln_elu_bwd_dx_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], p->ln_g[l], dy, hidden,
+                                   dxp, hidden, st));
+    DM_TRY(dm_ln_elu_bwd_params_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], dy, hidden,
+                                       g->ln_g[l], g->ln_b[l], splitk, skb, st));
+    DmGemm q;   // dW_l[h][i] = sum_r dxp[r][h] in[r][i]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = hidden; q.N = kin; q.K = rows;
+    q.A = dxp; q.lda = hidden;
+    q.B = in; q.ldb = ldin;
+    q.C = g->w[l]; q.ldc = kin;
+    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    DM_TRY(dm_colsum_launch(rows, hidden, dxp, hidden, g->b[l], splitk, skb, st));
+    if (l > 0 || dx) {
+      DmGemm d;   // d(in)[r][i] = sum_h dxp[r][h] W_l[h][i]
+      d.a_layout = 0; d.b_layout = 1;
+      d.M = rows; d.N = kin; d.K = hidden;
+      d.A = dxp; d.lda = hidden;
+      d.B = p->w[l]; d.ldb = kin;
+      if (l > 0) { d.C = dy; d.ldc = hidden; }
+      else { d.C = dx; d.ldc = lddx; d.flags = dx_accum ? DM_GEMM_ACCUM : 0; }
+      DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+    }
+  }
+  return DM_OK;
+}

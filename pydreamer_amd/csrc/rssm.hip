@@ -1,0 +1,274 @@
+// RSSM posterior sequence with BPTT, batched prior, and the imagination rollout.
+// Reference: RSSMCore.forward (rssm.py:21-78), RSSMCell.forward / forward_prior / batch_prior (rssm.py:125-193),
+// nn.GRUCell via GRUCellStack (rnn.py:40-67), Dreamer.dream (dreamer.py:188-216), ActorCritic.forward_actor (a2c.py:43-55).
+//
+// Design notes
+//  * a_mlp(action) and post_mlp_e(embed) are loop-invariant and hoisted out of the T loop as two (T*B)-row GEMMs.
+//  * h and z of every step are written straight into the (T*B, D+Z) feature matrix (h at column 0, z at column D),
+//    so to_feature()'s concat (rssm.py:83-84) never materialises; consumers read sub-matrices through leading dims.
+//  * Only the data-path GEMMs (d? @ W) are inside the sequential BPTT loop; every weight gradient is one
+//    (T*B)-row split-K GEMM after the loop, every bias / LayerNorm-parameter gradient one column-sum.
+//  * reset masks (rssm.py:41,134-135) are applied forward by a tiny row-scale kernel (the masked states are saved
+//    for backward) and backward through the GEMM / GRU epilogues' row_zero option.
+#include "common.h"
+
+struct RssmActs {
+  float *ea, *ee, *hin, *zin, *x1, *st1, *za, *gi, *gh, *x2, *st2, *pin, *x3, *st3, *prin;
+};
+static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
+  const size_t N = (size_t)s->T * s->B, Hd = s->Hd, D = s->D, Z = (size_t)s->S * s->C;
+  DmArena ar(base, (size_t)1 << 62);
+  RssmActs t;
+  t.ea = ar.take(N * Hd); t.ee = ar.take(N * Hd);
+  t.hin = ar.take(N * D); t.zin = ar.take(N * Z);
+  t.x1 = ar.take(N * Hd); t.st1 = ar.take(N * 2); t.za = ar.take(N * Hd);
+  t.gi = ar.take(N * 3 * D); t.gh = ar.take(N * 3 * D);
+  t.x2 = ar.take(N * Hd); t.st2 = ar.take(N * 2); t.pin = ar.take(N * Hd);
+  t.x3 = ar.take(N * Hd); t.st3 = ar.take(N * 2); t.prin = ar.take(N * Hd);
+  if (a) *a = t;
+  return ar.off;
+}
+extern "C" size_t dm_rssm_acts_floats(const dm_shape* shp) {
+  if (!shp) return 0;
+  return rssm_carve(shp, nullptr, nullptr);
+}
+
+static int rssm_check(const dm_shape* s) {
+  DM_REQUIRE(s->I == 1, DM_E_SHAPE, "rssm: iwae_samples=%d unsupported (only 1)", s->I);
+  DM_REQUIRE(s->T >= 1 && s->B >= 1 && s->D >= 4 && s->Hd >= 4 && s->S >= 1 && s->C >= 2 && s->A >= 1 && s->E >= 1,
+             DM_E_SHAPE, "rssm: bad shape");
+  DM_REQUIRE((s->D & 3) == 0, DM_E_SHAPE, "rssm: deter_dim must be a multiple of 4 (got %d)", s->D);
+  return DM_OK;
+}
+
+// y = x @ W^T (+ bias) (+ add)
+static int linear(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* x, int ldx,
+                  const float* W, const float* bias, const float* add, int ldadd, float* y, int ldy) {
+  DmGemm q;
+  q.M = rows; q.N = nout; q.K = kin;
+  q.A = x; q.lda = ldx;
+  q.B = W; q.ldb = kin;
+  q.C = y; q.ldc = ldy;
+  q.bias = bias; q.add = add; q.ldadd = ldadd;
+  return dm_gemm_launch(q, sk, skb, st);
+}
+// dW[o][i] = sum_r dy[r][o] x[r][i]
+static int wgrad(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* dy, int lddy,
+                 const float* x, int ldx, float* dW) {
+  DmGemm q;
+  q.a_layout = 1; q.b_layout = 1;
+  q.M = nout; q.N = kin; q.K = rows;
+  q.A = dy; q.lda = lddy;
+  q.B = x; q.ldb = ldx;
+  q.C = dW; q.ldc = kin;
+  return dm_gemm_launch(q, sk, skb, st);
+}
+// dx[r][i] (+)= mask_r * sum_o dy[r][o] W[o][i]
+static int dgrad(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* dy, int lddy,
+                 const float* W, float* dx, int lddx, int accum, const uint8_t* row_zero) {
+  DmGemm q;
+  q.a_layout = 0; q.b_layout = 1;
+  q.M = rows; q.N = kin; q.K = nout;
+  q.A = dy; q.lda = lddy;
+  q.B = W; q.ldb = kin;
+  q.C = dx; q.ldc = lddx;
+  q.flags = accum ? DM_GEMM_ACCUM : 0;
+  q.row_zero = row_zero;
+  return dm_gemm_launch(q, sk, skb, st);
+}
+
+extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
+                                    const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
+                                    const dm_rssm_params* P, float* acts, float* feat, float* post, float* prior,
+                                    int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(s && embed && action && reset && h0 && z0 && P && acts && feat && post && prior && ws, DM_E_NULL,
+             "rssm_sequence_fwd: null pointer");
+  DM_REQUIRE(u || forced_idx, DM_E_NULL, "rssm_sequence_fwd: need uniforms or forced indices");
+  DM_TRY(rssm_check(s));
+  DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "rssm_sequence_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
+  const int N = T * B;
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  RssmActs a;
+  rssm_carve(s, acts, &a);
+  const float* const* p = P->p;
+
+  DM_TRY(linear(st, ws, skb, N, Hd, A, action, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea, Hd));
+  DM_TRY(linear(st, ws, skb, N, Hd, E, embed, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee, Hd));
+
+  for (int t = 0; t < T; ++t) {
+    const size_t r0 = (size_t)t * B;
+    const float* ph = t == 0 ? h0 : feat + (r0 - B) * F;
+    const float* pz = t == 0 ? z0 : feat + (r0 - B) * F + D;
+    const int ldp_h = t == 0 ? D : F, ldp_z = t == 0 ? Z : F;
+    float* hin = a.hin + r0 * D;
+    float* zin = a.zin + r0 * Z;
+    DM_TRY(dm_mask_rows_launch(B, D, ph, ldp_h, reset + r0, hin, D, st));
+    DM_TRY(dm_mask_rows_launch(B, Z, pz, ldp_z, reset + r0, zin, Z, st));
+    // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
+    DM_TRY(linear(st, ws, skb, B, Hd, Z, zin, Z, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd, a.x1 + r0 * Hd, Hd));
+    DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
+                                a.st1 + r0 * 2, st));
+    // h = GRUCell(za, h_in)                                                             rssm.py:141
+    DM_TRY(linear(st, ws, skb, B, 3 * D, Hd, a.za + r0 * Hd, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0,
+                  a.gi + r0 * 3 * D, 3 * D));
+    DM_TRY(linear(st, ws, skb, B, 3 * D, D, hin, D, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0,
+                  a.gh + r0 * 3 * D, 3 * D));
+    DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, st));
+    // post = post_mlp(ELU(post_norm(post_mlp_h(h) + post_mlp_e(embed))))               rssm.py:143-146
+    DM_TRY(linear(st, ws, skb, B, Hd, D, feat + r0 * F, F, p[DM_RSSM_POST_H_W], p[DM_RSSM_POST_H_B], a.ee + r0 * Hd, Hd,
+                  a.x2 + r0 * Hd, Hd));
+    DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
+                                Hd, a.st2 + r0 * 2, st));
+    DM_TRY(linear(st, ws, skb, B, Z, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
+                  post + r0 * Z, Z));
+    // z ~ OneHotCategoricalStraightThrough(post)                                       rssm.py:147-148
+    DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * Z, Z, u ? u + r0 * S : nullptr,
+                                   forced_idx ? forced_idx + r0 * S : nullptr, feat + r0 * F + D, F,
+                                   idx ? idx + r0 * S : nullptr, st));
+  }
+  // batch_prior over all (T*B) rows                                                    rssm.py:61,186-193
+  DM_TRY(linear(st, ws, skb, N, Hd, D, feat, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, a.x3, Hd));
+  DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x3, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin, Hd, a.st3, st));
+  DM_TRY(linear(st, ws, skb, N, Z, Hd, a.prin, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
+  return DM_OK;
+}
+
+extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
+                                    const dm_rssm_params* P, const float* acts, const float* feat, const float* post,
+                                    float* dfeat, float* dpost, float* dprior, const dm_rssm_grads* G, float* dembed,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(s && embed && action && reset && P && acts && feat && post && dfeat && dpost && dprior && G && ws, DM_E_NULL,
+             "rssm_sequence_bwd: null pointer");
+  DM_TRY(rssm_check(s));
+  hipStream_t st = (hipStream_t)stream;
+  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
+  const int N = T * B;
+  RssmActs a;
+  rssm_carve(s, const_cast<float*>(acts), &a);
+  const float* const* p = P->p;
+  float* const* g = G->p;
+
+  DmArena ar(ws, ws_bytes);
+  float* sk = ar.take(DM_SPLITK_FLOATS);
+  float* dprin = ar.take((size_t)N * Hd);
+  float* dx3 = ar.take((size_t)N * Hd);
+  float* dpin = ar.take((size_t)N * Hd);
+  float* dx2 = ar.take((size_t)N * Hd);
+  float* dgi = ar.take((size_t)N * 3 * D);
+  float* dgh = ar.take((size_t)N * 3 * D);
+  float* dza = ar.take((size_t)N * Hd);
+  float* dx1 = ar.take((size_t)N * Hd);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  // ---- prior branch, batched over all rows
+  DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dprior, Z, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
+  DM_TRY(dm_colsum_launch(N, Z, dprior, Z, g[DM_RSSM_PRIOR_OB], sk, skb, st));
+  DM_TRY(dgrad(st, sk, skb, N, Z, Hd, dprior, Z, p[DM_RSSM_PRIOR_W], dprin, Hd, 0, nullptr));
+  DM_TRY(dm_ln_elu_bwd_dx_launch(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, p[DM_RSSM_PRIOR_G], dprin, Hd, dx3, Hd, st));
+  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
+                                     g[DM_RSSM_PRIOR_B], sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
+  DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk, skb, st));
+  DM_TRY(dgrad(st, sk, skb, N, Hd, D, dx3, Hd, p[DM_RSSM_PRIOR_H_W], dfeat, F, 1, nullptr));
+
+  // ---- BPTT
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t r0 = (size_t)t * B;
+    float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
+    float* dpt = dpost + r0 * Z;
+    // straight-through sample: dpost += softmax'(post)^T dz'
+    DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * Z, Z, dft + D, F, dpt, Z, 1, st));
+    // post_mlp, post_norm+ELU, post_mlp_h
+    DM_TRY(dgrad(st, sk, skb, B, Z, Hd, dpt, Z, p[DM_RSSM_POST_W], dpin + r0 * Hd, Hd, 0, nullptr));
+    DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x2 + r0 * Hd, Hd, a.pin + r0 * Hd, Hd, a.st2 + r0 * 2, p[DM_RSSM_POST_G],
+                                   dpin + r0 * Hd, Hd, dx2 + r0 * Hd, Hd, st));
+    DM_TRY(dgrad(st, sk, skb, B, Hd, D, dx2 + r0 * Hd, Hd, p[DM_RSSM_POST_H_W], dft, F, 1, nullptr));
+    // GRU gates; the direct path dh'*u goes (masked) straight into step t-1's dh'
+    const uint8_t* rz = reset + r0;
+    float* dprev = t > 0 ? dfeat + (r0 - B) * F : nullptr;
+    DM_TRY(dm_gru_gates_bwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, dft, F,
+                                   dgi + r0 * 3 * D, dgh + r0 * 3 * D, dprev, F, 1, rz, st));
+    DM_TRY(dgrad(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, p[DM_RSSM_GRU_WIH], dza + r0 * Hd, Hd, 0, nullptr));
+    DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
+                                   dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
+    if (t > 0) {
+      DM_TRY(dgrad(st, sk, skb, B, 3 * D, D, dgh + r0 * 3 * D, 3 * D, p[DM_RSSM_GRU_WHH], dprev, F, 1, rz));
+      DM_TRY(dgrad(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, p[DM_RSSM_Z_W], dprev + D, F, 1, rz));
+    }
+  }
+
+  // ---- weight / bias / LayerNorm gradients, batched over all rows
+  DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dpost, Z, a.pin, Hd, g[DM_RSSM_POST_W]));
+  DM_TRY(dm_colsum_launch(N, Z, dpost, Z, g[DM_RSSM_POST_OB], sk, skb, st));
+  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, dpin, Hd, g[DM_RSSM_POST_G], g[DM_RSSM_POST_B],
+                                     sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx2, Hd, feat, F, g[DM_RSSM_POST_H_W]));
+  DM_TRY(dm_colsum_launch(N, Hd, dx2, Hd, g[DM_RSSM_POST_H_B], sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, Hd, E, dx2, Hd, embed, E, g[DM_RSSM_POST_E_W]));
+  if (dembed) DM_TRY(dgrad(st, sk, skb, N, Hd, E, dx2, Hd, p[DM_RSSM_POST_E_W], dembed, E, 0, nullptr));
+  DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
+  DM_TRY(dm_colsum_launch(N, 3 * D, dgi, 3 * D, g[DM_RSSM_GRU_BIH], sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, 3 * D, D, dgh, 3 * D, a.hin, D, g[DM_RSSM_GRU_WHH]));
+  DM_TRY(dm_colsum_launch(N, 3 * D, dgh, 3 * D, g[DM_RSSM_GRU_BHH], sk, skb, st));
+  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x1, Hd, a.za, Hd, a.st1, dza, Hd, g[DM_RSSM_IN_G], g[DM_RSSM_IN_B], sk, skb,
+                                     st));
+  DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
+  DM_TRY(dm_colsum_launch(N, Hd, dx1, Hd, g[DM_RSSM_Z_B], sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, Hd, A, dx1, Hd, action, A, g[DM_RSSM_A_W]));
+  return DM_OK;
+}
+
+// ---------------------------------------------------------------- imagination -------------------
+extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, const dm_rssm_params* P,
+                                const dm_mlp_params* actor, const float* u_act, const float* u_prior, float* feats,
+                                float* actions, int32_t* act_idx, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(s && start && P && actor && u_act && u_prior && feats && actions && ws, DM_E_NULL,
+             "dream_rollout: null pointer");
+  DM_TRY(rssm_check(s));
+  DM_REQUIRE(M >= 1 && s->H >= 1, DM_E_SHAPE, "dream_rollout: M=%d H=%d", M, s->H);
+  hipStream_t st = (hipStream_t)stream;
+  const int H = s->H, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, A = s->A;
+  const int Hm = s->mlp_hidden, L = s->mlp_layers;
+  const float* const* p = P->p;
+
+  DmArena ar(ws, ws_bytes);
+  float* sk = ar.take(DM_SPLITK_FLOATS);
+  float* macts = ar.take(dm_mlp_acts_floats(M, Hm, L));
+  float* logits = ar.take((size_t)M * A);
+  float* ea = ar.take((size_t)M * Hd);
+  float* x1 = ar.take((size_t)M * Hd);
+  float* za = ar.take((size_t)M * Hd);
+  float* stats = ar.take((size_t)M * 2);
+  float* gi = ar.take((size_t)M * 3 * D);
+  float* gh = ar.take((size_t)M * 3 * D);
+  float* prior = ar.take((size_t)M * Z);
+  DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
+  const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  hipError_t e = hipMemcpyAsync(feats, start, (size_t)M * F * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "dream_rollout: %s", hipGetErrorString(e));
+  for (int i = 0; i < H; ++i) {
+    const float* cur = feats + (size_t)i * M * F;
+    float* nxt = feats + (size_t)(i + 1) * M * F;
+    float* act = actions + (size_t)i * M * A;
+    // action ~ OneHotCategorical(actor(feature))                                        dreamer.py:195-200
+    DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, macts, logits, A, sk, skb, st));
+    DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
+                                   act_idx ? act_idx + (size_t)i * M : nullptr, st));
+    // cell.forward_prior(action, None, (h, z))                                          rssm.py:155-184
+    DM_TRY(linear(st, sk, skb, M, Hd, A, act, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, ea, Hd));
+    DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));
+    DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
+    DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
+    DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
+    DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, st));
+    DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
+    DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
+    DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
+    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, nullptr, st));
+  }
+  return DM_OK;
+}

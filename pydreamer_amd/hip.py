@@ -1,0 +1,213 @@
+"""ctypes binding of libdreamer_hip.so (the C-ABI declared in include/dreamer_hip.h).
+
+No torch types cross the boundary: tensors are passed as raw device pointers (`tensor.data_ptr()`), the
+stream as `torch.cuda.current_stream().cuda_stream`.  Every call checks the return code and raises
+`DreamerHipError` with the library's thread-local message.  There is no CPU fallback: if the shared
+library is missing, or a tensor is not a contiguous CUDA(HIP) fp32 tensor, the call fails loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdreamer_hip.so')
+
+DM_MAX_MLP_LAYERS = 8
+DM_GEMM_ACCUM = 1
+DM_GEMM_ELU = 2
+DM_C2I_ELU = 1
+
+RSSM_PARAM_ORDER = [
+    'z_mlp.weight', 'z_mlp.bias', 'a_mlp.weight', 'in_norm.weight', 'in_norm.bias',
+    'gru.layers.0.weight_ih', 'gru.layers.0.weight_hh', 'gru.layers.0.bias_ih', 'gru.layers.0.bias_hh',
+    'prior_mlp_h.weight', 'prior_mlp_h.bias', 'prior_norm.weight', 'prior_norm.bias', 'prior_mlp.weight', 'prior_mlp.bias',
+    'post_mlp_h.weight', 'post_mlp_h.bias', 'post_mlp_e.weight', 'post_norm.weight', 'post_norm.bias',
+    'post_mlp.weight', 'post_mlp.bias',
+]
+DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER)
+
+
+class DreamerHipError(RuntimeError):
+    pass
+
+
+class dm_shape(Structure):
+    _fields_ = [(n, c_int32) for n in ('T', 'B', 'I', 'H', 'D', 'Hd', 'S', 'C', 'E', 'A', 'mlp_hidden', 'mlp_layers',
+                                       'cnn_depth', 'img', 'img_ch', 'flags')]
+
+
+class dm_mlp_params(Structure):
+    _fields_ = [('w', c_void_p * (DM_MAX_MLP_LAYERS + 1)), ('b', c_void_p * (DM_MAX_MLP_LAYERS + 1)),
+                ('ln_g', c_void_p * DM_MAX_MLP_LAYERS), ('ln_b', c_void_p * DM_MAX_MLP_LAYERS)]
+
+
+dm_mlp_grads = dm_mlp_params   # identical layout (float* instead of const float*)
+
+
+class dm_conv_params(Structure):
+    _fields_ = [('w', c_void_p * 5), ('b', c_void_p * 5)]
+
+
+dm_conv_grads = dm_conv_params
+
+
+class dm_rssm_params(Structure):
+    _fields_ = [('p', c_void_p * DM_RSSM_NPARAMS)]
+
+
+dm_rssm_grads = dm_rssm_params
+
+
+class dm_reduce_item(Structure):
+    _fields_ = [('x', c_void_p), ('n', c_int64), ('scale', c_float)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    'dm_version': (c_int, []),
+    'dm_last_error': (c_char_p, []),
+    'dm_device_check': (c_int, []),
+    'dm_workspace_bytes': (c_size_t, [POINTER(dm_shape)]),
+    'dm_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int,
+                            _P, c_size_t, _P]),
+    'dm_ln_elu_fwd': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_float, _P, c_int, _P, _P]),
+    'dm_ln_elu_bwd': (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_size_t, _P]),
+    'dm_colsum': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    'dm_gru_gates_fwd': (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P]),
+    'dm_gru_gates_bwd': (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
+    'dm_sample_onehot': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
+    'dm_kl_balance_fwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'dm_kl_balance_bwd': (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
+    'dm_st_softmax_bwd': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P]),
+    'dm_mask_rows': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_int, _P]),
+    'dm_im2col_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    'dm_col2im_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
+    'dm_mlp_acts_floats': (c_size_t, [c_int, c_int, c_int]),
+    'dm_mlp_head_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P,
+                                c_size_t, _P]),
+    'dm_mlp_head_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P,
+                                POINTER(dm_mlp_grads), _P, c_int, c_int, _P, c_size_t, _P]),
+    'dm_head_loss': (c_int, [c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    'dm_conv_encoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
+    'dm_conv_encoder_fwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, _P, c_size_t, _P]),
+    'dm_conv_encoder_bwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, POINTER(dm_conv_grads), _P,
+                                    c_size_t, _P]),
+    'dm_conv_decoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
+    'dm_conv_decoder_mse_fwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, _P, _P, _P,
+                                        c_size_t, _P]),
+    'dm_conv_decoder_mse_bwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, c_float,
+                                        POINTER(dm_conv_grads), _P, c_int, _P, c_size_t, _P]),
+    'dm_rssm_acts_floats': (c_size_t, [POINTER(dm_shape)]),
+    'dm_rssm_sequence_fwd': (c_int, [POINTER(dm_shape), _P, _P, _P, _P, _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P,
+                                     _P, _P, _P, c_size_t, _P]),
+    'dm_rssm_sequence_bwd': (c_int, [POINTER(dm_shape), _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P, _P, _P, _P,
+                                     POINTER(dm_rssm_grads), _P, _P, c_size_t, _P]),
+    'dm_dream_rollout': (c_int, [POINTER(dm_shape), c_int, _P, POINTER(dm_rssm_params), POINTER(dm_mlp_params), _P, _P,
+                                 _P, _P, _P, _P, c_size_t, _P]),
+    'dm_gae_losses': (c_int, [c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'dm_actor_loss': (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    'dm_critic_loss': (c_int, [c_int, _P, _P, _P, c_float, _P, _P, _P]),
+    'dm_multi_sum': (c_int, [c_int, POINTER(dm_reduce_item), _P, _P]),
+    'dm_multi_tensor_norm_clip': (c_int, [_P, c_int64, c_float, _P, _P, c_size_t, _P]),
+    'dm_scale_inplace': (c_int, [_P, c_int64, _P, _P]),
+    'dm_adamw_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
+    'dm_copy_params': (c_int, [_P, _P, c_int64, _P]),
+    'dm_axpby': (c_int, [c_int64, c_float, _P, c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DreamerHipError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C pydreamer_amd/csrc`). There is no CPU fallback for the training path.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        msg = lib().dm_last_error().decode('utf-8', 'replace')
+        raise DreamerHipError(f'{name} failed with code {rc}: {msg}')
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (or NULL for None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DreamerHipError(f'expected a CUDA/HIP tensor, got device {t.device} (no CPU path)')
+    if not t.is_contiguous():
+        raise DreamerHipError(f'expected a contiguous tensor, got strides {t.stride()} for shape {tuple(t.shape)}')
+    return c_void_p(t.data_ptr())
+
+
+def fptr(t):
+    if t is not None and t.dtype != torch.float32:
+        raise DreamerHipError(f'expected float32, got {t.dtype}')
+    return ptr(t)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_shape(**kw):
+    s = dm_shape()
+    for k, v in kw.items():
+        setattr(s, k, int(v))
+    return s
+
+
+def workspace_bytes(shape):
+    return int(lib().dm_workspace_bytes(ctypes.byref(shape)))
+
+
+def mlp_struct(tensors_w, tensors_b, tensors_g, tensors_be, cls=dm_mlp_params):
+    """Pack per-layer tensors into a dm_mlp_params / dm_mlp_grads struct (keeps no references)."""
+    s = cls()
+    for i, t in enumerate(tensors_w):
+        s.w[i] = t.data_ptr()
+    for i, t in enumerate(tensors_b):
+        s.b[i] = t.data_ptr()
+    for i, t in enumerate(tensors_g):
+        s.ln_g[i] = t.data_ptr()
+    for i, t in enumerate(tensors_be):
+        s.ln_b[i] = t.data_ptr()
+    return s
+
+
+def conv_struct(ws, bs, cls=dm_conv_params):
+    s = cls()
+    for i, t in enumerate(ws):
+        s.w[i] = t.data_ptr()
+    for i, t in enumerate(bs):
+        s.b[i] = t.data_ptr()
+    return s
+
+
+def rssm_struct(tensors, cls=dm_rssm_params):
+    assert len(tensors) == DM_RSSM_NPARAMS
+    s = cls()
+    for i, t in enumerate(tensors):
+        s.p[i] = t.data_ptr()
+    return s
