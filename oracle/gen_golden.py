@@ -1,0 +1,167 @@
+"""Generate golden vectors from the REAL reference (runs only in the build container, where /root/reference exists).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+What it does:
+  * builds `argparse.Namespace conf` from /root/reference/config/defaults.yaml exactly as launch.py:16-41 does
+    (sections merged in order, then overrides);
+  * imports `pydreamer.models.Dreamer` from /root/reference (never copied, never shipped);
+  * loads the closed-form weights of `oracle.dreamer_oracle.make_params` into it (strict key/shape match);
+  * patches `torch.multinomial` — the reference's only sampler call site (torch/distributions/categorical.py:147) —
+    with the inverse-CDF rule over uniforms supplied in call order;
+  * runs the trainer section train.py:165-198 (forward, 4 x backward, clip, 4 x AdamW) for 2 consecutive steps with
+    the recurrent state carried (keep_state) so the critic_target refresh at call 0 and the TBTT carry are covered;
+  * stores inputs (uint8 images, actions, rewards, resets, uniforms) and outputs (losses, metrics, tensors, sampled
+    indices, per-parameter grad norms, a few full gradients, post-AdamW parameter checksums).
+
+The fixtures are data only.  `tests/test_oracle_golden.py` replays them through oracle/dreamer_oracle.py.
+"""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+from oracle import dreamer_oracle as O   # noqa: E402
+
+
+def reference_conf(sections, overrides):
+    with open(os.path.join(REF, 'config', 'defaults.yaml')) as f:
+        allc = yaml.safe_load(f)
+    conf = {}
+    for s in sections:
+        conf.update(allc[s])
+    conf.update(overrides)
+    return Namespace(**conf)
+
+
+class MultinomialPatch:
+    """Replaces torch.multinomial(probs_2d, 1, True) by the shared inverse-CDF rule on queued uniforms."""
+
+    def __init__(self):
+        self.queue = []
+        self.calls = []
+        self.idx = []
+        self.orig = torch.multinomial
+
+    def __enter__(self):
+        torch.multinomial = self
+        return self
+
+    def __exit__(self, *a):
+        torch.multinomial = self.orig
+
+    def __call__(self, probs, num_samples, replacement=False, **kw):
+        assert num_samples == 1 and probs.dim() == 2
+        u = self.queue.pop(0).reshape(-1)
+        assert u.numel() == probs.shape[0], (u.shape, probs.shape)
+        idx = O.sample_inverse_cdf(probs, u)
+        self.calls.append(tuple(probs.shape))
+        self.idx.append(idx.clone())
+        return idx.unsqueeze(-1)
+
+
+def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames=1):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REF)
+    from pydreamer.models import Dreamer          # the reference, imported in place
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)   # train.py:30
+
+    rconf = reference_conf(sections, overrides)
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    model = Dreamer(rconf)
+    params = O.make_params(oconf, seed=0)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(params.keys()), 'state_dict key order differs from oracle.param_shapes'
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(params[k].shape), (k, sd[k].shape, params[k].shape)
+    model.load_state_dict(params, strict=True)
+    optimizers = model.init_optimizers(rconf.adam_lr, rconf.adam_lr_actor, rconf.adam_lr_critic, rconf.adam_eps)
+
+    T, B, S, H = rconf.batch_length, rconf.batch_size, rconf.stoch_dim, rconf.imag_horizon
+    out = {'conf_json': np.array(repr(sorted(vars(oconf).items())))}
+    state = model.init_state(B * rconf.iwae_samples)
+    for step in range(steps):
+        raw = O.synthetic_batch(oconf, seed=1234 + step, first=(step == 0))
+        obs = O.preprocess(raw, oconf)
+        noise = O.make_noise(oconf, seed=777 + step)
+        with MultinomialPatch() as mp:
+            mp.queue = [noise['u_post'][t] for t in range(T)]
+            for i in range(H):
+                mp.queue += [noise['u_act'][i], noise['u_prior'][i]]
+            losses, new_state, metrics, tensors, _ = model.training_step(obs, state)
+            assert not mp.queue, f'{len(mp.queue)} uniforms unused'
+            M = T * B * rconf.iwae_samples
+            post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
+            act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
+            lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
+        for opt in optimizers:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
+        grad_metrics = model.grad_clip(rconf.grad_clip, rconf.grad_clip_ac)
+        named = dict(model.named_parameters())
+        grads = {k: v.grad.detach().clone() for k, v in named.items() if v.grad is not None}
+        for opt in optimizers:
+            opt.step()
+
+        pre = f's{step}_'
+        for k, v in raw.items():
+            out[pre + 'in_' + k] = v
+        for k, v in noise.items():
+            out[pre + 'in_' + k] = v.numpy()
+        out[pre + 'in_state_h'] = state[0].numpy()
+        out[pre + 'in_state_z'] = state[1].numpy()
+        out[pre + 'losses'] = np.array([float(l) for l in losses], dtype=np.float64)
+        for k, v in {**metrics, **grad_metrics}.items():
+            out[pre + 'metric_' + k] = np.array(float(v), dtype=np.float64)
+        for k, v in tensors.items():
+            if k == 'image_rec':
+                out[pre + 'tensor_image_rec_sum'] = np.array(float(v.double().sum()))
+                out[pre + 'tensor_image_rec_frames'] = v[:save_image_rec_frames, :1].numpy()
+            else:
+                out[pre + 'tensor_' + k] = v.detach().numpy()
+        out[pre + 'out_state_h'] = new_state[0].numpy()
+        out[pre + 'out_state_z'] = new_state[1].numpy()
+        out[pre + 'idx_post'] = post_idx.numpy().astype(np.uint8)
+        out[pre + 'idx_act'] = act_idx.numpy().astype(np.uint8)
+        out[pre + 'idx_lat'] = lat_idx.numpy().astype(np.uint8)
+        out[pre + 'grad_norms'] = np.array([float(g.double().norm()) for g in grads.values()])
+        out[pre + 'grad_names'] = np.array(list(grads.keys()))
+        for k in full_grads:
+            out[pre + 'grad_' + k] = grads[k].numpy()
+        post = dict(model.state_dict())
+        out[pre + 'param_sums'] = np.array([float(v.double().sum()) for v in post.values()])
+        out[pre + 'param_abs_sums'] = np.array([float(v.double().abs().sum()) for v in post.values()])
+        state = new_state
+        print(f'[{name}] step {step}: losses', out[pre + 'losses'], 'grad_norm', float(grad_metrics['grad_norm']))
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
+SMALL_GRADS = ('wm.core.cell.a_mlp.weight', 'wm.core.cell.gru.layers.0.bias_hh', 'wm.core.cell.post_norm.weight',
+               'wm.core.cell.prior_mlp.bias', 'wm.encoder.encoder_image.model.0.weight',
+               'wm.decoder.image.model.8.weight', 'ac.actor.model.12.weight', 'ac.critic.model.1.weight')
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['tiny', 'debug']
+    if 'tiny' in which:
+        t = O.tiny_conf()
+        run('tiny', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon), full_grads=SMALL_GRADS)
+    if 'debug' in which:
+        # BASELINE.json configs[0]: defaults+atari+debug on CPU, B=4,T=10,H=5, discrete(6)
+        run('debug_literal', ['defaults', 'atari', 'debug'],
+            dict(batch_size=4, batch_length=10, imag_horizon=5, action_dim=6), steps=1,
+            full_grads=('wm.core.cell.gru.layers.0.bias_hh', 'ac.actor.model.12.weight'))

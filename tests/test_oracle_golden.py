@@ -1,0 +1,122 @@
+"""CPU (-m "not gpu"): pin oracle/dreamer_oracle.py against golden vectors produced by the real reference
+(oracle/gen_golden.py, run in the build container where /root/reference exists).
+
+Bars: sampled indices (posterior / actor / imagined latents) bit-exact; losses and metrics within 2e-5 relative
+(fp32, same torch CPU kernels, different op grouping); per-parameter gradient norms within 1e-4 relative (+1e-7 abs);
+stored full gradients within 1e-4 of the tensor's max; post-AdamW parameter checksums within 1e-6 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dreamer_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, f'{name}.npz'), allow_pickle=False)
+
+
+def _conf_from(g):
+    items = eval(str(g['conf_json']))      # repr of a sorted (key, value) list written by gen_golden.py
+    return O.make_conf(**dict(items))
+
+
+def _replay(name, steps):
+    g = _load(name)
+    conf = _conf_from(g)
+    torch.manual_seed(0)
+    model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
+    model.init_optimizers()
+    state = model.init_state(conf.batch_size)
+    results = []
+    for s in range(steps):
+        pre = f's{s}_'
+        raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+        obs = O.preprocess(raw, conf)
+        noise = {k: torch.from_numpy(g[pre + 'in_' + k]) for k in ('u_post', 'u_act', 'u_prior')}
+        assert np.array_equal(state[0].numpy(), g[pre + 'in_state_h']) or s > 0
+        losses, new_state, metrics, tensors, extras = model.training_step(obs, state, noise)
+        grad_metrics, grads = model.backward_clip_step(losses)
+        sums = np.array([float(v.detach().double().sum()) for v in model.p.values()])
+        abss = np.array([float(v.detach().double().abs().sum()) for v in model.p.values()])
+        results.append((pre, losses, new_state, metrics, tensors, extras, grad_metrics, grads, (sums, abss)))
+        state = new_state
+    return g, conf, results
+
+
+def _rel(a, b):
+    a = float(a.detach()) if torch.is_tensor(a) else float(a)
+    return abs(a - float(b)) / max(abs(float(b)), 1e-12)
+
+
+def _check_step(g, conf, res):
+    pre, losses, new_state, metrics, tensors, extras, grad_metrics, grads, (sums, abss) = res
+    T, B, S, H = conf.batch_length, conf.batch_size, conf.stoch_dim, conf.imag_horizon
+    # integer outputs: bit-exact
+    assert np.array_equal(extras['post_idx'].reshape(T, B, S).numpy().astype(np.uint8), g[pre + 'idx_post'])
+    assert np.array_equal(extras['act_idx'].numpy().astype(np.uint8), g[pre + 'idx_act'])
+    assert np.array_equal(extras['lat_idx'].numpy().astype(np.uint8), g[pre + 'idx_lat'])
+    # losses / metrics
+    for i, l in enumerate(losses):
+        assert _rel(l, g[pre + 'losses'][i]) < 2e-5 or abs(float(l) - g[pre + 'losses'][i]) < 2e-6, (i, float(l), g[pre + 'losses'][i])
+    for k, v in {**metrics, **grad_metrics}.items():
+        ref = float(g[pre + 'metric_' + k])
+        assert _rel(v, ref) < 5e-5 or abs(float(v) - ref) < 2e-6, (k, float(v), ref)
+    # tensors
+    for k, v in tensors.items():
+        if k == 'image_rec':
+            assert _rel(v.double().sum(), g[pre + 'tensor_image_rec_sum']) < 1e-5
+            np.testing.assert_allclose(v[:1, :1].numpy(), g[pre + 'tensor_image_rec_frames'], rtol=0, atol=2e-5)
+        else:
+            ref = g[pre + 'tensor_' + k]
+            np.testing.assert_allclose(v.numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(new_state[0].numpy(), g[pre + 'out_state_h'], rtol=0, atol=2e-6)
+    assert np.array_equal(new_state[1].numpy(), g[pre + 'out_state_z'])
+    # gradients
+    names = [str(n) for n in g[pre + 'grad_names']]
+    assert names == list(grads.keys())
+    for n, ref in zip(names, g[pre + 'grad_norms']):
+        got = float(grads[n].double().norm())
+        assert abs(got - ref) <= 1e-4 * ref + 1e-7, (n, got, ref)
+    for key in g.files:
+        if key.startswith(pre + 'grad_') and key not in (pre + 'grad_norms', pre + 'grad_names'):
+            n = key[len(pre + 'grad_'):]
+            ref = g[key]
+            np.testing.assert_allclose(grads[n].numpy(), ref, rtol=0, atol=1e-4 * max(np.abs(ref).max(), 1e-8))
+    # post-step parameters
+    np.testing.assert_allclose(abss, g[pre + 'param_abs_sums'], rtol=1e-6)
+    np.testing.assert_allclose(sums, g[pre + 'param_sums'], rtol=0, atol=1e-6 * abss.max())
+
+
+def test_param_table_matches_reference_state_dict():
+    """The golden generator asserted strict key/shape equality with the reference's state_dict; here we pin the count
+    and total size it saw (Atari-literal 25.3 M parameters incl. critic_target)."""
+    conf = O.atari_literal_conf()
+    shapes = O.param_shapes(conf)
+    total = sum(int(np.prod(s)) for k, s in shapes.items() if not k.startswith('ac.critic_target'))
+    assert abs(total - 25.3e6) < 0.1e6, total
+    assert len(shapes) == len(set(shapes))
+
+
+def test_oracle_matches_reference_tiny_two_steps():
+    g, conf, results = _replay('tiny', 2)
+    for res in results:
+        _check_step(g, conf, res)
+
+
+def test_oracle_matches_reference_debug_literal():
+    """BASELINE.json configs[0]: defaults+atari+debug, B=4, T=10, H=5, discrete(6)."""
+    g, conf, results = _replay('debug_literal', 1)
+    assert (conf.batch_size, conf.batch_length, conf.imag_horizon, conf.action_dim, conf.deter_dim) == (4, 10, 5, 6, 1024)
+    _check_step(g, conf, results[0])
+
+
+def test_sampler_rule_edges():
+    """Inverse-CDF rule: u=0 -> first category with mass, u->1 -> last, delta distribution exact."""
+    p = torch.tensor([[0.0, 0.5, 0.5, 0.0], [0.25, 0.25, 0.25, 0.25], [0.0, 0.0, 1.0, 0.0]])
+    assert O.sample_inverse_cdf(p, torch.tensor([0.0, 0.0, 0.3])).tolist() == [1, 0, 2]
+    assert O.sample_inverse_cdf(p, torch.tensor([0.999, 0.999999, 0.999])).tolist() == [2, 3, 2]
