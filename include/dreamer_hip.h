@@ -208,8 +208,14 @@ int dm_critic_loss(int rows, const float* value, const float* value_target, cons
                    float* loss, float* dvalue, void* stream);
 
 /* out[i] = scale[i] * sum(x_i[0..n_i)) for up to 32 arrays in one launch (losses / metrics, dreamer.py:362-379, a2c.py:133-147). */
-typedef struct dm_reduce_item { const float* x; int64_t n; float scale; } dm_reduce_item;
+typedef struct dm_reduce_item {
+  const float* x; int64_t n; float scale;
+  int32_t mode;            /* 0: sum x ; 1: sum (x - *center)^2  (for reward1.std(), a2c.py:140) */
+  const float* center;     /* device scalar, mode 1 only */
+} dm_reduce_item;
 int dm_multi_sum(int count, const dm_reduce_item* items /* host array */, float* out, void* stream);
+/* out[0] = sum_i w[i] * x[i]  (x device, w host; count <= 16): loss_model from its weighted terms (dreamer.py:362-365). */
+int dm_combine(int count, const float* x, const float* w, float* out, void* stream);
 
 /* Optimizer (dreamer.py:60-87; torch.optim.AdamW defaults, clip_grad_norm_). */
 /* norm_out[0] = ||g||_2 ; norm_out[1] = min(1, max_norm/(norm+1e-6)). */

@@ -645,8 +645,10 @@ extern "C" int dm_critic_loss(int rows, const float* value, const float* value_t
 // ------------------------------------------------------------------------------------------------
 struct MultiSumArgs {
   const float* x[32];
+  const float* center[32];
   long long n[32];
   float scale[32];
+  int mode[32];
 };
 __global__ void __launch_bounds__(256) multi_sum_kernel(const MultiSumArgs a, float* __restrict__ out) {
   __shared__ float red[4];
@@ -654,7 +656,15 @@ __global__ void __launch_bounds__(256) multi_sum_kernel(const MultiSumArgs a, fl
   const float* x = a.x[item];
   const long long n = a.n[item];
   float s = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+  if (a.mode[item] == 0) {
+    for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+  } else {
+    const float c = a.center[item][0];
+    for (long long i = threadIdx.x; i < n; i += 256) {
+      const float d = x[i] - c;
+      s += d * d;
+    }
+  }
   s = dm_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -666,11 +676,32 @@ extern "C" int dm_multi_sum(int count, const dm_reduce_item* items, float* out, 
   MultiSumArgs a;
   for (int i = 0; i < count; ++i) {
     DM_REQUIRE(items[i].x || items[i].n == 0, DM_E_NULL, "multi_sum: item %d null", i);
+    DM_REQUIRE(items[i].mode == 0 || (items[i].mode == 1 && items[i].center), DM_E_SHAPE, "multi_sum: item %d bad mode", i);
     a.x[i] = items[i].x;
+    a.center[i] = items[i].center;
     a.n[i] = items[i].n;
     a.scale[i] = items[i].scale;
+    a.mode[i] = items[i].mode;
   }
   hipLaunchKernelGGL(multi_sum_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, a, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+struct CombineArgs { float w[16]; };
+__global__ void combine_kernel(int count, const float* __restrict__ x, const CombineArgs a, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < count; ++i) s += a.w[i] * x[i];
+    out[0] = s;
+  }
+}
+extern "C" int dm_combine(int count, const float* x, const float* w, float* out, void* stream) {
+  DM_REQUIRE(x && w && out, DM_E_NULL, "combine: null pointer");
+  DM_REQUIRE(count >= 1 && count <= 16, DM_E_SHAPE, "combine: count %d not in [1,16]", count);
+  CombineArgs a;
+  for (int i = 0; i < count; ++i) a.w[i] = w[i];
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, x, a, out);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

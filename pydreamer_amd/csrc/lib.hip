@@ -27,29 +27,48 @@ extern "C" int dm_device_check(void) {
   return DM_OK;
 }
 
-// Scratch sizing: the largest transient of any fused operator at this shape (see DESIGN.md "HBM layout").
-//  - conv decoder layer 3 column matrix: rows = N*13*13, cols = 36*cnn_depth (k6 x k6 x 48 at depth 48)
-//  - conv encoder layer 2 patch matrix: rows = N*14*14, cols = 16*cnn_depth
-//  - split-K partials: bounded by 64 MiB
+// Scratch sizing: the largest transient of any fused operator at this shape, mirroring the arena carves in
+// conv.hip / rssm.hip / mlp.hip (every carve is rounded up to 64 floats).  See DESIGN.md "HBM layout".
+static size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
 extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (!s) return 0;
   const size_t N = (size_t)s->T * s->B * (s->I > 0 ? s->I : 1);
-  const size_t d = (size_t)s->cnn_depth;
-  size_t conv = 0;
-  // decoder column matrices (fwd) / patch matrices (bwd), image 64: spatial 1->5->13->30->64
-  const size_t dec2 = N * 25 * (25 * 2 * d);     // layer 2: rows N*5*5, cols k5*k5*(2d)
-  const size_t dec3 = N * 169 * (36 * d);        // layer 3: rows N*13*13, cols k6*k6*d
-  const size_t dec4 = N * 900 * (36 * (size_t)s->img_ch);
-  const size_t enc1 = N * 961 * (16 * (size_t)s->img_ch);
-  const size_t enc2 = N * 196 * (16 * d);
-  const size_t enc3 = N * 36 * (16 * 2 * d);
-  conv = dec2;
-  if (dec3 > conv) conv = dec3;
-  if (dec4 > conv) conv = dec4;
-  if (enc1 > conv) conv = enc1;
-  if (enc2 > conv) conv = enc2;
-  if (enc3 > conv) conv = enc3;
-  // two column-sized scratch matrices (column matrix + its gradient) + split-K partial region + slack
-  size_t floats = 2 * conv + (size_t)16 * 1024 * 1024 + (size_t)(s->H + 2) * N * 64 + (1u << 20);
-  return floats * sizeof(float);
+  const size_t d = (size_t)s->cnn_depth, ch = (size_t)s->img_ch;
+  const size_t D = s->D, Hd = s->Hd, Z = (size_t)s->S * s->C, A = s->A;
+  const size_t Hm = s->mlp_hidden, L = s->mlp_layers, H = s->H > 0 ? s->H : 1;
+  const size_t SK = DM_SPLITK_FLOATS;
+  // encoder backward: ga (N*31*31*d) + gb (N*14*14*2d) + dwr (8d*64d) + dxcol (max patch matrix, l>=1)
+  size_t xc = N * 196 * 16 * d;
+  if (N * 36 * 32 * d > xc) xc = N * 36 * 32 * d;
+  if (N * 4 * 64 * d > xc) xc = N * 4 * 64 * d;
+  const size_t enc_bwd = SK + pad64(N * 961 * d) + pad64(N * 196 * 2 * d) + pad64(8 * d * 64 * d) + pad64(xc);
+  // decoder: column matrices rows_small * k*k*cout for layers 1..4
+  size_t col = N * 25 * 4 * d;
+  if (N * 25 * 25 * 2 * d > col) col = N * 25 * 25 * 2 * d;
+  if (N * 169 * 36 * d > col) col = N * 169 * 36 * d;
+  if (N * 900 * 36 * ch > col) col = N * 900 * 36 * ch;
+  size_t gmax = N * 25 * 4 * d;
+  if (N * 169 * 2 * d > gmax) gmax = N * 169 * 2 * d;
+  if (N * 900 * d > gmax) gmax = N * 900 * d;
+  if (N * 4096 * ch > gmax) gmax = N * 4096 * ch;
+  if (N * 32 * d > gmax) gmax = N * 32 * d;
+  size_t wmax = 32 * d * 25 * 4 * d;
+  if (4 * d * 25 * 2 * d > wmax) wmax = 4 * d * 25 * 2 * d;
+  if (2 * d * 36 * d > wmax) wmax = 2 * d * 36 * d;
+  if (d * 36 * ch > wmax) wmax = d * 36 * ch;
+  const size_t dec_fwd = SK + pad64(col);
+  const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax);
+  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D);
+  const size_t rows = (H + 1) * N;
+  const size_t mlp_bwd = SK + 2 * pad64(rows * Hm);
+  const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
+                       2 * pad64(N * 3 * D) + pad64(N * Z);
+  size_t m = enc_bwd;
+  if (dec_fwd > m) m = dec_fwd;
+  if (dec_bwd > m) m = dec_bwd;
+  if (rssm_bwd > m) m = rssm_bwd;
+  if (mlp_bwd > m) m = mlp_bwd;
+  if (dream > m) m = dream;
+  return (m + 4096) * sizeof(float);
 }

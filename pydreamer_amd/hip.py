@@ -61,7 +61,7 @@ dm_rssm_grads = dm_rssm_params
 
 
 class dm_reduce_item(Structure):
-    _fields_ = [('x', c_void_p), ('n', c_int64), ('scale', c_float)]
+    _fields_ = [('x', c_void_p), ('n', c_int64), ('scale', c_float), ('mode', c_int32), ('center', c_void_p)]
 
 
 _P = c_void_p
@@ -110,6 +110,7 @@ _SIGNATURES = {
     'dm_actor_loss': (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     'dm_critic_loss': (c_int, [c_int, _P, _P, _P, c_float, _P, _P, _P]),
     'dm_multi_sum': (c_int, [c_int, POINTER(dm_reduce_item), _P, _P]),
+    'dm_combine': (c_int, [c_int, _P, POINTER(c_float), _P, _P]),
     'dm_multi_tensor_norm_clip': (c_int, [_P, c_int64, c_float, _P, _P, c_size_t, _P]),
     'dm_scale_inplace': (c_int, [_P, c_int64, _P, _P]),
     'dm_adamw_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),

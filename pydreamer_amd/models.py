@@ -1,0 +1,818 @@
+"""Dreamer / WorldModel / ActorCritic with pydreamer's module API, executing on hand-written HIP kernels.
+
+Mirrors the reference module tree so `state_dict()` keys, shapes and optimizer grouping are identical
+(reference: pydreamer/models/{dreamer,rssm,rnn,a2c,encoders,decoders,common,probes}.py), but no module here has a
+torch `forward`: the nn.Modules only own `nn.Parameter`s.  `Dreamer.training_step()` packs raw device pointers and
+calls the C-ABI of libdreamer_hip.so (pydreamer_amd/hip.py) through three `torch.autograd.Function`s — world
+model, actor, critic — so each of the 4 returned losses supports an independent `.backward()` exactly like the
+reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
+
+Supported configuration (everything else raises NotImplementedError): iwae_samples=1, gru_type='gru', gru_layers=1,
+stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist='onehot', actor_grad='reinforce',
+probe_model='none', no aux critic / vecobs / reward_input.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip as H
+from .optim import FusedAdamW
+
+MLP_HIDDEN = 400          # a2c.py:16, decoders.py:259,289
+REWARD_STD = 0.3989422804  # decoders.py:289
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parameter holders (no forward): names/shapes follow torch.nn so state_dict keys equal the reference's
+# ---------------------------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError('pydreamer_amd modules hold parameters only; compute runs in libdreamer_hip.so')
+
+
+class LinearP(_Params):
+    def __init__(self, in_dim, out_dim, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
+        self.bias = nn.Parameter(torch.empty(out_dim)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))           # torch.nn.Linear default (used by `ac`)
+        if bias:
+            bound = 1 / math.sqrt(in_dim)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class LayerNormP(_Params):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class ConvP(_Params):
+    def __init__(self, shape, bias_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.zeros(bias_dim))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class GRUCellP(_Params):
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.weight_ih = nn.Parameter(torch.empty(3 * hidden_size, input_size))
+        self.weight_hh = nn.Parameter(torch.empty(3 * hidden_size, hidden_size))
+        self.bias_ih = nn.Parameter(torch.zeros(3 * hidden_size))
+        self.bias_hh = nn.Parameter(torch.zeros(3 * hidden_size))
+
+
+class _Slot(_Params):
+    """Parameter-free placeholder keeping nn.Sequential indices aligned with the reference (LN/ELU/Flatten slots)."""
+
+
+def init_weights_tf2(m):
+    """functions.py:81-94, applied to the world model only (dreamer.py:283-284)."""
+    if isinstance(m, (LinearP, ConvP)):
+        nn.init.xavier_uniform_(m.weight.data)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias.data)
+    if isinstance(m, GRUCellP):
+        nn.init.xavier_uniform_(m.weight_ih.data)
+        nn.init.orthogonal_(m.weight_hh.data)
+        nn.init.zeros_(m.bias_ih.data)
+        nn.init.zeros_(m.bias_hh.data)
+
+
+class MLP(_Params):
+    """common.py:37-65: model = Sequential[Linear, LayerNorm, ELU]*L + [Linear] (+Flatten if out_dim==1)."""
+
+    def __init__(self, in_dim, out_dim, hidden_dim, hidden_layers, layer_norm=True):
+        super().__init__()
+        if not layer_norm:
+            raise NotImplementedError('layer_norm=False is not built in the HIP path')
+        self.in_dim, self.out_dim, self.hidden_dim, self.hidden_layers = in_dim, out_dim, hidden_dim, hidden_layers
+        layers, dim = [], in_dim
+        for _ in range(hidden_layers):
+            layers += [LinearP(dim, hidden_dim), LayerNormP(hidden_dim), _Slot()]
+            dim = hidden_dim
+        layers += [LinearP(dim, out_dim)]
+        if out_dim == 1:
+            layers += [_Slot()]
+        self.model = nn.Sequential(*layers)
+
+    # --- C-ABI marshalling
+    def tensors(self):
+        L = self.hidden_layers
+        w = [self.model[3 * i].weight for i in range(L)] + [self.model[3 * L].weight]
+        b = [self.model[3 * i].bias for i in range(L)] + [self.model[3 * L].bias]
+        g = [self.model[3 * i + 1].weight for i in range(L)]
+        be = [self.model[3 * i + 1].bias for i in range(L)]
+        return w, b, g, be
+
+    def param_list(self):
+        """Parameters in nn.Module.parameters() order (the order of the flat gradient buffer)."""
+        return list(self.parameters())
+
+    def struct(self):
+        return H.mlp_struct(*self.tensors())
+
+    def grad_struct(self, grads_by_param):
+        w, b, g, be = self.tensors()
+        pick = lambda ts: [grads_by_param[id(t)] for t in ts]
+        return H.mlp_struct(pick(w), pick(b), pick(g), pick(be), cls=H.dm_mlp_grads)
+
+    def acts_floats(self, rows):
+        return int(H.lib().dm_mlp_acts_floats(rows, self.hidden_dim, self.hidden_layers))
+
+    def fwd(self, x2d, ldx, rows, ws, acts=None):
+        """x2d: device tensor whose rows (leading dim ldx floats) hold in_dim features. Returns (out, acts)."""
+        if acts is None:
+            acts = torch.empty(self.acts_floats(rows), device=x2d.device)
+        out = torch.empty(rows, self.out_dim, device=x2d.device)
+        st = self.struct()
+        H.call('dm_mlp_head_fwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
+               ctypes.byref(st), H.fptr(acts), H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
+        return out, acts
+
+    def bwd(self, x2d, ldx, rows, acts, dout, ws, dx=None, lddx=0, dx_accum=False):
+        """Returns the list of parameter gradients in parameters() order (views of one flat buffer)."""
+        plist = self.param_list()
+        flat = torch.empty(sum(p.numel() for p in plist), device=x2d.device)
+        grads, off = {}, 0
+        out = []
+        for p in plist:
+            gview = flat[off:off + p.numel()].view(p.shape)
+            grads[id(p)] = gview
+            out.append(gview)
+            off += p.numel()
+        st, gs = self.struct(), self.grad_struct(grads)
+        H.call('dm_mlp_head_bwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
+               ctypes.byref(st), H.fptr(acts), H.fptr(dout), ctypes.byref(gs), H.fptr(dx) if dx is not None else None, lddx,
+               1 if dx_accum else 0, H.ptr(ws), ws.numel(), H.stream())
+        return out, flat
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world-model sub-modules (parameter trees only)
+# ---------------------------------------------------------------------------------------------------------------
+class ConvEncoder(_Params):
+    """encoders.py:72-96."""
+
+    def __init__(self, in_channels=3, cnn_depth=32):
+        super().__init__()
+        self.out_dim = cnn_depth * 32
+        d = cnn_depth
+        chans = [(in_channels, d), (d, 2 * d), (2 * d, 4 * d), (4 * d, 8 * d)]
+        layers = []
+        for ci, co in chans:
+            layers += [ConvP((co, ci, 4, 4), co), _Slot()]
+        layers += [_Slot()]
+        self.model = nn.Sequential(*layers)
+
+    def convs(self):
+        return [self.model[i] for i in (0, 2, 4, 6)]
+
+
+class MultiEncoder(_Params):
+    """encoders.py:10-69 (image encoder only)."""
+
+    def __init__(self, conf):
+        super().__init__()
+        if conf.reward_input or conf.vecobs_size or conf.image_encoder != 'cnn':
+            raise NotImplementedError('only image_encoder=cnn without reward_input/vecobs is built in the HIP path')
+        self.encoder_image = ConvEncoder(in_channels=conf.image_channels, cnn_depth=conf.cnn_depth)
+        self.out_dim = self.encoder_image.out_dim
+
+
+class ConvDecoder(_Params):
+    """decoders.py:111-180 (mlp_layers=0)."""
+
+    def __init__(self, in_dim, out_channels=3, cnn_depth=32):
+        super().__init__()
+        self.in_dim = in_dim
+        d = cnn_depth
+        self.model = nn.Sequential(
+            LinearP(in_dim, d * 32), _Slot(),
+            ConvP((d * 32, d * 4, 5, 5), d * 4), _Slot(),
+            ConvP((d * 4, d * 2, 5, 5), d * 2), _Slot(),
+            ConvP((d * 2, d, 6, 6), d), _Slot(),
+            ConvP((d, out_channels, 6, 6), out_channels))
+
+    def layers(self):
+        return [self.model[i] for i in (0, 2, 4, 6, 8)]
+
+
+class DenseNormalDecoder(_Params):
+    """decoders.py:287-319."""
+
+    def __init__(self, in_dim, hidden_layers, layer_norm=True):
+        super().__init__()
+        self.model = MLP(in_dim, 1, MLP_HIDDEN, hidden_layers, layer_norm)
+        self.std = REWARD_STD
+
+
+class DenseBernoulliDecoder(_Params):
+    """decoders.py:257-284."""
+
+    def __init__(self, in_dim, hidden_layers, layer_norm=True):
+        super().__init__()
+        self.model = MLP(in_dim, 1, MLP_HIDDEN, hidden_layers, layer_norm)
+
+
+class MultiDecoder(_Params):
+    """decoders.py:10-108."""
+
+    def __init__(self, features_dim, conf):
+        super().__init__()
+        if conf.image_decoder != 'cnn' or conf.reward_decoder_categorical or conf.vecobs_size:
+            raise NotImplementedError('only image_decoder=cnn with Normal reward decoder is built in the HIP path')
+        self.image_weight, self.reward_weight, self.terminal_weight = conf.image_weight, conf.reward_weight, conf.terminal_weight
+        self.image = ConvDecoder(in_dim=features_dim, out_channels=conf.image_channels, cnn_depth=conf.cnn_depth)
+        self.reward = DenseNormalDecoder(features_dim, conf.reward_decoder_layers, conf.layer_norm)
+        self.terminal = DenseBernoulliDecoder(features_dim, conf.terminal_decoder_layers, conf.layer_norm)
+
+
+class GRUCellStack(_Params):
+    """rnn.py:40-67 with cell_type='gru', num_layers=1."""
+
+    def __init__(self, input_size, hidden_size, num_layers, cell_type):
+        super().__init__()
+        if cell_type != 'gru' or num_layers != 1:
+            raise NotImplementedError(f'gru_type={cell_type!r}, gru_layers={num_layers} not built in the HIP path')
+        self.layers = nn.ModuleList([GRUCellP(input_size, hidden_size)])
+
+
+class RSSMCell(_Params):
+    """rssm.py:97-203."""
+
+    def __init__(self, embed_dim, action_dim, deter_dim, stoch_dim, stoch_discrete, hidden_dim, gru_layers, gru_type, layer_norm):
+        super().__init__()
+        if not stoch_discrete or not layer_norm:
+            raise NotImplementedError('continuous latents / layer_norm=False not built in the HIP path')
+        self.stoch_dim, self.stoch_discrete, self.deter_dim = stoch_dim, stoch_discrete, deter_dim
+        Z = stoch_dim * stoch_discrete
+        self.z_mlp = LinearP(Z, hidden_dim)
+        self.a_mlp = LinearP(action_dim, hidden_dim, bias=False)
+        self.in_norm = LayerNormP(hidden_dim)
+        self.gru = GRUCellStack(hidden_dim, deter_dim, gru_layers, gru_type)
+        self.prior_mlp_h = LinearP(deter_dim, hidden_dim)
+        self.prior_norm = LayerNormP(hidden_dim)
+        self.prior_mlp = LinearP(hidden_dim, Z)
+        self.post_mlp_h = LinearP(deter_dim, hidden_dim)
+        self.post_mlp_e = LinearP(embed_dim, hidden_dim, bias=False)
+        self.post_norm = LayerNormP(hidden_dim)
+        self.post_mlp = LinearP(hidden_dim, Z)
+
+    def ordered(self):
+        """Tensors in the DM_RSSM_* order of include/dreamer_hip.h."""
+        named = dict(self.named_parameters())
+        return [named[n] for n in H.RSSM_PARAM_ORDER]
+
+    def init_state(self, batch_size):
+        dev = self.z_mlp.weight.device
+        return (torch.zeros((batch_size, self.deter_dim), device=dev),
+                torch.zeros((batch_size, self.stoch_dim * self.stoch_discrete), device=dev))
+
+
+class RSSMCore(_Params):
+    """rssm.py:15-93."""
+
+    def __init__(self, embed_dim, action_dim, deter_dim, stoch_dim, stoch_discrete, hidden_dim, gru_layers, gru_type, layer_norm):
+        super().__init__()
+        self.cell = RSSMCell(embed_dim, action_dim, deter_dim, stoch_dim, stoch_discrete, hidden_dim, gru_layers, gru_type, layer_norm)
+
+    def init_state(self, batch_size):
+        return self.cell.init_state(batch_size)
+
+
+class NoProbeHead(nn.Module):
+    """probes.py:140-150: keeps the 4-loss / 4-optimizer structure."""
+
+    def __init__(self):
+        super().__init__()
+        self.dummy = nn.Parameter(torch.zeros(1), requires_grad=True)
+
+    def training_step(self, features, obs):
+        return torch.square(self.dummy), {}, {}
+
+
+class _Mean:
+    """Stand-in for the torch.distributions objects Dreamer.dream returns: only `.mean` is consumed (dreamer.py:155-156)."""
+
+    def __init__(self, mean):
+        self.mean = mean
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------
+def _flat_views(plist, device):
+    flat = torch.empty(sum(p.numel() for p in plist), device=device)
+    views, off = [], 0
+    for p in plist:
+        views.append(flat[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    return flat, views
+
+
+def _multi_sum(items, device):
+    """items: list of (tensor, scale) or (tensor, scale, center_tensor) -> 1-D tensor of results."""
+    arr = (H.dm_reduce_item * len(items))()
+    for i, it in enumerate(items):
+        arr[i].x = it[0].data_ptr()
+        arr[i].n = it[0].numel()
+        arr[i].scale = it[1]
+        if len(it) > 2:
+            arr[i].mode = 1
+            arr[i].center = it[2].data_ptr()
+        else:
+            arr[i].mode = 0
+            arr[i].center = None
+    out = torch.empty(len(items), device=device)
+    H.call('dm_multi_sum', len(items), arr, H.fptr(out), H.stream())
+    return out
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise H.DreamerHipError(f'{what} is on {t.device}: pydreamer_amd has no CPU path (the HIP library is the product)')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world model
+# ---------------------------------------------------------------------------------------------------------------
+class _WMStep(torch.autograd.Function):
+    """loss_model = WorldModel forward; backward = hand-written BPTT + conv backward through the C-ABI."""
+
+    @staticmethod
+    def forward(ctx, wm, pack, *params):
+        ctx.wm, ctx.pack = wm, pack
+        return pack['loss'].clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        wm, pk = ctx.wm, ctx.pack
+        if pk.get('consumed'):
+            raise RuntimeError('loss_model.backward() called twice (saved activations were released)')
+        grads = wm._backward(pk, grad_loss)
+        pk['consumed'] = True
+        return (None, None) + tuple(grads)
+
+
+class WorldModel(_Params):
+    """dreamer.py:228-396."""
+
+    def __init__(self, conf):
+        super().__init__()
+        if conf.iwae_samples != 1 or conf.aux_critic:
+            raise NotImplementedError('iwae_samples>1 / aux_critic are not built in the HIP path')
+        if conf.image_size != 64:
+            raise NotImplementedError('conv geometry is built for 64x64 observations')
+        self.conf = conf
+        self.deter_dim, self.stoch_dim, self.stoch_discrete = conf.deter_dim, conf.stoch_dim, conf.stoch_discrete
+        self.kl_weight = conf.kl_weight
+        self.kl_balance = None if conf.kl_balance == 0.5 else conf.kl_balance     # dreamer.py:241
+        self.aux_critic_weight = conf.aux_critic_weight
+        self.encoder = MultiEncoder(conf)
+        features_dim = conf.deter_dim + conf.stoch_dim * (conf.stoch_discrete or 1)
+        self.features_dim = features_dim
+        self.decoder = MultiDecoder(features_dim, conf)
+        self.core = RSSMCore(embed_dim=self.encoder.out_dim, action_dim=conf.action_dim, deter_dim=conf.deter_dim,
+                             stoch_dim=conf.stoch_dim, stoch_discrete=conf.stoch_discrete, hidden_dim=conf.hidden_dim,
+                             gru_layers=conf.gru_layers, gru_type=conf.gru_type, layer_norm=conf.layer_norm)
+        self.ac_aux = None
+        for m in self.modules():
+            init_weights_tf2(m)
+        self._ws = None
+
+    def init_state(self, batch_size):
+        return self.core.init_state(batch_size)
+
+    # ---- shape / workspace
+    def shape(self, T, B, H_):
+        c = self.conf
+        return H.make_shape(T=T, B=B, I=1, H=H_, D=c.deter_dim, Hd=c.hidden_dim, S=c.stoch_dim, C=c.stoch_discrete,
+                            E=self.encoder.out_dim, A=c.action_dim, mlp_hidden=MLP_HIDDEN, mlp_layers=4,
+                            cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels, flags=0)
+
+    def workspace(self, shp, device):
+        need = H.workspace_bytes(shp)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward(self, obs, in_state):
+        """dreamer.py:289-295: features and out_state only (used by Dreamer.inference)."""
+        with torch.no_grad():
+            pk = self._forward(obs, in_state, None, None, forward_only=True)
+        T, B = obs['action'].shape[:2]
+        return pk['feat'].view(T, B, 1, -1), pk['out_state']
+
+    # ---- forward through the C-ABI
+    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1):
+        c = self.conf
+        image, action = obs['image'], obs['action']
+        _require_cuda(image, "obs['image']")
+        T, B = action.shape[:2]
+        N, dev = T * B, image.device
+        D_, Z, F_, E = c.deter_dim, c.stoch_dim * c.stoch_discrete, self.features_dim, self.encoder.out_dim
+        shp = self.shape(T, B, imag_horizon)
+        ws = self.workspace(shp, dev)
+        image = image.float().contiguous()
+        action = action.float().contiguous()
+        reset = obs['reset'].to(torch.uint8).contiguous()
+        h0, z0 = (x.float().contiguous() for x in in_state)
+        if u_post is None and forced_idx is None:
+            u_post = torch.rand(T, B, c.stoch_dim, device=dev)
+        lib = H.lib()
+
+        enc = self.encoder.encoder_image
+        enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
+        enc_acts = torch.empty(int(lib.dm_conv_encoder_acts_floats(ctypes.byref(shp))), device=dev)
+        embed = torch.empty(N, E, device=dev)
+        H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed),
+               H.ptr(ws), ws.numel(), H.stream())
+
+        cell = self.core.cell
+        rssm_p = H.rssm_struct(cell.ordered())
+        rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp))), device=dev)
+        feat = torch.empty(N, F_, device=dev)
+        post = torch.empty(N, Z, device=dev)
+        prior = torch.empty(N, Z, device=dev)
+        idx = torch.empty(N, c.stoch_dim, dtype=torch.int32, device=dev)
+        fidx = forced_idx.to(torch.int32).contiguous() if forced_idx is not None else None
+        H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
+               H.fptr(u_post.contiguous()) if u_post is not None else None, H.ptr(fidx), ctypes.byref(rssm_p),
+               H.fptr(rssm_acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
+        last = feat[(T - 1) * B:]
+        out_state = (last[:, :D_].clone(), last[:, D_:].clone())                  # detached by construction (rssm.py:77)
+        pk = dict(shp=shp, T=T, B=B, feat=feat, post=post, prior=prior, idx=idx, out_state=out_state, embed=embed)
+        if forward_only:
+            return pk
+
+        # decoders (decoders.py:50-108)
+        dec = self.decoder
+        dl = dec.image.layers()
+        dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+        dec_acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
+        loss_image = torch.empty(N, device=dev)
+        image_rec = torch.empty_like(image)
+        H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(image), ctypes.byref(dec_p),
+               H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(), H.stream())
+
+        reward_t = obs['reward'].float().contiguous()
+        terminal_t = obs['terminal'].float().contiguous()
+        mu, r_acts = dec.reward.model.fwd(feat, F_, N, ws)
+        tl, t_acts = dec.terminal.model.fwd(feat, F_, N, ws)
+        loss_reward, dmu, reward_rec = (torch.empty(N, device=dev) for _ in range(3))
+        loss_terminal, dtl, terminal_rec = (torch.empty(N, device=dev) for _ in range(3))
+        # -Normal(mu, std).log_prob(y) * std^2 = 0.5 (mu-y)^2 + std^2 (log std + log sqrt(2 pi))   (decoders.py:296-304)
+        loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
+        H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), dec.reward_weight / N, loss_const, H.fptr(loss_reward),
+               H.fptr(dmu), H.fptr(reward_rec), H.stream())
+        H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), dec.terminal_weight / N, 0.0, H.fptr(loss_terminal),
+               H.fptr(dtl), H.fptr(terminal_rec), H.stream())
+
+        # KL + entropies (dreamer.py:326-343,369-379)
+        kl, ent_post, ent_prior = (torch.empty(N, device=dev) for _ in range(3))
+        H.call('dm_kl_balance_fwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(post), H.fptr(prior), H.fptr(kl),
+               H.fptr(ent_post), H.fptr(ent_prior), H.stream())
+
+        means = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
+                            (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev)
+        loss = torch.empty((), device=dev)
+        w = (ctypes.c_float * 4)(self.kl_weight, dec.image_weight, dec.reward_weight, dec.terminal_weight)
+        H.call('dm_combine', 4, H.fptr(means), w, H.fptr(loss), H.stream())     # dreamer.py:362-365
+
+        pk.update(loss=loss, image=image, action=action, reset=reset, enc_acts=enc_acts, rssm_acts=rssm_acts,
+                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws)
+        tb = lambda x: x.view(T, B)
+        pk['tensors'] = dict(loss_kl=tb(kl), entropy_prior=tb(ent_prior), entropy_post=tb(ent_post),
+                             loss_image=tb(loss_image), image_rec=image_rec.view(obs['image'].shape),
+                             loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
+                             loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
+        pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
+                             loss_image=means[1], loss_reward=means[2], loss_terminal=means[3])
+        return pk
+
+    def _param_order(self):
+        return list(self.parameters())
+
+    def _backward(self, pk, grad_loss):
+        c = self.conf
+        shp, T, B = pk['shp'], pk['T'], pk['B']
+        N = T * B
+        feat, dev = pk['feat'], pk['feat'].device
+        F_, Z, E = self.features_dim, c.stoch_dim * c.stoch_discrete, self.encoder.out_dim
+        ws = self.workspace(shp, dev)
+        plist = self._param_order()
+        flat, views = _flat_views(plist, dev)
+        gof = {id(p): v for p, v in zip(plist, views)}
+        dec = self.decoder
+
+        dfeat = torch.zeros(N, F_, device=dev)
+        # dense heads (decoders.py:73-83)
+        for head, acts, dout in ((dec.reward.model, pk['r_acts'], pk['dmu']), (dec.terminal.model, pk['t_acts'], pk['dtl'])):
+            st, gs = head.struct(), head.grad_struct(gof)
+            H.call('dm_mlp_head_bwd', N, F_, head.hidden_dim, head.hidden_layers, 1, H.fptr(feat), F_, ctypes.byref(st),
+                   H.fptr(acts), H.fptr(dout), ctypes.byref(gs), H.fptr(dfeat), F_, 1, H.ptr(ws), ws.numel(), H.stream())
+        # image decoder
+        dl = dec.image.layers()
+        dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+        dec_g = H.conv_struct([gof[id(m.weight)] for m in dl], [gof[id(m.bias)] for m in dl], cls=H.dm_conv_grads)
+        H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(pk['image']), ctypes.byref(dec_p),
+               H.fptr(pk['dec_acts']), dec.image_weight / N, ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws), ws.numel(),
+               H.stream())
+        # KL (dreamer.py:334-339)
+        dpost = torch.empty(N, Z, device=dev)
+        dprior = torch.empty(N, Z, device=dev)
+        if self.kl_balance is None:
+            sp = sq = self.kl_weight / N
+        else:
+            sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
+        H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
+               H.fptr(dpost), H.fptr(dprior), H.stream())
+        # RSSM BPTT
+        cell = self.core.cell
+        rssm_p = H.rssm_struct(cell.ordered())
+        rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
+        dembed = torch.empty(N, E, device=dev)
+        H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(pk['embed']), H.fptr(pk['action']), H.ptr(pk['reset']),
+               ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']), H.fptr(dfeat), H.fptr(dpost),
+               H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(), H.stream())
+        # encoder
+        enc = self.encoder.encoder_image
+        enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
+        enc_g = H.conv_struct([gof[id(m.weight)] for m in enc.convs()], [gof[id(m.bias)] for m in enc.convs()],
+                              cls=H.dm_conv_grads)
+        H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
+               H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
+        # chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync
+        gl = grad_loss.detach().float().reshape(1).contiguous()
+        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
+        for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
+            pk.pop(k, None)
+        return views
+
+    def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
+                      u_post=None, forced_idx=None, imag_horizon=1):
+        """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
+        if iwae_samples != 1 or do_open_loop or do_image_pred:
+            raise NotImplementedError('iwae_samples>1 / do_open_loop / do_image_pred are evaluation variants not built yet')
+        T, B = obs['action'].shape[:2]
+        if forward_only:
+            feats, out_state = self.forward(obs, in_state)
+            return torch.tensor(0.0), feats, None, out_state, {}, {}
+        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon)
+        loss = _WMStep.apply(self, pk, *self._param_order())
+        D_ = self.deter_dim
+        feat = pk['feat']
+        features = feat.view(T, B, 1, -1)
+        states = (feat[:, :D_].view(T, B, 1, -1), feat[:, D_:].view(T, B, 1, -1))
+        self._last_pack = pk
+        return loss, features, states, pk['out_state'], pk['metrics'], pk['tensors']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# actor critic
+# ---------------------------------------------------------------------------------------------------------------
+class _HeadLoss(torch.autograd.Function):
+    """A scalar loss whose gradient w.r.t. one MLP's parameters is produced by dm_mlp_head_bwd."""
+
+    @staticmethod
+    def forward(ctx, mlp, pack, *params):
+        ctx.mlp, ctx.pack = mlp, pack
+        return pack['loss'].clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        mlp, pk = ctx.mlp, ctx.pack
+        grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
+        gl = grad_loss.detach().float().reshape(1).contiguous()
+        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
+        pk.pop('acts', None)
+        return (None, None) + tuple(grads)
+
+
+class ActorCritic(_Params):
+    """a2c.py:11-152."""
+
+    def __init__(self, in_dim, out_actions, hidden_dim=400, hidden_layers=4, layer_norm=True, gamma=0.999, lambda_gae=0.95,
+                 entropy_weight=1e-3, target_interval=100, actor_grad='reinforce', actor_dist='onehot'):
+        super().__init__()
+        if actor_dist != 'onehot' or actor_grad != 'reinforce':
+            raise NotImplementedError(f'actor_dist={actor_dist!r} / actor_grad={actor_grad!r}: only onehot + reinforce is built '
+                                      f'in the HIP path (the dmc section is not runnable in the reference either, SURVEY 0.5)')
+        self.in_dim, self.out_actions = in_dim, out_actions
+        self.gamma, self.lambda_, self.entropy_weight = gamma, lambda_gae, entropy_weight
+        self.target_interval, self.actor_grad, self.actor_dist = target_interval, actor_grad, actor_dist
+        self.actor = MLP(in_dim, out_actions, hidden_dim, hidden_layers, layer_norm)
+        self.critic = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
+        self.critic_target = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
+        self.critic_target.requires_grad_(False)
+        self.train_steps = 0
+
+    def update_critic_target(self):
+        """a2c.py:151-152."""
+        with torch.no_grad():
+            for dst, src in zip(self.critic_target.parameters(), self.critic.parameters()):
+                H.call('dm_copy_params', H.fptr(dst), H.fptr(src), dst.numel(), H.stream())
+
+    def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None):
+        """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149."""
+        _require_cuda(features, 'features')
+        if not log_only:
+            if self.train_steps % self.target_interval == 0:
+                self.update_critic_target()
+            self.train_steps += 1
+        J, M, F_ = features.shape
+        Hh, A, dev = J - 1, self.out_actions, features.device
+        feats = features.contiguous().view(J * M, F_)
+        rewards, terminals = rewards.contiguous(), terminals.contiguous()
+        if act_idx is None:
+            act_idx = actions.argmax(-1).to(torch.int32)
+        act_idx = act_idx.contiguous().view(-1)
+        if ws is None:
+            raise H.DreamerHipError('ActorCritic.training_step needs the model workspace (called through Dreamer.training_step)')
+
+        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws)
+        value, c_acts = self.critic.fwd(feats, F_, J * M, ws)
+        logits, a_acts = self.actor.fwd(feats, F_, Hh * M, ws)       # features[:-1] = first H*M rows
+        adv, agae, vtgt, wgt = (torch.empty(Hh, M, device=dev) for _ in range(4))
+        H.call('dm_gae_losses', Hh, M, self.gamma, self.lambda_, H.fptr(rewards), H.fptr(terminals), H.fptr(value_t),
+               H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
+        rows = Hh * M
+        lc = torch.empty(rows, device=dev)
+        dvalue = torch.zeros(J * M, device=dev)                      # value[-1] gets no gradient
+        H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), 1.0 / rows, H.fptr(lc), H.fptr(dvalue),
+               H.stream())
+        la, ent = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        dlogits = torch.empty(rows, A, device=dev)
+        H.call('dm_actor_loss', rows, A, H.fptr(logits), H.ptr(act_idx), H.fptr(agae), H.fptr(wgt), self.entropy_weight,
+               1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits), H.stream())
+        value2d = value.view(J, M)
+        reward1 = rewards.view(J, M)[1:]
+        s = _multi_sum([(lc, 1.0 / rows), (la, 1.0 / rows), (ent, 1.0 / rows), (value2d[0], 1.0 / M),
+                        (value2d[:-1], 1.0 / rows), (reward1, 1.0 / rows)], dev)
+        var = _multi_sum([(reward1, 1.0 / max(rows - 1, 1), s[5:6])], dev)
+        loss_critic_v, loss_actor_v = s[0], s[1]
+        if log_only:
+            loss_actor, loss_critic = loss_actor_v, loss_critic_v
+        else:
+            pa = dict(loss=loss_actor_v, x=feats, ldx=F_, rows=rows, acts=a_acts, dout=dlogits, ws=ws)
+            pc = dict(loss=loss_critic_v, x=feats, ldx=F_, rows=J * M, acts=c_acts, dout=dvalue.view(J * M, 1), ws=ws)
+            loss_actor = _HeadLoss.apply(self.actor, pa, *self.actor.param_list())
+            loss_critic = _HeadLoss.apply(self.critic, pc, *self.critic.param_list())
+        metrics = dict(loss_critic=loss_critic_v, loss_actor=loss_actor_v, policy_entropy=s[2], policy_value=s[3],
+                       policy_value_im=s[4], policy_reward=s[5], policy_reward_std=var[0].sqrt())
+        tensors = dict(value=value2d, value_target=vtgt, value_advantage=adv, value_advantage_gae=agae, value_weight=wgt)
+        return (loss_actor, loss_critic), metrics, tensors
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dreamer
+# ---------------------------------------------------------------------------------------------------------------
+class Dreamer(nn.Module):
+    """dreamer.py:19-226."""
+
+    def __init__(self, conf):
+        super().__init__()
+        assert conf.action_dim > 0, 'Need to set action_dim to match environment'
+        if conf.probe_model != 'none' or conf.probe_gradients:
+            raise NotImplementedError('probe models are research heads outside the hot path')
+        features_dim = conf.deter_dim + conf.stoch_dim * (conf.stoch_discrete or 1)
+        self.conf = conf
+        self.iwae_samples, self.imag_horizon = conf.iwae_samples, conf.imag_horizon
+        self.wm = WorldModel(conf)
+        self.ac = ActorCritic(in_dim=features_dim, out_actions=conf.action_dim, layer_norm=conf.layer_norm, gamma=conf.gamma,
+                              lambda_gae=conf.lambda_gae, entropy_weight=conf.entropy, target_interval=conf.target_interval,
+                              actor_grad=conf.actor_grad, actor_dist=conf.actor_dist)
+        self.probe_model = NoProbeHead()
+        self.probe_gradients = conf.probe_gradients
+        self._groups = None
+
+    # ---- optimizers (dreamer.py:60-87)
+    def param_groups(self):
+        return dict(wm=list(self.wm.parameters()), probe=list(self.probe_model.parameters()),
+                    actor=list(self.ac.actor.parameters()), critic=list(self.ac.critic.parameters()))
+
+    def init_optimizers(self, lr, lr_actor=None, lr_critic=None, eps=1e-5):
+        groups = self.param_groups()
+        self._opt = dict(wm=FusedAdamW(groups['wm'], lr=lr, eps=eps), probe=FusedAdamW(groups['probe'], lr=lr, eps=eps),
+                         actor=FusedAdamW(groups['actor'], lr=lr_actor or lr, eps=eps),
+                         critic=FusedAdamW(groups['critic'], lr=lr_critic or lr, eps=eps))
+        return self._opt['wm'], self._opt['probe'], self._opt['actor'], self._opt['critic']
+
+    def grad_clip(self, grad_clip, grad_clip_ac=None):
+        if getattr(self, '_opt', None) is None:
+            raise RuntimeError('call init_optimizers() before grad_clip(): clipping runs on the optimizers\' flat buffers')
+        o = self._opt
+        return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip), grad_norm_probe=o['probe'].clip_grad_norm(grad_clip),
+                    grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip),
+                    grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip))
+
+    def init_state(self, batch_size):
+        return self.wm.init_state(batch_size)
+
+    # ---- inference (dreamer.py:92-111)
+    def inference(self, obs, in_state):
+        assert 'action' in obs, 'Observation should contain previous action'
+        act_shape = obs['action'].shape
+        assert len(act_shape) == 3 and act_shape[0] == 1, f'Expected shape (1,B,A), got {act_shape}'
+        features, out_state = self.wm.forward(obs, in_state)
+        B = act_shape[1]
+        feat = features.reshape(B, -1)
+        shp = self.wm.shape(1, B, 1)
+        ws = self.wm.workspace(shp, feat.device)
+        logits, _ = self.ac.actor.fwd(feat, feat.shape[1], B, ws)
+        value, _ = self.ac.critic.fwd(feat, feat.shape[1], B, ws)
+        action_distr = torch.distributions.OneHotCategorical(logits=logits.view(1, B, -1))
+        return action_distr, out_state, dict(policy_value=value.mean())
+
+    # ---- imagination (dreamer.py:188-216)
+    def dream(self, in_state, imag_horizon, dynamics_gradients=False, u_act=None, u_prior=None, _pack=None):
+        if dynamics_gradients:
+            raise NotImplementedError('actor_grad=dynamics is not built (and not runnable in the reference, SURVEY 0.5)')
+        h, z = in_state
+        _require_cuda(h, 'in_state')
+        Hh = int(imag_horizon)
+        start = torch.cat((h, z), -1).contiguous()           # to_feature (rssm.py:83-84)
+        return self._dream_from_features(start, Hh, u_act, u_prior, _pack)
+
+    def _dream_from_features(self, start, Hh, u_act=None, u_prior=None, _pack=None):
+        """start: (M,F) rows [h|z] (the world model's feature matrix is passed as is, no concat copy)."""
+        c = self.conf
+        M, dev = start.shape[0], start.device
+        F_, A, S = self.wm.features_dim, c.action_dim, c.stoch_dim
+        shp = self.wm.shape(1, M, Hh)                        # T*B = M rows for workspace sizing
+        ws = self.wm.workspace(shp, dev)
+        if u_act is None:
+            u_act = torch.rand(Hh, M, device=dev)
+        if u_prior is None:
+            u_prior = torch.rand(Hh, M, S, device=dev)
+        feats = torch.empty(Hh + 1, M, F_, device=dev)
+        actions = torch.empty(Hh, M, A, device=dev)
+        act_idx = torch.empty(Hh, M, dtype=torch.int32, device=dev)
+        cell_p = H.rssm_struct(self.wm.core.cell.ordered())
+        actor_p = self.ac.actor.struct()
+        H.call('dm_dream_rollout', ctypes.byref(shp), M, H.fptr(start), ctypes.byref(cell_p), ctypes.byref(actor_p),
+               H.fptr(u_act.contiguous()), H.fptr(u_prior.contiguous()), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
+               H.ptr(ws), ws.numel(), H.stream())
+        rows = (Hh + 1) * M
+        f2 = feats.view(rows, F_)
+        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws)
+        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws)
+        term = torch.empty(rows, device=dev)
+        H.call('dm_head_loss', 1, rows, H.fptr(tl), None, 0.0, 0.0, None, None, H.fptr(term), H.stream())
+        if _pack is not None:
+            _pack.update(act_idx=act_idx, ws=ws)
+        return feats, actions, _Mean(mu.view(Hh + 1, M)), _Mean(term.view(Hh + 1, M))
+
+    # ---- training step (dreamer.py:113-186)
+    def training_step(self, obs, in_state, iwae_samples=None, imag_horizon=None, do_open_loop=False, do_image_pred=False,
+                      do_dream_tensors=False, noise=None, forced_idx=None):
+        """Extra keyword arguments beyond the reference signature: `noise` = dict(u_post (T,B,S), u_act (H,M), u_prior
+        (H,M,S)) of explicit uniforms for the three sampler call sites, `forced_idx` (T,B,S) to teacher-force the posterior."""
+        for k in ('action', 'reward', 'reset', 'terminal'):
+            assert k in obs, f'`{k}` required in observation'
+        iwae_samples = int(iwae_samples or self.iwae_samples)
+        imag_horizon = int(imag_horizon or self.imag_horizon)
+        if do_dream_tensors:
+            raise NotImplementedError('do_dream_tensors is a logging variant not built yet')
+        T, B = obs['action'].shape[:2]
+        noise = noise or {}
+        u_post = noise.get('u_post')
+        if u_post is not None:
+            u_post = u_post.reshape(T, B, -1)
+
+        loss_model, features, states, out_state, metrics, tensors = \
+            self.wm.training_step(obs, in_state, iwae_samples=iwae_samples, do_open_loop=do_open_loop,
+                                  do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
+                                  imag_horizon=imag_horizon)
+        pk = self.wm._last_pack
+        metrics, tensors = dict(metrics), dict(tensors)
+        loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
+        metrics.update(**metrics_probe)
+        tensors.update(**tensors_probe)
+
+        # (T,B,I) => (TBI): the feature matrix [h|z] of all posterior states, detached (dreamer.py:149)
+        dpk = {}
+        features_dream, actions_dream, rewards_dream, terminals_dream = \
+            self._dream_from_features(pk['feat'], imag_horizon, noise.get('u_act'), noise.get('u_prior'), _pack=dpk)
+        (loss_actor, loss_critic), metrics_ac, tensors_ac = \
+            self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
+                                  act_idx=dpk['act_idx'], ws=dpk['ws'])
+        metrics.update(**metrics_ac)
+        tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
+        self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], dream_features=features_dream,
+                                ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'])
+        losses = (loss_model, loss_probe, loss_actor, loss_critic)
+        return losses, out_state, metrics, tensors, {}
+
+    def __str__(self):
+        count = lambda m: sum(p.numel() for p in m.parameters())
+        s = [f'Model: {count(self)} parameters']
+        for sub in (self.wm.encoder, self.wm.decoder, self.wm.core, self.ac, self.probe_model):
+            s.append(f'  {type(sub).__name__:<15}: {count(sub)} parameters')
+        return '\n'.join(s)

@@ -1,0 +1,112 @@
+"""Flat-buffer AdamW + global-norm clipping on HIP kernels (reference: Dreamer.init_optimizers / grad_clip,
+dreamer.py:60-87 = torch.optim.AdamW(lr, eps; betas (0.9,0.999), weight_decay 0.01 defaults) + clip_grad_norm_).
+
+Each optimizer group (wm / probe / actor / critic) owns ONE contiguous fp32 parameter buffer, one gradient buffer and
+two moment buffers; the nn.Parameters become views into the parameter buffer and their `.grad`s views into the gradient
+buffer, so that
+  * the norm, the in-place clip and the AdamW update are three streaming kernels per group instead of ~100 small ones;
+  * data-parallel training all-reduces one buffer per group over RCCL (see pydreamer_amd/dist.py).
+"""
+import ctypes
+
+import torch
+
+from . import hip as H
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.01):
+        params = list(params)
+        if not params:
+            raise ValueError('FusedAdamW got an empty parameter list')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._plist = params
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise H.DreamerHipError(f'FusedAdamW needs parameters on a gfx950 device, got {dev} '
+                                    f'(call model.to(device) before init_optimizers; there is no CPU optimizer path)')
+        n = sum(p.numel() for p in params)
+        self.numel = n
+        self.flat_param = torch.empty(n, device=dev)
+        self.flat_grad = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.norm_buf = torch.zeros(2, device=dev)        # [total_norm, clip_coef]
+        self._ws = torch.empty(4096, device=dev)
+        self.step_count = 0
+        self.dp = None                                    # set by dist.attach(): (process_group, weight)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_param[off:off + k].view(p.shape)
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                off += k
+
+    def _grads_are_views(self):
+        off = 0
+        for p in self._plist:
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def _regather(self):
+        """A caller replaced `.grad` (e.g. zero_grad(set_to_none=True) elsewhere): copy into the flat buffer and re-view."""
+        off = 0
+        with torch.no_grad():
+            for p in self._plist:
+                k = p.numel()
+                dst = self.flat_grad[off:off + k]
+                if p.grad is None:
+                    dst.zero_()
+                elif p.grad.data_ptr() != dst.data_ptr():
+                    dst.copy_(p.grad.reshape(-1))
+                p.grad = dst.view(p.shape)
+                off += k
+
+    def zero_grad(self, set_to_none=False):
+        """Zeroes the flat gradient buffer and keeps the `.grad` views alive (set_to_none is ignored by design)."""
+        if not self._grads_are_views():
+            self._regather()
+        self.flat_grad.zero_()
+
+    def clip_grad_norm(self, max_norm):
+        """clip_grad_norm_ on the flat buffer: returns the pre-clip total norm as a 0-d device tensor (no host sync)."""
+        if not self._grads_are_views():
+            self._regather()
+        if self.dp is not None:
+            from . import dist as D
+            D.allreduce_grads(self)
+        H.call('dm_multi_tensor_norm_clip', H.fptr(self.flat_grad), self.numel, float(max_norm), H.fptr(self.norm_buf),
+               H.fptr(self._ws), self._ws.numel() * 4, H.stream())
+        H.call('dm_scale_inplace', H.fptr(self.flat_grad), self.numel, ctypes.c_void_p(self.norm_buf.data_ptr() + 4),
+               H.stream())
+        return self.norm_buf[0].clone()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError('closures are not used by the trainer section (train.py:193-198)')
+        if not self._grads_are_views():
+            self._regather()
+        g = self.param_groups[0]
+        self.step_count += 1
+        H.call('dm_adamw_step', H.fptr(self.flat_param), H.fptr(self.flat_grad), H.fptr(self.exp_avg),
+               H.fptr(self.exp_avg_sq), self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
+               self.step_count, None, H.stream())
+
+    # checkpoint format: same top-level keys as torch optimizers ('state', 'param_groups') with flat moments
+    def state_dict(self):
+        return dict(state=dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone()),
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != 'params'}])
+
+    def load_state_dict(self, sd):
+        st = sd['state']
+        self.step_count = int(st['step'])
+        self.exp_avg.copy_(st['exp_avg'])
+        self.exp_avg_sq.copy_(st['exp_avg_sq'])
+        for k, v in sd['param_groups'][0].items():
+            self.param_groups[0][k] = v

@@ -1,0 +1,118 @@
+"""CPU (-m "not gpu"): host-side logic — the C-ABI library loads and exports every symbol include/dreamer_hip.h
+declares (no compute without a GPU), config surface, state_dict compatibility with the reference's key table,
+workspace/acts sizing, sharding bounds, loud failure off-device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import dreamer_oracle as O
+from pydreamer_amd import config, dist as DP, hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
+    lib = hip.lib()
+    assert lib.dm_version() == 1
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
+
+
+def test_error_reporting_without_gpu():
+    """Argument validation happens on the host: bad calls return DM_E_* with a message, never crash."""
+    with pytest.raises(hip.DreamerHipError) as e:
+        hip.call('dm_gemm_f32', 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, 0, None, 0, None)
+    assert 'null' in str(e.value)
+    with pytest.raises(hip.DreamerHipError):
+        hip.call('dm_gae_losses', 0, 5, 0.99, 0.95, None, None, None, None, None, None, None, None)
+    if not torch.cuda.is_available():
+        with pytest.raises(hip.DreamerHipError) as e:
+            hip.call('dm_device_check')
+        assert 'gfx950' in str(e.value) or 'HIP device' in str(e.value)
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(hip.dm_shape) == 16 * 4
+    assert ctypes.sizeof(hip.dm_reduce_item) == 32
+    assert ctypes.sizeof(hip.dm_mlp_params) == 8 * (9 + 9 + 8 + 8)
+    assert ctypes.sizeof(hip.dm_conv_params) == 8 * 10
+    assert ctypes.sizeof(hip.dm_rssm_params) == 8 * 22
+
+
+def test_config_surface():
+    c = config.load_config('defaults', 'atari')
+    assert (c.batch_size, c.batch_length, c.deter_dim, c.kl_weight, c.gamma, c.entropy, c.action_dim) == (32, 48, 1024, 0.1, 0.99, 0.001, 18)
+    lit = config.atari_literal()
+    assert (lit.batch_size, lit.batch_length, lit.imag_horizon, lit.deter_dim, lit.stoch_dim, lit.stoch_discrete) == (50, 50, 15, 600, 32, 32)
+    dbg = config.load_config('defaults', 'atari', 'debug', batch_size=4, batch_length=10, imag_horizon=5, action_dim=6)
+    assert (dbg.batch_size, dbg.imag_horizon, dbg.action_dim) == (4, 5, 6)
+    with pytest.raises(KeyError):
+        config.load_config('defaults', nonexistent_key=1)
+    # oracle and product agree on every shared key
+    oc = O.make_conf(O.ATARI)
+    for k, v in vars(oc).items():
+        assert getattr(c, k) == v, k
+
+
+def test_state_dict_keys_match_reference_table():
+    """oracle.param_shapes was asserted key-for-key against the reference's state_dict by gen_golden.py."""
+    from pydreamer_amd.models import Dreamer
+    for oconf in (O.tiny_conf(), O.atari_literal_conf()):
+        shapes = O.param_shapes(oconf)
+        conf = config.load_config('defaults', 'atari', **vars(oconf))
+        with torch.device('meta'):
+            sd = Dreamer(conf).state_dict()
+        assert list(sd.keys()) == list(shapes.keys())
+        for k, s in shapes.items():
+            assert tuple(sd[k].shape) == tuple(s), k
+
+
+def test_unsupported_configs_fail_loudly():
+    from pydreamer_amd.models import Dreamer
+    for kw in (dict(iwae_samples=3), dict(gru_type='gru_layernorm'), dict(actor_dist='tanh_normal'), dict(actor_grad='dynamics'),
+               dict(image_size=32), dict(stoch_discrete=0), dict(layer_norm=False)):
+        conf = config.load_config('defaults', 'atari', **kw)
+        with pytest.raises(NotImplementedError):
+            Dreamer(conf)
+
+
+def test_workspace_and_acts_sizing():
+    lib = hip.lib()
+    tiny = hip.make_shape(T=5, B=3, I=1, H=4, D=64, Hd=64, S=8, C=8, E=256, A=6, mlp_hidden=400, mlp_layers=4,
+                          cnn_depth=8, img=64, img_ch=3, flags=0)
+    lit = hip.make_shape(T=50, B=50, I=1, H=15, D=600, Hd=1000, S=32, C=32, E=1536, A=18, mlp_hidden=400, mlp_layers=4,
+                         cnn_depth=48, img=64, img_ch=3, flags=0)
+    assert 64 << 20 <= hip.workspace_bytes(tiny) < 256 << 20
+    big = hip.workspace_bytes(lit)
+    assert 3 << 30 < big < 8 << 30, big          # dominated by the decoder layer-3 column matrix (2.9 GB) + grads
+    enc = int(lib.dm_conv_encoder_acts_floats(ctypes.byref(lit))) * 4
+    dec = int(lib.dm_conv_decoder_acts_floats(ctypes.byref(lit))) * 4
+    rssm = int(lib.dm_rssm_acts_floats(ctypes.byref(lit))) * 4
+    assert 2.5e9 < enc < 4e9 and 0.5e9 < dec < 1.5e9 and 0.1e9 < rssm < 0.3e9, (enc, dec, rssm)
+    assert int(lib.dm_mlp_acts_floats(2500, 400, 4)) >= 2500 * (400 * 2 + 2) * 4
+
+
+def test_shard_bounds_cover_batch():
+    for B in (50, 7, 8, 1):
+        for world in (1, 2, 4, 8):
+            spans = [DP.shard_bounds(B, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [hi - lo for lo, hi in (DP.shard_bounds(50, 8, r) for r in range(8))] == [7, 7, 6, 6, 6, 6, 6, 6]
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under pydreamer_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'pydreamer_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'dreamer_oracle' not in text, f
