@@ -1,0 +1,211 @@
+"""grad-steps/s of the DreamerV2 gradient step on MI355X (BASELINE.json metric), 1..N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic replay batch: Dreamer.training_step (world model fwd, dream,
+actor-critic fwd) -> zero_grad -> 4 x backward -> grad_clip -> 4 x AdamW, i.e. train.py:165-198 of the reference.
+Workload: BASELINE.json configs[1] "Atari defaults" at B=50,T=50,H=15, deter=600, stoch=32x32, fp32, offline synthetic
+replay already resident in HBM (a ring of pre-generated batches).  With N>1 the GLOBAL batch stays 50 and is sharded on
+the batch axis (7,7,6,6,6,6,6,6 at N=8) with one RCCL all-reduce per optimizer group -> "scaling": "strong".
+
+The JSON line also carries
+  roofline     : the GEMM kernel family (every dense contraction of the step runs on it), algorithmic 2MNK flops per
+                 launch / HIP-event launch durations recorded on the launch stream in a profiled pass of the same steps
+                 that directly follows the timed region (events are kept out of the timed region so `value` is unperturbed);
+                 peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline : oracle/dreamer_oracle.py (torch CPU restatement pinned to the reference by goldens, kind "port") timed
+                 on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = 'grad-steps/sec (world-model+AC) at B=50,T=50,H=15, 64×64 obs, 1/2/4/8 GPU'
+
+
+def make_ring(conf, b_local, n_batches, device, seed):
+    """Offline synthetic replay: uint8 frames -> x/255-0.5 CHW float, one-hot actions, tanh rewards."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    T, A = conf.batch_length, conf.action_dim
+    ring = []
+    for i in range(n_batches):
+        u8 = torch.randint(0, 256, (T, b_local, conf.image_size, conf.image_size, conf.image_channels), generator=g,
+                           device=device, dtype=torch.uint8)
+        image = u8.float().div_(255.0).sub_(0.5).permute(0, 1, 4, 2, 3).contiguous()
+        act = torch.randint(0, A, (T, b_local), generator=g, device=device)
+        action = torch.nn.functional.one_hot(act, A).float()
+        reward = torch.tanh(torch.randn(T, b_local, generator=g, device=device))
+        terminal = (torch.rand(T, b_local, generator=g, device=device) < 0.005).float()
+        reset = torch.zeros(T, b_local, dtype=torch.bool, device=device)
+        reset[0] = torch.rand(b_local, generator=g, device=device) < (1.0 / 200)
+        if i == 0:
+            reset[0, 0] = True
+        ring.append(dict(image=image, action=action, reward=reward, terminal=terminal, reset=reset))
+    return ring
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle (test infrastructure) as the CPU baseline: full Atari-literal grad steps on the host cores."""
+    from oracle import dreamer_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    tiny = O.tiny_conf()
+    warm = O.OracleDreamer(tiny, O.make_params(tiny))
+    warm.init_optimizers()
+    lw, *_ = warm.training_step(O.preprocess(O.synthetic_batch(tiny), tiny), warm.init_state(tiny.batch_size), O.make_noise(tiny))
+    warm.backward_clip_step(lw)
+    conf = O.atari_literal_conf()
+    model = O.OracleDreamer(conf, O.make_params(conf))
+    model.init_optimizers()
+    state = model.init_state(conf.batch_size)
+    obs = O.preprocess(O.synthetic_batch(conf), conf)
+    noise = O.make_noise(conf)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        losses, state, *_ = model.training_step(obs, state, noise)
+        model.backward_clip_step(losses)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= 10.0 or n >= 3 or el * (n + 1) / n > max_seconds:
+            break
+    return dict(value=n / el, unit='grad-steps/s', cores=cores, kind='port',
+                sample=f'{n} full grad step(s) (fwd + 4 bwd + clip + 4 AdamW) of the same Atari-literal batch, torch CPU fp32, '
+                       f'{cores} threads, {el:.1f} s, first step included')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--ring', type=int, default=8)
+    ap.add_argument('--prof-steps', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from pydreamer_amd import config, hip
+    from pydreamer_amd import dist as DP
+    from pydreamer_amd.models import Dreamer
+    hip.call('dm_device_check')
+
+    gconf = config.atari_literal()
+    B = gconf.batch_size
+    lo, hi = DP.shard_bounds(B, world, rank)
+    conf = config.atari_literal(batch_size=hi - lo)
+    torch.manual_seed(0)                               # identical replicas on every rank
+    model = Dreamer(conf).to(dev)
+    opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+    DP.attach(opts, hi - lo, B)
+    ring = make_ring(conf, hi - lo, args.ring, dev, 1234 + rank)
+    torch.manual_seed(777 + rank)                      # sampler uniforms
+    state = {'s': model.init_state(hi - lo)}
+
+    def step(i):
+        obs = ring[i % len(ring)]
+        losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'])
+        state['s'] = new_state                          # keep_state (train.py:177-178)
+        for opt in opts:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
+        model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+        for opt in opts:
+            opt.step()
+        return metrics
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        metrics = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_model = float(metrics['loss_model'])
+
+    # profiled pass: HIP events around every GEMM launch on the launch stream (same steps, right after the timed region)
+    roof = None
+    if args.prof_steps > 0:
+        hip.call('dm_prof_begin', 400000)
+        for i in range(args.prof_steps):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        out = (ctypes.c_double * 24)()
+        n = hip.lib().dm_prof_end(out, 8)
+        kinds = []
+        names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
+        for k in range(8):
+            cnt, fl, ms = out[3 * k], out[3 * k + 1], out[3 * k + 2]
+            if cnt:
+                kinds.append(dict(kernel=f"gemm_f32_kernel<{'128,128' if k >= 4 else '64,64'},{(k >> 1) & 1},{k & 1}>",
+                                  layout=names[k & 3], launches_per_step=cnt / args.prof_steps,
+                                  avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
+                                  ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12))
+        tot_fl = sum(out[3 * k + 1] for k in range(8))
+        tot_ms = sum(out[3 * k + 2] for k in range(8))
+        dom = max(kinds, key=lambda d: d['ms_per_step'])
+        peak = 157.3
+        roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=None,
+                    kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
+                    all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
+                                  gflop_per_step=tot_fl / 1e9 / args.prof_steps, ms_per_step=tot_ms / args.prof_steps,
+                                  launches_per_step=n / args.prof_steps),
+                    kinds=kinds, note='HIP events on the launch stream, profiled pass of the same steps after the timed region')
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        line = dict(metric=METRIC, value=args.steps / elapsed, unit='grad-steps/s', n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None,
+                    dtype='f32', data='synthetic',
+                    config=dict(workload='atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
+                                         'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, fp32; '
+                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM',
+                                global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
+                                parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
+                                algorithmic_tflop_per_step=2.76),
+                    loss_model_last=loss_model,
+                    step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

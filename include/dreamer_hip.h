@@ -228,6 +228,12 @@ int dm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* clip_coef, void* stream);
 int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* critic_target <- critic, a2c.py:151-152 */
+/* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
+ * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
+ * out[kind*3+{0,1,2}] = {launches, algorithmic flops (2MNK), milliseconds} for
+ * kind = (128x128 tile ? 4 : 0) + a_layout*2 + b_layout (8 kinds) and returns the number of launches recorded. */
+int dm_prof_begin(int max_launches);
+int dm_prof_end(double* out, int nkinds);
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
 

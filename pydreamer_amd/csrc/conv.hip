@@ -101,8 +101,8 @@ static inline int grid_for(size_t total) {
 }
 
 int dm_im2col_s2_launch(int n, int hb, int wb, int c, int k, const float* big, int big_nchw, float* col, hipStream_t st) {
-  DM_REQUIRE(hb >= k && wb >= k && ((hb - k) % 2) == 0 && ((wb - k) % 2) == 0, DM_E_SHAPE,
-             "im2col_s2: big %dx%d incompatible with k=%d stride 2", hb, wb, k);
+  // "valid" stride-2 geometry: a trailing row/column that no window reaches is simply never read (31 -> 14 at k=4)
+  DM_REQUIRE(hb >= k && wb >= k && k >= 1, DM_E_SHAPE, "im2col_s2: big %dx%d smaller than k=%d", hb, wb, k);
   const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
   const size_t total = (size_t)n * hs * ws * k * k * c;
   if (total == 0) return DM_OK;
@@ -121,8 +121,8 @@ int dm_im2col_s2_launch(int n, int hb, int wb, int c, int k, const float* big, i
 
 int dm_col2im_s2_launch(int n, int hb, int wb, int c, int k, const float* col, const float* bias, int flags,
                         const float* elu_ref, float* big, hipStream_t st) {
-  DM_REQUIRE(hb >= k && wb >= k && ((hb - k) % 2) == 0 && ((wb - k) % 2) == 0, DM_E_SHAPE,
-             "col2im_s2: big %dx%d incompatible with k=%d stride 2", hb, wb, k);
+  // rows/columns of `big` that no window reaches receive only the bias (zero gradient in the conv backward use)
+  DM_REQUIRE(hb >= k && wb >= k && k >= 1, DM_E_SHAPE, "col2im_s2: big %dx%d smaller than k=%d", hb, wb, k);
   const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
   const size_t total = (size_t)n * hb * wb * c;
   if (total == 0) return DM_OK;

@@ -238,6 +238,61 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs
   }
 }
 
+// ---- optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline line -------
+#include <vector>
+struct GemmProf {
+  bool on = false;
+  size_t cap = 0, n = 0;
+  std::vector<hipEvent_t> ev;      // 2 per slot
+  std::vector<double> flops;
+  std::vector<int> kind;
+};
+static GemmProf g_prof;
+static int prof_before(int kind, double flops, hipStream_t st) {
+  if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+  const int slot = (int)g_prof.n++;
+  g_prof.flops[slot] = flops;
+  g_prof.kind[slot] = kind;
+  (void)hipEventRecord(g_prof.ev[2 * slot], st);
+  return slot;
+}
+static void prof_after(int slot, hipStream_t st) {
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+}
+extern "C" int dm_prof_begin(int max_launches) {
+  DM_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), DM_E_SHAPE, "prof_begin: max_launches %d", max_launches);
+  if ((size_t)max_launches > g_prof.ev.size() / 2) {
+    const size_t have = g_prof.ev.size();
+    g_prof.ev.resize(2 * (size_t)max_launches);
+    for (size_t i = have; i < g_prof.ev.size(); ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return dm_fail(DM_E_HIP, "prof_begin: hipEventCreate failed");
+  }
+  g_prof.flops.assign(max_launches, 0.0);
+  g_prof.kind.assign(max_launches, 0);
+  g_prof.cap = max_launches;
+  g_prof.n = 0;
+  g_prof.on = true;
+  return DM_OK;
+}
+// out[kind*3 + {0,1,2}] = {launches, flops, milliseconds} for kind = (tile128 ? 4 : 0) + a_layout*2 + b_layout; returns
+// the number of recorded launches (negative on error).  Synchronises on the recorded events.
+extern "C" int dm_prof_end(double* out, int nkinds) {
+  DM_REQUIRE(out && nkinds >= 8, DM_E_SHAPE, "prof_end: need room for 8 kinds");
+  g_prof.on = false;
+  for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < g_prof.n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return dm_fail(DM_E_HIP, "prof_end: event sync failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      return dm_fail(DM_E_HIP, "prof_end: hipEventElapsedTime failed");
+    const int k = g_prof.kind[i];
+    out[k * 3 + 0] += 1.0;
+    out[k * 3 + 1] += g_prof.flops[i];
+    out[k * 3 + 2] += ms;
+  }
+  return (int)g_prof.n;
+}
+
 template <int BM, int BN>
 static void gemm_dispatch(const GemmKArgs& a, int al, int bl, dim3 grid, hipStream_t stream) {
   if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, stream, a);
@@ -288,8 +343,11 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.partial = nsplit > 1 ? (float*)ws : nullptr;
 
   dim3 grid((unsigned)tiles, (unsigned)nsplit);
+  const int kind = (big ? 4 : 0) + q.a_layout * 2 + q.b_layout;
+  const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
   if (big) gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, grid, stream);
   else gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, grid, stream);
+  prof_after(slot, stream);
   DM_LAUNCH_CHECK();
   if (nsplit > 1) {
     const size_t total = (size_t)q.M * q.N;

@@ -278,7 +278,7 @@ def test_mask_rows(hip):
 
 
 # ------------------------------------------------------------------------------------------- conv gathers
-@pytest.mark.parametrize('hb,c,k', [(14, 8, 4), (13, 16, 5), (30, 8, 6), (64, 3, 6), (5, 32, 5)])
+@pytest.mark.parametrize('hb,c,k', [(14, 8, 4), (13, 16, 5), (30, 8, 6), (64, 3, 6), (5, 32, 5), (31, 8, 4)])
 def test_im2col_col2im(hip, hb, c, k):
     n = 5
     hs = (hb - k) // 2 + 1
