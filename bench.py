@@ -55,17 +55,16 @@ def make_ring(conf, b_local, n_batches, device, seed):
     return ring
 
 
-def cpu_baseline(max_seconds=30.0):
-    """Oracle (test infrastructure) as the CPU baseline: full Atari-literal grad steps on the host cores."""
+def cpu_baseline(sample_batch=10, threads_cap=32):
+    """Oracle (test infrastructure) as the CPU baseline, on a bounded sample: `sample_batch` of the 50 batch columns
+    of the Atari-literal step (same T, H, model), scaled to grad-steps/s by sample_batch/50.  Threads are capped:
+    torch CPU with one thread per core of a 256-core host is two orders of magnitude SLOWER on these op sizes."""
     from oracle import dreamer_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    tiny = O.tiny_conf()
-    warm = O.OracleDreamer(tiny, O.make_params(tiny))
-    warm.init_optimizers()
-    lw, *_ = warm.training_step(O.preprocess(O.synthetic_batch(tiny), tiny), warm.init_state(tiny.batch_size), O.make_noise(tiny))
-    warm.backward_clip_step(lw)
-    conf = O.atari_literal_conf()
+    threads = min(cores, threads_cap)
+    torch.set_num_threads(threads)
+    full = O.atari_literal_conf()
+    conf = O.atari_literal_conf(batch_size=sample_batch)
     model = O.OracleDreamer(conf, O.make_params(conf))
     model.init_optimizers()
     state = model.init_state(conf.batch_size)
@@ -77,11 +76,13 @@ def cpu_baseline(max_seconds=30.0):
         model.backward_clip_step(losses)
         n += 1
         el = time.perf_counter() - t0
-        if el >= 10.0 or n >= 3 or el * (n + 1) / n > max_seconds:
+        if el >= 10.0 or n >= 4:
             break
-    return dict(value=n / el, unit='grad-steps/s', cores=cores, kind='port',
-                sample=f'{n} full grad step(s) (fwd + 4 bwd + clip + 4 AdamW) of the same Atari-literal batch, torch CPU fp32, '
-                       f'{cores} threads, {el:.1f} s, first step included')
+    frac = sample_batch / full.batch_size
+    return dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port', host_cores=cores,
+                sample=f'{n} grad step(s) (fwd + 4 bwd + clip + 4 AdamW) on {sample_batch} of the {full.batch_size} batch columns '
+                       f'(T=50, H=15, same model) in {el:.1f} s with {threads} torch threads, first step included; scaled by '
+                       f'{sample_batch}/{full.batch_size} to full-batch grad-steps/s')
 
 
 def main():
@@ -158,7 +159,7 @@ def main():
     # profiled pass: HIP events around every GEMM launch on the launch stream (same steps, right after the timed region)
     roof = None
     if args.prof_steps > 0:
-        hip.call('dm_prof_begin', 400000)
+        hip.call('dm_prof_begin', 8192 * args.prof_steps)     # ~4-5k GEMM launches per step at Atari-literal
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()

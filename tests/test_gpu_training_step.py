@@ -167,8 +167,9 @@ def _run_pair(oconf, steps, forced=False, seed=0):
             opt.zero_grad()
         for loss in lh:
             loss.backward()
-        gh = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None and v.requires_grad}
         gmh = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+        # like the oracle's, gradients are compared AFTER clip_grad_norm_ scaled them in place (norm > 200 for some seeds)
+        gh = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None and v.requires_grad}
         for opt in opts:
             opt.step()
         out.append(dict(lo=lo, lh=lh, mo={**mo, **gmo}, mh={**mh, **gmh}, to=to, th=th, xo=xo, xh=model.last_extras,
