@@ -55,13 +55,27 @@ def make_ring(conf, b_local, n_batches, device, seed):
     return ring
 
 
-def cpu_baseline(sample_batch=10, threads_cap=32):
-    """Oracle (test infrastructure) as the CPU baseline, on a bounded sample: `sample_batch` of the 50 batch columns
-    of the Atari-literal step (same T, H, model), scaled to grad-steps/s by sample_batch/50.  Threads are capped:
-    torch CPU with one thread per core of a 256-core host is two orders of magnitude SLOWER on these op sizes."""
-    from oracle import dreamer_oracle as O
+def _effective_cores():
+    """Host cores this process may really use: affinity mask capped by a cgroup CPU quota if there is one."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    threads = min(cores, threads_cap)
+    try:
+        q = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q[0] != 'max':
+            cores = max(1, min(cores, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                cores = max(1, min(cores, quota // period))
+        except Exception:
+            pass
+    return cores
+
+
+def cpu_baseline_worker(sample_batch, threads):
+    """Runs in a subprocess (see cpu_baseline): oracle grad steps on `sample_batch` of the 50 batch columns."""
+    from oracle import dreamer_oracle as O
     torch.set_num_threads(threads)
     full = O.atari_literal_conf()
     conf = O.atari_literal_conf(batch_size=sample_batch)
@@ -79,13 +93,35 @@ def cpu_baseline(sample_batch=10, threads_cap=32):
         if el >= 10.0 or n >= 4:
             break
     frac = sample_batch / full.batch_size
-    return dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port', host_cores=cores,
-                sample=f'{n} grad step(s) (fwd + 4 bwd + clip + 4 AdamW) on {sample_batch} of the {full.batch_size} batch columns '
-                       f'(T=50, H=15, same model) in {el:.1f} s with {threads} torch threads, first step included; scaled by '
-                       f'{sample_batch}/{full.batch_size} to full-batch grad-steps/s')
+    print(json.dumps(dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port',
+                          sample=f'{n} grad step(s) (fwd + 4 bwd + clip + 4 AdamW) on {sample_batch} of the {full.batch_size} batch '
+                                 f'columns (T=50, H=15, same model) in {el:.1f} s with {threads} torch threads, first step '
+                                 f'included; scaled by {sample_batch}/{full.batch_size} to full-batch grad-steps/s')))
+
+
+def cpu_baseline(sample_batch=5, threads_cap=32, timeout_s=150):
+    """Oracle (test infrastructure, kind "port") as the CPU baseline on a bounded sample, in a subprocess with a hard
+    timeout so a pathological host (thread oversubscription cost 889 s for one step in the first run of this round)
+    can never stall the bench; returns a dict with value=None and the reason if it does not finish."""
+    import subprocess
+    cores = _effective_cores()
+    threads = max(1, min(cores, threads_cap))
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(sample_batch), str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+        res = json.loads(line)
+        res['host_cores'] = cores
+        return res
+    except Exception as e:       # timeout or crash: report, never hang
+        return dict(value=None, unit='grad-steps/s', cores=threads, kind='port', host_cores=cores,
+                    sample=f'oracle sample of {sample_batch}/50 batch columns did not finish within {timeout_s} s ({type(e).__name__})')
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == '--cpu-baseline-worker':
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)

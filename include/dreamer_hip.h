@@ -190,10 +190,13 @@ int dm_rssm_sequence_bwd(const dm_shape* shp, const float* embed, const float* a
                          const dm_rssm_grads* g, float* dembed, void* ws, size_t ws_bytes, void* stream);
 
 /* Imagination rollout (dreamer.py:188-216, rssm.py:155-184, a2c.py:43-55), no autograd graph (actor_grad=reinforce).
- * start (M,F) = [h|z] rows; feats (H+1,M,F); actions one-hot (H,M,A); act_idx (H,M); u_act (H,M); u_prior (H,M,S). */
+ * start (M,F) = [h|z] rows; feats (H+1,M,F); actions one-hot (H,M,A); act_idx (H,M); u_act (H,M); u_prior (H,M,S).
+ * actor_acts (dm_mlp_acts_floats(H*M, hidden, layers) floats) + actor_logits (H*M, A): optional (both or neither);
+ * when given, the actor activations of all H steps are kept for dm_mlp_head_bwd (rows = H*M). */
 int dm_dream_rollout(const dm_shape* shp, int M, const float* start, const dm_rssm_params* cell,
                      const dm_mlp_params* actor, const float* u_act, const float* u_prior,
-                     float* feats, float* actions, int32_t* act_idx, void* ws, size_t ws_bytes, void* stream);
+                     float* feats, float* actions, int32_t* act_idx, float* actor_acts, float* actor_logits,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* GAE + reality weight (a2c.py:81-108). All (J,M)/(H,M) row-major with J=H+1. */
 int dm_gae_losses(int H, int M, float gamma, float lambda, const float* reward, const float* terminal,

@@ -93,7 +93,8 @@ int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int
 
 // fused MLP (mlp.hip)
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
-                      const dm_mlp_params* p, float* acts, float* out, int ldout, void* ws, size_t ws_bytes, hipStream_t st);
+                      const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
+                      void* ws, size_t ws_bytes, hipStream_t st);
 
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;

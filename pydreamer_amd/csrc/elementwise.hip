@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) ln_elu_bwd_dx_kernel(int rows, int n, con
 }
 
 // Column partial sums over row chunks.  MODE 0: sum x.  MODE 1: LayerNorm dgamma/dbeta.
-// Block = 64 columns x 4 row lanes; partial[(chunk*nq + q)*n + col].
+// Block = 64 columns x 4 row lanes, 4 independent accumulators per thread; partial[(chunk*nq + q)*n + col].
 template <int MODE>
 __global__ void __launch_bounds__(256) colsum_partial_kernel(int rows, int n, int rows_per_chunk,
                                                              const float* __restrict__ x, int ldx,
@@ -81,10 +81,19 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(int rows, int n, in
   const int r1 = min(rows, r0 + rows_per_chunk);
   float a0 = 0.f, a1 = 0.f;
   if (col < n) {
-    for (int r = r0 + ry; r < r1; r += 4) {
-      if (MODE == 0) {
-        a0 += x[(size_t)r * ldx + col];
-      } else {
+    if (MODE == 0) {
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      int r = r0 + ry;
+      for (; r + 12 < r1; r += 16) {
+        b0 += x[(size_t)r * ldx + col];
+        b1 += x[(size_t)(r + 4) * ldx + col];
+        b2 += x[(size_t)(r + 8) * ldx + col];
+        b3 += x[(size_t)(r + 12) * ldx + col];
+      }
+      for (; r < r1; r += 4) b0 += x[(size_t)r * ldx + col];
+      a0 = (b0 + b1) + (b2 + b3);
+    } else {
+      for (int r = r0 + ry; r < r1; r += 4) {
         const float dl = dy[(size_t)r * lddy + col] * dm_elu_grad_from_y(y[(size_t)r * ldy + col]);
         const float xh = (x[(size_t)r * ldx + col] - stats[2 * r]) * stats[2 * r + 1];
         a0 += dl * xh;   // dgamma
@@ -106,20 +115,60 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(int rows, int n, in
   }
 }
 
-__global__ void __launch_bounds__(256) colsum_final_kernel(int n, int chunks, int nq, const float* __restrict__ partial,
-                                                           float* __restrict__ out0, float* __restrict__ out1) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= n) return;
-  for (int q = 0; q < nq; ++q) {
+// Narrow dense matrices (n <= 64, ld == n; conv bias gradients over millions of pixels): the matrix is walked as a
+// flat array with a per-iteration stride that is a multiple of n, so every thread stays on ONE column and every
+// wave reads 256 contiguous bytes.  partial[chunk*n + col]; fixed reduction order.
+__global__ void __launch_bounds__(256) colsum_flat_kernel(long long total, int n, long long chunk_elems,
+                                                          const float* __restrict__ x, float* __restrict__ partial) {
+  __shared__ float sh[256];
+  const long long base = (long long)blockIdx.x * chunk_elems;
+  const long long end = min(total, base + chunk_elems);
+  const long long stride = 256LL * n;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  long long i = base + threadIdx.x;
+  for (; i + 3 * stride < end; i += 4 * stride) {
+    b0 += x[i];
+    b1 += x[i + stride];
+    b2 += x[i + 2 * stride];
+    b3 += x[i + 3 * stride];
+  }
+  for (; i < end; i += stride) b0 += x[i];
+  sh[threadIdx.x] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[((size_t)c * nq + q) * n + col];
-    (q == 0 ? out0 : out1)[col] = s;
+    for (int t = threadIdx.x; t < 256; t += n) s += sh[t];   // threads t == col (mod n) hold column `col`
+    partial[(size_t)blockIdx.x * n + threadIdx.x] = s;
   }
 }
 
-static int colsum_plan(int rows, int* rows_per_chunk) {
-  int chunks = dm_cdiv(rows, 32);
-  if (chunks > 256) chunks = 256;
+// out_q[col] = sum_chunks partial[(c*nq+q)*n + col]; block = 32 columns x 8 chunk lanes
+__global__ void __launch_bounds__(256) colsum_final_kernel(int n, int chunks, int nq, const float* __restrict__ partial,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, cy = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  for (int q = 0; q < nq; ++q) {
+    float s = 0.f;
+    if (col < n)
+      for (int c = cy; c < chunks; c += 8) s += partial[((size_t)c * nq + q) * n + col];
+    red[cy][cx] = s;
+    __syncthreads();
+    if (cy == 0 && col < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][cx];
+      (q == 0 ? out0 : out1)[col] = t;
+    }
+    __syncthreads();
+  }
+}
+
+static int colsum_plan(int rows, size_t budget_floats, int n, int nq, int* rows_per_chunk) {
+  int chunks = dm_cdiv(rows, 64);
+  if (chunks > 1024) chunks = 1024;
+  const size_t per = (size_t)n * nq;
+  if (per > 0 && (size_t)chunks * per > budget_floats) chunks = (int)(budget_floats / per);
   if (chunks < 1) chunks = 1;
   *rows_per_chunk = dm_cdiv(rows, chunks);
   return dm_cdiv(rows, *rows_per_chunk);
@@ -127,17 +176,31 @@ static int colsum_plan(int rows, int* rows_per_chunk) {
 
 int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (n <= 0) return DM_OK;
-  int rpc;
-  const int chunks = rows > 0 ? colsum_plan(rows, &rpc) : 0;
-  if (chunks == 0) {
+  if (rows <= 0) {
     (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st);
     return DM_OK;
   }
-  DM_REQUIRE(ws && (size_t)chunks * n * sizeof(float) <= ws_bytes, DM_E_WORKSPACE, "colsum: workspace too small");
-  hipLaunchKernelGGL((colsum_partial_kernel<0>), dim3(dm_cdiv(n, 64), chunks), dim3(256), 0, st, rows, n, rpc, x, ld,
-                     nullptr, 0, nullptr, nullptr, 0, (float*)ws);
+  DM_REQUIRE(ws && ws_bytes >= (size_t)n * sizeof(float), DM_E_WORKSPACE, "colsum: workspace too small");
+  const size_t budget = ws_bytes / sizeof(float);
+  int chunks;
+  if (n <= 64 && ld == n && (long long)rows * n >= (1 << 16)) {
+    const long long total = (long long)rows * n;
+    long long want = total / (256LL * n * 8);            // ~8 strided iterations per thread
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    if ((size_t)want * n > budget) want = (long long)(budget / n);
+    long long chunk_elems = (total + want - 1) / want;
+    chunk_elems = (chunk_elems + 256LL * n - 1) / (256LL * n) * (256LL * n);   // multiple of 256*n (hence of n)
+    chunks = (int)((total + chunk_elems - 1) / chunk_elems);
+    hipLaunchKernelGGL(colsum_flat_kernel, dim3(chunks), dim3(256), 0, st, total, n, chunk_elems, x, (float*)ws);
+  } else {
+    int rpc;
+    chunks = colsum_plan(rows, budget, n, 1, &rpc);
+    hipLaunchKernelGGL((colsum_partial_kernel<0>), dim3(dm_cdiv(n, 64), chunks), dim3(256), 0, st, rows, n, rpc, x, ld,
+                       nullptr, 0, nullptr, nullptr, 0, (float*)ws);
+  }
   DM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 256)), dim3(256), 0, st, n, chunks, 1, (const float*)ws, out,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 32)), dim3(256), 0, st, n, chunks, 1, (const float*)ws, out,
                      nullptr);
   DM_LAUNCH_CHECK();
   return DM_OK;
@@ -167,12 +230,12 @@ int dm_ln_elu_bwd_params_launch(int rows, int n, const float* x, int ldx, const 
                                 const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                 hipStream_t st) {
   int rpc;
-  const int chunks = colsum_plan(rows, &rpc);
-  DM_REQUIRE(ws && (size_t)chunks * 2 * n * sizeof(float) <= ws_bytes, DM_E_WORKSPACE, "ln_bwd: workspace too small");
+  DM_REQUIRE(ws && ws_bytes >= (size_t)2 * n * sizeof(float), DM_E_WORKSPACE, "ln_bwd: workspace too small");
+  const int chunks = colsum_plan(rows, ws_bytes / sizeof(float), n, 2, &rpc);
   hipLaunchKernelGGL((colsum_partial_kernel<1>), dim3(dm_cdiv(n, 64), chunks), dim3(256), 0, st, rows, n, rpc, x, ldx, y,
                      ldy, stats, dy, lddy, (float*)ws);
   DM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 256)), dim3(256), 0, st, n, chunks, 2, (const float*)ws, dgamma,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(dm_cdiv(n, 32)), dim3(256), 0, st, n, chunks, 2, (const float*)ws, dgamma,
                      dbeta);
   DM_LAUNCH_CHECK();
   return DM_OK;
@@ -329,11 +392,69 @@ __global__ void __launch_bounds__(256) sample_onehot_kernel(int rows, int groups
   }
 }
 
+// Same rule, LPG lanes per group (power of two >= C): lane k owns category k, so logits are read and the one-hot is
+// written coalesced.  The sums that define the rule stay SEQUENTIAL in k (a chain of C adds fed by lane broadcasts),
+// so the result is bit-identical to sample_onehot_kernel; only max (order independent) uses a butterfly.
+template <int LPG>
+__global__ void __launch_bounds__(256) sample_onehot_wave_kernel(int rows, int groups, int C,
+                                                                 const float* __restrict__ logits, int ldl,
+                                                                 const float* __restrict__ u,
+                                                                 const int32_t* __restrict__ forced,
+                                                                 float* __restrict__ onehot, int ldo,
+                                                                 int32_t* __restrict__ idx_out) {
+  constexpr int GPB = 256 / LPG;
+  const int k = threadIdx.x % LPG;
+  const int lane = threadIdx.x & 63;
+  const int gbase = lane - k;                              // first lane of this group inside the wave
+  const int total = rows * groups;
+  for (int i0 = blockIdx.x * GPB; i0 < total; i0 += gridDim.x * GPB) {
+    const int i = i0 + threadIdx.x / LPG;
+    const bool grp = i < total;
+    const bool live = grp && k < C;
+    const int r = grp ? i / groups : 0, gq = grp ? i % groups : 0;
+    const size_t off = (size_t)gq * C + k;
+    int idx = 0;
+    if (forced) {
+      idx = grp ? forced[i] : 0;
+    } else {
+      const float x = live ? logits[(size_t)r * ldl + off] : -INFINITY;
+      float mx = x;
+#pragma unroll
+      for (int o = LPG / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float e = live ? expf(x - mx) : 0.f;
+      float sum = 0.f;
+      for (int j = 0; j < C; ++j) sum += __shfl(e, gbase + j, 64);
+      const float p = e / sum;
+      float total_p = 0.f;
+      for (int j = 0; j < C; ++j) total_p += __shfl(p, gbase + j, 64);
+      const float target = (grp ? u[i] : 0.f) * total_p;
+      float cdf = 0.f;
+      for (int j = 0; j < C; ++j) {
+        cdf += __shfl(p, gbase + j, 64);
+        idx += (cdf <= target) ? 1 : 0;
+      }
+      if (idx > C - 1) idx = C - 1;
+    }
+    if (live) onehot[(size_t)r * ldo + off] = (k == idx) ? 1.f : 0.f;
+    if (grp && k == 0 && idx_out) idx_out[i] = idx;
+  }
+}
+
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                             const int32_t* forced, float* onehot, int ldo, int32_t* idx, hipStream_t st) {
   if (rows <= 0) return DM_OK;
-  hipLaunchKernelGGL(sample_onehot_kernel, dim3(ew_blocks((size_t)rows * groups)), dim3(256), 0, st, rows, groups, C,
-                     logits, ldl, u, forced, onehot, ldo, idx);
+  const size_t tg = (size_t)rows * groups;
+#define DM_SAMPLE_WAVE(L)                                                                                              \
+  hipLaunchKernelGGL((sample_onehot_wave_kernel<L>), dim3(ew_blocks(tg * L)), dim3(256), 0, st, rows, groups, C, logits, \
+                     ldl, u, forced, onehot, ldo, idx)
+  if (C <= 8) DM_SAMPLE_WAVE(8);
+  else if (C <= 16) DM_SAMPLE_WAVE(16);
+  else if (C <= 32) DM_SAMPLE_WAVE(32);
+  else if (C <= 64) DM_SAMPLE_WAVE(64);
+  else
+    hipLaunchKernelGGL(sample_onehot_kernel, dim3(ew_blocks(tg)), dim3(256), 0, st, rows, groups, C, logits, ldl, u, forced,
+                       onehot, ldo, idx);
+#undef DM_SAMPLE_WAVE
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -409,21 +530,37 @@ __global__ void __launch_bounds__(256) kl_bwd_kernel(int rows, int S, int C, con
 }
 
 // straight-through: sample = onehot + (p - sg(p)) => dlogits_k = p_k (g_k - sum_j p_j g_j)
+// LPG lanes per group (power of two >= C, <= 64): lane k of a group owns category k; reductions are xor-shuffles
+// inside the group's lanes, so the 50-row RSSM steps cost one short wave each instead of a 96-expf serial chain.
+template <int LPG>
 __global__ void __launch_bounds__(256) st_softmax_bwd_kernel(int rows, int groups, int C, const float* __restrict__ logits,
                                                              int ldl, const float* __restrict__ dz, int lddz,
                                                              float* __restrict__ dlogits, int lddl, int accum) {
+  constexpr int GPB = 256 / LPG;                      // groups per block
+  const int k = threadIdx.x % LPG;
   const int total = rows * groups;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int r = i / groups, gq = i % groups;
-    const float* x = logits + (size_t)r * ldl + (size_t)gq * C;
-    const float* g = dz + (size_t)r * lddz + (size_t)gq * C;
-    float* o = dlogits + (size_t)r * lddl + (size_t)gq * C;
-    const float l = dm_group_lse(x, C);
-    float dot = 0.f;
-    for (int k = 0; k < C; ++k) dot += expf(x[k] - l) * g[k];
-    for (int k = 0; k < C; ++k) {
-      const float v = expf(x[k] - l) * (g[k] - dot);
-      o[k] = accum ? o[k] + v : v;
+  for (int i0 = blockIdx.x * GPB; i0 < total; i0 += gridDim.x * GPB) {
+    const int i = i0 + threadIdx.x / LPG;
+    const bool live = i < total && k < C;
+    const int r = live ? i / groups : 0, gq = live ? i % groups : 0;
+    const size_t off = (size_t)gq * C + k;
+    const float x = live ? logits[(size_t)r * ldl + off] : -INFINITY;
+    const float g = live ? dz[(size_t)r * lddz + off] : 0.f;
+    float mx = x;
+#pragma unroll
+    for (int o = LPG / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = live ? expf(x - mx) : 0.f;
+    float se = e, sg = e * g;
+#pragma unroll
+    for (int o = LPG / 2; o > 0; o >>= 1) {
+      se += __shfl_xor(se, o, 64);
+      sg += __shfl_xor(sg, o, 64);
+    }
+    if (live) {
+      const float p = e / se;
+      const float v = p * (g - sg / se);
+      float* o = dlogits + (size_t)r * lddl + off;
+      *o = accum ? *o + v : v;
     }
   }
 }
@@ -446,8 +583,12 @@ int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* pri
 int dm_st_softmax_bwd_launch(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
                              float* dlogits, int lddl, int accum, hipStream_t st) {
   if (rows <= 0) return DM_OK;
-  hipLaunchKernelGGL(st_softmax_bwd_kernel, dim3(ew_blocks((size_t)rows * groups)), dim3(256), 0, st, rows, groups, C,
-                     logits, ldl, dz, lddz, dlogits, lddl, accum);
+  DM_REQUIRE(C >= 1 && C <= 64, DM_E_SHAPE, "st_softmax_bwd: C=%d not in [1,64]", C);
+  const size_t tg = (size_t)rows * groups;
+  if (C <= 8) hipLaunchKernelGGL((st_softmax_bwd_kernel<8>), dim3(ew_blocks(tg * 8)), dim3(256), 0, st, rows, groups, C, logits, ldl, dz, lddz, dlogits, lddl, accum);
+  else if (C <= 16) hipLaunchKernelGGL((st_softmax_bwd_kernel<16>), dim3(ew_blocks(tg * 16)), dim3(256), 0, st, rows, groups, C, logits, ldl, dz, lddz, dlogits, lddl, accum);
+  else if (C <= 32) hipLaunchKernelGGL((st_softmax_bwd_kernel<32>), dim3(ew_blocks(tg * 32)), dim3(256), 0, st, rows, groups, C, logits, ldl, dz, lddz, dlogits, lddl, accum);
+  else hipLaunchKernelGGL((st_softmax_bwd_kernel<64>), dim3(ew_blocks(tg * 64)), dim3(256), 0, st, rows, groups, C, logits, ldl, dz, lddz, dlogits, lddl, accum);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -19,6 +19,7 @@
 // feed k = 8g + j and lanes 32-63 feed k = 8g + 4 + j at step j (0..3); A and B therefore always agree.
 // Global loads of tile t+1 are issued into registers before the MFMAs of tile t (register prefetch).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -319,22 +320,51 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.lda & 3) == 0) ? 1 : 0;
   a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.ldb & 3) == 0) ? 1 : 0;
 
-  const int64_t t128 = (int64_t)dm_cdiv(q.M, 128) * dm_cdiv(q.N, 128);
-  const bool big = t128 >= 192;
-  const int BM = big ? 128 : 64, BN = BM;
+  // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
+  // Candidates in order of per-tile MFMA efficiency: 128x128 (64 MFMA per fragment fetch group), 128x64, 64x64.
+  // A 128-wide tile dimension is only considered when that dimension is >= 96 (else >25 % of the tile is padding).
+  // Split-K is allowed up to the point where the partial-sum traffic (nsplit*M*N) reaches 1/4 of the operand
+  // traffic ((M+N)*K): long reductions with small outputs (weight gradients, 50-row RSSM steps) split deeply,
+  // square-ish GEMMs never do.  The first candidate that yields >= 192 workgroups wins, else the one with the most.
+  const int ktiles = dm_cdiv(q.K, 32);
+  const double out_elems = (double)q.M * q.N;
+  int max_split = (int)(0.25 * ((double)q.M + q.N) * q.K / (out_elems > 0 ? out_elems : 1));
+  if (max_split > ktiles / 2) max_split = ktiles / 2;
+  if (max_split > 512) max_split = 512;
+  {
+    const size_t per = (size_t)q.M * q.N * sizeof(float);
+    if (ws == nullptr) max_split = 1;
+    else if ((size_t)max_split * per > ws_bytes) max_split = (int)(ws_bytes / per);
+  }
+  if (max_split < 1) max_split = 1;
+  static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  // tuning overrides for scripts/gemm_bench.py only (unset in production): DM_GEMM_TILE=1|2|3 forces a candidate,
+  // DM_GEMM_SPLIT=n forces the split count
+  static const int force_tile = getenv("DM_GEMM_TILE") ? atoi(getenv("DM_GEMM_TILE")) : 0;
+  static const int force_split = getenv("DM_GEMM_SPLIT") ? atoi(getenv("DM_GEMM_SPLIT")) : 0;
+  int BM = 64, BN = 64, nsplit = 1;
+  int64_t best_blocks = -1;
+  for (int c = 0; c < 3; ++c) {
+    const int bm = cand[c][0], bn = cand[c][1];
+    if (force_tile) {
+      if (c != force_tile - 1) continue;
+    } else {
+      if (bm == 128 && q.M < 96) continue;
+      if (bn == 128 && q.N < 96) continue;
+    }
+    const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
+    int sp = 1;
+    if (t < 256) {
+      sp = dm_cdiv(512, t);
+      if (sp > max_split) sp = max_split;
+    }
+    if (force_split > 0) sp = force_split <= (ktiles > 0 ? ktiles : 1) ? force_split : (ktiles > 0 ? ktiles : 1);
+    const int64_t blocks = t * sp;
+    if (blocks >= 192) { BM = bm; BN = bn; nsplit = sp; best_blocks = blocks; break; }
+    if (blocks > best_blocks) { BM = bm; BN = bn; nsplit = sp; best_blocks = blocks; }
+  }
   const int tiles_m = dm_cdiv(q.M, BM), tiles_n = dm_cdiv(q.N, BN);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
-  const int ktiles = dm_cdiv(q.K, 32);
-  int nsplit = 1;
-  if (tiles < 256 && ktiles >= 8) {
-    int want = dm_cdiv(512, tiles);
-    nsplit = want < ktiles / 4 ? want : ktiles / 4;
-    if (nsplit > 64) nsplit = 64;
-    const size_t per = (size_t)q.M * q.N * sizeof(float);
-    if (ws == nullptr || per == 0) nsplit = 1;
-    else if ((size_t)nsplit * per > ws_bytes) nsplit = (int)(ws_bytes / per);
-    if (nsplit < 2) nsplit = 1;
-  }
   int k_per_split = dm_cdiv(ktiles > 0 ? ktiles : 1, nsplit) * 32;
   nsplit = q.K > 0 ? dm_cdiv(q.K, k_per_split) : 1;
   a.k_per_split = k_per_split;
@@ -343,9 +373,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.partial = nsplit > 1 ? (float*)ws : nullptr;
 
   dim3 grid((unsigned)tiles, (unsigned)nsplit);
-  const int kind = (big ? 4 : 0) + q.a_layout * 2 + q.b_layout;
+  const int kind = (BM == 128 ? 4 : 0) + q.a_layout * 2 + q.b_layout;
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
-  if (big) gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, grid, stream);
+  if (BM == 128 && BN == 128) gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, grid, stream);
+  else if (BM == 128) gemm_dispatch<128, 64>(a, q.a_layout, q.b_layout, grid, stream);
   else gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, grid, stream);
   prof_after(slot, stream);
   DM_LAUNCH_CHECK();

@@ -23,13 +23,21 @@ extern "C" size_t dm_mlp_acts_floats(int rows, int hidden, int layers) {
   return mlp_carve(rows, hidden, layers, nullptr, nullptr);
 }
 
+// `acts` is carved for acts_total_rows rows; this call fills rows [acts_row_off, acts_row_off + rows) of every
+// per-layer array (the imagination rollout writes one horizon step at a time into one (H*M)-row activation set).
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
-                      const dm_mlp_params* p, float* acts, float* out, int ldout, void* ws, size_t ws_bytes,
-                      hipStream_t st) {
+                      const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
+  DM_REQUIRE(acts_row_off >= 0 && acts_row_off + rows <= acts_total_rows, DM_E_SHAPE, "mlp_fwd: acts row window");
   MlpActs a;
-  mlp_carve(rows, hidden, layers, acts, &a);
+  mlp_carve(acts_total_rows, hidden, layers, acts, &a);
+  for (int l = 0; l < layers; ++l) {
+    a.xpre[l] += (size_t)acts_row_off * hidden;
+    a.stats[l] += (size_t)acts_row_off * 2;
+    a.y[l] += (size_t)acts_row_off * hidden;
+  }
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   const float* in = x;
   int ldin = ldx, kin = in_dim;
@@ -57,7 +65,7 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
 extern "C" int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                                const dm_mlp_params* p, float* acts, float* out, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(x && p && acts && out && ws, DM_E_NULL, "mlp_head_fwd: null pointer");
-  return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, out, out_dim, ws, ws_bytes,
+  return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, rows, 0, out, out_dim, ws, ws_bytes,
                            (hipStream_t)stream);
 }
 

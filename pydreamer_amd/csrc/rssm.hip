@@ -224,7 +224,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
 // ---------------------------------------------------------------- imagination -------------------
 extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, const dm_rssm_params* P,
                                 const dm_mlp_params* actor, const float* u_act, const float* u_prior, float* feats,
-                                float* actions, int32_t* act_idx, void* ws, size_t ws_bytes, void* stream) {
+                                float* actions, int32_t* act_idx, float* actor_acts, float* actor_logits, void* ws,
+                                size_t ws_bytes, void* stream) {
   DM_REQUIRE(s && start && P && actor && u_act && u_prior && feats && actions && ws, DM_E_NULL,
              "dream_rollout: null pointer");
   DM_TRY(rssm_check(s));
@@ -236,8 +237,10 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
 
   DmArena ar(ws, ws_bytes);
   float* sk = ar.take(DM_SPLITK_FLOATS);
-  float* macts = ar.take(dm_mlp_acts_floats(M, Hm, L));
-  float* logits = ar.take((size_t)M * A);
+  DM_REQUIRE((actor_acts == nullptr) == (actor_logits == nullptr), DM_E_NULL,
+             "dream_rollout: actor_acts and actor_logits must be given together");
+  float* macts = ar.take(actor_acts ? 0 : dm_mlp_acts_floats(M, Hm, L));
+  float* logits_ws = ar.take(actor_acts ? 0 : (size_t)M * A);
   float* ea = ar.take((size_t)M * Hd);
   float* x1 = ar.take((size_t)M * Hd);
   float* za = ar.take((size_t)M * Hd);
@@ -255,7 +258,11 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     float* nxt = feats + (size_t)(i + 1) * M * F;
     float* act = actions + (size_t)i * M * A;
     // action ~ OneHotCategorical(actor(feature))                                        dreamer.py:195-200
-    DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, macts, logits, A, sk, skb, st));
+    // with actor_acts the activations of all H steps are kept (rows i*M..) so ActorCritic's policy-gradient backward
+    // reuses them instead of recomputing forward_actor(features[:-1]) (the reference's own TODO, a2c.py:119)
+    float* logits = actor_acts ? actor_logits + (size_t)i * M * A : logits_ws;
+    if (actor_acts) DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, actor_acts, H * M, i * M, logits, A, sk, skb, st));
+    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, macts, M, 0, logits, A, sk, skb, st));
     DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
                                    act_idx ? act_idx + (size_t)i * M : nullptr, st));
     // cell.forward_prior(action, None, (h, z))                                          rssm.py:155-184

@@ -105,7 +105,7 @@ _SIGNATURES = {
     'dm_rssm_sequence_bwd': (c_int, [POINTER(dm_shape), _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P, _P, _P, _P,
                                      POINTER(dm_rssm_grads), _P, _P, c_size_t, _P]),
     'dm_dream_rollout': (c_int, [POINTER(dm_shape), c_int, _P, POINTER(dm_rssm_params), POINTER(dm_mlp_params), _P, _P,
-                                 _P, _P, _P, _P, c_size_t, _P]),
+                                 _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'dm_gae_losses': (c_int, [c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     'dm_actor_loss': (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     'dm_critic_loss': (c_int, [c_int, _P, _P, _P, c_float, _P, _P, _P]),

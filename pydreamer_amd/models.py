@@ -619,8 +619,11 @@ class ActorCritic(_Params):
             for dst, src in zip(self.critic_target.parameters(), self.critic.parameters()):
                 H.call('dm_copy_params', H.fptr(dst), H.fptr(src), dst.numel(), H.stream())
 
-    def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None):
-        """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149."""
+    def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None,
+                      actor_acts=None, actor_logits=None):
+        """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149.
+        actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
+        features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
         _require_cuda(features, 'features')
         if not log_only:
             if self.train_steps % self.target_interval == 0:
@@ -638,7 +641,10 @@ class ActorCritic(_Params):
 
         value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws)
         value, c_acts = self.critic.fwd(feats, F_, J * M, ws)
-        logits, a_acts = self.actor.fwd(feats, F_, Hh * M, ws)       # features[:-1] = first H*M rows
+        if actor_acts is not None:
+            logits, a_acts = actor_logits, actor_acts
+        else:
+            logits, a_acts = self.actor.fwd(feats, F_, Hh * M, ws)   # features[:-1] = first H*M rows
         adv, agae, vtgt, wgt = (torch.empty(Hh, M, device=dev) for _ in range(4))
         H.call('dm_gae_losses', Hh, M, self.gamma, self.lambda_, H.fptr(rewards), H.fptr(terminals), H.fptr(value_t),
                H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
@@ -756,9 +762,13 @@ class Dreamer(nn.Module):
         act_idx = torch.empty(Hh, M, dtype=torch.int32, device=dev)
         cell_p = H.rssm_struct(self.wm.core.cell.ordered())
         actor_p = self.ac.actor.struct()
+        a_acts = a_logits = None
+        if _pack is not None:          # training: keep the actor activations of all H steps for the policy-gradient backward
+            a_acts = torch.empty(self.ac.actor.acts_floats(Hh * M), device=dev)
+            a_logits = torch.empty(Hh * M, A, device=dev)
         H.call('dm_dream_rollout', ctypes.byref(shp), M, H.fptr(start), ctypes.byref(cell_p), ctypes.byref(actor_p),
                H.fptr(u_act.contiguous()), H.fptr(u_prior.contiguous()), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
-               H.ptr(ws), ws.numel(), H.stream())
+               H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
         rows = (Hh + 1) * M
         f2 = feats.view(rows, F_)
         mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws)
@@ -766,7 +776,7 @@ class Dreamer(nn.Module):
         term = torch.empty(rows, device=dev)
         H.call('dm_head_loss', 1, rows, H.fptr(tl), None, 0.0, 0.0, None, None, H.fptr(term), H.stream())
         if _pack is not None:
-            _pack.update(act_idx=act_idx, ws=ws)
+            _pack.update(act_idx=act_idx, ws=ws, actor_acts=a_acts, actor_logits=a_logits)
         return feats, actions, _Mean(mu.view(Hh + 1, M)), _Mean(term.view(Hh + 1, M))
 
     # ---- training step (dreamer.py:113-186)
@@ -802,7 +812,8 @@ class Dreamer(nn.Module):
             self._dream_from_features(pk['feat'], imag_horizon, noise.get('u_act'), noise.get('u_prior'), _pack=dpk)
         (loss_actor, loss_critic), metrics_ac, tensors_ac = \
             self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
-                                  act_idx=dpk['act_idx'], ws=dpk['ws'])
+                                  act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
+                                  actor_logits=dpk['actor_logits'])
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], dream_features=features_dream,

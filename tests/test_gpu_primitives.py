@@ -139,12 +139,14 @@ def test_ln_elu_fwd_bwd(hip, rows, n):
     _close(db, bd.grad, 1e-4, 1e-4 * np.sqrt(rows), 'ln_elu dbeta')
 
 
-def test_colsum(hip):
-    x = _rand(2500, 1800, seed=5)
-    out = torch.empty(1800, device=DEV)
+@pytest.mark.parametrize('rows,n', [(2500, 1800), (200000, 48), (1000003, 3), (40000, 1), (70000, 64), (300, 7)])
+def test_colsum(hip, rows, n):
+    """Bias-gradient column sums: wide (GEMM outputs), narrow dense (conv channels over millions of pixels), ragged."""
+    x = _rand(rows, n, seed=5)
+    out = torch.empty(n, device=DEV)
     ws = _ws(64 << 20)
-    hip.call('dm_colsum', 2500, 1800, hip.fptr(x), 1800, hip.fptr(out), hip.ptr(ws), ws.numel(), hip.stream())
-    _close(out, x.double().sum(0), 1e-5, 1e-4, 'colsum')
+    hip.call('dm_colsum', rows, n, hip.fptr(x), n, hip.fptr(out), hip.ptr(ws), ws.numel(), hip.stream())
+    _close(out, x.double().sum(0), 1e-5, 2e-4 * np.sqrt(rows / 2500), 'colsum')
 
 
 # ------------------------------------------------------------------------------------------- GRU
