@@ -116,28 +116,29 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(int rows, int n, in
 }
 
 // Narrow dense matrices (n <= 64, ld == n; conv bias gradients over millions of pixels): the matrix is walked as a
-// flat array with a per-iteration stride that is a multiple of n, so every thread stays on ONE column and every
-// wave reads 256 contiguous bytes.  partial[chunk*n + col]; fixed reduction order.
-__global__ void __launch_bounds__(256) colsum_flat_kernel(long long total, int n, long long chunk_elems,
+// flat array in slabs of W = 256 - 256 % n consecutive floats (a multiple of n), one float per thread, so every
+// thread stays on ONE column (t % n) and every wave reads contiguous memory.  partial[chunk*n + col]; fixed order.
+__global__ void __launch_bounds__(256) colsum_flat_kernel(long long total, int n, int W, long long chunk_elems,
                                                           const float* __restrict__ x, float* __restrict__ partial) {
   __shared__ float sh[256];
-  const long long base = (long long)blockIdx.x * chunk_elems;
+  const long long base = (long long)blockIdx.x * chunk_elems;      // multiple of W, hence of n
   const long long end = min(total, base + chunk_elems);
-  const long long stride = 256LL * n;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-  long long i = base + threadIdx.x;
-  for (; i + 3 * stride < end; i += 4 * stride) {
-    b0 += x[i];
-    b1 += x[i + stride];
-    b2 += x[i + 2 * stride];
-    b3 += x[i + 3 * stride];
+  if ((int)threadIdx.x < W) {
+    long long i = base + threadIdx.x;
+    for (; i + 3LL * W < end; i += 4LL * W) {
+      b0 += x[i];
+      b1 += x[i + W];
+      b2 += x[i + 2LL * W];
+      b3 += x[i + 3LL * W];
+    }
+    for (; i < end; i += W) b0 += x[i];
   }
-  for (; i < end; i += stride) b0 += x[i];
   sh[threadIdx.x] = (b0 + b1) + (b2 + b3);
   __syncthreads();
   if ((int)threadIdx.x < n) {
     float s = 0.f;
-    for (int t = threadIdx.x; t < 256; t += n) s += sh[t];   // threads t == col (mod n) hold column `col`
+    for (int t = threadIdx.x; t < W; t += n) s += sh[t];      // threads t == col (mod n) hold column `col`
     partial[(size_t)blockIdx.x * n + threadIdx.x] = s;
   }
 }
@@ -185,14 +186,15 @@ int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* 
   int chunks;
   if (n <= 64 && ld == n && (long long)rows * n >= (1 << 16)) {
     const long long total = (long long)rows * n;
-    long long want = total / (256LL * n * 8);            // ~8 strided iterations per thread
+    const int W = 256 - 256 % n;                          // slab width: the largest multiple of n that fits a block
+    long long want = total / ((long long)W * 16);         // ~16 slabs per block
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     if ((size_t)want * n > budget) want = (long long)(budget / n);
     long long chunk_elems = (total + want - 1) / want;
-    chunk_elems = (chunk_elems + 256LL * n - 1) / (256LL * n) * (256LL * n);   // multiple of 256*n (hence of n)
+    chunk_elems = (chunk_elems + W - 1) / W * W;          // multiple of W (hence of n)
     chunks = (int)((total + chunk_elems - 1) / chunk_elems);
-    hipLaunchKernelGGL(colsum_flat_kernel, dim3(chunks), dim3(256), 0, st, total, n, chunk_elems, x, (float*)ws);
+    hipLaunchKernelGGL(colsum_flat_kernel, dim3(chunks), dim3(256), 0, st, total, n, W, chunk_elems, x, (float*)ws);
   } else {
     int rpc;
     chunks = colsum_plan(rows, budget, n, 1, &rpc);

@@ -321,11 +321,13 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.ldb & 3) == 0) ? 1 : 0;
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
-  // Candidates in order of per-tile MFMA efficiency: 128x128 (64 MFMA per fragment fetch group), 128x64, 64x64.
-  // A 128-wide tile dimension is only considered when that dimension is >= 96 (else >25 % of the tile is padding).
-  // Split-K is allowed up to the point where the partial-sum traffic (nsplit*M*N) reaches 1/4 of the operand
-  // traffic ((M+N)*K): long reductions with small outputs (weight gradients, 50-row RSSM steps) split deeply,
-  // square-ish GEMMs never do.  The first candidate that yields >= 192 workgroups wins, else the one with the most.
+  // Cost model fitted to scripts/gemm_bench.py on MI355X (profiles/r01_gemm_shapes.txt), in MACs per CU:
+  //   cost = ceil(workgroups / 256 CUs) * BM*BN * (K_slice + K_eq) / rate  (+ split-K reduce traffic and launch)
+  // K_eq is the fixed prologue/epilogue price of one tile expressed in k-steps (large tiles pay ~8 us, small ~0.7 us),
+  // `rate` the relative steady-state MFMA rate of the tile shape (128x128 streams fastest, 64x64 has the smallest
+  // tail).  Split-K is considered only when the grid would not fill the chip, and only up to the point where the
+  // partial-sum traffic (nsplit*M*N) reaches 1/4 of the operand traffic ((M+N)*K): weight gradients and the 50-row
+  // RSSM steps split deeply, square-ish GEMMs never do.
   const int ktiles = dm_cdiv(q.K, 32);
   const double out_elems = (double)q.M * q.N;
   int max_split = (int)(0.25 * ((double)q.M + q.N) * q.K / (out_elems > 0 ? out_elems : 1));
@@ -338,30 +340,30 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   }
   if (max_split < 1) max_split = 1;
   static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  static const double keq[3] = {100.0, 60.0, 30.0};
+  static const double rate[3] = {1.0, 0.93, 0.86};
   // tuning overrides for scripts/gemm_bench.py only (unset in production): DM_GEMM_TILE=1|2|3 forces a candidate,
   // DM_GEMM_SPLIT=n forces the split count
   static const int force_tile = getenv("DM_GEMM_TILE") ? atoi(getenv("DM_GEMM_TILE")) : 0;
   static const int force_split = getenv("DM_GEMM_SPLIT") ? atoi(getenv("DM_GEMM_SPLIT")) : 0;
   int BM = 64, BN = 64, nsplit = 1;
-  int64_t best_blocks = -1;
+  double best_cost = -1.0;
   for (int c = 0; c < 3; ++c) {
+    if (force_tile && c != force_tile - 1) continue;
     const int bm = cand[c][0], bn = cand[c][1];
-    if (force_tile) {
-      if (c != force_tile - 1) continue;
-    } else {
-      if (bm == 128 && q.M < 96) continue;
-      if (bn == 128 && q.N < 96) continue;
-    }
     const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
     int sp = 1;
     if (t < 256) {
       sp = dm_cdiv(512, t);
       if (sp > max_split) sp = max_split;
     }
-    if (force_split > 0) sp = force_split <= (ktiles > 0 ? ktiles : 1) ? force_split : (ktiles > 0 ? ktiles : 1);
-    const int64_t blocks = t * sp;
-    if (blocks >= 192) { BM = bm; BN = bn; nsplit = sp; best_blocks = blocks; break; }
-    if (blocks > best_blocks) { BM = bm; BN = bn; nsplit = sp; best_blocks = blocks; }
+    if (force_split > 0) sp = force_split;
+    if (sp > (ktiles > 0 ? ktiles : 1)) sp = ktiles > 0 ? ktiles : 1;
+    const double rounds = (double)dm_cdiv(t * sp, 256);
+    const double kslice = (double)dm_cdiv(ktiles > 0 ? ktiles : 1, sp) * 32.0;
+    double cost = rounds * bm * bn * (kslice + keq[c]) / rate[c];
+    if (sp > 1) cost += 0.4 * sp * out_elems + 1.2e6;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
   }
   const int tiles_m = dm_cdiv(q.M, BM), tiles_n = dm_cdiv(q.N, BN);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
