@@ -37,8 +37,14 @@ SHAPES = [
 ]
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')       # comma-separated indices into SHAPES
+    ap.add_argument('--reps', type=int, default=10)
+    args = ap.parse_args()
+    shapes = [SHAPES[int(i)] for i in args.only.split(',')] if args.only else SHAPES
     ws = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
-    for al, bl, M, N, K, what in SHAPES:
+    for al, bl, M, N, K, what in shapes:
         A = torch.randn((M, K) if al == 0 else (K, M), device='cuda')
         B = torch.randn((N, K) if bl == 0 else (K, N), device='cuda')
         C = torch.empty(M, N, device='cuda')
@@ -48,7 +54,7 @@ def main():
         for _ in range(3):
             run()
         torch.cuda.synchronize()
-        reps = 10
+        reps = args.reps
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
