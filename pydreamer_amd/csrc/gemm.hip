@@ -38,6 +38,8 @@ struct GemmKArgs {
   int k_per_split;
   int nsplit;
   int tiles_m;
+  int n_tiles, n_items;
+  int tiles_n, n_fast;
   int a_vec, b_vec;
 };
 
@@ -106,7 +108,45 @@ __device__ __forceinline__ void gemm_store_tile(const float4 (&r)[NF4], float* S
   }
 }
 
-template <int BM, int BN, int AL, int BL>
+// Work item -> (tile, split).  Workgroup b is observed to run on XCD b % 8 (used for L2 affinity only, never for
+// correctness): each XCD is given one CONTIGUOUS chunk of the item list, so the tiles an XCD's L2 sees share B panels
+// (tile_m runs fastest inside a chunk).  Bijective for any item count (q = n/8, r = n%8).
+__device__ __forceinline__ int gemm_item_of(int id, int n_items) {
+  const int q = n_items >> 3, r = n_items & 7;
+  const int xcd = id & 7, j = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+struct GemmItem {
+  int m0, n0, kbeg, kend, nkt, split;
+};
+template <int BM, int BN>
+__device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
+  const int item = gemm_item_of(id, g.n_items);
+  const int tile = item % g.n_tiles;
+  GemmItem it;
+  it.split = item / g.n_tiles;
+  // the index of the dimension with FEWER tiles runs fastest: the tiles that re-read one panel of the big operand
+  // (activation rows for M >> N, patch rows for weight gradients) are then neighbours in the same XCD's chunk
+  if (g.n_fast) {
+    it.n0 = (tile % g.tiles_n) * BN;
+    it.m0 = (tile / g.tiles_n) * BM;
+  } else {
+    it.m0 = (tile % g.tiles_m) * BM;
+    it.n0 = (tile / g.tiles_m) * BN;
+  }
+  it.kbeg = it.split * g.k_per_split;
+  it.kend = min(g.K, it.kbeg + g.k_per_split);
+  it.nkt = (it.kend > it.kbeg) ? (it.kend - it.kbeg + 31) / 32 : 0;
+  return it;
+}
+
+// Persistent workgroups: the grid is sized to the chip's residency and every workgroup walks a strided list of work
+// items; the global loads of the NEXT item's first k-tile are issued under the MFMAs of the current item's last
+// k-tile, so the per-tile prologue latency (HBM/L2 round trip) and the epilogue stores overlap with compute.
+// PERSIST = false compiles the same body as a one-item-per-workgroup kernel (grid = n_items): the cross-item prefetch
+// keeps 32 staging registers live across the epilogue, which costs the 128x128 instance its 3-blocks-per-CU residency.
+template <int BM, int BN, int AL, int BL, bool PERSIST>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int BK = 32;
   constexpr int LDK = 36;
@@ -126,98 +166,109 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   const int l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int bid = blockIdx.x;
-  const int m0 = (bid % g.tiles_m) * BM;
-  const int n0 = (bid / g.tiles_m) * BN;
-  const int split = blockIdx.y;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-  const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int id = blockIdx.x;
+  if (id >= g.n_items) return;
+  GemmItem cur = gemm_decode<BM, BN>(g, id);
 
   float4 ra[A_F4], rb[B_F4];
-  if (nkt > 0) {
-    gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec, tid);
-    gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.b_vec, tid);
+  if (cur.nkt > 0) {
+    gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_vec, tid);
+    gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_vec, tid);
   }
-  for (int kt = 0; kt < nkt; ++kt) {
-    gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
-    gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, m0, g.M, k0, kend, g.a_vec, tid);
-      gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, n0, g.N, k0, kend, g.b_vec, tid);
-    }
+  for (;;) {
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      float a[MB][4], b[NB][4];
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int row = wm * (BM / 2) + mb * 32 + l31;
-        if (AL == 0) {
-          const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
-          a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
-        } else {
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[mb][j] = As[(kg * 8 + half * 4 + j) * LDMA + row];
-        }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int next_id = id + gridDim.x;
+    const bool has_next = PERSIST && next_id < g.n_items;
+    GemmItem nxt = cur;
+    if (has_next) nxt = gemm_decode<BM, BN>(g, next_id);
+
+    for (int kt = 0; kt < cur.nkt; ++kt) {
+      gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
+      gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
+      __syncthreads();
+      // one prefetch site for both cases (next k-tile of this item / first k-tile of the next item): the selection
+      // is wave-uniform scalar work, so the load code and its address registers exist once
+      const bool same = kt + 1 < cur.nkt;
+      if (same || has_next) {
+        const int lm0 = same ? cur.m0 : nxt.m0, ln0 = same ? cur.n0 : nxt.n0;
+        const int lk0 = same ? cur.kbeg + (kt + 1) * BK : nxt.kbeg;
+        const int lkend = same ? cur.kend : nxt.kend;
+        gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, lm0, g.M, lk0, lkend, g.a_vec, tid);
+        gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, ln0, g.N, lk0, lkend, g.b_vec, tid);
       }
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        float a[MB][4], b[NB][4];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int row = wm * (BM / 2) + mb * 32 + l31;
+          if (AL == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
+            a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[mb][j] = As[(kg * 8 + half * 4 + j) * LDMA + row];
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int row = wn * (BN / 2) + nb * 32 + l31;
+          if (BL == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
+            b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nb][j] = Bs[(kg * 8 + half * 4 + j) * LDMB + row];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+
+    // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int row = wn * (BN / 2) + nb * 32 + l31;
-        if (BL == 0) {
-          const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
-          b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
-        } else {
+        const int col = cur.n0 + wn * (BN / 2) + nb * 32 + l31;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[nb][j] = Bs[(kg * 8 + half * 4 + j) * LDMB + row];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int col = n0 + wn * (BN / 2) + nb * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N) {
-          float v = acc[mb][nb][r];
-          if (g.nsplit > 1) {
-            g.partial[((size_t)split * g.M + row) * g.N + col] = v;
-          } else {
-            if (g.row_zero && g.row_zero[row]) v = 0.f;
-            if (g.bias) v += g.bias[col];
-            if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-            float* c = g.C + (size_t)row * g.ldc + col;
-            if (g.flags & DM_GEMM_ACCUM) v += *c;
-            if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
-            if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
-            *c = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = cur.m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < g.M && col < g.N) {
+            float v = acc[mb][nb][r];
+            if (g.nsplit > 1) {
+              g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
+            } else {
+              if (g.row_zero && g.row_zero[row]) v = 0.f;
+              if (g.bias) v += g.bias[col];
+              if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+              float* c = g.C + (size_t)row * g.ldc + col;
+              if (g.flags & DM_GEMM_ACCUM) v += *c;
+              if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
+              if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
+              *c = v;
+            }
           }
         }
       }
     }
+    if (!has_next) break;
+    id = next_id;
+    cur = nxt;
   }
 }
 
@@ -294,16 +345,16 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
   return (int)g_prof.n;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool P>
 static void gemm_dispatch(const GemmKArgs& a, int al, int bl, dim3 grid, hipStream_t stream) {
-  if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, stream, a);
+  if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, P>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, P>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, P>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, P>), grid, dim3(256), 0, stream, a);
 }
 
 int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
-  DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 0, DM_E_SHAPE, "gemm: negative dims %d %d %d", q.M, q.N, q.K);
+  DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1, DM_E_SHAPE, "gemm: bad dims M=%d N=%d K=%d (K must be >= 1)", q.M, q.N, q.K);
   if (q.M == 0 || q.N == 0) return DM_OK;
   DM_REQUIRE(q.A && q.B && q.C, DM_E_NULL, "gemm: null operand");
   DM_REQUIRE((unsigned)q.a_layout < 2 && (unsigned)q.b_layout < 2, DM_E_SHAPE, "gemm: bad layout");
@@ -374,12 +425,31 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.tiles_m = tiles_m;
   a.partial = nsplit > 1 ? (float*)ws : nullptr;
 
-  dim3 grid((unsigned)tiles, (unsigned)nsplit);
+  DM_REQUIRE(tiles * nsplit < (int64_t)1 << 30, DM_E_SHAPE, "gemm: too many work items");
+  a.n_tiles = (int)tiles;
+  a.tiles_n = tiles_n;
+  a.n_fast = tiles_n <= tiles_m ? 1 : 0;
+  a.n_items = (int)(tiles * nsplit);
+  // persistent walk for the small tiles (4-6 workgroups resident per CU); one item per workgroup for 128x128.
+  // DM_GEMM_PERSIST=0|1 overrides for scripts/gemm_bench.py A/B runs.
+  static const int force_persist = getenv("DM_GEMM_PERSIST") ? atoi(getenv("DM_GEMM_PERSIST")) : -1;
+  const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 ? 1 : 2);
+  static const bool persist_default[3] = {false, true, true};
+  const bool persist = force_persist >= 0 ? force_persist != 0 : persist_default[tc];
+  static const int resident_per_cu[3] = {1, 2, 4};
+  const int resident = 256 * resident_per_cu[tc];
+  dim3 grid((unsigned)(persist && a.n_items > resident ? resident : a.n_items));
   const int kind = (BM == 128 ? 4 : 0) + q.a_layout * 2 + q.b_layout;
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
-  if (BM == 128 && BN == 128) gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, grid, stream);
-  else if (BM == 128) gemm_dispatch<128, 64>(a, q.a_layout, q.b_layout, grid, stream);
-  else gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, grid, stream);
+  if (persist) {
+    if (tc == 0) gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, grid, stream);
+    else if (tc == 1) gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, grid, stream);
+    else gemm_dispatch<64, 64, true>(a, q.a_layout, q.b_layout, grid, stream);
+  } else {
+    if (tc == 0) gemm_dispatch<128, 128, false>(a, q.a_layout, q.b_layout, grid, stream);
+    else if (tc == 1) gemm_dispatch<128, 64, false>(a, q.a_layout, q.b_layout, grid, stream);
+    else gemm_dispatch<64, 64, false>(a, q.a_layout, q.b_layout, grid, stream);
+  }
   prof_after(slot, stream);
   DM_LAUNCH_CHECK();
   if (nsplit > 1) {
