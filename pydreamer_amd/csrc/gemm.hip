@@ -403,18 +403,22 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     if (force_tile && c != force_tile - 1) continue;
     const int bm = cand[c][0], bn = cand[c][1];
     const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
-    int sp = 1;
+    int sp_fill = 1;
     if (t < 256) {
-      sp = dm_cdiv(512, t);
-      if (sp > max_split) sp = max_split;
+      sp_fill = dm_cdiv(512, t);
+      if (sp_fill > max_split) sp_fill = max_split;
     }
-    if (force_split > 0) sp = force_split;
-    if (sp > (ktiles > 0 ? ktiles : 1)) sp = ktiles > 0 ? ktiles : 1;
-    const double rounds = (double)dm_cdiv(t * sp, 256);
-    const double kslice = (double)dm_cdiv(ktiles > 0 ? ktiles : 1, sp) * 32.0;
-    double cost = rounds * bm * bn * (kslice + keq[c]) / rate[c];
-    if (sp > 1) cost += 0.4 * sp * out_elems + 1.2e6;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
+    if (force_split > 0) sp_fill = force_split;
+    if (sp_fill > (ktiles > 0 ? ktiles : 1)) sp_fill = ktiles > 0 ? ktiles : 1;
+    for (int pass = 0; pass < 2; ++pass) {                 // unsplit, and split to fill the chip
+      const int sp = pass == 0 ? (force_split > 0 ? sp_fill : 1) : sp_fill;
+      if (pass == 1 && sp == 1) break;
+      const double rounds = (double)dm_cdiv(t * sp, 256);
+      const double kslice = (double)dm_cdiv(ktiles > 0 ? ktiles : 1, sp) * 32.0;
+      double cost = rounds * bm * bn * (kslice + keq[c]) / rate[c];
+      if (sp > 1) cost += 0.4 * sp * out_elems + 1.2e6;
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
+    }
   }
   const int tiles_m = dm_cdiv(q.M, BM), tiles_n = dm_cdiv(q.N, BN);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -434,7 +438,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   // DM_GEMM_PERSIST=0|1 overrides for scripts/gemm_bench.py A/B runs.
   static const int force_persist = getenv("DM_GEMM_PERSIST") ? atoi(getenv("DM_GEMM_PERSIST")) : -1;
   const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 ? 1 : 2);
-  static const bool persist_default[3] = {false, true, true};
+  static const bool persist_default[3] = {false, false, false};   // A/B on MI355X (profiles/r01_gemm_persist_ab.txt): residency beats prefetch
   const bool persist = force_persist >= 0 ? force_persist != 0 : persist_default[tc];
   static const int resident_per_cu[3] = {1, 2, 4};
   const int resident = 256 * resident_per_cu[tc];
