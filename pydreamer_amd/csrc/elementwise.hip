@@ -6,6 +6,8 @@
 // ------------------------------------------------------------------------------------------------
 // LayerNorm(eps) + ELU, one wave per row (common.py:44-49; rssm.py:105-115; torch LayerNorm: biased variance)
 // ------------------------------------------------------------------------------------------------
+// CACHE = true keeps the row in registers (n <= 1024: 16 values per lane), so x / y / dy are read from memory once.
+template <bool CACHE>
 __global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, float* __restrict__ y, int ldy, float* __restrict__ stats) {
@@ -13,20 +15,43 @@ __global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const 
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
+  float xc[16];
   float s = 0.f;
-  for (int c = lane; c < n; c += 64) s += xr[c];
+  if (CACHE) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      xc[j] = c < n ? xr[c] : 0.f;
+      s += xc[j];
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) s += xr[c];
+  }
   const float mean = dm_wave_sum(s) / (float)n;
   float v = 0.f;
-  for (int c = lane; c < n; c += 64) {
-    const float d = xr[c] - mean;
-    v += d * d;
+  if (CACHE) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float d = (lane + 64 * j < n) ? xc[j] - mean : 0.f;
+      v += d * d;
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      const float d = xr[c] - mean;
+      v += d * d;
+    }
   }
   const float var = dm_wave_sum(v) / (float)n;
   const float rstd = 1.0f / sqrtf(var + eps);
   float* yr = y + (size_t)row * ldy;
-  for (int c = lane; c < n; c += 64) {
-    const float t = (xr[c] - mean) * rstd * gamma[c] + beta[c];
-    yr[c] = dm_elu(t);
+  if (CACHE) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      if (c < n) yr[c] = dm_elu((xc[j] - mean) * rstd * gamma[c] + beta[c]);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) yr[c] = dm_elu((xr[c] - mean) * rstd * gamma[c] + beta[c]);
   }
   if (lane == 0) {
     stats[2 * row] = mean;
@@ -35,6 +60,7 @@ __global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const 
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * ELU'(y) * gamma
+template <bool CACHE>
 __global__ void __launch_bounds__(256) ln_elu_bwd_dx_kernel(int rows, int n, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ y, int ldy,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -47,20 +73,43 @@ __global__ void __launch_bounds__(256) ln_elu_bwd_dx_kernel(int rows, int n, con
   const float* xr = x + (size_t)row * ldx;
   const float* yr = y + (size_t)row * ldy;
   const float* dyr = dy + (size_t)row * lddy;
+  float gc[16], hc[16];
   float sg = 0.f, sgx = 0.f;
-  for (int c = lane; c < n; c += 64) {
-    const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
-    const float xh = (xr[c] - mean) * rstd;
-    sg += g;
-    sgx += g * xh;
+  if (CACHE) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      gc[j] = 0.f; hc[j] = 0.f;
+      if (c < n) {
+        gc[j] = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
+        hc[j] = (xr[c] - mean) * rstd;
+      }
+      sg += gc[j];
+      sgx += gc[j] * hc[j];
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
+      const float xh = (xr[c] - mean) * rstd;
+      sg += g;
+      sgx += g * xh;
+    }
   }
   sg = dm_wave_sum(sg) / (float)n;
   sgx = dm_wave_sum(sgx) / (float)n;
   float* dxr = dx + (size_t)row * lddx;
-  for (int c = lane; c < n; c += 64) {
-    const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
-    const float xh = (xr[c] - mean) * rstd;
-    dxr[c] = rstd * (g - sg - xh * sgx);
+  if (CACHE) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      if (c < n) dxr[c] = rstd * (gc[j] - sg - hc[j] * sgx);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      const float g = dyr[c] * dm_elu_grad_from_y(yr[c]) * gamma[c];
+      const float xh = (xr[c] - mean) * rstd;
+      dxr[c] = rstd * (g - sg - xh * sgx);
+    }
   }
 }
 
@@ -211,8 +260,12 @@ int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* 
 int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
                          float* y, int ldy, float* stats, hipStream_t st) {
   if (rows <= 0) return DM_OK;
-  hipLaunchKernelGGL(ln_elu_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta, eps, y,
-                     ldy, stats);
+  if (n <= 1024)
+    hipLaunchKernelGGL((ln_elu_fwd_kernel<true>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta,
+                       eps, y, ldy, stats);
+  else
+    hipLaunchKernelGGL((ln_elu_fwd_kernel<false>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta,
+                       eps, y, ldy, stats);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -221,8 +274,12 @@ int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* 
 int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
                             const float* gamma, const float* dy, int lddy, float* dx, int lddx, hipStream_t st) {
   if (rows <= 0) return DM_OK;
-  hipLaunchKernelGGL(ln_elu_bwd_dx_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, y, ldy, stats,
-                     gamma, dy, lddy, dx, lddx);
+  if (n <= 1024)
+    hipLaunchKernelGGL((ln_elu_bwd_dx_kernel<true>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, y, ldy,
+                       stats, gamma, dy, lddy, dx, lddx);
+  else
+    hipLaunchKernelGGL((ln_elu_bwd_dx_kernel<false>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, y, ldy,
+                       stats, gamma, dy, lddy, dx, lddx);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -112,7 +112,7 @@ def test_gemm_onehot_rows_exact(hip):
 
 
 # ------------------------------------------------------------------------------------------- LayerNorm+ELU
-@pytest.mark.parametrize('rows,n', [(50, 1000), (2500, 400), (3, 64), (130, 1001)])
+@pytest.mark.parametrize('rows,n', [(50, 1000), (2500, 400), (3, 64), (130, 1001), (10, 1500), (7, 1024)])
 def test_ln_elu_fwd_bwd(hip, rows, n):
     x = _rand(rows, n, seed=1, scale=2.0)
     gamma = 1 + 0.1 * _rand(n, seed=2)
