@@ -199,19 +199,20 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
-        out = (ctypes.c_double * 24)()
-        n = hip.lib().dm_prof_end(out, 8)
+        out = (ctypes.c_double * 36)()
+        n = hip.lib().dm_prof_end(out, 12)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
-        for k in range(8):
+        tiles = ('128,128', '128,64', '64,64')
+        for k in range(12):
             cnt, fl, ms = out[3 * k], out[3 * k + 1], out[3 * k + 2]
             if cnt:
-                kinds.append(dict(kernel=f"gemm_f32_kernel<{'128,128' if k >= 4 else '64,64'},{(k >> 1) & 1},{k & 1}>",
+                kinds.append(dict(kernel=f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>",
                                   layout=names[k & 3], launches_per_step=cnt / args.prof_steps,
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
                                   ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12))
-        tot_fl = sum(out[3 * k + 1] for k in range(8))
-        tot_ms = sum(out[3 * k + 2] for k in range(8))
+        tot_fl = sum(out[3 * k + 1] for k in range(12))
+        tot_ms = sum(out[3 * k + 2] for k in range(12))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3
         roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=None,

@@ -234,7 +234,8 @@ int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* 
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*3+{0,1,2}] = {launches, algorithmic flops (2MNK), milliseconds} for
- * kind = (128x128 tile ? 4 : 0) + a_layout*2 + b_layout (8 kinds) and returns the number of launches recorded. */
+ * kind = tile*4 + a_layout*2 + b_layout with tile 0/1/2 = 128x128 / 128x64 / 64x64 (12 kinds; nkinds >= 12) and returns the
+ * number of launches recorded. */
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
 /* y = a*x + b*y */

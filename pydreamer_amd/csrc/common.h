@@ -54,6 +54,10 @@ struct DmGemm {
   const float* add = nullptr; int ldadd = 0;
   const float* mulref = nullptr; int ldmul = 0;   // v *= ELU'(mulref[m,n]) (mulref holds ELU outputs), applied last
   const uint8_t* row_zero = nullptr;              // rows with row_zero[m] != 0 contribute 0 (reset masks), applied first
+  // separable gather operands (implicit im2col): element = P[maj[major] + min[minor]] with major = the strided index
+  // of the layout (row for layout 0, k for layout 1); *_tab_vec: 4 consecutive minors are 4 aligned consecutive floats
+  const int* a_maj = nullptr; const int* a_min = nullptr; int a_tab_vec = 0;
+  const int* b_maj = nullptr; const int* b_min = nullptr; int b_tab_vec = 0;
   int flags = 0;
 };
 int dm_gemm_launch(const DmGemm& g, void* ws, size_t ws_bytes, hipStream_t stream);

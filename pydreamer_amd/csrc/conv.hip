@@ -176,6 +176,35 @@ int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int
   return DM_OK;
 }
 
+// ---------------------------------------------------------------- implicit im2col tables ----------
+// The stride-2 patch matrix col[(i,ys,xs)][(ky,kx,c)] = big[i, 2ys+ky, 2xs+kx, c] (NHWC) is a SEPARABLE gather:
+//   address = rowoff[(i,ys,xs)] + koff[(ky,kx,c)],  rowoff = ((i*hb + 2ys)*wb + 2xs)*c,  koff = ky*wb*c + kx*c + cc
+// so the GEMM loaders (gemm.hip, gather operands) read patches straight from the activation tensor and the patch
+// matrix is never materialised.  Both tables are tiny (rows + k*k*c ints) and L2-resident.
+__global__ void __launch_bounds__(256) conv_tables_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
+                                                          int* __restrict__ rowoff, int* __restrict__ koff) {
+  const int rows = n * hs * ws;
+  const int kc = k * c;
+  const int kdim = k * kc;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < rows + kdim; e += gridDim.x * 256) {
+    if (e < rows) {
+      const int xs = e % ws, ys = (e / ws) % hs, i = e / (ws * hs);
+      rowoff[e] = ((i * hb + 2 * ys) * wb + 2 * xs) * c;
+    } else {
+      const int q = e - rows;
+      koff[q] = (q / kc) * (wb * c) + q % kc;
+    }
+  }
+}
+static int conv_tables_launch(int n, int hb, int wb, int c, int k, int* rowoff, int* koff, hipStream_t st) {
+  const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
+  DM_REQUIRE((int64_t)n * hb * wb * c < ((int64_t)1 << 31), DM_E_SHAPE, "conv tables: tensor exceeds 2^31 elements");
+  const int total = n * hs * ws + k * k * c;
+  hipLaunchKernelGGL(conv_tables_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, rowoff, koff);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // ---------------------------------------------------------------- MSE (decoders.py:163-167) -----
 // pred NHWC (n,hw,c), target NCHW (n,c,hw).  loss[n] = 0.5*sum (pred-target)^2 ; dpred = scale*(pred-target) (NHWC);
 // rec = pred in NCHW.  One block per frame, fixed reduction order.
@@ -255,16 +284,20 @@ struct DecGeom {
 // ---------------------------------------------------------------- encoder -----------------------
 struct EncActs {
   float* wr[4];    // repacked weights (l>=1)
-  float* xcol[4];
+  float* xcol[4];  // explicit patch matrix: layer 0 only (reads the NCHW batch, 3 channels)
+  int* rowoff[4];  // implicit-im2col tables (l>=1), see conv_tables_kernel
+  int* koff[4];
   float* y[4];     // post-ELU NHWC outputs
 };
 static size_t enc_carve(const EncGeom& g, float* base, size_t cap_floats, EncActs* a) {
   DmArena ar(base, cap_floats * sizeof(float));
   for (int l = 0; l < 4; ++l) {
     float* w = ar.take(l == 0 ? 0 : (size_t)g.cout[l] * g.kdim[l]);
-    float* xc = ar.take(g.rows[l] * g.kdim[l]);
+    float* xc = ar.take(l == 0 ? g.rows[l] * g.kdim[l] : 0);
+    float* ro = ar.take(l == 0 ? 0 : g.rows[l]);
+    float* ko = ar.take(l == 0 ? 0 : g.kdim[l]);
     float* yy = ar.take(g.rows[l] * g.cout[l]);
-    if (a) { a->wr[l] = w; a->xcol[l] = xc; a->y[l] = yy; }
+    if (a) { a->wr[l] = w; a->xcol[l] = xc; a->rowoff[l] = (int*)ro; a->koff[l] = (int*)ko; a->y[l] = yy; }
   }
   return ar.off;
 }
@@ -299,8 +332,8 @@ extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, cons
   enc_carve(g, acts, (size_t)1 << 60, &a);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small");
   for (int l = 0; l < 4; ++l) {
-    const float* src = l == 0 ? image : a.y[l - 1];
-    DM_TRY(dm_im2col_s2_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, src, l == 0, a.xcol[l], st));
+    if (l == 0) DM_TRY(dm_im2col_s2_launch(g.N, g.hb[0], g.hb[0], g.cin[0], 4, image, 1, a.xcol[0], st));
+    else DM_TRY(conv_tables_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, a.rowoff[l], a.koff[l], st));
     const float* w = p->w[l];
     if (l > 0) {
       DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cout[l], g.cin[l], 4, 4, 0, 2, 3, 1, st));
@@ -309,7 +342,8 @@ extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, cons
     DmGemm q;
     q.a_layout = 0; q.b_layout = 0;
     q.M = (int)g.rows[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
-    q.A = a.xcol[l]; q.lda = q.K;
+    if (l == 0) { q.A = a.xcol[0]; q.lda = q.K; }
+    else { q.A = a.y[l - 1]; q.a_maj = a.rowoff[l]; q.a_min = a.koff[l]; q.a_tab_vec = (g.cin[l] & 3) == 0; }
     q.B = w; q.ldb = q.K;
     q.C = a.y[l]; q.ldc = q.N;
     q.bias = p->b[l];
@@ -358,7 +392,8 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
     q.a_layout = 1; q.b_layout = 1;
     q.M = co; q.N = kd; q.K = rows;
     q.A = G; q.lda = co;
-    q.B = a.xcol[l]; q.ldb = kd;
+    if (l == 0) { q.B = a.xcol[0]; q.ldb = kd; }
+    else { q.B = a.y[l - 1]; q.b_maj = a.rowoff[l]; q.b_min = a.koff[l]; q.b_tab_vec = (g.cin[l] & 3) == 0; }
     q.C = (l == 0) ? gr->w[0] : dwr; q.ldc = kd;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
     if (l > 0) {
@@ -474,6 +509,13 @@ extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, i
   float* ga = ar.take(gmax);
   float* gb = ar.take(gmax);
   float* dwr = ar.take(wmax);
+  size_t romax = 0, komax = 0;
+  for (int l = 1; l <= 4; ++l) {
+    if (g.rows_s[l] > romax) romax = g.rows_s[l];
+    if ((size_t)g.k[l] * g.k[l] * g.cout[l] > komax) komax = (size_t)g.k[l] * g.k[l] * g.cout[l];
+  }
+  int* rowoff = (int*)ar.take(romax);
+  int* koff = (int*)ar.take(komax);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -487,12 +529,17 @@ extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, i
     const int ncol = kk * g.cout[l];
     const int rows_s = (int)g.rows_s[l];
     DM_TRY(dm_colsum_launch((int)g.rows_b[l], g.cout[l], G, g.cout[l], gr->b[l], splitk, skb, st));
-    DM_TRY(dm_im2col_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], G, 0, dycol, st));
+    // patches of the output gradient: implicit (gather tables) when the channel count allows 16-byte gathers,
+    // else (the 3-channel image layer) an explicit patch matrix
+    const bool implicit = (g.cout[l] & 3) == 0;
+    if (implicit) DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], rowoff, koff, st));
+    else DM_TRY(dm_im2col_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], G, 0, dycol, st));
     DmGemm q;   // dWr[i][(ky,kx,o)] = sum_rows X[row][i] * dYcol[row][(ky,kx,o)]
     q.a_layout = 1; q.b_layout = 1;
     q.M = g.cin[l]; q.N = ncol; q.K = rows_s;
     q.A = a.x[l - 1]; q.lda = g.cin[l];
-    q.B = dycol; q.ldb = ncol;
+    if (implicit) { q.B = G; q.b_maj = rowoff; q.b_min = koff; q.b_tab_vec = 1; }
+    else { q.B = dycol; q.ldb = ncol; }
     q.C = dwr; q.ldc = ncol;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
     DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, st));
@@ -500,7 +547,8 @@ extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, i
     DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
     d.a_layout = 0; d.b_layout = 0;
     d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
-    d.A = dycol; d.lda = ncol;
+    if (implicit) { d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1; }
+    else { d.A = dycol; d.lda = ncol; }
     d.B = a.wr[l]; d.ldb = ncol;
     d.C = Gn; d.ldc = g.cin[l];
     if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }

@@ -31,6 +31,8 @@ struct GemmKArgs {
   const float* add;
   const float* mulref;
   const uint8_t* row_zero;
+  const int* a_maj; const int* a_min;   // optional separable-gather tables: element = A[a_maj[major] + a_min[minor]]
+  const int* b_maj; const int* b_min;
   float* partial;
   int M, N, K;
   int lda, ldb, ldc, ldadd, ldmul;
@@ -44,43 +46,52 @@ struct GemmKArgs {
 };
 
 // Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).
-template <int ROWS, int LAYOUT, int NF4>
+// LAYOUT 0: the k index is contiguous in memory (major = row, minor = k); LAYOUT 1: the row index is (major = k).
+// With gather tables (tmaj != nullptr) an element lives at P[tmaj[major] + tmin[minor]] — the implicit-im2col operand:
+// tmaj = start of a conv patch, tmin = offset of tap (ky,kx,c) inside it; `vec` then promises that 4 consecutive
+// minors are 4 consecutive, 16-byte aligned floats (channels % 4 == 0).
+template <int ROWS, int LAYOUT, int NF4, bool GATHER>
 __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __restrict__ P, int ld, int row0,
-                                               int nrows, int k0, int kend, int vec, int tid) {
+                                               int nrows, int k0, int kend, int vec, const int* __restrict__ tmaj,
+                                               const int* __restrict__ tmin, int tid) {
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const int f = tid + i * 256;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int major, minor, minor_end;
+    bool ok;
     if (LAYOUT == 0) {
-      const int row = f >> 3;
-      const int gk = k0 + ((f & 7) << 2);
-      const int grow = row0 + row;
-      if (grow < nrows && gk < kend) {
-        const float* p = P + (size_t)grow * ld + gk;
-        if (vec && gk + 3 < kend) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          v.x = p[0];
-          if (gk + 1 < kend) v.y = p[1];
-          if (gk + 2 < kend) v.z = p[2];
-          if (gk + 3 < kend) v.w = p[3];
-        }
-      }
+      major = row0 + (f >> 3);
+      minor = k0 + ((f & 7) << 2);
+      minor_end = kend;
+      ok = major < nrows && minor < kend;
     } else {
       constexpr int F4_PER_K = ROWS / 4;
-      const int kr = f / F4_PER_K;
-      const int r4 = (f % F4_PER_K) << 2;
-      const int gk = k0 + kr;
-      const int grow = row0 + r4;
-      if (gk < kend && grow < nrows) {
-        const float* p = P + (size_t)gk * ld + grow;
-        if (vec && grow + 3 < nrows) {
+      major = k0 + f / F4_PER_K;
+      minor = row0 + ((f % F4_PER_K) << 2);
+      minor_end = nrows;
+      ok = major < kend && minor < nrows;
+    }
+    if (ok) {
+      if (GATHER) {
+        const float* base = P + tmaj[major];
+        if (vec && minor + 3 < minor_end) {
+          v = *reinterpret_cast<const float4*>(base + tmin[minor]);
+        } else {
+          v.x = base[tmin[minor]];
+          if (minor + 1 < minor_end) v.y = base[tmin[minor + 1]];
+          if (minor + 2 < minor_end) v.z = base[tmin[minor + 2]];
+          if (minor + 3 < minor_end) v.w = base[tmin[minor + 3]];
+        }
+      } else {
+        const float* p = P + (size_t)major * ld + minor;
+        if (vec && minor + 3 < minor_end) {
           v = *reinterpret_cast<const float4*>(p);
         } else {
           v.x = p[0];
-          if (grow + 1 < nrows) v.y = p[1];
-          if (grow + 2 < nrows) v.z = p[2];
-          if (grow + 3 < nrows) v.w = p[3];
+          if (minor + 1 < minor_end) v.y = p[1];
+          if (minor + 2 < minor_end) v.z = p[2];
+          if (minor + 3 < minor_end) v.w = p[3];
         }
       }
     }
@@ -146,7 +157,8 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 // k-tile, so the per-tile prologue latency (HBM/L2 round trip) and the epilogue stores overlap with compute.
 // PERSIST = false compiles the same body as a one-item-per-workgroup kernel (grid = n_items): the cross-item prefetch
 // keeps 32 staging registers live across the epilogue, which costs the 128x128 instance its 3-blocks-per-CU residency.
-template <int BM, int BN, int AL, int BL, bool PERSIST>
+// GA / GB: operand A / B is a separable gather (compile-time, so the plain instances keep their register budget).
+template <int BM, int BN, int AL, int BL, bool PERSIST, bool GA = false, bool GB = false>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int BK = 32;
   constexpr int LDK = 36;
@@ -172,8 +184,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
 
   float4 ra[A_F4], rb[B_F4];
   if (cur.nkt > 0) {
-    gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_vec, tid);
-    gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_vec, tid);
+    gemm_load_tile<BM, AL, A_F4, GA>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
+    gemm_load_tile<BN, BL, B_F4, GB>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
   }
   for (;;) {
     f32x16 acc[MB][NB];
@@ -200,8 +212,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
         const int lm0 = same ? cur.m0 : nxt.m0, ln0 = same ? cur.n0 : nxt.n0;
         const int lk0 = same ? cur.kbeg + (kt + 1) * BK : nxt.kbeg;
         const int lkend = same ? cur.kend : nxt.kend;
-        gemm_load_tile<BM, AL, A_F4>(ra, g.A, g.lda, lm0, g.M, lk0, lkend, g.a_vec, tid);
-        gemm_load_tile<BN, BL, B_F4>(rb, g.B, g.ldb, ln0, g.N, lk0, lkend, g.b_vec, tid);
+        gemm_load_tile<BM, AL, A_F4, GA>(ra, g.A, g.lda, lm0, g.M, lk0, lkend, g.a_vec, g.a_maj, g.a_min, tid);
+        gemm_load_tile<BN, BL, B_F4, GB>(rb, g.B, g.ldb, ln0, g.N, lk0, lkend, g.b_vec, g.b_maj, g.b_min, tid);
       }
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
@@ -329,7 +341,7 @@ extern "C" int dm_prof_begin(int max_launches) {
 // out[kind*3 + {0,1,2}] = {launches, flops, milliseconds} for kind = (tile128 ? 4 : 0) + a_layout*2 + b_layout; returns
 // the number of recorded launches (negative on error).  Synchronises on the recorded events.
 extern "C" int dm_prof_end(double* out, int nkinds) {
-  DM_REQUIRE(out && nkinds >= 8, DM_E_SHAPE, "prof_end: need room for 8 kinds");
+  DM_REQUIRE(out && nkinds >= 12, DM_E_SHAPE, "prof_end: need room for 12 kinds");
   g_prof.on = false;
   for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
   for (size_t i = 0; i < g_prof.n; ++i) {
@@ -345,12 +357,20 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
   return (int)g_prof.n;
 }
 
-template <int BM, int BN, bool P>
-static void gemm_dispatch(const GemmKArgs& a, int al, int bl, dim3 grid, hipStream_t stream) {
-  if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, P>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, P>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, P>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, P>), grid, dim3(256), 0, stream, a);
+// gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
+template <int BM, int BN>
+static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
+  if (gather == 1) {
+    if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, false, true, false>), grid, dim3(256), 0, stream, a);
+  } else if (gather == 2) {
+    if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false, false, true>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, false>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false>), grid, dim3(256), 0, stream, a);
+  return DM_OK;
 }
 
 int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -358,8 +378,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   if (q.M == 0 || q.N == 0) return DM_OK;
   DM_REQUIRE(q.A && q.B && q.C, DM_E_NULL, "gemm: null operand");
   DM_REQUIRE((unsigned)q.a_layout < 2 && (unsigned)q.b_layout < 2, DM_E_SHAPE, "gemm: bad layout");
-  DM_REQUIRE(q.lda >= (q.a_layout == 0 ? q.K : q.M), DM_E_SHAPE, "gemm: lda %d too small", q.lda);
-  DM_REQUIRE(q.ldb >= (q.b_layout == 0 ? q.K : q.N), DM_E_SHAPE, "gemm: ldb %d too small", q.ldb);
+  DM_REQUIRE(q.a_maj || q.lda >= (q.a_layout == 0 ? q.K : q.M), DM_E_SHAPE, "gemm: lda %d too small", q.lda);
+  DM_REQUIRE(q.b_maj || q.ldb >= (q.b_layout == 0 ? q.K : q.N), DM_E_SHAPE, "gemm: ldb %d too small", q.ldb);
+  DM_REQUIRE((q.a_maj == nullptr) == (q.a_min == nullptr) && (q.b_maj == nullptr) == (q.b_min == nullptr), DM_E_NULL,
+             "gemm: gather tables must come in (major, minor) pairs");
   DM_REQUIRE(q.ldc >= q.N, DM_E_SHAPE, "gemm: ldc %d < N %d", q.ldc, q.N);
   DM_REQUIRE(!q.add || q.ldadd >= q.N, DM_E_SHAPE, "gemm: ldadd %d < N %d", q.ldadd, q.N);
 
@@ -368,8 +390,9 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.M = q.M; a.N = q.N; a.K = q.K;
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
   a.flags = q.flags;
-  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.lda & 3) == 0) ? 1 : 0;
-  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.ldb & 3) == 0) ? 1 : 0;
+  a.a_maj = q.a_maj; a.a_min = q.a_min; a.b_maj = q.b_maj; a.b_min = q.b_min;
+  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0)) ? 1 : 0;
+  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.b_maj ? q.b_tab_vec != 0 : (q.ldb & 3) == 0)) ? 1 : 0;
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
   // Cost model fitted to scripts/gemm_bench.py on MI355X (profiles/r01_gemm_shapes.txt), in MACs per CU:
@@ -434,26 +457,19 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.tiles_n = tiles_n;
   a.n_fast = tiles_n <= tiles_m ? 1 : 0;
   a.n_items = (int)(tiles * nsplit);
-  // persistent walk for the small tiles (4-6 workgroups resident per CU); one item per workgroup for 128x128.
-  // DM_GEMM_PERSIST=0|1 overrides for scripts/gemm_bench.py A/B runs.
-  static const int force_persist = getenv("DM_GEMM_PERSIST") ? atoi(getenv("DM_GEMM_PERSIST")) : -1;
+  // one work item per workgroup: the persistent walk (PERSIST = true) lost the A/B on MI355X, see
+  // profiles/r01_gemm_persist_ab.txt — residency (3-8 workgroups per CU) beats cross-tile prefetch
   const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 ? 1 : 2);
-  static const bool persist_default[3] = {false, false, false};   // A/B on MI355X (profiles/r01_gemm_persist_ab.txt): residency beats prefetch
-  const bool persist = force_persist >= 0 ? force_persist != 0 : persist_default[tc];
-  static const int resident_per_cu[3] = {1, 2, 4};
-  const int resident = 256 * resident_per_cu[tc];
-  dim3 grid((unsigned)(persist && a.n_items > resident ? resident : a.n_items));
-  const int kind = (BM == 128 ? 4 : 0) + q.a_layout * 2 + q.b_layout;
+  dim3 grid((unsigned)a.n_items);
+  const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
+  DM_REQUIRE(!(q.a_maj && q.b_maj), DM_E_SHAPE, "gemm: only one gathered operand per call");
+  const int kind = tc * 4 + q.a_layout * 2 + q.b_layout;
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
-  if (persist) {
-    if (tc == 0) gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, grid, stream);
-    else if (tc == 1) gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, grid, stream);
-    else gemm_dispatch<64, 64, true>(a, q.a_layout, q.b_layout, grid, stream);
-  } else {
-    if (tc == 0) gemm_dispatch<128, 128, false>(a, q.a_layout, q.b_layout, grid, stream);
-    else if (tc == 1) gemm_dispatch<128, 64, false>(a, q.a_layout, q.b_layout, grid, stream);
-    else gemm_dispatch<64, 64, false>(a, q.a_layout, q.b_layout, grid, stream);
-  }
+  int rc;
+  if (tc == 0) rc = gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  else if (tc == 1) rc = gemm_dispatch<128, 64>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  else rc = gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  if (rc != DM_OK) return rc;
   prof_after(slot, stream);
   DM_LAUNCH_CHECK();
   if (nsplit > 1) {

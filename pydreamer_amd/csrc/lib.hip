@@ -58,7 +58,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (2 * d * 36 * d > wmax) wmax = 2 * d * 36 * d;
   if (d * 36 * ch > wmax) wmax = d * 36 * ch;
   const size_t dec_fwd = SK + pad64(col);
-  const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax);
+  const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax) + pad64(N * 900) + pad64(100 * d + 36 * ch);   // + gather tables
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D);
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = SK + 2 * pad64(rows * Hm);
