@@ -49,7 +49,7 @@ typedef struct dm_shape {
   int32_t mlp_layers;       /* 4  (defaults.yaml:83,85; a2c.py:17) */
   int32_t cnn_depth;        /* 48 */
   int32_t img, img_ch;      /* 64, 3 */
-  int32_t flags;            /* reserved, 0 */
+  int32_t flags;            /* bits 0-1: actor distribution, 0 = onehot, 1 = tanh_normal, 2 = normal_tanh (a2c.py:43-55) */
 } dm_shape;
 
 /* ---------------------------------------------------------------- library ---------------------- */
@@ -190,7 +190,9 @@ int dm_rssm_sequence_bwd(const dm_shape* shp, const float* embed, const float* a
                          const dm_rssm_grads* g, float* dembed, void* ws, size_t ws_bytes, void* stream);
 
 /* Imagination rollout (dreamer.py:188-216, rssm.py:155-184, a2c.py:43-55), no autograd graph (actor_grad=reinforce).
- * start (M,F) = [h|z] rows; feats (H+1,M,F); actions one-hot (H,M,A); act_idx (H,M); u_act (H,M); u_prior (H,M,S).
+ * start (M,F) = [h|z] rows; feats (H+1,M,F); actions (H,M,A) one-hot (or continuous); act_idx (H,M) (onehot only);
+ * u_act: (H,M) uniforms for the one-hot actor, or (H,M,A) standard-normal noise for continuous actors (shp->flags);
+ * u_prior (H,M,S).
  * actor_acts (dm_mlp_acts_floats(H*M, hidden, layers) floats) + actor_logits (H*M, A): optional (both or neither);
  * when given, the actor activations of all H steps are kept for dm_mlp_head_bwd (rows = H*M). */
 int dm_dream_rollout(const dm_shape* shp, int M, const float* start, const dm_rssm_params* cell,
@@ -206,6 +208,15 @@ int dm_gae_losses(int H, int M, float gamma, float lambda, const float* reward, 
  * dlogits = scale * dloss/dlogits. */
 int dm_actor_loss(int rows, int A, const float* logits, const int32_t* act_idx, const float* adv_gae,
                   const float* weight, float ent_w, float scale, float* loss, float* entropy, float* dlogits, void* stream);
+/* Continuous actors (functions.py:59-78; a2c.py:43-55,119-130): kind 1 = tanh_normal, kind 2 = normal_tanh.
+ * params (rows,2A) = [mean_raw | std_raw]; eps (rows,A) standard-normal noise (torch.normal restated);
+ * action = tanh(mean + std*eps) (kind 1) or mean + std*eps (kind 2). */
+int dm_sample_continuous(int kind, int rows, int A, const float* params, const float* eps, float* action, void* stream);
+/* reinforce rows: loss[r] = (-log pi(a)*adv - ent_w*H)*w with TransformedDistribution(Normal, Tanh) log-prob (kind 1) and the
+ * base Normal's entropy; dparams (rows,2A) = scale * dloss/dparams. */
+int dm_actor_loss_continuous(int kind, int rows, int A, const float* params, const float* actions, const float* adv_gae,
+                             const float* weight, float ent_w, float scale, float* loss, float* entropy, float* dparams,
+                             void* stream);
 /* critic loss rows (a2c.py:112-115): loss[r] = 0.5*(vt-v)^2*w ; dvalue = scale * -(vt-v)*w. */
 int dm_critic_loss(int rows, const float* value, const float* value_target, const float* weight, float scale,
                    float* loss, float* dvalue, void* stream);

@@ -118,7 +118,7 @@ def param_shapes(conf):
     s[f'{c}.post_mlp_e.weight'] = (Hd, E)
     s[f'{c}.post_norm.weight'] = (Hd,); s[f'{c}.post_norm.bias'] = (Hd,)
     s[f'{c}.post_mlp.weight'] = (Z, Hd); s[f'{c}.post_mlp.bias'] = (Z,)
-    _mlp_shapes('ac.actor.model', Fd, A, 4, s)                                             # a2c.py:36-39
+    _mlp_shapes('ac.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s)   # a2c.py:35-39
     _mlp_shapes('ac.critic.model', Fd, 1, 4, s)
     _mlp_shapes('ac.critic_target.model', Fd, 1, 4, s)
     s['probe_model.dummy'] = (1,)                                                          # probes.py:144
@@ -194,9 +194,15 @@ def make_noise(conf, seed=777):
     T, B, S, H = conf.batch_length, conf.batch_size, conf.stoch_dim, conf.imag_horizon
     M = T * B * conf.iwae_samples
     rs = np.random.RandomState(seed)
-    return dict(u_post=torch.tensor(rs.rand(T, B * conf.iwae_samples, S), dtype=torch.float32),
-                u_act=torch.tensor(rs.rand(H, M), dtype=torch.float32),
-                u_prior=torch.tensor(rs.rand(H, M, S), dtype=torch.float32))
+    out = dict(u_post=torch.tensor(rs.rand(T, B * conf.iwae_samples, S), dtype=torch.float32),
+               u_act=torch.tensor(rs.rand(H, M), dtype=torch.float32),
+               u_prior=torch.tensor(rs.rand(H, M, S), dtype=torch.float32))
+    # continuous actors draw normal noise instead (torch.normal in Normal.sample): x = mean + std * eps.  The noise is
+    # scaled by 0.25 so that tanh(x) stays away from +-1: the reference's TanhTransform inverse is an un-clamped atanh,
+    # which returns inf (and a NaN loss_actor) once a sampled action saturates in fp32 — a property of the reference
+    # that parity data must avoid, not reproduce
+    out['eps_act'] = torch.tensor(0.25 * rs.randn(H, M, conf.action_dim), dtype=torch.float32)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -379,17 +385,46 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None):
 # ---------------------------------------------------------------------------------------------------------------
 # imagination (dreamer.py:188-216) and actor-critic (a2c.py:61-149)
 # ---------------------------------------------------------------------------------------------------------------
-def dream(p, conf, in_state, H, u_act, u_prior):
-    assert conf.actor_dist == 'onehot' and conf.actor_grad == 'reinforce'
+def actor_distribution(conf, y):
+    """ActorCritic.forward_actor (a2c.py:43-55) with functions.py:59-78 restated."""
+    y = y.float()
+    if conf.actor_dist == 'onehot':
+        return D.OneHotCategorical(logits=y)
+    mean_, std_ = y.chunk(2, -1)
+    if conf.actor_dist == 'normal_tanh':                      # functions.py:59-66
+        normal = D.Normal(torch.tanh(mean_), 1.0 * torch.sigmoid(std_) + 0.01)
+        return D.Independent(normal, 1)
+    if conf.actor_dist == 'tanh_normal':                      # functions.py:69-78
+        normal = D.Independent(D.Normal(5 * torch.tanh(mean_ / 5), F.softplus(std_) + 0.1), 1)
+        dist = D.TransformedDistribution(normal, [D.TanhTransform()])
+        dist.entropy = normal.entropy                         # the reference's entropy "HACK"
+        return dist
+    raise AssertionError(conf.actor_dist)
+
+
+def sample_continuous(conf, y, eps):
+    """Distribution.sample() with torch.normal(mean, std) restated as mean + std * eps."""
+    mean_, std_ = y.float().chunk(2, -1)
+    if conf.actor_dist == 'normal_tanh':
+        return torch.tanh(mean_) + (torch.sigmoid(std_) + 0.01) * eps
+    return torch.tanh(5 * torch.tanh(mean_ / 5) + (F.softplus(std_) + 0.1) * eps)
+
+
+def dream(p, conf, in_state, H, u_act, u_prior, eps_act=None):
+    assert conf.actor_grad == 'reinforce'
     h, z = in_state
     feats, actions, act_idx, lat_idx = [], [], [], []
     with torch.no_grad():
         for i in range(H):
             feature = torch.cat((h, z), -1)
             logits = mlp(p, 'ac.actor.model', feature, 4).float()             # a2c.py:43-47
-            lg = logits - logits.logsumexp(-1, keepdim=True)
-            idx = sample_inverse_cdf(torch.softmax(lg, -1), u_act[i])         # dreamer.py:198-200
-            action = F.one_hot(idx, conf.action_dim).float()
+            if conf.actor_dist == 'onehot':
+                lg = logits - logits.logsumexp(-1, keepdim=True)
+                idx = sample_inverse_cdf(torch.softmax(lg, -1), u_act[i])     # dreamer.py:198-200
+                action = F.one_hot(idx, conf.action_dim).float()
+            else:
+                action = sample_continuous(conf, logits, eps_act[i])
+                idx = torch.zeros(action.shape[0], dtype=torch.long)
             feats.append(feature); actions.append(action); act_idx.append(idx)
             _, h, z, zi = cell_forward_prior(p, conf, action, h, z, u_prior[i])   # dreamer.py:205
             lat_idx.append(zi)
@@ -422,7 +457,7 @@ def ac_training_step(p, conf, features, actions, rewards, terminals):
     loss_critic = (0.5 * torch.square(value_target.detach() - value0) * reality_weight).mean()
 
     logits = mlp(p, 'ac.actor.model', features[:-1], 4).float()
-    policy = D.OneHotCategorical(logits=logits)
+    policy = actor_distribution(conf, logits)
     loss_policy = -policy.log_prob(actions) * advantage_gae.detach()
     policy_entropy = policy.entropy()
     loss_actor = ((loss_policy - conf.entropy * policy_entropy) * reality_weight).mean()
@@ -474,7 +509,9 @@ class OracleDreamer:
                     if k.startswith('ac.critic_target.'):
                         p[k].copy_(p[k.replace('critic_target', 'critic')])
         self.train_steps += 1
-        feats, actions, rewards, terminals, dx = dream(p, c, in_dream, c.imag_horizon, noise['u_act'], noise['u_prior'])
+        feats, actions, rewards, terminals, dx = dream(p, c, in_dream, c.imag_horizon, noise['u_act'], noise['u_prior'],
+                                                      noise.get('eps_act'))
+        dx['actions'] = actions
         (loss_actor, loss_critic), m_ac, t_ac = ac_training_step(p, c, feats, actions, rewards, terminals)
         metrics.update(m_ac)
         tensors.update(policy_value=t_ac['value'][0].reshape(T, B, 1).mean(-1))    # dreamer.py:159

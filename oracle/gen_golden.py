@@ -42,20 +42,30 @@ def reference_conf(sections, overrides):
 
 
 class MultinomialPatch:
-    """Replaces torch.multinomial(probs_2d, 1, True) by the shared inverse-CDF rule on queued uniforms."""
+    """Replaces torch.multinomial(probs_2d, 1, True) by the shared inverse-CDF rule on queued uniforms, and
+    torch.normal(mean, std) (continuous actors: Normal.sample) by mean + std * eps on queued standard-normal noise."""
 
     def __init__(self):
         self.queue = []
+        self.eps_queue = []
         self.calls = []
         self.idx = []
         self.orig = torch.multinomial
+        self.orig_normal = torch.normal
 
     def __enter__(self):
         torch.multinomial = self
+        torch.normal = self.normal
         return self
 
     def __exit__(self, *a):
         torch.multinomial = self.orig
+        torch.normal = self.orig_normal
+
+    def normal(self, mean, std, *a, **kw):
+        eps = self.eps_queue.pop(0)
+        assert eps.shape == mean.shape, (eps.shape, mean.shape)
+        return mean + std * eps
 
     def __call__(self, probs, num_samples, replacement=False, **kw):
         assert num_samples == 1 and probs.dim() == 2
@@ -95,14 +105,21 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
         noise = O.make_noise(oconf, seed=777 + step)
         with MultinomialPatch() as mp:
             mp.queue = [noise['u_post'][t] for t in range(T)]
+            onehot = rconf.actor_dist == 'onehot'
             for i in range(H):
-                mp.queue += [noise['u_act'][i], noise['u_prior'][i]]
+                mp.queue += ([noise['u_act'][i]] if onehot else []) + [noise['u_prior'][i]]
+                if not onehot:
+                    mp.eps_queue.append(noise['eps_act'][i])
             losses, new_state, metrics, tensors, _ = model.training_step(obs, state)
-            assert not mp.queue, f'{len(mp.queue)} uniforms unused'
+            assert not mp.queue and not mp.eps_queue, f'{len(mp.queue)} uniforms / {len(mp.eps_queue)} normals unused'
             M = T * B * rconf.iwae_samples
             post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
-            act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
-            lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
+            if onehot:
+                act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
+                lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
+            else:
+                act_idx = torch.zeros(H, M, dtype=torch.long)
+                lat_idx = torch.stack(mp.idx[T:]).reshape(H, M, S)
         for opt in optimizers:
             opt.zero_grad()
         for loss in losses:
@@ -153,13 +170,22 @@ SMALL_GRADS = ('wm.core.cell.a_mlp.weight', 'wm.core.cell.gru.layers.0.bias_hh',
                'wm.decoder.image.model.8.weight', 'ac.actor.model.12.weight', 'ac.critic.model.1.weight')
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'debug']
+    which = sys.argv[1:] or ['tiny', 'debug', 'dmc']
     if 'tiny' in which:
         t = O.tiny_conf()
         run('tiny', ['defaults', 'atari'],
             dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
                  cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                  imag_horizon=t.imag_horizon), full_grads=SMALL_GRADS)
+    if 'dmc' in which:
+        # BASELINE.json configs[4] family: continuous actions (defaults+dmc, tanh_normal) with actor_grad=reinforce
+        # (the dmc section's actor_grad=dynamics asserts in the reference), tiny dims
+        t = O.tiny_conf()
+        run('tiny_dmc', ['defaults', 'dmc'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=4, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, actor_grad='reinforce'), steps=1,
+            full_grads=('ac.actor.model.12.weight', 'ac.actor.model.12.bias'))
     if 'debug' in which:
         # BASELINE.json configs[0]: defaults+atari+debug on CPU, B=4,T=10,H=5, discrete(6)
         run('debug_literal', ['defaults', 'atari', 'debug'],

@@ -86,6 +86,10 @@ int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* pri
 int dm_st_softmax_bwd_launch(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
                              float* dlogits, int lddl, int accum, hipStream_t st);
 int dm_mask_rows_launch(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, hipStream_t st);
+int dm_mask_rows2_launch(int rows, int n1, const float* x1, int ldx1, float* y1, int ldy1, int n2, const float* x2,
+                         int ldx2, float* y2, int ldy2, const uint8_t* reset, hipStream_t st);
+int dm_sample_continuous_launch(int kind, int rows, int A, const float* params, const float* eps, float* action,
+                                hipStream_t st);
 int dm_mul_elu_grad_launch(size_t n, const float* dy, const float* yact, float* out, hipStream_t st);
 
 // conv helpers (conv.hip)

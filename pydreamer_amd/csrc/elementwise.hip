@@ -679,6 +679,28 @@ __global__ void __launch_bounds__(256) mask_rows_kernel(int rows, int n, const f
     y[(size_t)r * ldy + c] = x[(size_t)r * ldx + c] * m;
   }
 }
+// both recurrent-state halves in one launch: y1 = x1 * m (n1 columns), y2 = x2 * m (n2 columns)
+__global__ void __launch_bounds__(256) mask_rows2_kernel(int rows, int n1, const float* __restrict__ x1, int ldx1,
+                                                         float* __restrict__ y1, int ldy1, int n2,
+                                                         const float* __restrict__ x2, int ldx2, float* __restrict__ y2,
+                                                         int ldy2, const uint8_t* __restrict__ reset) {
+  const int n = n1 + n2;
+  const size_t total = (size_t)rows * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    const float m = reset[r] ? 0.f : 1.f;
+    if (c < n1) y1[(size_t)r * ldy1 + c] = x1[(size_t)r * ldx1 + c] * m;
+    else y2[(size_t)r * ldy2 + (c - n1)] = x2[(size_t)r * ldx2 + (c - n1)] * m;
+  }
+}
+int dm_mask_rows2_launch(int rows, int n1, const float* x1, int ldx1, float* y1, int ldy1, int n2, const float* x2,
+                         int ldx2, float* y2, int ldy2, const uint8_t* reset, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(mask_rows2_kernel, dim3(ew_blocks((size_t)rows * (n1 + n2))), dim3(256), 0, st, rows, n1, x1, ldx1, y1,
+                     ldy1, n2, x2, ldx2, y2, ldy2, reset);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
 int dm_mask_rows_launch(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, hipStream_t st) {
   if (rows <= 0 || n <= 0) return DM_OK;
   hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_blocks((size_t)rows * n)), dim3(256), 0, st, rows, n, x, ldx, reset, y, ldy);
@@ -902,6 +924,106 @@ extern "C" int dm_combine(int count, const float* x, const float* w, float* out,
   CombineArgs a;
   for (int i = 0; i < count; ++i) a.w[i] = w[i];
   hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, x, a, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Continuous actors (functions.py:59-78, a2c.py:43-55,119-130; DMC config).  params row = [mean_raw (A) | std_raw (A)].
+//   kind 1  tanh_normal : mean = 5 tanh(m/5), std = softplus(s) + 0.1, action = tanh(N(mean, std)); entropy is the base
+//                         Normal's (the reference's own "HACK", functions.py:77)
+//   kind 2  normal_tanh : mean = tanh(m), std = sigmoid(s) + 0.01, action = N(mean, std) (no squashing)
+// The sample uses explicit standard-normal noise eps: x = mean + std * eps (torch.normal restated).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dm_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+__device__ __forceinline__ void dm_cont_params(int kind, float m, float s, float* mean, float* std, float* dmean_dm,
+                                               float* dstd_ds) {
+  if (kind == 1) {
+    const float t = tanhf(m / 5.f);
+    *mean = 5.f * t;
+    *dmean_dm = 1.f - t * t;
+    *std = dm_softplus(s) + 0.1f;
+    *dstd_ds = dm_sigmoid(s);
+  } else {
+    const float t = tanhf(m);
+    *mean = t;
+    *dmean_dm = 1.f - t * t;
+    const float sg = dm_sigmoid(s);
+    *std = sg + 0.01f;
+    *dstd_ds = sg * (1.f - sg);
+  }
+}
+
+__global__ void __launch_bounds__(256) sample_continuous_kernel(int kind, int rows, int A, const float* __restrict__ params,
+                                                                const float* __restrict__ eps, float* __restrict__ action) {
+  const int total = rows * A;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / A, a = i % A;
+    float mean, std, d0, d1;
+    dm_cont_params(kind, params[(size_t)r * 2 * A + a], params[(size_t)r * 2 * A + A + a], &mean, &std, &d0, &d1);
+    const float x = mean + std * eps[i];
+    action[i] = kind == 1 ? tanhf(x) : x;
+  }
+}
+extern "C" int dm_sample_continuous(int kind, int rows, int A, const float* params, const float* eps, float* action,
+                                    void* stream) {
+  DM_REQUIRE(params && eps && action, DM_E_NULL, "sample_continuous: null pointer");
+  DM_REQUIRE(kind == 1 || kind == 2, DM_E_SHAPE, "sample_continuous: kind %d", kind);
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(sample_continuous_kernel, dim3(ew_blocks((size_t)rows * A)), dim3(256), 0, (hipStream_t)stream, kind,
+                     rows, A, params, eps, action);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_sample_continuous_launch(int kind, int rows, int A, const float* params, const float* eps, float* action,
+                                hipStream_t st) {
+  return dm_sample_continuous(kind, rows, A, params, eps, action, (void*)st);
+}
+
+// reinforce loss rows for continuous actors: loss[r] = (-log pi(a) * adv - ent_w * H) * w ; dparams = scale * dloss/dparams.
+// log pi(a) for kind 1 = sum_a [ logN(x; mean, std) - 2 (log 2 - x - softplus(-2x)) ], x = atanh(a)   (TanhTransform)
+__global__ void __launch_bounds__(256) actor_loss_continuous_kernel(int kind, int rows, int A,
+                                                                    const float* __restrict__ params,
+                                                                    const float* __restrict__ actions,
+                                                                    const float* __restrict__ adv,
+                                                                    const float* __restrict__ weight, float ent_w,
+                                                                    float scale, float* __restrict__ loss,
+                                                                    float* __restrict__ entropy,
+                                                                    float* __restrict__ dparams) {
+  const float LOG_SQRT_2PI = 0.9189385332046727f;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+    const float w = weight[r], ad = adv[r];
+    float logp = 0.f, ent = 0.f;
+    for (int a = 0; a < A; ++a) {
+      float mean, std, dm_, ds_;
+      dm_cont_params(kind, params[(size_t)r * 2 * A + a], params[(size_t)r * 2 * A + A + a], &mean, &std, &dm_, &ds_);
+      const float y = actions[(size_t)r * A + a];
+      const float x = kind == 1 ? atanhf(y) : y;
+      const float z = (x - mean) / std;
+      logp += -0.5f * z * z - logf(std) - LOG_SQRT_2PI;
+      if (kind == 1) logp -= 2.f * (0.6931471805599453f - x - dm_softplus(-2.f * x));
+      ent += 0.5f + LOG_SQRT_2PI + logf(std);
+      if (dparams) {
+        // d(-logp*ad - ent_w*ent)/dmean = -ad * z/std ; /dstd = -ad * (z*z - 1)/std - ent_w / std
+        const float dmean = -ad * z / std;
+        const float dstd = -ad * (z * z - 1.f) / std - ent_w / std;
+        dparams[(size_t)r * 2 * A + a] = scale * w * dmean * dm_;
+        dparams[(size_t)r * 2 * A + A + a] = scale * w * dstd * ds_;
+      }
+    }
+    if (loss) loss[r] = (-logp * ad - ent_w * ent) * w;
+    if (entropy) entropy[r] = ent;
+  }
+}
+extern "C" int dm_actor_loss_continuous(int kind, int rows, int A, const float* params, const float* actions,
+                                        const float* adv_gae, const float* weight, float ent_w, float scale, float* loss,
+                                        float* entropy, float* dparams, void* stream) {
+  DM_REQUIRE(params && actions && adv_gae && weight, DM_E_NULL, "actor_loss_continuous: null pointer");
+  DM_REQUIRE(kind == 1 || kind == 2, DM_E_SHAPE, "actor_loss_continuous: kind %d", kind);
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(actor_loss_continuous_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, kind, rows, A,
+                     params, actions, adv_gae, weight, ent_w, scale, loss, entropy, dparams);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

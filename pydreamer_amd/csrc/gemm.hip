@@ -400,11 +400,11 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   // K_eq is the fixed prologue/epilogue price of one tile expressed in k-steps (large tiles pay ~8 us, small ~0.7 us),
   // `rate` the relative steady-state MFMA rate of the tile shape (128x128 streams fastest, 64x64 has the smallest
   // tail).  Split-K is considered only when the grid would not fill the chip, and only up to the point where the
-  // partial-sum traffic (nsplit*M*N) reaches 1/4 of the operand traffic ((M+N)*K): weight gradients and the 50-row
+  // partial-sum traffic (nsplit*M*N) reaches 1/2 of the operand traffic ((M+N)*K): weight gradients and the 50-row
   // RSSM steps split deeply, square-ish GEMMs never do.
   const int ktiles = dm_cdiv(q.K, 32);
   const double out_elems = (double)q.M * q.N;
-  int max_split = (int)(0.25 * ((double)q.M + q.N) * q.K / (out_elems > 0 ? out_elems : 1));
+  int max_split = (int)(0.5 * ((double)q.M + q.N) * q.K / (out_elems > 0 ? out_elems : 1));
   if (max_split > ktiles / 2) max_split = ktiles / 2;
   if (max_split > 512) max_split = 512;
   {
@@ -433,9 +433,12 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     }
     if (force_split > 0) sp_fill = force_split;
     if (sp_fill > (ktiles > 0 ? ktiles : 1)) sp_fill = ktiles > 0 ? ktiles : 1;
-    for (int pass = 0; pass < 2; ++pass) {                 // unsplit, and split to fill the chip
-      const int sp = pass == 0 ? (force_split > 0 ? sp_fill : 1) : sp_fill;
-      if (pass == 1 && sp == 1) break;
+    const int sps[4] = {1, 2, 4, sp_fill};                 // unsplit, lightly split (evens out a ragged last round), fill
+    for (int pass = 0; pass < 4; ++pass) {
+      int sp = force_split > 0 ? sp_fill : sps[pass];
+      if (sp > max_split && force_split <= 0) sp = max_split;
+      if (sp > (ktiles > 0 ? ktiles : 1)) sp = ktiles > 0 ? ktiles : 1;
+      if (sp < 1) sp = 1;
       const double rounds = (double)dm_cdiv(t * sp, 256);
       const double kslice = (double)dm_cdiv(ktiles > 0 ? ktiles : 1, sp) * 32.0;
       double cost = rounds * bm * bn * (kslice + keq[c]) / rate[c];

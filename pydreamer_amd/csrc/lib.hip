@@ -62,7 +62,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D);
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = SK + 2 * pad64(rows * Hm);
-  const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
+  const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
                        2 * pad64(N * 3 * D) + pad64(N * Z);
   size_t m = enc_bwd;
   if (dec_fwd > m) m = dec_fwd;

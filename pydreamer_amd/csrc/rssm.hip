@@ -104,8 +104,7 @@ extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const
     const int ldp_h = t == 0 ? D : F, ldp_z = t == 0 ? Z : F;
     float* hin = a.hin + r0 * D;
     float* zin = a.zin + r0 * Z;
-    DM_TRY(dm_mask_rows_launch(B, D, ph, ldp_h, reset + r0, hin, D, st));
-    DM_TRY(dm_mask_rows_launch(B, Z, pz, ldp_z, reset + r0, zin, Z, st));
+    DM_TRY(dm_mask_rows2_launch(B, D, ph, ldp_h, hin, D, Z, pz, ldp_z, zin, Z, reset + r0, st));
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
     DM_TRY(linear(st, ws, skb, B, Hd, Z, zin, Z, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd, a.x1 + r0 * Hd, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
@@ -233,6 +232,9 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   hipStream_t st = (hipStream_t)stream;
   const int H = s->H, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, A = s->A;
   const int Hm = s->mlp_hidden, L = s->mlp_layers;
+  const int adist = s->flags & 3;                 // 0 onehot, 1 tanh_normal, 2 normal_tanh
+  DM_REQUIRE(adist <= 2, DM_E_SHAPE, "dream_rollout: unknown actor distribution %d", adist);
+  const int AO = adist == 0 ? A : 2 * A;         // actor output width (a2c.py:35)
   const float* const* p = P->p;
 
   DmArena ar(ws, ws_bytes);
@@ -240,7 +242,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   DM_REQUIRE((actor_acts == nullptr) == (actor_logits == nullptr), DM_E_NULL,
              "dream_rollout: actor_acts and actor_logits must be given together");
   float* macts = ar.take(actor_acts ? 0 : dm_mlp_acts_floats(M, Hm, L));
-  float* logits_ws = ar.take(actor_acts ? 0 : (size_t)M * A);
+  float* logits_ws = ar.take(actor_acts ? 0 : (size_t)M * AO);
   float* ea = ar.take((size_t)M * Hd);
   float* x1 = ar.take((size_t)M * Hd);
   float* za = ar.take((size_t)M * Hd);
@@ -260,11 +262,14 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     // action ~ OneHotCategorical(actor(feature))                                        dreamer.py:195-200
     // with actor_acts the activations of all H steps are kept (rows i*M..) so ActorCritic's policy-gradient backward
     // reuses them instead of recomputing forward_actor(features[:-1]) (the reference's own TODO, a2c.py:119)
-    float* logits = actor_acts ? actor_logits + (size_t)i * M * A : logits_ws;
-    if (actor_acts) DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, actor_acts, H * M, i * M, logits, A, sk, skb, st));
-    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, A, cur, F, actor, macts, M, 0, logits, A, sk, skb, st));
-    DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
-                                   act_idx ? act_idx + (size_t)i * M : nullptr, st));
+    float* logits = actor_acts ? actor_logits + (size_t)i * M * AO : logits_ws;
+    if (actor_acts) DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st));
+    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st));
+    if (adist == 0)
+      DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
+                                     act_idx ? act_idx + (size_t)i * M : nullptr, st));
+    else
+      DM_TRY(dm_sample_continuous_launch(adist, M, A, logits, u_act + (size_t)i * M * A, act, st));
     // cell.forward_prior(action, None, (h, z))                                          rssm.py:155-184
     DM_TRY(linear(st, sk, skb, M, Hd, A, act, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, ea, Hd));
     DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));

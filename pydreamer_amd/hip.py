@@ -109,6 +109,8 @@ _SIGNATURES = {
     'dm_gae_losses': (c_int, [c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     'dm_actor_loss': (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     'dm_critic_loss': (c_int, [c_int, _P, _P, _P, c_float, _P, _P, _P]),
+    'dm_sample_continuous': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
+    'dm_actor_loss_continuous': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     'dm_multi_sum': (c_int, [c_int, POINTER(dm_reduce_item), _P, _P]),
     'dm_combine': (c_int, [c_int, _P, POINTER(c_float), _P, _P]),
     'dm_multi_tensor_norm_clip': (c_int, [_P, c_int64, c_float, _P, _P, c_size_t, _P]),

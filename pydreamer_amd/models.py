@@ -8,7 +8,8 @@ model, actor, critic — so each of the 4 returned losses supports an independen
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
 Supported configuration (everything else raises NotImplementedError): iwae_samples=1, gru_type='gru', gru_layers=1,
-stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist='onehot', actor_grad='reinforce',
+stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh},
+actor_grad='reinforce',
 probe_model='none', no aux critic / vecobs / reward_input.
 """
 import ctypes
@@ -21,6 +22,7 @@ from . import hip as H
 from .optim import FusedAdamW
 
 MLP_HIDDEN = 400          # a2c.py:16, decoders.py:259,289
+ACTOR_KINDS = {'onehot': 0, 'tanh_normal': 1, 'normal_tanh': 2}   # dm_shape.flags bits 0-1
 REWARD_STD = 0.3989422804  # decoders.py:289
 
 
@@ -297,6 +299,22 @@ class NoProbeHead(nn.Module):
         return torch.square(self.dummy), {}, {}
 
 
+def _torch_actor_distribution(actor_dist, y):
+    """The distribution object Dreamer.inference hands to the acting process (a2c.py:43-55, functions.py:59-78); the
+    parameters come from the HIP actor, the torch.distributions wrapper is only the return type of the reference API."""
+    import torch.distributions as D
+    import torch.nn.functional as F
+    if actor_dist == 'onehot':
+        return D.OneHotCategorical(logits=y)
+    mean_, std_ = y.chunk(2, -1)
+    if actor_dist == 'normal_tanh':
+        return D.Independent(D.Normal(torch.tanh(mean_), torch.sigmoid(std_) + 0.01), 1)
+    normal = D.Independent(D.Normal(5 * torch.tanh(mean_ / 5), F.softplus(std_) + 0.1), 1)
+    dist = D.TransformedDistribution(normal, [D.TanhTransform()])
+    dist.entropy = normal.entropy
+    return dist
+
+
 class _Mean:
     """Stand-in for the torch.distributions objects Dreamer.dream returns: only `.mean` is consumed (dreamer.py:155-156)."""
 
@@ -394,7 +412,8 @@ class WorldModel(_Params):
         c = self.conf
         return H.make_shape(T=T, B=B, I=1, H=H_, D=c.deter_dim, Hd=c.hidden_dim, S=c.stoch_dim, C=c.stoch_discrete,
                             E=self.encoder.out_dim, A=c.action_dim, mlp_hidden=MLP_HIDDEN, mlp_layers=4,
-                            cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels, flags=0)
+                            cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels,
+                            flags=ACTOR_KINDS.get(c.actor_dist, 0))
 
     def workspace(self, shp, device):
         need = H.workspace_bytes(shp)
@@ -601,13 +620,16 @@ class ActorCritic(_Params):
     def __init__(self, in_dim, out_actions, hidden_dim=400, hidden_layers=4, layer_norm=True, gamma=0.999, lambda_gae=0.95,
                  entropy_weight=1e-3, target_interval=100, actor_grad='reinforce', actor_dist='onehot'):
         super().__init__()
-        if actor_dist != 'onehot' or actor_grad != 'reinforce':
-            raise NotImplementedError(f'actor_dist={actor_dist!r} / actor_grad={actor_grad!r}: only onehot + reinforce is built '
-                                      f'in the HIP path (the dmc section is not runnable in the reference either, SURVEY 0.5)')
+        if actor_dist not in ACTOR_KINDS or actor_grad != 'reinforce':
+            raise NotImplementedError(f'actor_dist={actor_dist!r} / actor_grad={actor_grad!r}: the HIP path builds onehot, '
+                                      f'tanh_normal and normal_tanh actors with actor_grad=reinforce (actor_grad=dynamics '
+                                      f'asserts in the reference itself, SURVEY 0.5)')
+        self.dist_kind = ACTOR_KINDS[actor_dist]
         self.in_dim, self.out_actions = in_dim, out_actions
         self.gamma, self.lambda_, self.entropy_weight = gamma, lambda_gae, entropy_weight
         self.target_interval, self.actor_grad, self.actor_dist = target_interval, actor_grad, actor_dist
-        self.actor = MLP(in_dim, out_actions, hidden_dim, hidden_layers, layer_norm)
+        actor_out_dim = out_actions if actor_dist == 'onehot' else 2 * out_actions      # a2c.py:35
+        self.actor = MLP(in_dim, actor_out_dim, hidden_dim, hidden_layers, layer_norm)
         self.critic = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
         self.critic_target = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
         self.critic_target.requires_grad_(False)
@@ -633,9 +655,10 @@ class ActorCritic(_Params):
         Hh, A, dev = J - 1, self.out_actions, features.device
         feats = features.contiguous().view(J * M, F_)
         rewards, terminals = rewards.contiguous(), terminals.contiguous()
-        if act_idx is None:
-            act_idx = actions.argmax(-1).to(torch.int32)
-        act_idx = act_idx.contiguous().view(-1)
+        if self.dist_kind == 0:
+            if act_idx is None:
+                act_idx = actions.argmax(-1).to(torch.int32)
+            act_idx = act_idx.contiguous().view(-1)
         if ws is None:
             raise H.DreamerHipError('ActorCritic.training_step needs the model workspace (called through Dreamer.training_step)')
 
@@ -654,9 +677,14 @@ class ActorCritic(_Params):
         H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), 1.0 / rows, H.fptr(lc), H.fptr(dvalue),
                H.stream())
         la, ent = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-        dlogits = torch.empty(rows, A, device=dev)
-        H.call('dm_actor_loss', rows, A, H.fptr(logits), H.ptr(act_idx), H.fptr(agae), H.fptr(wgt), self.entropy_weight,
-               1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits), H.stream())
+        dlogits = torch.empty(rows, self.actor.out_dim, device=dev)
+        if self.dist_kind == 0:
+            H.call('dm_actor_loss', rows, A, H.fptr(logits), H.ptr(act_idx), H.fptr(agae), H.fptr(wgt), self.entropy_weight,
+                   1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits), H.stream())
+        else:
+            H.call('dm_actor_loss_continuous', self.dist_kind, rows, A, H.fptr(logits), H.fptr(actions.contiguous()),
+                   H.fptr(agae), H.fptr(wgt), self.entropy_weight, 1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits),
+                   H.stream())
         value2d = value.view(J, M)
         reward1 = rewards.view(J, M)[1:]
         s = _multi_sum([(lc, 1.0 / rows), (la, 1.0 / rows), (ent, 1.0 / rows), (value2d[0], 1.0 / M),
@@ -733,7 +761,7 @@ class Dreamer(nn.Module):
         ws = self.wm.workspace(shp, feat.device)
         logits, _ = self.ac.actor.fwd(feat, feat.shape[1], B, ws)
         value, _ = self.ac.critic.fwd(feat, feat.shape[1], B, ws)
-        action_distr = torch.distributions.OneHotCategorical(logits=logits.view(1, B, -1))
+        action_distr = _torch_actor_distribution(self.ac.actor_dist, logits.view(1, B, -1))
         return action_distr, out_state, dict(policy_value=value.mean())
 
     # ---- imagination (dreamer.py:188-216)
@@ -753,8 +781,11 @@ class Dreamer(nn.Module):
         F_, A, S = self.wm.features_dim, c.action_dim, c.stoch_dim
         shp = self.wm.shape(1, M, Hh)                        # T*B = M rows for workspace sizing
         ws = self.wm.workspace(shp, dev)
-        if u_act is None:
-            u_act = torch.rand(Hh, M, device=dev)
+        kind = self.ac.dist_kind
+        if u_act is None:     # uniforms for the one-hot actor, standard-normal noise for continuous actors
+            u_act = torch.rand(Hh, M, device=dev) if kind == 0 else torch.randn(Hh, M, A, device=dev)
+        if tuple(u_act.shape) != ((Hh, M) if kind == 0 else (Hh, M, A)):
+            raise ValueError(f'actor noise has shape {tuple(u_act.shape)}, expected {(Hh, M) if kind == 0 else (Hh, M, A)}')
         if u_prior is None:
             u_prior = torch.rand(Hh, M, S, device=dev)
         feats = torch.empty(Hh + 1, M, F_, device=dev)
@@ -765,7 +796,7 @@ class Dreamer(nn.Module):
         a_acts = a_logits = None
         if _pack is not None:          # training: keep the actor activations of all H steps for the policy-gradient backward
             a_acts = torch.empty(self.ac.actor.acts_floats(Hh * M), device=dev)
-            a_logits = torch.empty(Hh * M, A, device=dev)
+            a_logits = torch.empty(Hh * M, self.ac.actor.out_dim, device=dev)
         H.call('dm_dream_rollout', ctypes.byref(shp), M, H.fptr(start), ctypes.byref(cell_p), ctypes.byref(actor_p),
                H.fptr(u_act.contiguous()), H.fptr(u_prior.contiguous()), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
                H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
@@ -809,14 +840,17 @@ class Dreamer(nn.Module):
         # (T,B,I) => (TBI): the feature matrix [h|z] of all posterior states, detached (dreamer.py:149)
         dpk = {}
         features_dream, actions_dream, rewards_dream, terminals_dream = \
-            self._dream_from_features(pk['feat'], imag_horizon, noise.get('u_act'), noise.get('u_prior'), _pack=dpk)
+            self._dream_from_features(pk['feat'], imag_horizon,
+                                      noise.get('u_act') if self.ac.dist_kind == 0 else noise.get('eps_act'),
+                                      noise.get('u_prior'), _pack=dpk)
         (loss_actor, loss_critic), metrics_ac, tensors_ac = \
             self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
                                   actor_logits=dpk['actor_logits'])
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
-        self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], dream_features=features_dream,
+        self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,
+                                dream_features=features_dream,
                                 ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'])
         losses = (loss_model, loss_probe, loss_actor, loss_critic)
         return losses, out_state, metrics, tensors, {}

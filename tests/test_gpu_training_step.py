@@ -186,7 +186,10 @@ def _check_pair(r, oconf, free_running=True):
         pi_h = r['xh']['post_idx'].cpu().long().reshape(T, B, S)
         pi_o = r['xo']['post_idx'].reshape(T, B, S)
         assert torch.equal(pi_h, pi_o), f'{int((pi_h != pi_o).sum())} posterior index mismatches'
-        assert torch.equal(r['xh']['act_idx'].cpu().long(), r['xo']['act_idx']), 'dream action index mismatch'
+        if oconf.actor_dist == 'onehot':
+            assert torch.equal(r['xh']['act_idx'].cpu().long(), r['xo']['act_idx']), 'dream action index mismatch'
+        else:
+            _close(r['xh']['actions'], r['xo']['actions'], 1e-4, 1e-5, 'dream continuous actions')
         lat_h = r['xh']['dream_features'][1:, :, oconf.deter_dim:].reshape(oconf.imag_horizon, -1, S, oconf.stoch_discrete).argmax(-1).cpu()
         assert torch.equal(lat_h, r['xo']['lat_idx']), 'dream latent index mismatch'
     names = ('loss_model', 'loss_probe', 'loss_actor', 'loss_critic')
@@ -224,9 +227,17 @@ def test_training_step_teacher_forced_vs_oracle(hip):
         _check_pair(r, oconf, free_running=False)
 
 
+def test_training_step_continuous_actor_vs_oracle(hip):
+    """DMC-style Gaussian actors (BASELINE configs[4] family): tanh_normal and normal_tanh with actor_grad=reinforce."""
+    for dist in ('tanh_normal', 'normal_tanh'):
+        oconf = O.tiny_conf(actor_dist=dist, action_dim=4, entropy=1.0e-4, gamma=0.995)
+        for r in _run_pair(oconf, 1):
+            _check_pair(r, oconf)
+
+
 def test_training_step_matches_reference_goldens(hip):
-    """Directly against the fixtures written by the real reference (tests/golden/tiny.npz, debug_literal.npz)."""
-    for name, steps in (('tiny', 2), ('debug_literal', 1)):
+    """Directly against the fixtures written by the real reference (tests/golden/tiny.npz, debug_literal.npz, tiny_dmc.npz)."""
+    for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)
@@ -238,7 +249,8 @@ def test_training_step_matches_reference_goldens(hip):
             pre = f's{s}_'
             raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
             obs = _to_dev(O.preprocess(raw, oconf))
-            noise = {k: torch.from_numpy(g[pre + 'in_' + k]).to(DEV) for k in ('u_post', 'u_act', 'u_prior')}
+            noise = {k: torch.from_numpy(g[pre + 'in_' + k]).to(DEV) for k in ('u_post', 'u_act', 'u_prior', 'eps_act')
+                     if pre + 'in_' + k in g.files}
             losses, state, metrics, tensors, _ = model.training_step(obs, state, noise=noise)
             for opt in opts:
                 opt.zero_grad()
@@ -248,7 +260,8 @@ def test_training_step_matches_reference_goldens(hip):
             for opt in opts:
                 opt.step()
             assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_post']), name
-            assert np.array_equal(model.last_extras['act_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_act']), name
+            if oconf.actor_dist == 'onehot':
+                assert np.array_equal(model.last_extras['act_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_act']), name
             for i, l in enumerate(losses):
                 ref = g[pre + 'losses'][i]
                 assert _rel(l, ref) < 2e-5 or abs(float(l) - ref) < 2e-6, (name, s, i, float(l), ref)

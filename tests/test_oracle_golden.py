@@ -37,7 +37,7 @@ def _replay(name, steps):
         pre = f's{s}_'
         raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
         obs = O.preprocess(raw, conf)
-        noise = {k: torch.from_numpy(g[pre + 'in_' + k]) for k in ('u_post', 'u_act', 'u_prior')}
+        noise = {k: torch.from_numpy(g[pre + 'in_' + k]) for k in ('u_post', 'u_act', 'u_prior', 'eps_act') if pre + 'in_' + k in g.files}
         assert np.array_equal(state[0].numpy(), g[pre + 'in_state_h']) or s > 0
         losses, new_state, metrics, tensors, extras = model.training_step(obs, state, noise)
         grad_metrics, grads = model.backward_clip_step(losses)
@@ -113,6 +113,14 @@ def test_oracle_matches_reference_debug_literal():
     g, conf, results = _replay('debug_literal', 1)
     assert (conf.batch_size, conf.batch_length, conf.imag_horizon, conf.action_dim, conf.deter_dim) == (4, 10, 5, 6, 1024)
     _check_step(g, conf, results[0])
+
+
+def test_oracle_matches_reference_continuous_actor():
+    """BASELINE.json configs[4] family: defaults+dmc (tanh_normal Gaussian actor) with actor_grad=reinforce, tiny dims."""
+    g, conf, results = _replay('tiny_dmc', 1)
+    assert (conf.actor_dist, conf.actor_grad, conf.action_dim, conf.entropy) == ('tanh_normal', 'reinforce', 4, 1.0e-4)
+    _check_step(g, conf, results[0])
+    assert np.isfinite(g['s0_losses']).all()
 
 
 def test_sampler_rule_edges():
