@@ -18,6 +18,7 @@ DM_MAX_MLP_LAYERS = 8
 DM_GEMM_ACCUM = 1
 DM_GEMM_ELU = 2
 DM_C2I_ELU = 1
+DM_SPLITK_FLOATS = 16 * 1024 * 1024    # split-K partial region carved at the front of every operator workspace
 
 RSSM_PARAM_ORDER = [
     'z_mlp.weight', 'z_mlp.bias', 'a_mlp.weight', 'in_norm.weight', 'in_norm.bias',

@@ -352,6 +352,22 @@ def _multi_sum(items, device):
     return out
 
 
+class _Overlap:
+    """Two side streams for the backward passes.  The world-model backward contains the strictly sequential BPTT chain
+    (T steps of 50-row kernels that leave most of the 256 CUs idle); the actor and critic backward passes are
+    independent of it (dreamer.py:153-157 detaches everything they consume), so they run on a second HIP stream that
+    is released exactly when the BPTT loop starts.  Both streams are joined into the caller's stream before the
+    gradients are handed to autograd, so callers see ordinary stream semantics."""
+
+    def __init__(self, device):
+        self.s_wm = torch.cuda.Stream(device)
+        self.s_ac = torch.cuda.Stream(device)
+        self.ev_fwd = torch.cuda.Event()
+        self.ev_bptt = torch.cuda.Event()
+        self.bptt_armed = False
+        self.ws_ac = None
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise H.DreamerHipError(f'{what} is on {t.device}: pydreamer_amd has no CPU path (the HIP library is the product)')
@@ -373,7 +389,18 @@ class _WMStep(torch.autograd.Function):
         wm, pk = ctx.wm, ctx.pack
         if pk.get('consumed'):
             raise RuntimeError('loss_model.backward() called twice (saved activations were released)')
-        grads = wm._backward(pk, grad_loss)
+        ov = pk.get('overlap')
+        if ov is None:
+            grads, flat = wm._backward(pk)
+        else:
+            main = torch.cuda.current_stream()
+            ov.s_wm.wait_stream(main)
+            with torch.cuda.stream(ov.s_wm):
+                grads, flat = wm._backward(pk)
+            main.wait_stream(ov.s_wm)
+        # chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync
+        gl = grad_loss.detach().float().reshape(1).contiguous()
+        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
         pk['consumed'] = True
         return (None, None) + tuple(grads)
 
@@ -518,7 +545,7 @@ class WorldModel(_Params):
     def _param_order(self):
         return list(self.parameters())
 
-    def _backward(self, pk, grad_loss):
+    def _backward(self, pk):
         c = self.conf
         shp, T, B = pk['shp'], pk['T'], pk['B']
         N = T * B
@@ -552,7 +579,11 @@ class WorldModel(_Params):
             sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
         H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
                H.fptr(dpost), H.fptr(dprior), H.stream())
-        # RSSM BPTT
+        # RSSM BPTT (latency-bound: release the actor/critic backward stream now)
+        ov = pk.get('overlap')
+        if ov is not None:
+            ov.ev_bptt.record(torch.cuda.current_stream())
+            ov.bptt_armed = True
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
@@ -567,12 +598,9 @@ class WorldModel(_Params):
                               cls=H.dm_conv_grads)
         H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
                H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
-        # chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync
-        gl = grad_loss.detach().float().reshape(1).contiguous()
-        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
         for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
             pk.pop(k, None)
-        return views
+        return views, flat
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
                       u_post=None, forced_idx=None, imag_horizon=1):
@@ -607,7 +635,17 @@ class _HeadLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         mlp, pk = ctx.mlp, ctx.pack
-        grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
+        ov = pk.get('overlap')
+        if ov is None:
+            grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
+        else:
+            main = torch.cuda.current_stream()
+            ov.s_ac.wait_event(ov.ev_fwd)                 # everything this pass reads was produced by the forward
+            if ov.bptt_armed:
+                ov.s_ac.wait_event(ov.ev_bptt)            # start when the world model enters its BPTT chain
+            with torch.cuda.stream(ov.s_ac):
+                grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
+            main.wait_stream(ov.s_ac)
         gl = grad_loss.detach().float().reshape(1).contiguous()
         H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
         pk.pop('acts', None)
@@ -642,7 +680,7 @@ class ActorCritic(_Params):
                 H.call('dm_copy_params', H.fptr(dst), H.fptr(src), dst.numel(), H.stream())
 
     def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None,
-                      actor_acts=None, actor_logits=None):
+                      actor_acts=None, actor_logits=None, overlap=None):
         """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149.
         actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
         features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
@@ -694,8 +732,9 @@ class ActorCritic(_Params):
         if log_only:
             loss_actor, loss_critic = loss_actor_v, loss_critic_v
         else:
-            pa = dict(loss=loss_actor_v, x=feats, ldx=F_, rows=rows, acts=a_acts, dout=dlogits, ws=ws)
-            pc = dict(loss=loss_critic_v, x=feats, ldx=F_, rows=J * M, acts=c_acts, dout=dvalue.view(J * M, 1), ws=ws)
+            pa = dict(loss=loss_actor_v, x=feats, ldx=F_, rows=rows, acts=a_acts, dout=dlogits, ws=ws, overlap=overlap)
+            pc = dict(loss=loss_critic_v, x=feats, ldx=F_, rows=J * M, acts=c_acts, dout=dvalue.view(J * M, 1), ws=ws,
+                      overlap=overlap)
             loss_actor = _HeadLoss.apply(self.actor, pa, *self.actor.param_list())
             loss_critic = _HeadLoss.apply(self.critic, pc, *self.critic.param_list())
         metrics = dict(loss_critic=loss_critic_v, loss_actor=loss_actor_v, policy_entropy=s[2], policy_value=s[3],
@@ -725,6 +764,8 @@ class Dreamer(nn.Module):
         self.probe_model = NoProbeHead()
         self.probe_gradients = conf.probe_gradients
         self._groups = None
+        self._overlap = None
+        self.overlap_backward = True      # run actor/critic backward concurrently with the world model's BPTT chain
 
     # ---- optimizers (dreamer.py:60-87)
     def param_groups(self):
@@ -832,6 +873,14 @@ class Dreamer(nn.Module):
                                   do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
                                   imag_horizon=imag_horizon)
         pk = self.wm._last_pack
+        ov = None
+        if self.overlap_backward:
+            dev = pk['feat'].device
+            if self._overlap is None or self._overlap.s_wm.device != dev:
+                self._overlap = _Overlap(dev)
+            ov = self._overlap
+            ov.bptt_armed = False
+            pk['overlap'] = ov
         metrics, tensors = dict(metrics), dict(tensors)
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)
@@ -846,7 +895,12 @@ class Dreamer(nn.Module):
         (loss_actor, loss_critic), metrics_ac, tensors_ac = \
             self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
-                                  actor_logits=dpk['actor_logits'])
+                                  actor_logits=dpk['actor_logits'], overlap=ov)
+        if ov is not None:
+            need = (int(H.DM_SPLITK_FLOATS) + 2 * ((imag_horizon + 1) * T * B * MLP_HIDDEN + 64) + 4096) * 4
+            if ov.ws_ac is None or ov.ws_ac.numel() < need:
+                ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
+            ov.ev_fwd.record(torch.cuda.current_stream())
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,
