@@ -366,6 +366,7 @@ class _Overlap:
         self.ev_bptt = torch.cuda.Event()
         self.bptt_armed = False
         self.ws_ac = None
+        self.pending = []          # (mlp, pack) of this step's actor / critic losses, precomputed inside the WM backward
 
 
 def _require_cuda(t, what):
@@ -582,8 +583,17 @@ class WorldModel(_Params):
         # RSSM BPTT (latency-bound: release the actor/critic backward stream now)
         ov = pk.get('overlap')
         if ov is not None:
+            # Host order matters as much as stream order: the actor / critic backward launches are ENQUEUED here, ahead
+            # of the ~700 BPTT launches, on the second stream gated by ev_bptt, so the GPU has them in hand when the
+            # sequential chain starts.  loss_actor/loss_critic.backward() later only join the stream and return them.
             ov.ev_bptt.record(torch.cuda.current_stream())
             ov.bptt_armed = True
+            for mlp, hp in ov.pending:
+                if 'pre' not in hp and 'acts' in hp:
+                    ov.s_ac.wait_event(ov.ev_fwd)
+                    ov.s_ac.wait_event(ov.ev_bptt)
+                    with torch.cuda.stream(ov.s_ac):
+                        hp['pre'] = mlp.bwd(hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac)
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
@@ -640,11 +650,12 @@ class _HeadLoss(torch.autograd.Function):
             grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
         else:
             main = torch.cuda.current_stream()
-            ov.s_ac.wait_event(ov.ev_fwd)                 # everything this pass reads was produced by the forward
-            if ov.bptt_armed:
-                ov.s_ac.wait_event(ov.ev_bptt)            # start when the world model enters its BPTT chain
-            with torch.cuda.stream(ov.s_ac):
-                grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
+            if 'pre' in pk:                               # already enqueued from inside the world-model backward
+                grads, flat = pk.pop('pre')
+            else:
+                ov.s_ac.wait_event(ov.ev_fwd)             # everything this pass reads was produced by the forward
+                with torch.cuda.stream(ov.s_ac):
+                    grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
             main.wait_stream(ov.s_ac)
         gl = grad_loss.detach().float().reshape(1).contiguous()
         H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
@@ -737,6 +748,8 @@ class ActorCritic(_Params):
                       overlap=overlap)
             loss_actor = _HeadLoss.apply(self.actor, pa, *self.actor.param_list())
             loss_critic = _HeadLoss.apply(self.critic, pc, *self.critic.param_list())
+            if overlap is not None:
+                overlap.pending = [(self.actor, pa), (self.critic, pc)]
         metrics = dict(loss_critic=loss_critic_v, loss_actor=loss_actor_v, policy_entropy=s[2], policy_value=s[3],
                        policy_value_im=s[4], policy_reward=s[5], policy_reward_std=var[0].sqrt())
         tensors = dict(value=value2d, value_target=vtgt, value_advantage=adv, value_advantage_gae=agae, value_weight=wgt)
