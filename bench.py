@@ -129,6 +129,7 @@ def main():
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -155,6 +156,7 @@ def main():
     conf = config.atari_literal(batch_size=hi - lo)
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
+    model.overlap_backward = not args.no_overlap
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
     DP.attach(opts, hi - lo, B)
     ring = make_ring(conf, hi - lo, args.ring, dev, 1234 + rank)

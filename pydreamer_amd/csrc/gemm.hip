@@ -433,7 +433,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     }
     if (force_split > 0) sp_fill = force_split;
     if (sp_fill > (ktiles > 0 ? ktiles : 1)) sp_fill = ktiles > 0 ? ktiles : 1;
-    const int sps[4] = {1, 2, 4, sp_fill};                 // unsplit, lightly split (evens out a ragged last round), fill
+    // unsplit; split to fill an under-subscribed chip (t < 256: long reductions need >= 2 workgroups per CU to hide the
+    // load latency of their serial k loop, so never fewer splits than `fill`); light splits only to even out a ragged
+    // last round of an already full grid (t >= 256)
+    const int sps[4] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill};
     for (int pass = 0; pass < 4; ++pass) {
       int sp = force_split > 0 ? sp_fill : sps[pass];
       if (sp > max_split && force_split <= 0) sp = max_split;

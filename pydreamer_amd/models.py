@@ -360,8 +360,10 @@ class _Overlap:
     gradients are handed to autograd, so callers see ordinary stream semantics."""
 
     def __init__(self, device):
-        self.s_wm = torch.cuda.Stream(device)
-        self.s_ac = torch.cuda.Stream(device)
+        # the latency-bound chain gets the high-priority queue: its 16-30-workgroup kernels must be dispatched ahead of
+        # the thousands of queued GEMM workgroups of the concurrent actor/critic backward, or the chain just slows down
+        self.s_wm = torch.cuda.Stream(device, priority=-1)
+        self.s_ac = torch.cuda.Stream(device, priority=0)
         self.ev_fwd = torch.cuda.Event()
         self.ev_bptt = torch.cuda.Event()
         self.bptt_armed = False
