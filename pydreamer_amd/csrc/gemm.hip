@@ -47,17 +47,18 @@ struct GemmKArgs {
 
 // Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).
 // LAYOUT 0: the k index is contiguous in memory (major = row, minor = k); LAYOUT 1: the row index is (major = k).
-// With gather tables (tmaj != nullptr) an element lives at P[tmaj[major] + tmin[minor]] — the implicit-im2col operand:
+// With gather tables (GATHER) an element lives at P[tmaj[major] + tmin[minor]] — the implicit-im2col operand:
 // tmaj = start of a conv patch, tmin = offset of tap (ky,kx,c) inside it; `vec` then promises that 4 consecutive
 // minors are 4 consecutive, 16-byte aligned floats (channels % 4 == 0).
-template <int ROWS, int LAYOUT, int NF4, bool GATHER>
+// CHECKED = false is the interior fast path (tile fully inside the matrix, full k-tile, vector loads legal): no
+// predicates, no branches — 4-8 back-to-back 16-byte loads per thread.
+template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool CHECKED>
 __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __restrict__ P, int ld, int row0,
                                                int nrows, int k0, int kend, int vec, const int* __restrict__ tmaj,
                                                const int* __restrict__ tmin, int tid) {
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const int f = tid + i * 256;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     int major, minor, minor_end;
     bool ok;
     if (LAYOUT == 0) {
@@ -72,6 +73,12 @@ __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __
       minor_end = nrows;
       ok = major < kend && minor < nrows;
     }
+    if (!CHECKED) {
+      const float* p = GATHER ? P + tmaj[major] + tmin[minor] : P + (size_t)major * ld + minor;
+      r[i] = *reinterpret_cast<const float4*>(p);
+      continue;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
       if (GATHER) {
         const float* base = P + tmaj[major];
@@ -152,14 +159,14 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
   return it;
 }
 
-// Persistent workgroups: the grid is sized to the chip's residency and every workgroup walks a strided list of work
-// items; the global loads of the NEXT item's first k-tile are issued under the MFMAs of the current item's last
-// k-tile, so the per-tile prologue latency (HBM/L2 round trip) and the epilogue stores overlap with compute.
-// PERSIST = false compiles the same body as a one-item-per-workgroup kernel (grid = n_items): the cross-item prefetch
-// keeps 32 staging registers live across the epilogue, which costs the 128x128 instance its 3-blocks-per-CU residency.
+// One work item (tile x k-slice) per workgroup.  (A persistent tile walk with cross-tile prefetch was built and lost the
+// A/B on MI355X — it costs the 3-8 workgroups/CU residency that hides the k-loop's load latency; numbers in
+// profiles/r01_gemm_persist_ab.txt.)
 // GA / GB: operand A / B is a separable gather (compile-time, so the plain instances keep their register budget).
-template <int BM, int BN, int AL, int BL, bool PERSIST, bool GA = false, bool GB = false>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
+// The 128x128 instances are held to 168 VGPRs (3 waves per SIMD = 3 workgroups per CU): residency is what hides the
+// k-loop's load latency (second __launch_bounds__ argument = minimum waves per SIMD).
+template <int BM, int BN, int AL, int BL, bool GA = false, bool GB = false>
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int BK = 32;
   constexpr int LDK = 36;
   constexpr int LDMA = BM + 4, LDMB = BN + 4;
@@ -178,109 +185,96 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   const int l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
-  int id = blockIdx.x;
-  if (id >= g.n_items) return;
-  GemmItem cur = gemm_decode<BM, BN>(g, id);
+  const GemmItem cur = gemm_decode<BM, BN>(g, blockIdx.x);
+  // interior tile with legal vector loads: every k-tile except a ragged last one takes the unchecked load path
+  const bool interior = cur.m0 + BM <= g.M && cur.n0 + BN <= g.N && g.a_vec && g.b_vec;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[A_F4], rb[B_F4];
-  if (cur.nkt > 0) {
-    gemm_load_tile<BM, AL, A_F4, GA>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
-    gemm_load_tile<BN, BL, B_F4, GB>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
-  }
-  for (;;) {
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int next_id = id + gridDim.x;
-    const bool has_next = PERSIST && next_id < g.n_items;
-    GemmItem nxt = cur;
-    if (has_next) nxt = gemm_decode<BM, BN>(g, next_id);
-
-    for (int kt = 0; kt < cur.nkt; ++kt) {
-      gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
-      gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
-      __syncthreads();
-      // one prefetch site for both cases (next k-tile of this item / first k-tile of the next item): the selection
-      // is wave-uniform scalar work, so the load code and its address registers exist once
-      const bool same = kt + 1 < cur.nkt;
-      if (same || has_next) {
-        const int lm0 = same ? cur.m0 : nxt.m0, ln0 = same ? cur.n0 : nxt.n0;
-        const int lk0 = same ? cur.kbeg + (kt + 1) * BK : nxt.kbeg;
-        const int lkend = same ? cur.kend : nxt.kend;
-        gemm_load_tile<BM, AL, A_F4, GA>(ra, g.A, g.lda, lm0, g.M, lk0, lkend, g.a_vec, g.a_maj, g.a_min, tid);
-        gemm_load_tile<BN, BL, B_F4, GB>(rb, g.B, g.ldb, ln0, g.N, lk0, lkend, g.b_vec, g.b_maj, g.b_min, tid);
-      }
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        float a[MB][4], b[NB][4];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const int row = wm * (BM / 2) + mb * 32 + l31;
-          if (AL == 0) {
-            const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
-            a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[mb][j] = As[(kg * 8 + half * 4 + j) * LDMA + row];
-          }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int row = wn * (BN / 2) + nb * 32 + l31;
-          if (BL == 0) {
-            const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
-            b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[nb][j] = Bs[(kg * 8 + half * 4 + j) * LDMB + row];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
-      }
-      __syncthreads();
+  auto load = [&](int k0) {
+    if (interior && k0 + BK <= cur.kend) {
+      gemm_load_tile<BM, AL, A_F4, GA, false>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, 1, g.a_maj, g.a_min, tid);
+      gemm_load_tile<BN, BL, B_F4, GB, false>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, 1, g.b_maj, g.b_min, tid);
+    } else {
+      gemm_load_tile<BM, AL, A_F4, GA, true>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
+      gemm_load_tile<BN, BL, B_F4, GB, true>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
     }
-
-    // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  };
+  if (cur.nkt > 0) load(cur.kbeg);
+  for (int kt = 0; kt < cur.nkt; ++kt) {
+    gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
+    gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
+    __syncthreads();
+    if (kt + 1 < cur.nkt) load(cur.kbeg + (kt + 1) * BK);     // register prefetch under the MFMAs below
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+    for (int kg = 0; kg < 4; ++kg) {
+      float a[MB][4], b[NB][4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int row = wm * (BM / 2) + mb * 32 + l31;
+        if (AL == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
+          a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[mb][j] = As[(kg * 8 + half * 4 + j) * LDMA + row];
+        }
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int col = cur.n0 + wn * (BN / 2) + nb * 32 + l31;
+        const int row = wn * (BN / 2) + nb * 32 + l31;
+        if (BL == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
+          b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = cur.m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < g.M && col < g.N) {
-            float v = acc[mb][nb][r];
-            if (g.nsplit > 1) {
-              g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
-            } else {
-              if (g.row_zero && g.row_zero[row]) v = 0.f;
-              if (g.bias) v += g.bias[col];
-              if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-              float* c = g.C + (size_t)row * g.ldc + col;
-              if (g.flags & DM_GEMM_ACCUM) v += *c;
-              if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
-              if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
-              *c = v;
-            }
+          for (int j = 0; j < 4; ++j) b[nb][j] = Bs[(kg * 8 + half * 4 + j) * LDMB + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = cur.n0 + wn * (BN / 2) + nb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cur.m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M && col < g.N) {
+          float v = acc[mb][nb][r];
+          if (g.nsplit > 1) {
+            g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
+          } else {
+            if (g.row_zero && g.row_zero[row]) v = 0.f;
+            if (g.bias) v += g.bias[col];
+            if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+            float* c = g.C + (size_t)row * g.ldc + col;
+            if (g.flags & DM_GEMM_ACCUM) v += *c;
+            if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
+            if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
+            *c = v;
           }
         }
       }
     }
-    if (!has_next) break;
-    id = next_id;
-    cur = nxt;
   }
 }
 
@@ -362,14 +356,14 @@ template <int BM, int BN>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, false, true, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, true, false>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
     if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false, false, true>), grid, dim3(256), 0, stream, a);
-  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, false>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, false>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, false>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false, true>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, stream, a);
   return DM_OK;
 }
 
@@ -463,8 +457,6 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.tiles_n = tiles_n;
   a.n_fast = tiles_n <= tiles_m ? 1 : 0;
   a.n_items = (int)(tiles * nsplit);
-  // one work item per workgroup: the persistent walk (PERSIST = true) lost the A/B on MI355X, see
-  // profiles/r01_gemm_persist_ab.txt — residency (3-8 workgroups per CU) beats cross-tile prefetch
   const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 ? 1 : 2);
   dim3 grid((unsigned)a.n_items);
   const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
