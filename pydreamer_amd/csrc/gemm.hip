@@ -198,21 +198,20 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[A_F4], rb[B_F4];
-  auto load = [&](int k0) {
-    if (interior && k0 + BK <= cur.kend) {
-      gemm_load_tile<BM, AL, A_F4, GA, false>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, 1, g.a_maj, g.a_min, tid);
-      gemm_load_tile<BN, BL, B_F4, GB, false>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, 1, g.b_maj, g.b_min, tid);
-    } else {
-      gemm_load_tile<BM, AL, A_F4, GA, true>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
-      gemm_load_tile<BN, BL, B_F4, GB, true>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
-    }
+  auto load_fast = [&](int k0) {
+    gemm_load_tile<BM, AL, A_F4, GA, false>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, 1, g.a_maj, g.a_min, tid);
+    gemm_load_tile<BN, BL, B_F4, GB, false>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, 1, g.b_maj, g.b_min, tid);
   };
-  if (cur.nkt > 0) load(cur.kbeg);
-  for (int kt = 0; kt < cur.nkt; ++kt) {
+  auto load_checked = [&](int k0) {
+    gemm_load_tile<BM, AL, A_F4, GA, true>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
+    gemm_load_tile<BN, BL, B_F4, GB, true>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
+  };
+  auto stage = [&]() {
     gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
     gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
     __syncthreads();
-    if (kt + 1 < cur.nkt) load(cur.kbeg + (kt + 1) * BK);     // register prefetch under the MFMAs below
+  };
+  auto compute = [&]() {
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       float a[MB][4], b[NB][4];
@@ -247,6 +246,29 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
     }
     __syncthreads();
+  };
+  // Two k-loops instead of one loop with a per-tile choice: a choice inside the loop merges "loads in flight" with
+  // "zero-filled" register definitions at the join and the compiler then drains vmcnt right after the loads, which
+  // serialises the register prefetch (measured 2.6x slower on the weight-gradient shapes).
+  //   fast loop   : interior tile, iterations whose NEXT k-tile is also full -> unchecked 16-byte prefetch
+  //   checked loop: everything else (edge tiles, the ragged last k-tile, unaligned operands)
+  const int nfull = (cur.kend - cur.kbeg) / BK;
+  const int nfast = (interior && nfull >= 1) ? nfull - 1 : 0;
+  if (cur.nkt > 0) {
+    if (interior && nfull >= 1) load_fast(cur.kbeg);
+    else load_checked(cur.kbeg);
+  }
+  int kt = 0;
+  for (; kt < nfast; ++kt) {
+    stage();
+    load_fast(cur.kbeg + (kt + 1) * BK);                      // register prefetch under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
+    compute();
+  }
+  for (; kt < cur.nkt; ++kt) {
+    stage();
+    if (kt + 1 < cur.nkt) load_checked(cur.kbeg + (kt + 1) * BK);
+    compute();
   }
 
   // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
