@@ -45,71 +45,74 @@ struct GemmKArgs {
   int a_vec, b_vec;
 };
 
-// Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).
+// Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).  Branch-free: out-of-range
+// groups read a clamped (always valid) address and are zeroed by a select, so edge tiles cost the same instruction
+// stream as interior ones and the loads issue back to back ahead of the MFMAs.
 // LAYOUT 0: the k index is contiguous in memory (major = row, minor = k); LAYOUT 1: the row index is (major = k).
-// With gather tables (GATHER) an element lives at P[tmaj[major] + tmin[minor]] — the implicit-im2col operand:
-// tmaj = start of a conv patch, tmin = offset of tap (ky,kx,c) inside it; `vec` then promises that 4 consecutive
-// minors are 4 consecutive, 16-byte aligned floats (channels % 4 == 0).
-// CHECKED = false is the interior fast path (tile fully inside the matrix, full k-tile, vector loads legal): no
-// predicates, no branches — 4-8 back-to-back 16-byte loads per thread.
-template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool CHECKED>
+// GATHER: an element lives at P[tmaj[major] + tmin[minor]] — the implicit-im2col operand (tmaj = start of a conv patch,
+// tmin = offset of tap (ky,kx,c) inside it).
+// VEC (chosen on the host, grid-uniform): the minor extent is a multiple of 4 and rows are 16-byte aligned, so every
+// group of 4 minors is entirely inside or entirely outside and is one 16-byte load; otherwise 4 predicated scalar loads.
+template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __restrict__ P, int ld, int row0,
-                                               int nrows, int k0, int kend, int vec, const int* __restrict__ tmaj,
-                                               const int* __restrict__ tmin, int tid) {
+                                               int nrows, int k0, int kend, const int* __restrict__ tmaj,
+                                               const int* __restrict__ tmin, int tid, unsigned& mask) {
+  // `mask` gets one validity bit per loaded float; the zero-fill select is applied by gemm_store_tile AFTER the MFMAs
+  // of the current tile — selecting here would consume the loads at once and drain vmcnt before the MFMAs start.
+  mask = 0u;
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const int f = tid + i * 256;
-    int major, minor, minor_end;
-    bool ok;
+    int major, minor, major_end, minor_end;
     if (LAYOUT == 0) {
       major = row0 + (f >> 3);
       minor = k0 + ((f & 7) << 2);
+      major_end = nrows;
       minor_end = kend;
-      ok = major < nrows && minor < kend;
     } else {
       constexpr int F4_PER_K = ROWS / 4;
       major = k0 + f / F4_PER_K;
       minor = row0 + ((f % F4_PER_K) << 2);
+      major_end = kend;
       minor_end = nrows;
-      ok = major < kend && minor < nrows;
     }
-    if (!CHECKED) {
-      const float* p = GATHER ? P + tmaj[major] + tmin[minor] : P + (size_t)major * ld + minor;
-      r[i] = *reinterpret_cast<const float4*>(p);
-      continue;
-    }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
-      if (GATHER) {
-        const float* base = P + tmaj[major];
-        if (vec && minor + 3 < minor_end) {
-          v = *reinterpret_cast<const float4*>(base + tmin[minor]);
-        } else {
-          v.x = base[tmin[minor]];
-          if (minor + 1 < minor_end) v.y = base[tmin[minor + 1]];
-          if (minor + 2 < minor_end) v.z = base[tmin[minor + 2]];
-          if (minor + 3 < minor_end) v.w = base[tmin[minor + 3]];
-        }
-      } else {
-        const float* p = P + (size_t)major * ld + minor;
-        if (vec && minor + 3 < minor_end) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          v.x = p[0];
-          if (minor + 1 < minor_end) v.y = p[1];
-          if (minor + 2 < minor_end) v.z = p[2];
-          if (minor + 3 < minor_end) v.w = p[3];
-        }
+    const bool okm = major < major_end;
+    const int mj = okm ? major : 0;
+    float4 v;
+    if (VEC) {
+      const bool ok = okm && minor < minor_end;
+      const int mn = ok ? minor : 0;
+      const size_t off = GATHER ? (size_t)(tmaj[mj] + tmin[mn]) : (size_t)mj * ld + mn;
+      v = *reinterpret_cast<const float4*>(P + (ok ? off : 0));
+      mask |= ok ? (0xFu << (4 * i)) : 0u;
+    } else {
+      float e[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = okm && minor + j < minor_end;
+        const int mn = ok ? minor + j : 0;
+        const size_t off = GATHER ? (size_t)(tmaj[mj] + tmin[mn]) : (size_t)mj * ld + mn;
+        e[j] = P[ok ? off : 0];
+        mask |= ok ? (1u << (4 * i + j)) : 0u;
       }
+      v = make_float4(e[0], e[1], e[2], e[3]);
     }
     r[i] = v;
   }
 }
 
 template <int ROWS, int LAYOUT, int NF4>
-__device__ __forceinline__ void gemm_store_tile(const float4 (&r)[NF4], float* S, int tid) {
+__device__ __forceinline__ void gemm_store_tile(const float4 (&rr)[NF4], unsigned mask, float* S, int tid) {
   constexpr int LDK = 36;
   constexpr int LDM = ROWS + 4;
+  float4 r[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    r[i].x = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
+    r[i].y = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
+    r[i].z = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
+    r[i].w = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const int f = tid + i * 256;
@@ -163,10 +166,9 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 // A/B on MI355X — it costs the 3-8 workgroups/CU residency that hides the k-loop's load latency; numbers in
 // profiles/r01_gemm_persist_ab.txt.)
 // GA / GB: operand A / B is a separable gather (compile-time, so the plain instances keep their register budget).
-// The 128x128 instances are held to 168 VGPRs (3 waves per SIMD = 3 workgroups per CU): residency is what hides the
-// k-loop's load latency (second __launch_bounds__ argument = minimum waves per SIMD).
-template <int BM, int BN, int AL, int BL, bool GA = false, bool GB = false>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_kernel(const GemmKArgs g) {
+// VEC: both operands take the 16-byte load path (host-checked alignment and extents).
+template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int BK = 32;
   constexpr int LDK = 36;
   constexpr int LDMA = BM + 4, LDMB = BN + 4;
@@ -186,8 +188,6 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_
   const int wm = wave >> 1, wn = wave & 1;
 
   const GemmItem cur = gemm_decode<BM, BN>(g, blockIdx.x);
-  // interior tile with legal vector loads: every k-tile except a ragged last one takes the unchecked load path
-  const bool interior = cur.m0 + BM <= g.M && cur.n0 + BN <= g.N && g.a_vec && g.b_vec;
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -198,20 +198,21 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[A_F4], rb[B_F4];
-  auto load_fast = [&](int k0) {
-    gemm_load_tile<BM, AL, A_F4, GA, false>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, 1, g.a_maj, g.a_min, tid);
-    gemm_load_tile<BN, BL, B_F4, GB, false>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, 1, g.b_maj, g.b_min, tid);
-  };
-  auto load_checked = [&](int k0) {
-    gemm_load_tile<BM, AL, A_F4, GA, true>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_vec, g.a_maj, g.a_min, tid);
-    gemm_load_tile<BN, BL, B_F4, GB, true>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_vec, g.b_maj, g.b_min, tid);
-  };
-  auto stage = [&]() {
-    gemm_store_tile<BM, AL, A_F4>(ra, As, tid);
-    gemm_store_tile<BN, BL, B_F4>(rb, Bs, tid);
+  unsigned ma = 0u, mb_ = 0u;
+  if (cur.nkt > 0) {
+    gemm_load_tile<BM, AL, A_F4, GA, VEC>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_maj, g.a_min, tid, ma);
+    gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_maj, g.b_min, tid, mb_);
+  }
+  for (int kt = 0; kt < cur.nkt; ++kt) {
+    gemm_store_tile<BM, AL, A_F4>(ra, ma, As, tid);
+    gemm_store_tile<BN, BL, B_F4>(rb, mb_, Bs, tid);
     __syncthreads();
-  };
-  auto compute = [&]() {
+    if (kt + 1 < cur.nkt) {                                   // register prefetch under the MFMAs below
+      const int k0 = cur.kbeg + (kt + 1) * BK;
+      gemm_load_tile<BM, AL, A_F4, GA, VEC>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_maj, g.a_min, tid, ma);
+      gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_maj, g.b_min, tid, mb_);
+    }
+    __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       float a[MB][4], b[NB][4];
@@ -246,29 +247,6 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 1) gemm_f32_
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
     }
     __syncthreads();
-  };
-  // Two k-loops instead of one loop with a per-tile choice: a choice inside the loop merges "loads in flight" with
-  // "zero-filled" register definitions at the join and the compiler then drains vmcnt right after the loads, which
-  // serialises the register prefetch (measured 2.6x slower on the weight-gradient shapes).
-  //   fast loop   : interior tile, iterations whose NEXT k-tile is also full -> unchecked 16-byte prefetch
-  //   checked loop: everything else (edge tiles, the ragged last k-tile, unaligned operands)
-  const int nfull = (cur.kend - cur.kbeg) / BK;
-  const int nfast = (interior && nfull >= 1) ? nfull - 1 : 0;
-  if (cur.nkt > 0) {
-    if (interior && nfull >= 1) load_fast(cur.kbeg);
-    else load_checked(cur.kbeg);
-  }
-  int kt = 0;
-  for (; kt < nfast; ++kt) {
-    stage();
-    load_fast(cur.kbeg + (kt + 1) * BK);                      // register prefetch under the MFMAs below
-    __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
-    compute();
-  }
-  for (; kt < cur.nkt; ++kt) {
-    stage();
-    if (kt + 1 < cur.nkt) load_checked(cur.kbeg + (kt + 1) * BK);
-    compute();
   }
 
   // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -374,18 +352,18 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
 }
 
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
-template <int BM, int BN>
+template <int BM, int BN, bool V>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, true, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
     if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, false, true>), grid, dim3(256), 0, stream, a);
-  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, true>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, V>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, V>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V>), grid, dim3(256), 0, stream, a);
   return DM_OK;
 }
 
@@ -407,8 +385,12 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
   a.flags = q.flags;
   a.a_maj = q.a_maj; a.a_min = q.a_min; a.b_maj = q.b_maj; a.b_min = q.b_min;
-  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0)) ? 1 : 0;
-  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.b_maj ? q.b_tab_vec != 0 : (q.ldb & 3) == 0)) ? 1 : 0;
+  // 16-byte load path: aligned base, rows a multiple of 4 floats apart, and the vectorised (minor) extent a multiple
+  // of 4 so that no group of 4 straddles the edge.  Minor extent: K for layout 0, M (resp. N) for layout 1.
+  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0) &&
+             (((q.a_layout == 0 ? q.K : q.M) & 3) == 0)) ? 1 : 0;
+  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.b_maj ? q.b_tab_vec != 0 : (q.ldb & 3) == 0) &&
+             (((q.b_layout == 0 ? q.K : q.N) & 3) == 0)) ? 1 : 0;
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
   // Cost model fitted to scripts/gemm_bench.py on MI355X (profiles/r01_gemm_shapes.txt), in MACs per CU:
@@ -440,6 +422,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   double best_cost = -1.0;
   for (int c = 0; c < 3; ++c) {
     if (force_tile && c != force_tile - 1) continue;
+    if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
     const int bm = cand[c][0], bn = cand[c][1];
     const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
     int sp_fill = 1;
@@ -486,9 +469,14 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   const int kind = tc * 4 + q.a_layout * 2 + q.b_layout;
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
   int rc;
-  if (tc == 0) rc = gemm_dispatch<128, 128>(a, q.a_layout, q.b_layout, gather, grid, stream);
-  else if (tc == 1) rc = gemm_dispatch<128, 64>(a, q.a_layout, q.b_layout, gather, grid, stream);
-  else rc = gemm_dispatch<64, 64>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  const bool vec = a.a_vec && a.b_vec;
+  if (vec) {
+    if (tc == 0) rc = gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 1) rc = gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else rc = gemm_dispatch<64, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  } else {      // rare shapes (K = action_dim = 18, single-row weight gradients): scalar loads, smallest tile only
+    rc = gemm_dispatch<64, 64, false>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  }
   if (rc != DM_OK) return rc;
   prof_after(slot, stream);
   DM_LAUNCH_CHECK();
