@@ -20,6 +20,7 @@
 // Global loads of tile t+1 are issued into registers before the MFMAs of tile t (register prefetch).
 #include "common.h"
 #include <stdlib.h>
+#include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -393,13 +394,16 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
              (((q.b_layout == 0 ? q.K : q.N) & 3) == 0)) ? 1 : 0;
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
-  // Cost model fitted to scripts/gemm_bench.py on MI355X (profiles/r01_gemm_shapes.txt), in MACs per CU:
-  //   cost = ceil(workgroups / 256 CUs) * BM*BN * (K_slice + K_eq) / rate  (+ split-K reduce traffic and launch)
-  // K_eq is the fixed prologue/epilogue price of one tile expressed in k-steps (large tiles pay ~8 us, small ~0.7 us),
-  // `rate` the relative steady-state MFMA rate of the tile shape (128x128 streams fastest, 64x64 has the smallest
-  // tail).  Split-K is considered only when the grid would not fill the chip, and only up to the point where the
-  // partial-sum traffic (nsplit*M*N) reaches 1/2 of the operand traffic ((M+N)*K): weight gradients and the 50-row
-  // RSSM steps split deeply, square-ish GEMMs never do.
+  // Cost model in MACs per CU, fitted offline (scripts/fit_gemm_model.py) to per-tile timings of 28 step shapes on
+  // MI355X (profiles/r01_gemm_shapes.txt; regret 43 us summed over all shapes vs the per-shape best tile):
+  //   a CU holds `avg` = workgroups/256 of this launch, at most R of them resident (R = 3 / 4 / 7 by registers);
+  //   per k-tile it needs max(conc * BM*BN*32 / rate, L): MFMA time of the `conc` co-resident workgroups, or the
+  //   ~1 MMAC-equivalent load latency when too few workgroups are resident to cover it (long reductions on few
+  //   workgroups are latency-bound: weight gradients want 128x128 tiles AND >= 2 workgroups per CU);
+  //   plus K_eq k-steps of prologue/epilogue per tile, plus split-K partial traffic and its reduce launch.
+  // Split-K is considered only when the grid would not fill the chip (t < 256), up to the point where the partial
+  // traffic (nsplit*M*N) reaches 1/2 of the operand traffic ((M+N)*K); full grids may take a light 2/4-way split to
+  // even out a ragged last wave.
   const int ktiles = dm_cdiv(q.K, 32);
   const double out_elems = (double)q.M * q.N;
   int max_split = (int)(0.5 * ((double)q.M + q.N) * q.K / (out_elems > 0 ? out_elems : 1));
@@ -412,14 +416,17 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   }
   if (max_split < 1) max_split = 1;
   static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-  static const double keq[3] = {100.0, 60.0, 30.0};
-  static const double rate[3] = {1.0, 0.93, 0.86};
+  static const double keq[3] = {150.0, 60.0, 45.0};
+  static const double rate[3] = {1.0, 0.9, 0.8};
+  static const double resid[3] = {3.0, 4.0, 7.0};
+  const double lat_macs = 1.0e6;
   // tuning overrides for scripts/gemm_bench.py only (unset in production): DM_GEMM_TILE=1|2|3 forces a candidate,
   // DM_GEMM_SPLIT=n forces the split count
   static const int force_tile = getenv("DM_GEMM_TILE") ? atoi(getenv("DM_GEMM_TILE")) : 0;
   static const int force_split = getenv("DM_GEMM_SPLIT") ? atoi(getenv("DM_GEMM_SPLIT")) : 0;
   int BM = 64, BN = 64, nsplit = 1;
   double best_cost = -1.0;
+  const int kt1 = ktiles > 0 ? ktiles : 1;
   for (int c = 0; c < 3; ++c) {
     if (force_tile && c != force_tile - 1) continue;
     if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
@@ -430,20 +437,22 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
       sp_fill = dm_cdiv(512, t);
       if (sp_fill > max_split) sp_fill = max_split;
     }
-    if (force_split > 0) sp_fill = force_split;
-    if (sp_fill > (ktiles > 0 ? ktiles : 1)) sp_fill = ktiles > 0 ? ktiles : 1;
-    // unsplit; split to fill an under-subscribed chip (t < 256: long reductions need >= 2 workgroups per CU to hide the
-    // load latency of their serial k loop, so never fewer splits than `fill`); light splits only to even out a ragged
-    // last round of an already full grid (t >= 256)
+    if (sp_fill > kt1) sp_fill = kt1;
+    if (sp_fill < 1) sp_fill = 1;
     const int sps[4] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill};
     for (int pass = 0; pass < 4; ++pass) {
-      int sp = force_split > 0 ? sp_fill : sps[pass];
-      if (sp > max_split && force_split <= 0) sp = max_split;
-      if (sp > (ktiles > 0 ? ktiles : 1)) sp = ktiles > 0 ? ktiles : 1;
+      int sp = force_split > 0 ? force_split : sps[pass];
+      if (force_split <= 0 && sp > max_split) sp = max_split;
+      if (sp > kt1) sp = kt1;
       if (sp < 1) sp = 1;
-      const double rounds = (double)dm_cdiv(t * sp, 256);
-      const double kslice = (double)dm_cdiv(ktiles > 0 ? ktiles : 1, sp) * 32.0;
-      double cost = rounds * bm * bn * (kslice + keq[c]) / rate[c];
+      const double avg = (double)(t * sp) / 256.0;
+      const double R = resid[c];
+      const double waves = avg > R ? ceil(avg / R) : 1.0;
+      const double conc = avg > R ? avg / waves : (avg > 1.0 ? avg : 1.0);
+      const double nkt = (double)dm_cdiv(kt1, sp);
+      const double tm = (double)bm * bn * 32.0 / rate[c];
+      const double per_kt = conc * tm > lat_macs ? conc * tm : lat_macs;
+      double cost = waves * (nkt * per_kt + conc * bm * bn * keq[c] / rate[c]);
       if (sp > 1) cost += 0.4 * sp * out_elems + 1.2e6;
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
     }
