@@ -25,9 +25,15 @@ class FusedAdamW(torch.optim.Optimizer):
         if dev.type != 'cuda':
             raise H.DreamerHipError(f'FusedAdamW needs parameters on a gfx950 device, got {dev} '
                                     f'(call model.to(device) before init_optimizers; there is no CPU optimizer path)')
-        n = sum(p.numel() for p in params)
+        # every parameter starts on a 256-byte boundary of the flat buffer: the GEMM operand loaders take their 16-byte
+        # path only for 16-byte aligned weights, and one 1-element bias (reward head) would otherwise misalign every
+        # tensor behind it (all RSSM weights).  Pad slots stay exactly zero (zero grad, zero moments, decay of zero).
+        self._offsets, n = [], 0
+        for p in params:
+            self._offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64
         self.numel = n
-        self.flat_param = torch.empty(n, device=dev)
+        self.flat_param = torch.zeros(n, device=dev)
         self.flat_grad = torch.zeros(n, device=dev)
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
@@ -35,29 +41,24 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ws = torch.empty(4096, device=dev)
         self.step_count = 0
         self.dp = None                                    # set by dist.attach(): (process_group, weight)
-        off = 0
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, self._offsets):
                 k = p.numel()
                 self.flat_param[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + k].view(p.shape)
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
-                off += k
 
     def _grads_are_views(self):
-        off = 0
-        for p in self._plist:
+        for p, off in zip(self._plist, self._offsets):
             g = p.grad
             if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 return False
-            off += p.numel()
         return True
 
     def _regather(self):
         """A caller replaced `.grad` (e.g. zero_grad(set_to_none=True) elsewhere): copy into the flat buffer and re-view."""
-        off = 0
         with torch.no_grad():
-            for p in self._plist:
+            for p, off in zip(self._plist, self._offsets):
                 k = p.numel()
                 dst = self.flat_grad[off:off + k]
                 if p.grad is None:
@@ -65,7 +66,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 elif p.grad.data_ptr() != dst.data_ptr():
                     dst.copy_(p.grad.reshape(-1))
                 p.grad = dst.view(p.shape)
-                off += k
 
     def zero_grad(self, set_to_none=False):
         """Zeroes the flat gradient buffer and keeps the `.grad` views alive (set_to_none is ignored by design)."""
