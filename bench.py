@@ -129,6 +129,7 @@ def main():
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured hipGraph (A/B switch)')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
     args = ap.parse_args()
 
@@ -163,14 +164,23 @@ def main():
     torch.manual_seed(777 + rank)                      # sampler uniforms
     state = {'s': model.init_state(hi - lo)}
 
-    def step(i):
+    graphed = None
+    if not args.no_graph:
+        from pydreamer_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opts, ring[0], state['s'])
+
+    def step(i, eager=False):
         obs = ring[i % len(ring)]
-        losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'])
-        state['s'] = new_state                          # keep_state (train.py:177-178)
-        for opt in opts:
-            opt.zero_grad()
-        for loss in losses:
-            loss.backward()
+        if graphed is not None and not eager:       # hipGraph replay of training_step + zero_grad + 4 backward (pydreamer_amd/graph.py)
+            losses, new_state, metrics, tensors, _ = graphed(obs, state['s'])
+            state['s'] = new_state                      # keep_state (train.py:177-178)
+        else:
+            losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'])
+            state['s'] = new_state
+            for opt in opts:
+                opt.zero_grad()
+            for loss in losses:
+                loss.backward()
         model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
         for opt in opts:
             opt.step()
@@ -184,6 +194,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         metrics = step(args.warmup + i)
+    t_enqueued = time.perf_counter() - t0               # host done enqueuing; the GPU may still be running
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,7 +210,7 @@ def main():
     if args.prof_steps > 0:
         hip.call('dm_prof_begin', 8192 * args.prof_steps)     # ~4-5k GEMM launches per step at Atari-literal
         for i in range(args.prof_steps):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
         out = (ctypes.c_double * 36)()
         n = hip.lib().dm_prof_end(out, 12)
@@ -222,7 +233,7 @@ def main():
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                   gflop_per_step=tot_fl / 1e9 / args.prof_steps, ms_per_step=tot_ms / args.prof_steps,
                                   launches_per_step=n / args.prof_steps),
-                    kinds=kinds, note='HIP events on the launch stream, profiled pass of the same steps after the timed region')
+                    kinds=kinds, note='HIP events on the launch stream around every GEMM launch, eager (un-graphed) pass of the same steps right after the timed region')
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,11 +246,11 @@ def main():
                     dtype='f32', data='synthetic',
                     config=dict(workload='atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
                                          'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, fp32; '
-                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM',
+                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('' if args.no_graph else '; fwd+bwd section replayed as one hipGraph'),
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=2.76),
-                    loss_model_last=loss_model,
+                    loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))

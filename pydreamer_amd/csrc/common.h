@@ -61,6 +61,7 @@ struct DmGemm {
   int flags = 0;
 };
 int dm_gemm_launch(const DmGemm& g, void* ws, size_t ws_bytes, hipStream_t stream);
+int dm_gemm_skinny_try(const DmGemm& g, hipStream_t stream);   // gemm_skinny.hip: 1 = handled, 0 = not applicable, <0 error
 
 // element-wise / row-wise launchers (elementwise.hip)
 int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st);

@@ -59,7 +59,8 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (d * 36 * ch > wmax) wmax = d * 36 * ch;
   const size_t dec_fwd = SK + pad64(col);
   const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax) + pad64(N * 900) + pad64(100 * d + 36 * ch);   // + gather tables
-  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D);
+  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
+                          pad64(3 * D * Hd) + pad64(3 * D * D);    // + the transposed BPTT weights
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = SK + 2 * pad64(rows * Hm);
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +

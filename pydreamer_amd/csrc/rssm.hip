@@ -77,6 +77,23 @@ static int dgrad(hipStream_t st, void* sk, size_t skb, int rows, int nout, int k
   return dm_gemm_launch(q, sk, skb, st);
 }
 
+// dx[r][i] (+)= mask_r * sum_o dy[r][o] Wt[i][o]   (Wt = W^T materialised once per backward pass: the B-row chain
+// products of the BPTT loop then read their weights k-contiguous, the layout the skinny kernel streams fastest)
+static int dgrad_t(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* dy, int lddy,
+                   const float* Wt, float* dx, int lddx, int accum, const uint8_t* row_zero) {
+  DmGemm q;
+  q.M = rows; q.N = kin; q.K = nout;
+  q.A = dy; q.lda = lddy;
+  q.B = Wt; q.ldb = nout;
+  q.C = dx; q.ldc = lddx;
+  q.flags = accum ? DM_GEMM_ACCUM : 0;
+  q.row_zero = row_zero;
+  return dm_gemm_launch(q, sk, skb, st);
+}
+static int transpose(hipStream_t st, const float* W, float* Wt, int rows, int cols) {
+  return dm_permute4_launch(W, Wt, 1, 1, rows, cols, 0, 1, 3, 2, st);
+}
+
 extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
                                     const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
                                     const dm_rssm_params* P, float* acts, float* feat, float* post, float* prior,
@@ -159,6 +176,11 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   float* dgh = ar.take((size_t)N * 3 * D);
   float* dza = ar.take((size_t)N * Hd);
   float* dx1 = ar.take((size_t)N * Hd);
+  float* wt_post = ar.take((size_t)Z * Hd);
+  float* wt_post_h = ar.take((size_t)Hd * D);
+  float* wt_ih = ar.take((size_t)3 * D * Hd);
+  float* wt_hh = ar.take((size_t)3 * D * D);
+  float* wt_z = ar.take((size_t)Hd * Z);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -173,7 +195,13 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk, skb, st));
   DM_TRY(dgrad(st, sk, skb, N, Hd, D, dx3, Hd, p[DM_RSSM_PRIOR_H_W], dfeat, F, 1, nullptr));
 
-  // ---- BPTT
+  // ---- BPTT.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
+  // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
+  DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, Z, Hd));
+  DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
+  DM_TRY(transpose(st, p[DM_RSSM_GRU_WIH], wt_ih, 3 * D, Hd));
+  DM_TRY(transpose(st, p[DM_RSSM_GRU_WHH], wt_hh, 3 * D, D));
+  DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
   for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
@@ -181,21 +209,21 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     // straight-through sample: dpost += softmax'(post)^T dz'
     DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * Z, Z, dft + D, F, dpt, Z, 1, st));
     // post_mlp, post_norm+ELU, post_mlp_h
-    DM_TRY(dgrad(st, sk, skb, B, Z, Hd, dpt, Z, p[DM_RSSM_POST_W], dpin + r0 * Hd, Hd, 0, nullptr));
+    DM_TRY(dgrad_t(st, sk, skb, B, Z, Hd, dpt, Z, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
     DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x2 + r0 * Hd, Hd, a.pin + r0 * Hd, Hd, a.st2 + r0 * 2, p[DM_RSSM_POST_G],
                                    dpin + r0 * Hd, Hd, dx2 + r0 * Hd, Hd, st));
-    DM_TRY(dgrad(st, sk, skb, B, Hd, D, dx2 + r0 * Hd, Hd, p[DM_RSSM_POST_H_W], dft, F, 1, nullptr));
+    DM_TRY(dgrad_t(st, sk, skb, B, Hd, D, dx2 + r0 * Hd, Hd, wt_post_h, dft, F, 1, nullptr));
     // GRU gates; the direct path dh'*u goes (masked) straight into step t-1's dh'
     const uint8_t* rz = reset + r0;
     float* dprev = t > 0 ? dfeat + (r0 - B) * F : nullptr;
     DM_TRY(dm_gru_gates_bwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, dft, F,
                                    dgi + r0 * 3 * D, dgh + r0 * 3 * D, dprev, F, 1, rz, st));
-    DM_TRY(dgrad(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, p[DM_RSSM_GRU_WIH], dza + r0 * Hd, Hd, 0, nullptr));
+    DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, wt_ih, dza + r0 * Hd, Hd, 0, nullptr));
     DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
                                    dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
     if (t > 0) {
-      DM_TRY(dgrad(st, sk, skb, B, 3 * D, D, dgh + r0 * 3 * D, 3 * D, p[DM_RSSM_GRU_WHH], dprev, F, 1, rz));
-      DM_TRY(dgrad(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, p[DM_RSSM_Z_W], dprev + D, F, 1, rz));
+      DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, D, dgh + r0 * 3 * D, 3 * D, wt_hh, dprev, F, 1, rz));
+      DM_TRY(dgrad_t(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, wt_z, dprev + D, F, 1, rz));
     }
   }
 

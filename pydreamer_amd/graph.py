@@ -1,0 +1,86 @@
+"""hipGraph capture of the trainer's inner section (reference train.py:171-192: training_step -> zero_grad -> backward x4).
+
+One Atari-literal gradient step is ~8000 kernel launches, most of them the 50-row products of the sequential T-step,
+BPTT and imagination chains; fed launch by launch the host needs ~45 ms to enqueue a step that the GPU executes in
+~55 ms, and every latency-bound chain runs at host-launch speed.  Capturing the section once and replaying it removes
+the host from the loop.  What is captured is exactly the eager code path (same kernels, same order, same side streams
+for the overlapped backward passes), so results are bit-identical to the eager step.
+
+Left outside the graph on purpose:
+  * the critic-target refresh (a2c.py:68-70: every `target_interval` steps, host-side condition) - done eagerly by
+    `__call__` before the replay;
+  * grad-clip + AdamW (train.py:193-198) - a dozen streaming launches; keeping them eager keeps the data-parallel
+    all-reduce (pydreamer_amd/dist.py), the step counter and learning-rate changes out of the captured graph.
+
+Static-shape contract: `obs` tensors and `in_state` of every call must have the shapes / dtypes of the example given at
+construction (they are copied into the graph's input buffers).  The returned losses / metrics / tensors / out_state are
+the graph's output buffers: they are overwritten by the next call, clone what must survive it.
+"""
+import torch
+
+from . import hip as H
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizers, obs, in_state, noise=None, warmup_iters=2, **step_kwargs):
+        dev = obs['action'].device
+        if dev.type != 'cuda':
+            raise H.DreamerHipError('GraphedTrainStep needs the batch on a gfx950 device (there is no CPU path)')
+        self.model, self.optimizers = model, [o for o in optimizers]
+        self.static_obs = {k: v.clone() for k, v in obs.items()}
+        self.static_state = tuple(x.clone() for x in in_state)
+        self.static_noise = None if noise is None else {k: v.clone() for k, v in noise.items()}
+        self.step_kwargs = dict(step_kwargs)
+        ac = model.ac
+
+        def section():
+            out = model.training_step(self.static_obs, self.static_state, noise=self.static_noise, **self.step_kwargs)
+            for opt in self.optimizers:
+                opt.zero_grad()
+            for loss in out[0]:
+                loss.backward()
+            return out
+
+        # warm-up on a side stream (lazy workspaces, side streams and the caching allocator settle before capture)
+        saved_steps = ac.train_steps
+        ac.defer_target_update = True
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, int(warmup_iters))):
+                    section()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                out = section()
+        finally:
+            ac.defer_target_update = False
+            ac.train_steps = saved_steps
+        losses, self.out_state, self.metrics, self.tensors, self.extra = out
+        self.losses = tuple(x.detach() for x in losses)
+
+    def __call__(self, obs, in_state, noise=None):
+        """Same return value as Dreamer.training_step(); the four backward passes have already run (gradients are in the
+        optimizers' flat buffers), so the caller continues with grad_clip() and optimizer.step()."""
+        for k, dst in self.static_obs.items():
+            src = obs[k]
+            if src.shape != dst.shape:
+                raise ValueError(f'obs[{k!r}] has shape {tuple(src.shape)}, the graph was captured for {tuple(dst.shape)}')
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for dst, src in zip(self.static_state, in_state):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if self.static_noise is not None:
+            if noise is None:
+                raise ValueError('this graph was captured with explicit sampler noise: pass `noise` on every call')
+            for k, dst in self.static_noise.items():
+                dst.copy_(noise[k].reshape(dst.shape), non_blocking=True)
+        ac = self.model.ac
+        if ac.train_steps % ac.target_interval == 0:        # a2c.py:68-70, host-side condition kept out of the graph
+            ac.update_critic_target()
+        ac.train_steps += 1
+        self.graph.replay()
+        return self.losses, self.out_state, self.metrics, self.tensors, self.extra

@@ -138,21 +138,16 @@ class MLP(_Params):
         return out, acts
 
     def bwd(self, x2d, ldx, rows, acts, dout, ws, dx=None, lddx=0, dx_accum=False):
-        """Returns the list of parameter gradients in parameters() order (views of one flat buffer)."""
+        """Returns (gradients in parameters() order, the flat buffer they are views of, direct): `direct` means the views
+        ARE the optimizer's `.grad` slots (freshly zeroed), so autograd has nothing left to accumulate."""
         plist = self.param_list()
-        flat = torch.empty(sum(p.numel() for p in plist), device=x2d.device)
-        grads, off = {}, 0
-        out = []
-        for p in plist:
-            gview = flat[off:off + p.numel()].view(p.shape)
-            grads[id(p)] = gview
-            out.append(gview)
-            off += p.numel()
+        flat, out, direct = _flat_views(plist, x2d.device, getattr(self, '_fused', None))
+        grads = {id(p): v for p, v in zip(plist, out)}
         st, gs = self.struct(), self.grad_struct(grads)
         H.call('dm_mlp_head_bwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
                ctypes.byref(st), H.fptr(acts), H.fptr(dout), ctypes.byref(gs), H.fptr(dx) if dx is not None else None, lddx,
                1 if dx_accum else 0, H.ptr(ws), ws.numel(), H.stream())
-        return out, flat
+        return out, flat, direct
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -325,13 +320,22 @@ class _Mean:
 # ---------------------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------------------
-def _flat_views(plist, device):
+def _flat_views(plist, device, fused=None):
+    """Gradient buffers for one backward pass: (flat, per-parameter views, direct).
+    With a FusedAdamW attached whose gradient buffer was just zeroed (the trainer's zero_grad -> backward order,
+    train.py:186-192) the views are the optimizer's own `.grad` slots: the kernels write the gradients in place and the
+    ~120 per-parameter AccumulateGrad additions of autograd disappear.  Otherwise (no fused optimizer, or a second
+    backward without zero_grad = gradient accumulation) a scratch buffer is returned and autograd accumulates as usual."""
+    if fused is not None:
+        views = fused.claim_fresh_grads(plist)
+        if views is not None:
+            return fused.flat_grad, views, True
     flat = torch.empty(sum(p.numel() for p in plist), device=device)
     views, off = [], 0
     for p in plist:
         views.append(flat[off:off + p.numel()].view(p.shape))
         off += p.numel()
-    return flat, views
+    return flat, views, False
 
 
 def _multi_sum(items, device):
@@ -394,18 +398,18 @@ class _WMStep(torch.autograd.Function):
             raise RuntimeError('loss_model.backward() called twice (saved activations were released)')
         ov = pk.get('overlap')
         if ov is None:
-            grads, flat = wm._backward(pk)
+            grads, flat, direct = wm._backward(pk)
         else:
             main = torch.cuda.current_stream()
             ov.s_wm.wait_stream(main)
             with torch.cuda.stream(ov.s_wm):
-                grads, flat = wm._backward(pk)
+                grads, flat, direct = wm._backward(pk)
             main.wait_stream(ov.s_wm)
         # chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync
         gl = grad_loss.detach().float().reshape(1).contiguous()
         H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
         pk['consumed'] = True
-        return (None, None) + tuple(grads)
+        return (None, None) + (tuple(None for _ in grads) if direct else tuple(grads))
 
 
 class WorldModel(_Params):
@@ -556,7 +560,7 @@ class WorldModel(_Params):
         F_, Z, E = self.features_dim, c.stoch_dim * c.stoch_discrete, self.encoder.out_dim
         ws = self.workspace(shp, dev)
         plist = self._param_order()
-        flat, views = _flat_views(plist, dev)
+        flat, views, direct = _flat_views(plist, dev, getattr(self, '_fused', None))
         gof = {id(p): v for p, v in zip(plist, views)}
         dec = self.decoder
 
@@ -593,7 +597,7 @@ class WorldModel(_Params):
             for mlp, hp in ov.pending:
                 if 'pre' not in hp and 'acts' in hp:
                     ov.s_ac.wait_event(ov.ev_fwd)
-                    ov.s_ac.wait_event(ov.ev_bptt)
+                    ov.s_ac.wait_event(ov.ev_bptt)             # also orders it after the caller's zero_grad()
                     with torch.cuda.stream(ov.s_ac):
                         hp['pre'] = mlp.bwd(hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac)
         cell = self.core.cell
@@ -612,7 +616,7 @@ class WorldModel(_Params):
                H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
         for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
             pk.pop(k, None)
-        return views, flat
+        return views, flat, direct
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
                       u_post=None, forced_idx=None, imag_horizon=1):
@@ -649,20 +653,20 @@ class _HeadLoss(torch.autograd.Function):
         mlp, pk = ctx.mlp, ctx.pack
         ov = pk.get('overlap')
         if ov is None:
-            grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
+            grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
         else:
             main = torch.cuda.current_stream()
             if 'pre' in pk:                               # already enqueued from inside the world-model backward
-                grads, flat = pk.pop('pre')
+                grads, flat, direct = pk.pop('pre')
             else:
-                ov.s_ac.wait_event(ov.ev_fwd)             # everything this pass reads was produced by the forward
+                ov.s_ac.wait_stream(main)                 # the forward that produced its inputs, and the caller's zero_grad()
                 with torch.cuda.stream(ov.s_ac):
-                    grads, flat = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
+                    grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
             main.wait_stream(ov.s_ac)
         gl = grad_loss.detach().float().reshape(1).contiguous()
         H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
         pk.pop('acts', None)
-        return (None, None) + tuple(grads)
+        return (None, None) + (tuple(None for _ in grads) if direct else tuple(grads))
 
 
 class ActorCritic(_Params):
@@ -685,6 +689,7 @@ class ActorCritic(_Params):
         self.critic_target = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
         self.critic_target.requires_grad_(False)
         self.train_steps = 0
+        self.defer_target_update = False      # set by pydreamer_amd.graph while capturing (refresh + counter done there)
 
     def update_critic_target(self):
         """a2c.py:151-152."""
@@ -698,7 +703,7 @@ class ActorCritic(_Params):
         actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
         features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
         _require_cuda(features, 'features')
-        if not log_only:
+        if not log_only and not self.defer_target_update:
             if self.train_steps % self.target_interval == 0:
                 self.update_critic_target()
             self.train_steps += 1
@@ -792,6 +797,8 @@ class Dreamer(nn.Module):
         self._opt = dict(wm=FusedAdamW(groups['wm'], lr=lr, eps=eps), probe=FusedAdamW(groups['probe'], lr=lr, eps=eps),
                          actor=FusedAdamW(groups['actor'], lr=lr_actor or lr, eps=eps),
                          critic=FusedAdamW(groups['critic'], lr=lr_critic or lr, eps=eps))
+        # the backward passes write straight into these optimizers' gradient buffers (see _flat_views)
+        self.wm._fused, self.ac.actor._fused, self.ac.critic._fused = self._opt['wm'], self._opt['actor'], self._opt['critic']
         return self._opt['wm'], self._opt['probe'], self._opt['actor'], self._opt['critic']
 
     def grad_clip(self, grad_clip, grad_clip_ac=None):

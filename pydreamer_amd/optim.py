@@ -41,6 +41,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ws = torch.empty(4096, device=dev)
         self.step_count = 0
         self.dp = None                                    # set by dist.attach(): (process_group, weight)
+        self.fresh = False                                # flat_grad is all zero and nobody has written to it yet
+        self._ids = {id(p) for p in params}
         with torch.no_grad():
             for p, off in zip(params, self._offsets):
                 k = p.numel()
@@ -72,6 +74,17 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self._grads_are_views():
             self._regather()
         self.flat_grad.zero_()
+        self.fresh = True
+
+    def claim_fresh_grads(self, plist):
+        """For a backward pass that produces the gradients of EXACTLY this group's parameters with '=' semantics: if the
+        buffer was zeroed since the last write, hand out the `.grad` views to be written in place (once); else None."""
+        if not self.fresh or len(plist) != len(self._plist) or any(id(p) not in self._ids for p in plist):
+            return None
+        if not self._grads_are_views():
+            return None
+        self.fresh = False
+        return [p.grad for p in plist]
 
     def clip_grad_norm(self, max_norm):
         """clip_grad_norm_ on the flat buffer: returns the pre-clip total norm as a 0-d device tensor (no host sync)."""

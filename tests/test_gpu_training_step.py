@@ -62,7 +62,7 @@ def test_mlp_head_fwd_bwd(hip):
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
     out, acts = m.fwd(x, in_dim, rows, ws)
     dx = torch.zeros(rows, in_dim, device=DEV)
-    grads, _ = m.bwd(x, in_dim, rows, acts, dout, ws, dx=dx, lddx=in_dim, dx_accum=False)
+    grads, _, _ = m.bwd(x, in_dim, rows, acts, dout, ws, dx=dx, lddx=in_dim, dx_accum=False)
     p = {f'h.{k}': v.detach().double().cpu().requires_grad_(True) for k, v in m.model.state_dict().items()}
     xr = x.double().cpu().requires_grad_(True)
     ref = O.mlp(p, 'h', xr, 4)
@@ -380,3 +380,48 @@ def test_no_cpu_fallback(hip):
     with pytest.raises(Exception) as e:
         model.training_step(obs, (torch.zeros(3, 64), torch.zeros(3, 64)))
     assert 'CPU' in str(e.value) or 'cuda' in str(e.value).lower()
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_graphed_step_is_bit_identical_to_eager(hip, overlap):
+    """pydreamer_amd.graph.GraphedTrainStep replays exactly the eager kernels: same losses, gradients, parameters and
+    carried state over three trainer iterations (incl. the step-0 critic-target refresh)."""
+    from pydreamer_amd.graph import GraphedTrainStep
+    oconf = O.tiny_conf()
+    params = O.make_params(oconf, seed=3)
+    runs = []
+    for graphed in (False, True):
+        model = _build(oconf, params)
+        model.overlap_backward = overlap
+        opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+        st = model.init_state(oconf.batch_size)
+        g, hist = None, []
+        for s in range(3):
+            obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=50 + s, first=(s == 0)), oconf))
+            noise = _to_dev(O.make_noise(oconf, seed=90 + s))
+            if graphed:
+                if g is None:
+                    g = GraphedTrainStep(model, opts, obs, st, noise=noise)
+                losses, st2, metrics, _, _ = g(obs, st, noise=noise)
+            else:
+                losses, st2, metrics, _, _ = model.training_step(obs, st, noise=noise)
+                for opt in opts:
+                    opt.zero_grad()
+                for loss in losses:
+                    loss.backward()
+            gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+            grads = torch.cat([o.flat_grad for o in opts]).clone()
+            for opt in opts:
+                opt.step()
+            st = tuple(x.clone() for x in st2)
+            hist.append(dict(losses=[float(x) for x in losses], gn=float(gm['grad_norm']), grads=grads.cpu(),
+                             state=[x.cpu() for x in st], params=torch.cat([o.flat_param for o in opts]).cpu(),
+                             steps=model.ac.train_steps))
+        runs.append(hist)
+    for s, (e, g) in enumerate(zip(*runs)):
+        assert e['losses'] == g['losses'], (s, e['losses'], g['losses'])
+        assert e['gn'] == g['gn']
+        assert torch.equal(e['grads'], g['grads']), f'step {s}: gradients differ'
+        assert torch.equal(e['params'], g['params']), f'step {s}: parameters differ'
+        assert all(torch.equal(a, b) for a, b in zip(e['state'], g['state']))
+        assert e['steps'] == g['steps'] == s + 1
