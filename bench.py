@@ -129,7 +129,8 @@ def main():
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying the captured hipGraph (A/B switch)')
+    ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
+                    'off by default: on ROCm 7.2 a graph with concurrent branches replays slower than the side streams run eagerly')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
     args = ap.parse_args()
 
@@ -165,7 +166,7 @@ def main():
     state = {'s': model.init_state(hi - lo)}
 
     graphed = None
-    if not args.no_graph:
+    if args.graph:
         from pydreamer_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, opts, ring[0], state['s'])
 
@@ -246,7 +247,7 @@ def main():
                     dtype='f32', data='synthetic',
                     config=dict(workload='atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
                                          'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, fp32; '
-                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('' if args.no_graph else '; fwd+bwd section replayed as one hipGraph'),
+                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('; fwd+bwd section replayed as one hipGraph' if args.graph else ''),
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=2.76),

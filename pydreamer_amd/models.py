@@ -137,11 +137,11 @@ class MLP(_Params):
                ctypes.byref(st), H.fptr(acts), H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
         return out, acts
 
-    def bwd(self, x2d, ldx, rows, acts, dout, ws, dx=None, lddx=0, dx_accum=False):
+    def bwd(self, x2d, ldx, rows, acts, dout, ws, dx=None, lddx=0, dx_accum=False, scratch=False):
         """Returns (gradients in parameters() order, the flat buffer they are views of, direct): `direct` means the views
         ARE the optimizer's `.grad` slots (freshly zeroed), so autograd has nothing left to accumulate."""
         plist = self.param_list()
-        flat, out, direct = _flat_views(plist, x2d.device, getattr(self, '_fused', None))
+        flat, out, direct = _flat_views(plist, x2d.device, getattr(self, '_fused', None), scratch)
         grads = {id(p): v for p, v in zip(plist, out)}
         st, gs = self.struct(), self.grad_struct(grads)
         H.call('dm_mlp_head_bwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
@@ -320,13 +320,19 @@ class _Mean:
 # ---------------------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------------------
-def _flat_views(plist, device, fused=None):
+def _flat_views(plist, device, fused=None, scratch=False):
     """Gradient buffers for one backward pass: (flat, per-parameter views, direct).
     With a FusedAdamW attached whose gradient buffer was just zeroed (the trainer's zero_grad -> backward order,
     train.py:186-192) the views are the optimizer's own `.grad` slots: the kernels write the gradients in place and the
     ~120 per-parameter AccumulateGrad additions of autograd disappear.  Otherwise (no fused optimizer, or a second
-    backward without zero_grad = gradient accumulation) a scratch buffer is returned and autograd accumulates as usual."""
-    if fused is not None:
+    backward without zero_grad = gradient accumulation) a scratch buffer is returned and autograd accumulates as usual.
+    scratch=True (backward passes pre-launched inside training_step, i.e. BEFORE the trainer's zero_grad): the optimizer's
+    persistent scratch buffer in the same padded layout; _finish_backward() moves it into `.grad` with one kernel."""
+    if fused is not None and scratch:
+        views = fused.scratch_views(plist)
+        if views is not None:
+            return fused.scratch, views, False
+    if fused is not None and not scratch:
         views = fused.claim_fresh_grads(plist)
         if views is not None:
             return fused.flat_grad, views, True
@@ -356,23 +362,42 @@ def _multi_sum(items, device):
     return out
 
 
+def _finish_backward(owner, grads, flat, direct, grad_loss):
+    """Chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync, and hand-over
+    of the gradients: returns the tuple for autograd (None when they already sit in the optimizer's `.grad` slots)."""
+    gl = grad_loss.detach().float().reshape(1).contiguous()
+    fused = getattr(owner, '_fused', None)
+    if fused is not None and flat is fused.scratch:
+        if fused.fresh:                      # zero_grad() since the last write: '=' semantics, one scale+copy kernel
+            torch.mul(flat, gl, out=fused.flat_grad)
+            fused.fresh = False
+        else:                                # gradient accumulation
+            fused.flat_grad.addcmul_(flat, gl.expand_as(flat))
+        return tuple(None for _ in grads)
+    H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
+    return tuple(None for _ in grads) if direct else tuple(grads)
+
+
 class _Overlap:
-    """Two side streams for the backward passes.  The world-model backward contains the strictly sequential BPTT chain
-    (T steps of 50-row kernels that leave most of the 256 CUs idle); the actor and critic backward passes are
-    independent of it (dreamer.py:153-157 detaches everything they consume), so they run on a second HIP stream that
-    is released exactly when the BPTT loop starts.  Both streams are joined into the caller's stream before the
-    gradients are handed to autograd, so callers see ordinary stream semantics."""
+    """Side streams for the backward passes.  Everything the three backward passes consume is fixed once the matching
+    forward has run (dreamer.py:149-157 detaches the features the actor-critic trains on), so training_step() launches
+      * the world-model backward (decoder / heads, the strictly sequential BPTT chain of T x ~9 small kernels that
+        leaves most of the 256 CUs idle, encoder) on `s_wm` right after the world-model forward, concurrently with the
+        imagination rollout and the actor-critic forward on the caller's stream, and
+      * the actor / critic backward on `s_ac` right after their forward.
+    They write into the optimizers' scratch buffers (the trainer calls zero_grad() between training_step() and
+    backward(), train.py:186-192); loss.backward() joins the stream and moves the result into `.grad`, so callers see
+    ordinary stream semantics.  Each stream has its own workspace."""
 
     def __init__(self, device):
-        # the latency-bound chain gets the high-priority queue: its 16-30-workgroup kernels must be dispatched ahead of
-        # the thousands of queued GEMM workgroups of the concurrent actor/critic backward, or the chain just slows down
+        # the latency-bound chain gets the high-priority queue: its 40-110-workgroup kernels must be dispatched ahead of
+        # the thousands of queued GEMM workgroups of the concurrent work, or the chain just slows down
         self.s_wm = torch.cuda.Stream(device, priority=-1)
         self.s_ac = torch.cuda.Stream(device, priority=0)
+        self.ev_wm_fwd = torch.cuda.Event()
         self.ev_fwd = torch.cuda.Event()
-        self.ev_bptt = torch.cuda.Event()
-        self.bptt_armed = False
+        self.ws_wm = None
         self.ws_ac = None
-        self.pending = []          # (mlp, pack) of this step's actor / critic losses, precomputed inside the WM backward
 
 
 def _require_cuda(t, what):
@@ -397,19 +422,15 @@ class _WMStep(torch.autograd.Function):
         if pk.get('consumed'):
             raise RuntimeError('loss_model.backward() called twice (saved activations were released)')
         ov = pk.get('overlap')
-        if ov is None:
-            grads, flat, direct = wm._backward(pk)
+        if 'pre' in pk:                                   # launched on s_wm inside training_step()
+            grads, flat, direct = pk.pop('pre')
+            torch.cuda.current_stream().wait_stream(ov.s_wm)
         else:
-            main = torch.cuda.current_stream()
-            ov.s_wm.wait_stream(main)
-            with torch.cuda.stream(ov.s_wm):
-                grads, flat, direct = wm._backward(pk)
-            main.wait_stream(ov.s_wm)
-        # chain rule with the incoming scalar gradient (1.0 unless a GradScaler is active) without a host sync
-        gl = grad_loss.detach().float().reshape(1).contiguous()
-        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
+            grads, flat, direct = wm._backward(pk, pk['ws'])
+        for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
+            pk.pop(k, None)                               # only now: the side stream may have been reading them
         pk['consumed'] = True
-        return (None, None) + (tuple(None for _ in grads) if direct else tuple(grads))
+        return (None, None) + _finish_backward(wm, grads, flat, direct, grad_loss)
 
 
 class WorldModel(_Params):
@@ -552,15 +573,14 @@ class WorldModel(_Params):
     def _param_order(self):
         return list(self.parameters())
 
-    def _backward(self, pk):
+    def _backward(self, pk, ws, scratch=False):
         c = self.conf
         shp, T, B = pk['shp'], pk['T'], pk['B']
         N = T * B
         feat, dev = pk['feat'], pk['feat'].device
         F_, Z, E = self.features_dim, c.stoch_dim * c.stoch_discrete, self.encoder.out_dim
-        ws = self.workspace(shp, dev)
         plist = self._param_order()
-        flat, views, direct = _flat_views(plist, dev, getattr(self, '_fused', None))
+        flat, views, direct = _flat_views(plist, dev, getattr(self, '_fused', None), scratch)
         gof = {id(p): v for p, v in zip(plist, views)}
         dec = self.decoder
 
@@ -586,20 +606,7 @@ class WorldModel(_Params):
             sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
         H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
                H.fptr(dpost), H.fptr(dprior), H.stream())
-        # RSSM BPTT (latency-bound: release the actor/critic backward stream now)
-        ov = pk.get('overlap')
-        if ov is not None:
-            # Host order matters as much as stream order: the actor / critic backward launches are ENQUEUED here, ahead
-            # of the ~700 BPTT launches, on the second stream gated by ev_bptt, so the GPU has them in hand when the
-            # sequential chain starts.  loss_actor/loss_critic.backward() later only join the stream and return them.
-            ov.ev_bptt.record(torch.cuda.current_stream())
-            ov.bptt_armed = True
-            for mlp, hp in ov.pending:
-                if 'pre' not in hp and 'acts' in hp:
-                    ov.s_ac.wait_event(ov.ev_fwd)
-                    ov.s_ac.wait_event(ov.ev_bptt)             # also orders it after the caller's zero_grad()
-                    with torch.cuda.stream(ov.s_ac):
-                        hp['pre'] = mlp.bwd(hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac)
+        # RSSM BPTT
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
@@ -614,8 +621,6 @@ class WorldModel(_Params):
                               cls=H.dm_conv_grads)
         H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
                H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
-        for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
-            pk.pop(k, None)
         return views, flat, direct
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
@@ -652,21 +657,13 @@ class _HeadLoss(torch.autograd.Function):
     def backward(ctx, grad_loss):
         mlp, pk = ctx.mlp, ctx.pack
         ov = pk.get('overlap')
-        if ov is None:
-            grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
+        if 'pre' in pk:                                   # launched on s_ac inside training_step()
+            grads, flat, direct = pk.pop('pre')
+            torch.cuda.current_stream().wait_stream(ov.s_ac)
         else:
-            main = torch.cuda.current_stream()
-            if 'pre' in pk:                               # already enqueued from inside the world-model backward
-                grads, flat, direct = pk.pop('pre')
-            else:
-                ov.s_ac.wait_stream(main)                 # the forward that produced its inputs, and the caller's zero_grad()
-                with torch.cuda.stream(ov.s_ac):
-                    grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], ov.ws_ac)
-            main.wait_stream(ov.s_ac)
-        gl = grad_loss.detach().float().reshape(1).contiguous()
-        H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
+            grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
         pk.pop('acts', None)
-        return (None, None) + (tuple(None for _ in grads) if direct else tuple(grads))
+        return (None, None) + _finish_backward(mlp, grads, flat, direct, grad_loss)
 
 
 class ActorCritic(_Params):
@@ -755,8 +752,7 @@ class ActorCritic(_Params):
                       overlap=overlap)
             loss_actor = _HeadLoss.apply(self.actor, pa, *self.actor.param_list())
             loss_critic = _HeadLoss.apply(self.critic, pc, *self.critic.param_list())
-            if overlap is not None:
-                overlap.pending = [(self.actor, pa), (self.critic, pc)]
+            self._last_packs = (pa, pc)
         metrics = dict(loss_critic=loss_critic_v, loss_actor=loss_actor_v, policy_entropy=s[2], policy_value=s[3],
                        policy_value_im=s[4], policy_reward=s[5], policy_reward_std=var[0].sqrt())
         tensors = dict(value=value2d, value_target=vtgt, value_advantage=adv, value_advantage_gae=agae, value_weight=wgt)
@@ -785,7 +781,7 @@ class Dreamer(nn.Module):
         self.probe_gradients = conf.probe_gradients
         self._groups = None
         self._overlap = None
-        self.overlap_backward = True      # run actor/critic backward concurrently with the world model's BPTT chain
+        self.overlap_backward = True      # pre-launch the three backward passes on side streams (see _Overlap)
 
     # ---- optimizers (dreamer.py:60-87)
     def param_groups(self):
@@ -896,13 +892,20 @@ class Dreamer(nn.Module):
                                   imag_horizon=imag_horizon)
         pk = self.wm._last_pack
         ov = None
-        if self.overlap_backward:
+        if self.overlap_backward and torch.is_grad_enabled():
             dev = pk['feat'].device
             if self._overlap is None or self._overlap.s_wm.device != dev:
                 self._overlap = _Overlap(dev)
             ov = self._overlap
-            ov.bptt_armed = False
             pk['overlap'] = ov
+            # world-model backward: on its own stream and workspace, concurrent with everything below
+            need = pk['ws'].numel()
+            if ov.ws_wm is None or ov.ws_wm.numel() < need:
+                ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
+            ov.ev_wm_fwd.record(torch.cuda.current_stream())
+            ov.s_wm.wait_event(ov.ev_wm_fwd)
+            with torch.cuda.stream(ov.s_wm):
+                pk['pre'] = self.wm._backward(pk, ov.ws_wm, scratch=True)
         metrics, tensors = dict(metrics), dict(tensors)
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)
@@ -923,6 +926,10 @@ class Dreamer(nn.Module):
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
             ov.ev_fwd.record(torch.cuda.current_stream())
+            ov.s_ac.wait_event(ov.ev_fwd)
+            with torch.cuda.stream(ov.s_ac):
+                for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
+                    hp['pre'] = mlp.bwd(hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True)
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,

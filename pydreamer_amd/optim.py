@@ -42,6 +42,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_count = 0
         self.dp = None                                    # set by dist.attach(): (process_group, weight)
         self.fresh = False                                # flat_grad is all zero and nobody has written to it yet
+        self.scratch = None                               # same layout as flat_grad, for pre-launched backward passes
         self._ids = {id(p) for p in params}
         with torch.no_grad():
             for p, off in zip(params, self._offsets):
@@ -75,6 +76,16 @@ class FusedAdamW(torch.optim.Optimizer):
             self._regather()
         self.flat_grad.zero_()
         self.fresh = True
+
+    def scratch_views(self, plist):
+        """Per-parameter views of the persistent scratch gradient buffer (pad slots stay zero forever), or None if
+        `plist` is not exactly this group's parameter set."""
+        if len(plist) != len(self._plist) or any(id(p) not in self._ids for p in plist):
+            return None
+        if self.scratch is None:
+            self.scratch = torch.zeros_like(self.flat_grad)
+            self._off_of = {id(p): off for p, off in zip(self._plist, self._offsets)}
+        return [self.scratch[self._off_of[id(p)]:self._off_of[id(p)] + p.numel()].view(p.shape) for p in plist]
 
     def claim_fresh_grads(self, plist):
         """For a backward pass that produces the gradients of EXACTLY this group's parameters with '=' semantics: if the
