@@ -131,6 +131,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
                     'off by default: on ROCm 7.2 a graph with concurrent branches replays slower than the side streams run eagerly')
+    ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
     args = ap.parse_args()
 
@@ -155,6 +156,8 @@ def main():
     gconf = config.atari_literal()
     B = gconf.batch_size
     lo, hi = DP.shard_bounds(B, world, rank)
+    if args.emulate_world > 1 and world == 1:
+        lo, hi = DP.shard_bounds(B, args.emulate_world, 0)
     conf = config.atari_literal(batch_size=hi - lo)
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
@@ -209,7 +212,8 @@ def main():
     # profiled pass: HIP events around every GEMM launch on the launch stream (same steps, right after the timed region)
     roof = None
     if args.prof_steps > 0:
-        hip.call('dm_prof_begin', 8192 * args.prof_steps)     # ~4-5k GEMM launches per step at Atari-literal
+        hip.call('dm_prof_begin', 8192 * args.prof_steps)
+        model.overlap_backward = False      # one stream, one launcher thread: per-launch events then time that launch alone
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
@@ -251,6 +255,7 @@ def main():
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=2.76),
+                    **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
                     roofline=roof, cpu_baseline=cpu)

@@ -398,6 +398,37 @@ class _Overlap:
         self.ev_fwd = torch.cuda.Event()
         self.ws_wm = None
         self.ws_ac = None
+        # The HIP runtime needs ~6 us of host time per kernel launch and a step is ~1800 launches; at small per-GPU
+        # batches (data parallel: B/8 rows) the step is bound by exactly that.  The pre-launched backward passes are
+        # therefore ENQUEUED by a second host thread (ctypes drops the GIL inside the C calls), in parallel with the
+        # caller's thread enqueuing the imagination rollout.
+        self.device = device
+        self.pool = None
+
+    def submit(self, stream, wait_event, fn):
+        """Run fn() on `stream` (after `wait_event`) from the launcher thread; returns a Future."""
+        if torch.cuda.is_current_stream_capturing():      # graph capture is bound to the capturing thread
+            stream.wait_event(wait_event)
+            with torch.cuda.stream(stream):
+                return _Done(fn())
+        if self.pool is None:
+            import concurrent.futures
+            self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='dm-launch')
+
+        def job():
+            with torch.cuda.device(self.device), torch.no_grad():
+                stream.wait_event(wait_event)
+                with torch.cuda.stream(stream):
+                    return fn()
+        return self.pool.submit(job)
+
+
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
 
 
 def _require_cuda(t, what):
@@ -423,7 +454,7 @@ class _WMStep(torch.autograd.Function):
             raise RuntimeError('loss_model.backward() called twice (saved activations were released)')
         ov = pk.get('overlap')
         if 'pre' in pk:                                   # launched on s_wm inside training_step()
-            grads, flat, direct = pk.pop('pre')
+            grads, flat, direct = pk.pop('pre').result()
             torch.cuda.current_stream().wait_stream(ov.s_wm)
         else:
             grads, flat, direct = wm._backward(pk, pk['ws'])
@@ -658,7 +689,7 @@ class _HeadLoss(torch.autograd.Function):
         mlp, pk = ctx.mlp, ctx.pack
         ov = pk.get('overlap')
         if 'pre' in pk:                                   # launched on s_ac inside training_step()
-            grads, flat, direct = pk.pop('pre')
+            grads, flat, direct = pk.pop('pre').result()
             torch.cuda.current_stream().wait_stream(ov.s_ac)
         else:
             grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
@@ -903,9 +934,7 @@ class Dreamer(nn.Module):
             if ov.ws_wm is None or ov.ws_wm.numel() < need:
                 ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
             ov.ev_wm_fwd.record(torch.cuda.current_stream())
-            ov.s_wm.wait_event(ov.ev_wm_fwd)
-            with torch.cuda.stream(ov.s_wm):
-                pk['pre'] = self.wm._backward(pk, ov.ws_wm, scratch=True)
+            pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: self.wm._backward(pk, ov.ws_wm, scratch=True))
         metrics, tensors = dict(metrics), dict(tensors)
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)
@@ -926,10 +955,9 @@ class Dreamer(nn.Module):
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
             ov.ev_fwd.record(torch.cuda.current_stream())
-            ov.s_ac.wait_event(ov.ev_fwd)
-            with torch.cuda.stream(ov.s_ac):
-                for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
-                    hp['pre'] = mlp.bwd(hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True)
+            for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
+                hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: mlp.bwd(
+                    hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True))
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,
