@@ -152,6 +152,11 @@ typedef struct dm_conv_grads { float* w[5]; float* b[5]; } dm_conv_grads;
 size_t dm_conv_encoder_acts_floats(const dm_shape* shp);
 int dm_conv_encoder_fwd(const dm_shape* shp, const float* image /* (N,ch,64,64) */, const dm_conv_params* p,
                         float* acts, float* embed /* (N,E) torch (c,y,x) order */, void* ws, size_t ws_bytes, void* stream);
+/* Frames [n0, n0+n) only (all buffers are the full-batch ones; every per-layer buffer is frame-major).  prepare != 0 also
+ * builds what all ranges share (gather tables, repacked weights); n = 0 prepares only.  Lets the host pipeline time chunks
+ * of encoder -> posterior loop -> decoder over three streams (the T-step loop is a latency chain that leaves most CUs idle). */
+int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* image, const dm_conv_params* p,
+                             float* acts, float* embed, void* ws, size_t ws_bytes, void* stream);
 int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_params* p, const float* acts,
                         const float* dembed, const dm_conv_grads* g, void* ws, size_t ws_bytes, void* stream);
 
@@ -161,6 +166,10 @@ size_t dm_conv_decoder_acts_floats(const dm_shape* shp);
 int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
                             const dm_conv_params* p, float* acts, float* loss_image, float* image_rec /* nullable, NCHW */,
                             void* ws, size_t ws_bytes, void* stream);
+/* Frame-range form, see dm_conv_encoder_fwd_rows; the workspace need scales with n. */
+int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* feat, int ldf,
+                                 const float* target, const dm_conv_params* p, float* acts, float* loss_image,
+                                 float* image_rec, void* ws, size_t ws_bytes, void* stream);
 /* dfeat (N,F) accumulated (+=) ; scale = image_weight / (T*B). */
 int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
                             const dm_conv_params* p, const float* acts, float scale,
@@ -182,6 +191,12 @@ int dm_rssm_sequence_fwd(const dm_shape* shp, const float* embed, const float* a
                          const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
                          const dm_rssm_params* p, float* acts, float* feat, float* post, float* prior, int32_t* idx,
                          void* ws, size_t ws_bytes, void* stream);
+/* Time steps [t0, t1) only: step t0 > 0 continues from the state step t0-1 left in `feat`; consecutive ranges issued in
+ * order on one stream equal one full call (rssm.py:38-58 is a plain loop over t). */
+int dm_rssm_sequence_fwd_steps(const dm_shape* shp, int t0, int t1, const float* embed, const float* action,
+                               const uint8_t* reset, const float* h0, const float* z0, const float* u,
+                               const int32_t* forced_idx, const dm_rssm_params* p, float* acts, float* feat, float* post,
+                               float* prior, int32_t* idx, void* ws, size_t ws_bytes, void* stream);
 /* dfeat (N,F) from decoders/heads (consumed, overwritten as scratch), dpost/dprior (N,Z) from the KL term.
  * Produces parameter grads and dembed (N,E). */
 int dm_rssm_sequence_bwd(const dm_shape* shp, const float* embed, const float* action, const uint8_t* reset,

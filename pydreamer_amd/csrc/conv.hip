@@ -321,40 +321,57 @@ __global__ void __launch_bounds__(256) nhwc_to_chw_flat_kernel(size_t n, int hw,
   }
 }
 
-extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, const dm_conv_params* p, float* acts,
-                                   float* embed, void* ws, size_t ws_bytes, void* stream) {
+// Frames [n0, n0+n) of the batch; `acts` / `embed` / `image` are the FULL-batch buffers (every per-layer buffer is
+// frame-major, so a frame range is a contiguous slice of each).  prepare != 0 additionally builds what all ranges share
+// (gather tables, repacked weights) - callers that pipeline ranges over several streams prepare once, with n = 0, on
+// the stream every range stream waits on.
+extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* image,
+                                        const dm_conv_params* p, float* acts, float* embed, void* ws, size_t ws_bytes,
+                                        void* stream) {
   DM_REQUIRE(shp && image && p && acts && embed && ws, DM_E_NULL, "conv_encoder_fwd: null pointer");
   EncGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry (img=%d, E=%d, depth=%d)", shp->img, shp->E,
              shp->cnn_depth);
+  DM_REQUIRE(n0 >= 0 && n >= 0 && n0 + n <= g.N, DM_E_SHAPE, "conv_encoder_fwd: frame range [%d,%d) outside 0..%d", n0,
+             n0 + n, g.N);
   hipStream_t st = (hipStream_t)stream;
   EncActs a;
   enc_carve(g, acts, (size_t)1 << 60, &a);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small");
-  for (int l = 0; l < 4; ++l) {
-    if (l == 0) DM_TRY(dm_im2col_s2_launch(g.N, g.hb[0], g.hb[0], g.cin[0], 4, image, 1, a.xcol[0], st));
-    else DM_TRY(conv_tables_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, a.rowoff[l], a.koff[l], st));
-    const float* w = p->w[l];
-    if (l > 0) {
+  if (prepare) {
+    for (int l = 1; l < 4; ++l) {
+      DM_TRY(conv_tables_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, a.rowoff[l], a.koff[l], st));
       DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cout[l], g.cin[l], 4, 4, 0, 2, 3, 1, st));
-      w = a.wr[l];
     }
+  }
+  if (n == 0) return DM_OK;
+  for (int l = 0; l < 4; ++l) {
+    const size_t r0 = (size_t)n0 * g.hs[l] * g.hs[l];          // first patch row of the range in layer l
+    if (l == 0)
+      DM_TRY(dm_im2col_s2_launch(n, g.hb[0], g.hb[0], g.cin[0], 4, image + (size_t)n0 * g.ch * g.hb[0] * g.hb[0], 1,
+                                 a.xcol[0] + r0 * g.kdim[0], st));
     DmGemm q;
     q.a_layout = 0; q.b_layout = 0;
-    q.M = (int)g.rows[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
-    if (l == 0) { q.A = a.xcol[0]; q.lda = q.K; }
-    else { q.A = a.y[l - 1]; q.a_maj = a.rowoff[l]; q.a_min = a.koff[l]; q.a_tab_vec = (g.cin[l] & 3) == 0; }
-    q.B = w; q.ldb = q.K;
-    q.C = a.y[l]; q.ldc = q.N;
+    q.M = n * g.hs[l] * g.hs[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
+    if (l == 0) { q.A = a.xcol[0] + r0 * g.kdim[0]; q.lda = q.K; }
+    else { q.A = a.y[l - 1]; q.a_maj = a.rowoff[l] + r0; q.a_min = a.koff[l]; q.a_tab_vec = (g.cin[l] & 3) == 0; }
+    q.B = l == 0 ? p->w[0] : a.wr[l]; q.ldb = q.K;
+    q.C = a.y[l] + r0 * g.cout[l]; q.ldc = q.N;
     q.bias = p->b[l];
     q.flags = DM_GEMM_ELU;
     DM_TRY(dm_gemm_launch(q, ws, DM_SPLITK_FLOATS * sizeof(float), st));
   }
-  const size_t tot = (size_t)g.N * 4 * g.cout[3];
-  hipLaunchKernelGGL(nhwc_to_chw_flat_kernel, dim3(grid_for(tot)), dim3(256), 0, st, (size_t)g.N, 4, g.cout[3], a.y[3],
-                     embed, 1);
+  const size_t tot = (size_t)n * 4 * g.cout[3];
+  hipLaunchKernelGGL(nhwc_to_chw_flat_kernel, dim3(grid_for(tot)), dim3(256), 0, st, (size_t)n, 4, g.cout[3],
+                     a.y[3] + (size_t)n0 * 4 * g.cout[3], embed + (size_t)n0 * 4 * g.cout[3], 1);
   DM_LAUNCH_CHECK();
   return DM_OK;
+}
+extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, const dm_conv_params* p, float* acts,
+                                   float* embed, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp, DM_E_NULL, "conv_encoder_fwd: null shape");
+  return dm_conv_encoder_fwd_rows(shp, 0, shp->T * shp->B * (shp->I > 0 ? shp->I : 1), 1, image, p, acts, embed, ws,
+                                  ws_bytes, stream);
 }
 
 extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_params* p, const float* acts,
@@ -436,20 +453,28 @@ extern "C" size_t dm_conv_decoder_acts_floats(const dm_shape* shp) {
   return dec_carve(g, nullptr, 0, nullptr);
 }
 
-extern "C" int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
-                                       const dm_conv_params* p, float* acts, float* loss_image, float* image_rec,
-                                       void* ws, size_t ws_bytes, void* stream) {
+// Frames [n0, n0+n); buffers are the full-batch ones (see dm_conv_encoder_fwd_rows).  The patch-matrix workspace
+// scales with n, so a range stream needs only 1/chunks of the full-batch workspace.
+extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* feat, int ldf,
+                                            const float* target, const dm_conv_params* p, float* acts, float* loss_image,
+                                            float* image_rec, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && feat && target && p && acts && ws, DM_E_NULL, "conv_decoder_fwd: null pointer");
   DecGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry (img=%d)", shp->img);
+  DM_REQUIRE(n0 >= 0 && n >= 0 && n0 + n <= g.N, DM_E_SHAPE, "conv_decoder_fwd: frame range [%d,%d) outside 0..%d", n0,
+             n0 + n, g.N);
   hipStream_t st = (hipStream_t)stream;
   DecActs a;
   dec_carve(g, acts, (size_t)1 << 60, &a);
+  if (prepare)
+    for (int l = 1; l <= 4; ++l)
+      DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cin[l], g.cout[l], g.k[l], g.k[l], 0, 2, 3, 1, st));
+  if (n == 0) return DM_OK;
   DmArena ar(ws, ws_bytes);
   float* splitk = ar.take(DM_SPLITK_FLOATS);
   size_t colmax = 0;
   for (int l = 1; l <= 4; ++l) {
-    const size_t c = g.rows_s[l] * g.k[l] * g.k[l] * g.cout[l];
+    const size_t c = (size_t)n * g.hsm[l] * g.hsm[l] * g.k[l] * g.k[l] * g.cout[l];
     if (c > colmax) colmax = c;
   }
   float* ycol = ar.take(colmax);
@@ -457,32 +482,42 @@ extern "C" int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, i
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   {
     DmGemm q;   // x0 = feat W^T + b
-    q.M = g.N; q.N = g.cin[1]; q.K = g.F;
-    q.A = feat; q.lda = ldf;
+    q.M = n; q.N = g.cin[1]; q.K = g.F;
+    q.A = feat + (size_t)n0 * ldf; q.lda = ldf;
     q.B = p->w[0]; q.ldb = g.F;
-    q.C = a.x[0]; q.ldc = q.N;
+    q.C = a.x[0] + (size_t)n0 * g.cin[1]; q.ldc = q.N;
     q.bias = p->b[0];
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
   }
   for (int l = 1; l <= 4; ++l) {
     const int kk = g.k[l] * g.k[l];
-    DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cin[l], g.cout[l], g.k[l], g.k[l], 0, 2, 3, 1, st));
+    const float* xin = l == 1 ? a.x[0] + (size_t)n0 * g.cin[1]
+                              : a.x[l - 1] + (size_t)n0 * g.hbg[l - 1] * g.hbg[l - 1] * g.cout[l - 1];
     DmGemm q;   // Ycol[(n,ys,xs)][(ky,kx,o)] = X[(n,ys,xs)][i] * Wr[i][(ky,kx,o)]
     q.a_layout = 0; q.b_layout = 1;
-    q.M = (int)g.rows_s[l]; q.N = kk * g.cout[l]; q.K = g.cin[l];
-    q.A = a.x[l - 1]; q.lda = q.K;
+    q.M = n * g.hsm[l] * g.hsm[l]; q.N = kk * g.cout[l]; q.K = g.cin[l];
+    q.A = xin; q.lda = q.K;
     q.B = a.wr[l]; q.ldb = q.N;
     q.C = ycol; q.ldc = q.N;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
-    DM_TRY(dm_col2im_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], ycol, p->b[l], l < 4 ? DM_C2I_ELU : 0, nullptr,
-                               a.x[l], st));
+    DM_TRY(dm_col2im_s2_launch(n, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], ycol, p->b[l], l < 4 ? DM_C2I_ELU : 0, nullptr,
+                               a.x[l] + (size_t)n0 * g.hbg[l] * g.hbg[l] * g.cout[l], st));
   }
   if (loss_image || image_rec) {
-    hipLaunchKernelGGL(mse_image_kernel, dim3(g.N), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4], target, 0.f,
-                       loss_image, nullptr, image_rec);
+    const size_t per = (size_t)g.hbg[4] * g.hbg[4] * g.ch;
+    hipLaunchKernelGGL(mse_image_kernel, dim3(n), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4] + n0 * per,
+                       target + n0 * per, 0.f, loss_image ? loss_image + n0 : nullptr, nullptr,
+                       image_rec ? image_rec + n0 * per : nullptr);
     DM_LAUNCH_CHECK();
   }
   return DM_OK;
+}
+extern "C" int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                       const dm_conv_params* p, float* acts, float* loss_image, float* image_rec,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(shp, DM_E_NULL, "conv_decoder_fwd: null shape");
+  return dm_conv_decoder_mse_fwd_rows(shp, 0, shp->T * shp->B * (shp->I > 0 ? shp->I : 1), 1, feat, ldf, target, p, acts,
+                                      loss_image, image_rec, ws, ws_bytes, stream);
 }
 
 extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,

@@ -380,6 +380,11 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   DM_REQUIRE(q.ldc >= q.N, DM_E_SHAPE, "gemm: ldc %d < N %d", q.ldc, q.N);
   DM_REQUIRE(!q.add || q.ldadd >= q.N, DM_E_SHAPE, "gemm: ldadd %d < N %d", q.ldadd, q.N);
 
+  {   // <= 64-row products of the sequential RSSM chains: one-launch skinny kernel (gemm_skinny.hip)
+    const int sk = dm_gemm_skinny_try(q, stream);
+    if (sk < 0) return sk;
+    if (sk == 1) return DM_OK;
+  }
   GemmKArgs a;
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.mulref = q.mulref; a.row_zero = q.row_zero; a.partial = nullptr;
   a.M = q.M; a.N = q.N; a.K = q.K;

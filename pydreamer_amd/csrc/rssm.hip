@@ -94,27 +94,35 @@ static int transpose(hipStream_t st, const float* W, float* Wt, int rows, int co
   return dm_permute4_launch(W, Wt, 1, 1, rows, cols, 0, 1, 3, 2, st);
 }
 
-extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
-                                    const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
-                                    const dm_rssm_params* P, float* acts, float* feat, float* post, float* prior,
-                                    int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+// Time steps [t0, t1) of the sequence; all buffers are the full (T*B)-row ones.  Step t0 > 0 continues from the state
+// that step t0-1 left in `feat`, so consecutive ranges issued in order on one stream equal one full call; the encoder
+// range that feeds them and the decoder range that consumes them can then run on other streams (see WorldModel._forward).
+extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, const float* embed, const float* action,
+                                          const uint8_t* reset, const float* h0, const float* z0, const float* u,
+                                          const int32_t* forced_idx, const dm_rssm_params* P, float* acts, float* feat,
+                                          float* post, float* prior, int32_t* idx, void* ws, size_t ws_bytes,
+                                          void* stream) {
   DM_REQUIRE(s && embed && action && reset && h0 && z0 && P && acts && feat && post && prior && ws, DM_E_NULL,
              "rssm_sequence_fwd: null pointer");
   DM_REQUIRE(u || forced_idx, DM_E_NULL, "rssm_sequence_fwd: need uniforms or forced indices");
   DM_TRY(rssm_check(s));
+  DM_REQUIRE(t0 >= 0 && t0 <= t1 && t1 <= s->T, DM_E_SHAPE, "rssm_sequence_fwd: step range [%d,%d) outside 0..%d", t0, t1, s->T);
+  if (t0 == t1) return DM_OK;
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "rssm_sequence_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
-  const int N = T * B;
+  (void)T;
+  const int N = (t1 - t0) * B;                        // rows of this range
+  const size_t q0 = (size_t)t0 * B;                   // its first row
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   RssmActs a;
   rssm_carve(s, acts, &a);
   const float* const* p = P->p;
 
-  DM_TRY(linear(st, ws, skb, N, Hd, A, action, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea, Hd));
-  DM_TRY(linear(st, ws, skb, N, Hd, E, embed, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee, Hd));
+  DM_TRY(linear(st, ws, skb, N, Hd, A, action + q0 * A, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea + q0 * Hd, Hd));
+  DM_TRY(linear(st, ws, skb, N, Hd, E, embed + q0 * E, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee + q0 * Hd, Hd));
 
-  for (int t = 0; t < T; ++t) {
+  for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)t * B;
     const float* ph = t == 0 ? h0 : feat + (r0 - B) * F;
     const float* pz = t == 0 ? z0 : feat + (r0 - B) * F + D;
@@ -145,10 +153,21 @@ extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const
                                    idx ? idx + r0 * S : nullptr, st));
   }
   // batch_prior over all (T*B) rows                                                    rssm.py:61,186-193
-  DM_TRY(linear(st, ws, skb, N, Hd, D, feat, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, a.x3, Hd));
-  DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x3, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin, Hd, a.st3, st));
-  DM_TRY(linear(st, ws, skb, N, Z, Hd, a.prin, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
+  DM_TRY(linear(st, ws, skb, N, Hd, D, feat + q0 * F, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0,
+                a.x3 + q0 * Hd, Hd));
+  DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x3 + q0 * Hd, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin + q0 * Hd,
+                              Hd, a.st3 + q0 * 2, st));
+  DM_TRY(linear(st, ws, skb, N, Z, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
+                prior + q0 * Z, Z));
   return DM_OK;
+}
+extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
+                                    const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
+                                    const dm_rssm_params* P, float* acts, float* feat, float* post, float* prior,
+                                    int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(s, DM_E_NULL, "rssm_sequence_fwd: null shape");
+  return dm_rssm_sequence_fwd_steps(s, 0, s->T, embed, action, reset, h0, z0, u, forced_idx, P, acts, feat, post, prior,
+                                    idx, ws, ws_bytes, stream);
 }
 
 extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,

@@ -93,16 +93,22 @@ _SIGNATURES = {
     'dm_head_loss': (c_int, [c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     'dm_conv_encoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
     'dm_conv_encoder_fwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, _P, c_size_t, _P]),
+    'dm_conv_encoder_fwd_rows': (c_int, [POINTER(dm_shape), c_int, c_int, c_int, _P, POINTER(dm_conv_params), _P, _P, _P,
+                                         c_size_t, _P]),
     'dm_conv_encoder_bwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, POINTER(dm_conv_grads), _P,
                                     c_size_t, _P]),
     'dm_conv_decoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
     'dm_conv_decoder_mse_fwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, _P, _P, _P,
                                         c_size_t, _P]),
+    'dm_conv_decoder_mse_fwd_rows': (c_int, [POINTER(dm_shape), c_int, c_int, c_int, _P, c_int, _P, POINTER(dm_conv_params),
+                                             _P, _P, _P, _P, c_size_t, _P]),
     'dm_conv_decoder_mse_bwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, c_float,
                                         POINTER(dm_conv_grads), _P, c_int, _P, c_size_t, _P]),
     'dm_rssm_acts_floats': (c_size_t, [POINTER(dm_shape)]),
     'dm_rssm_sequence_fwd': (c_int, [POINTER(dm_shape), _P, _P, _P, _P, _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P,
                                      _P, _P, _P, c_size_t, _P]),
+    'dm_rssm_sequence_fwd_steps': (c_int, [POINTER(dm_shape), c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                           POINTER(dm_rssm_params), _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'dm_rssm_sequence_bwd': (c_int, [POINTER(dm_shape), _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P, _P, _P, _P,
                                      POINTER(dm_rssm_grads), _P, _P, c_size_t, _P]),
     'dm_dream_rollout': (c_int, [POINTER(dm_shape), c_int, _P, POINTER(dm_rssm_params), POINTER(dm_mlp_params), _P, _P,

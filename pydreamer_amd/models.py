@@ -13,6 +13,7 @@ actor_grad='reinforce',
 probe_model='none', no aux critic / vecobs / reward_input.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -489,6 +490,12 @@ class WorldModel(_Params):
         for m in self.modules():
             init_weights_tf2(m)
         self._ws = None
+        self._pipe = None
+        # Forward time-chunk pipeline over 3 streams (encoder chunk i+1 | posterior steps of chunk i | decoder chunk i-1).
+        # OFF by default: measured on MI355X / ROCm 7.2 it LOSES (61.9 vs 47.7 ms per step at B=50, 33.1 vs 16.5 ms at
+        # B=7): the loop's 1024-thread workgroups starve behind the conv GEMMs of the other streams and every cross-stream
+        # dependency costs a cache writeback/invalidate between queues.  Kept because it is exact (tested) and cheap to flip.
+        self.pipeline_chunks = int(os.environ.get('DM_PIPELINE_CHUNKS', '1'))
 
     def init_state(self, batch_size):
         return self.core.init_state(batch_size)
@@ -506,6 +513,24 @@ class WorldModel(_Params):
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
+
+    def _pipeline(self, shp, T, B, chunks, device):
+        """Streams, events and per-stream workspaces of the forward time-chunk pipeline (cached per geometry)."""
+        key = (T, B, chunks, str(device))
+        pp = self._pipe
+        if pp is None or pp['key'] != key:
+            step = -(-T // chunks)
+            ranges = [(t, min(t + step, T)) for t in range(0, T, step)]
+            sub = H.dm_shape.from_buffer_copy(shp)
+            sub.T = step                                   # per-range decoder workspace: patch matrices scale with rows
+            pp = dict(key=key, ranges=ranges,
+                      s_chain=torch.cuda.Stream(device, priority=-1), s_dec=torch.cuda.Stream(device),
+                      ev_prep=torch.cuda.Event(), ev_enc=[torch.cuda.Event() for _ in ranges],
+                      ev_chain=[torch.cuda.Event() for _ in ranges],
+                      ws_chain=torch.empty((int(H.DM_SPLITK_FLOATS) + 4096) * 4, dtype=torch.uint8, device=device),
+                      ws_dec=torch.empty(H.workspace_bytes(sub), dtype=torch.uint8, device=device))
+            self._pipe = pp
+        return pp
 
     def forward(self, obs, in_state):
         """dreamer.py:289-295: features and out_state only (used by Dreamer.inference)."""
@@ -536,9 +561,6 @@ class WorldModel(_Params):
         enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
         enc_acts = torch.empty(int(lib.dm_conv_encoder_acts_floats(ctypes.byref(shp))), device=dev)
         embed = torch.empty(N, E, device=dev)
-        H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed),
-               H.ptr(ws), ws.numel(), H.stream())
-
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp))), device=dev)
@@ -547,24 +569,64 @@ class WorldModel(_Params):
         prior = torch.empty(N, Z, device=dev)
         idx = torch.empty(N, c.stoch_dim, dtype=torch.int32, device=dev)
         fidx = forced_idx.to(torch.int32).contiguous() if forced_idx is not None else None
-        H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
-               H.fptr(u_post.contiguous()) if u_post is not None else None, H.ptr(fidx), ctypes.byref(rssm_p),
-               H.fptr(rssm_acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
+        u_post = u_post.contiguous() if u_post is not None else None
+        u_ptr = H.fptr(u_post) if u_post is not None else None
+        dec = self.decoder
+        dl = dec.image.layers()
+        dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+        if not forward_only:
+            dec_acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
+            loss_image = torch.empty(N, device=dev)
+            image_rec = torch.empty_like(image)
+
+        chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only) else 1
+        if chunks <= 1:
+            H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
+                   H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
+            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0),
+                   H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
+                   H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
+            if not forward_only:
+                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(image), ctypes.byref(dec_p),
+                       H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(), H.stream())
+        else:
+            # Time-chunk pipeline over three streams: the posterior loop is a latency chain of T x ~10 small kernels
+            # (rssm.py:38-58) that leaves most CUs idle, so the encoder of chunk i+1 and the decoder of chunk i-1 run
+            # beside the loop steps of chunk i.  Same kernels on the same rows as the single-stream path.
+            pp = self._pipeline(shp, T, B, chunks, dev)
+            main = torch.cuda.current_stream()
+            H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(image), ctypes.byref(enc_p),
+                   H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
+            H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(feat), F_, H.fptr(image),
+                   ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(),
+                   H.stream())
+            pp['ev_prep'].record(main)
+            pp['s_chain'].wait_event(pp['ev_prep'])
+            pp['s_dec'].wait_event(pp['ev_prep'])
+            for i, (t0, t1) in enumerate(pp['ranges']):
+                H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.fptr(image),
+                       ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
+                pp['ev_enc'][i].record(main)
+                pp['s_chain'].wait_event(pp['ev_enc'][i])
+                with torch.cuda.stream(pp['s_chain']):
+                    H.call('dm_rssm_sequence_fwd_steps', ctypes.byref(shp), t0, t1, H.fptr(embed), H.fptr(action),
+                           H.ptr(reset), H.fptr(h0), H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p),
+                           H.fptr(rssm_acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(pp['ws_chain']),
+                           pp['ws_chain'].numel(), H.stream())
+                    pp['ev_chain'][i].record(pp['s_chain'])
+                pp['s_dec'].wait_event(pp['ev_chain'][i])
+                with torch.cuda.stream(pp['s_dec']):
+                    H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.fptr(feat), F_,
+                           H.fptr(image), ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec),
+                           H.ptr(pp['ws_dec']), pp['ws_dec'].numel(), H.stream())
+            main.wait_stream(pp['s_chain'])
+            main.wait_stream(pp['s_dec'])
+
         last = feat[(T - 1) * B:]
         out_state = (last[:, :D_].clone(), last[:, D_:].clone())                  # detached by construction (rssm.py:77)
         pk = dict(shp=shp, T=T, B=B, feat=feat, post=post, prior=prior, idx=idx, out_state=out_state, embed=embed)
         if forward_only:
             return pk
-
-        # decoders (decoders.py:50-108)
-        dec = self.decoder
-        dl = dec.image.layers()
-        dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
-        dec_acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
-        loss_image = torch.empty(N, device=dev)
-        image_rec = torch.empty_like(image)
-        H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(image), ctypes.byref(dec_p),
-               H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(), H.stream())
 
         reward_t = obs['reward'].float().contiguous()
         terminal_t = obs['terminal'].float().contiguous()

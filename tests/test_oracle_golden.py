@@ -130,8 +130,6 @@ def test_sampler_rule_edges():
     assert O.sample_inverse_cdf(p, torch.tensor([0.999, 0.999999, 0.999])).tolist() == [2, 3, 2]
 
 
-@pytest.mark.skipif(os.environ.get('DM_SLOW_TESTS', '0') != '1',
-                    reason='full-size oracle replay takes ~2 min of CPU; run with DM_SLOW_TESTS=1 (result recorded in DESIGN.md)')
 def test_oracle_matches_reference_at_atari_literal():
     """BASELINE.json configs[1] at full size (B=50,T=50,H=15, deter 600): the oracle against the slim golden written by the
     real reference.  Inputs are regenerated from the same seeds and fingerprinted."""
