@@ -62,6 +62,8 @@ struct DmGemm {
 };
 int dm_gemm_launch(const DmGemm& g, void* ws, size_t ws_bytes, hipStream_t stream);
 int dm_gemm_skinny_try(const DmGemm& g, hipStream_t stream);   // gemm_skinny.hip: 1 = handled, 0 = not applicable, <0 error
+// two independent products; one launch when both are <= 64-row skinny products, else two ordinary launches
+int dm_gemm_pair_launch(const DmGemm& g0, const DmGemm& g1, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // element-wise / row-wise launchers (elementwise.hip)
 int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st);
@@ -72,14 +74,17 @@ int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const floa
 int dm_ln_elu_bwd_params_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
                                 const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                 hipStream_t st);
+// h_next (optional, rows x D): the NEXT step's masked state input, next_reset[r] ? 0 : h_out   (rssm.py:134)
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
-                            int ldo, hipStream_t st);
+                            int ldo, float* h_next, const uint8_t* next_reset, hipStream_t st);
 // dh_in (+)= row_mask * dh_out*u  (accum: add into dh_in; row_zero: rows whose flag is set contribute 0)
 int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                             const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,
                             const uint8_t* row_zero, hipStream_t st);
+// z_next (optional, rows x groups*C): the NEXT step's masked sample input, next_reset[r] ? 0 : onehot
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
-                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, hipStream_t st);
+                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, float* z_next,
+                            const uint8_t* next_reset, hipStream_t st);
 int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* prior, float* kl, float* ep, float* eq,
                      hipStream_t st);
 int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* prior, float sp, float sq, float* dpost,

@@ -327,7 +327,9 @@ __device__ __forceinline__ float dm_sigmoid(float v) { return 1.0f / (1.0f + exp
 
 __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, const float* __restrict__ gi,
                                                             const float* __restrict__ gh, const float* __restrict__ h_in,
-                                                            int ldh, float* __restrict__ h_out, int ldo) {
+                                                            int ldh, float* __restrict__ h_out, int ldo,
+                                                            float* __restrict__ h_next,
+                                                            const uint8_t* __restrict__ next_reset) {
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / D), d = (int)(i % D);
@@ -337,7 +339,9 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
     const float ug = dm_sigmoid(gir[D + d] + ghr[D + d]);
     const float ng = tanhf(gir[2 * D + d] + rg * ghr[2 * D + d]);
     const float h = h_in[(size_t)r * ldh + d];
-    h_out[(size_t)r * ldo + d] = (h - ng) * ug + ng;
+    const float ho = (h - ng) * ug + ng;
+    h_out[(size_t)r * ldo + d] = ho;
+    if (h_next) h_next[(size_t)r * D + d] = (next_reset && next_reset[r]) ? 0.f : ho;
   }
 }
 
@@ -384,10 +388,10 @@ static inline int ew_blocks(size_t total) {
 }
 
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
-                            int ldo, hipStream_t st) {
+                            int ldo, float* h_next, const uint8_t* next_reset, hipStream_t st) {
   if (rows <= 0) return DM_OK;
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
-                     ldh, h_out, ldo);
+                     ldh, h_out, ldo, h_next, next_reset);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -403,7 +407,7 @@ int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, c
 extern "C" int dm_gru_gates_fwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                                 float* h_out, int ldo, void* stream) {
   DM_REQUIRE(gi && gh && h_in && h_out, DM_E_NULL, "gru_gates_fwd: null pointer");
-  return dm_gru_gates_fwd_launch(rows, D, gi, gh, h_in, ldh, h_out, ldo, (hipStream_t)stream);
+  return dm_gru_gates_fwd_launch(rows, D, gi, gh, h_in, ldh, h_out, ldo, nullptr, nullptr, (hipStream_t)stream);
 }
 extern "C" int dm_gru_gates_bwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                                 const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi,
@@ -507,7 +511,9 @@ __global__ void __launch_bounds__(256) sample_onehot_lane32_kernel(int rows, int
                                                                    int ldl, const float* __restrict__ u,
                                                                    const int32_t* __restrict__ forced,
                                                                    float* __restrict__ onehot, int ldo,
-                                                                   int32_t* __restrict__ idx_out) {
+                                                                   int32_t* __restrict__ idx_out,
+                                                                   float* __restrict__ z_next,
+                                                                   const uint8_t* __restrict__ next_reset) {
   constexpr int C = 32;
   const int total = rows * groups;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -548,16 +554,26 @@ __global__ void __launch_bounds__(256) sample_onehot_lane32_kernel(int rows, int
   for (int q = 0; q < C / 4; ++q)
     dst[q] = make_float4(idx == 4 * q ? 1.f : 0.f, idx == 4 * q + 1 ? 1.f : 0.f, idx == 4 * q + 2 ? 1.f : 0.f,
                          idx == 4 * q + 3 ? 1.f : 0.f);
+  if (z_next) {          // next step's sample input under its reset mask (rssm.py:135); rows are groups*C wide, dense
+    const int keep = (next_reset && next_reset[r]) ? -1 : idx;
+    float4* dn = reinterpret_cast<float4*>(z_next + ((size_t)r * groups + gq) * C);
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q)
+      dn[q] = make_float4(keep == 4 * q ? 1.f : 0.f, keep == 4 * q + 1 ? 1.f : 0.f, keep == 4 * q + 2 ? 1.f : 0.f,
+                          keep == 4 * q + 3 ? 1.f : 0.f);
+  }
   if (idx_out) idx_out[i] = idx;
 }
 
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
-                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, hipStream_t st) {
+                            const int32_t* forced, float* onehot, int ldo, int32_t* idx, float* z_next,
+                            const uint8_t* next_reset, hipStream_t st) {
   if (rows <= 0) return DM_OK;
   const size_t tg = (size_t)rows * groups;
-  if (C == 32 && (ldl & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)logits | (uintptr_t)onehot) & 15) == 0) {
+  if (C == 32 && (ldl & 3) == 0 && (ldo & 3) == 0 &&
+      (((uintptr_t)logits | (uintptr_t)onehot | (uintptr_t)z_next) & 15) == 0) {
     hipLaunchKernelGGL(sample_onehot_lane32_kernel, dim3((unsigned)dm_cdiv(tg, 256)), dim3(256), 0, st, rows, groups,
-                       logits, ldl, u, forced, onehot, ldo, idx);
+                       logits, ldl, u, forced, onehot, ldo, idx, z_next, next_reset);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
@@ -573,13 +589,15 @@ int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, in
                        onehot, ldo, idx);
 #undef DM_SAMPLE_WAVE
   DM_LAUNCH_CHECK();
+  if (z_next) DM_TRY(dm_mask_rows_launch(rows, groups * C, onehot, ldo, next_reset, z_next, groups * C, st));
   return DM_OK;
 }
 extern "C" int dm_sample_onehot(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                                 const int32_t* forced_idx, float* onehot, int ldo, int32_t* idx, void* stream) {
   DM_REQUIRE(logits && onehot && (u || forced_idx), DM_E_NULL, "sample_onehot: null pointer");
   DM_REQUIRE(C >= 1 && groups >= 1, DM_E_SHAPE, "sample_onehot: bad groups/C");
-  return dm_sample_onehot_launch(rows, groups, C, logits, ldl, u, forced_idx, onehot, ldo, idx, (hipStream_t)stream);
+  return dm_sample_onehot_launch(rows, groups, C, logits, ldl, u, forced_idx, onehot, ldo, idx, nullptr, nullptr,
+                                 (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -50,14 +50,14 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int n0, int c, 
   mask |= okb ? 16u : 0u;
 }
 
-constexpr int SK_WAVES = 16;   // waves per workgroup = K splits inside the workgroup
 constexpr int SK_DEPTH = 4;    // 16-k chunks loaded per round (all in flight before the first MFMA)
+constexpr int SK_WAVES = 16;   // waves per workgroup = K splits inside it (8 and 4 measured slower, also under contention)
 
+// One 64 x 16 output strip.
 template <int BL>
-__global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
-  __shared__ float part[SK_WAVES][64 * 16];
+__device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, float (*part)[64 * 16]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = strip * 16;
   const int chunks = (g.K + 15) / 16;
   const int per = (chunks + SK_WAVES - 1) / SK_WAVES;
   const int c_beg = wave * per * 16;
@@ -117,22 +117,59 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const Skinny
   }
 }
 
-// Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
-int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
-  static const int disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
-  if (disabled) return 0;
-  if (q.M > 64 || q.M < 1 || q.N < 1 || q.K < 16) return 0;
-  if (q.a_layout != 0 || q.a_maj || q.b_maj || q.mulref) return 0;
-  if ((q.K & 3) || (q.lda & 3) || ((uintptr_t)q.A & 15)) return 0;
-  if (q.b_layout == 0 && ((q.ldb & 3) || ((uintptr_t)q.B & 15))) return 0;
-  if ((int64_t)q.N * q.K < (int64_t)64 * 1024) return 0;                // tiny products: one tiled workgroup is fine
-  SkinnyArgs a;
+template <int BL>
+__global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
+  __shared__ float part[SK_WAVES][64 * 16];
+  skinny_strip<BL>(g, blockIdx.x, part);
+}
+// Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
+// host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
+// feed step t-1's state gradient.  Workgroups [0, nb0) serve the first product, the rest the second.
+struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0; };
+__global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
+  __shared__ float part[SK_WAVES][64 * 16];
+  const int b = blockIdx.x;
+  if (b < a.nb0) skinny_strip<0>(a.g[0], b, part);
+  else skinny_strip<0>(a.g[1], b - a.nb0, part);
+}
+
+static bool skinny_ok(const DmGemm& q) {
+  if (q.M > 64 || q.M < 1 || q.N < 1 || q.K < 16) return false;
+  if (q.a_layout != 0 || q.a_maj || q.b_maj || q.mulref) return false;
+  if ((q.K & 3) || (q.lda & 3) || ((uintptr_t)q.A & 15)) return false;
+  if (q.b_layout == 0 && ((q.ldb & 3) || ((uintptr_t)q.B & 15))) return false;
+  if ((int64_t)q.N * q.K < (int64_t)64 * 1024) return false;             // tiny products: one tiled workgroup is fine
+  return true;
+}
+static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.row_zero = q.row_zero;
   a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.flags = q.flags;
+}
+static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
+
+// Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
+int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
+  if (g_skinny_disabled || !skinny_ok(q)) return 0;
+  SkinnyArgs a;
+  skinny_fill(q, a);
   const dim3 grid((unsigned)dm_cdiv(q.N, 16));
   if (q.b_layout == 0) hipLaunchKernelGGL((skinny_gemm_kernel<0>), grid, dim3(SK_WAVES * 64), 0, stream, a);
   else hipLaunchKernelGGL((skinny_gemm_kernel<1>), grid, dim3(SK_WAVES * 64), 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "skinny gemm: %s", hipGetErrorString(e));
   return 1;
+}
+// Both products in one launch if both qualify (k-contiguous B); otherwise two ordinary launches.
+int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!g_skinny_disabled && skinny_ok(q0) && skinny_ok(q1) && q0.b_layout == 0 && q1.b_layout == 0) {
+    SkinnyPairArgs a;
+    skinny_fill(q0, a.g[0]);
+    skinny_fill(q1, a.g[1]);
+    a.nb0 = dm_cdiv(q0.N, 16);
+    hipLaunchKernelGGL(skinny_gemm_pair_kernel, dim3((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), dim3(SK_WAVES * 64), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  DM_TRY(dm_gemm_launch(q0, ws, ws_bytes, stream));
+  return dm_gemm_launch(q1, ws, ws_bytes, stream);
 }

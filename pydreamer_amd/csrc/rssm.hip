@@ -122,24 +122,37 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DM_TRY(linear(st, ws, skb, N, Hd, A, action + q0 * A, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea + q0 * Hd, Hd));
   DM_TRY(linear(st, ws, skb, N, Hd, E, embed + q0 * E, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee + q0 * Hd, Hd));
 
+  // 8 launches per step: the reset masks of step t+1 are applied by the kernels that produce h_t and z_t (only the
+  // first step of a range needs the stand-alone mask kernel), and the GRU's two gate products share one launch.
   for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)t * B;
-    const float* ph = t == 0 ? h0 : feat + (r0 - B) * F;
-    const float* pz = t == 0 ? z0 : feat + (r0 - B) * F + D;
-    const int ldp_h = t == 0 ? D : F, ldp_z = t == 0 ? Z : F;
     float* hin = a.hin + r0 * D;
     float* zin = a.zin + r0 * Z;
-    DM_TRY(dm_mask_rows2_launch(B, D, ph, ldp_h, hin, D, Z, pz, ldp_z, zin, Z, reset + r0, st));
+    if (t == t0) {
+      const float* ph = t == 0 ? h0 : feat + (r0 - B) * F;
+      const float* pz = t == 0 ? z0 : feat + (r0 - B) * F + D;
+      const int ldp_h = t == 0 ? D : F, ldp_z = t == 0 ? Z : F;
+      DM_TRY(dm_mask_rows2_launch(B, D, ph, ldp_h, hin, D, Z, pz, ldp_z, zin, Z, reset + r0, st));
+    }
+    const bool more = t + 1 < t1;
+    float* hin_next = more ? a.hin + (r0 + B) * D : nullptr;
+    float* zin_next = more ? a.zin + (r0 + B) * Z : nullptr;
+    const uint8_t* reset_next = more ? reset + r0 + B : nullptr;
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
     DM_TRY(linear(st, ws, skb, B, Hd, Z, zin, Z, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd, a.x1 + r0 * Hd, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
                                 a.st1 + r0 * 2, st));
     // h = GRUCell(za, h_in)                                                             rssm.py:141
-    DM_TRY(linear(st, ws, skb, B, 3 * D, Hd, a.za + r0 * Hd, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0,
-                  a.gi + r0 * 3 * D, 3 * D));
-    DM_TRY(linear(st, ws, skb, B, 3 * D, D, hin, D, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0,
-                  a.gh + r0 * 3 * D, 3 * D));
-    DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, st));
+    {
+      DmGemm gi_q, gh_q;
+      gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
+      gi_q.C = a.gi + r0 * 3 * D; gi_q.ldc = 3 * D; gi_q.bias = p[DM_RSSM_GRU_BIH];
+      gh_q.M = B; gh_q.N = 3 * D; gh_q.K = D; gh_q.A = hin; gh_q.lda = D; gh_q.B = p[DM_RSSM_GRU_WHH]; gh_q.ldb = D;
+      gh_q.C = a.gh + r0 * 3 * D; gh_q.ldc = 3 * D; gh_q.bias = p[DM_RSSM_GRU_BHH];
+      DM_TRY(dm_gemm_pair_launch(gi_q, gh_q, ws, skb, st));
+    }
+    DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, hin_next,
+                                   reset_next, st));
     // post = post_mlp(ELU(post_norm(post_mlp_h(h) + post_mlp_e(embed))))               rssm.py:143-146
     DM_TRY(linear(st, ws, skb, B, Hd, D, feat + r0 * F, F, p[DM_RSSM_POST_H_W], p[DM_RSSM_POST_H_B], a.ee + r0 * Hd, Hd,
                   a.x2 + r0 * Hd, Hd));
@@ -150,7 +163,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     // z ~ OneHotCategoricalStraightThrough(post)                                       rssm.py:147-148
     DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * Z, Z, u ? u + r0 * S : nullptr,
                                    forced_idx ? forced_idx + r0 * S : nullptr, feat + r0 * F + D, F,
-                                   idx ? idx + r0 * S : nullptr, st));
+                                   idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
   }
   // batch_prior over all (T*B) rows                                                    rssm.py:61,186-193
   DM_TRY(linear(st, ws, skb, N, Hd, D, feat + q0 * F, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0,
@@ -240,9 +253,13 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, wt_ih, dza + r0 * Hd, Hd, 0, nullptr));
     DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
                                    dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
-    if (t > 0) {
-      DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, D, dgh + r0 * 3 * D, 3 * D, wt_hh, dprev, F, 1, rz));
-      DM_TRY(dgrad_t(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, wt_z, dprev + D, F, 1, rz));
+    if (t > 0) {     // both products into step t-1's [dh' | dz'], one launch
+      DmGemm qh, qz;
+      qh.M = B; qh.N = D; qh.K = 3 * D; qh.A = dgh + r0 * 3 * D; qh.lda = 3 * D; qh.B = wt_hh; qh.ldb = 3 * D;
+      qh.C = dprev; qh.ldc = F; qh.flags = DM_GEMM_ACCUM; qh.row_zero = rz;
+      qz.M = B; qz.N = Z; qz.K = Hd; qz.A = dx1 + r0 * Hd; qz.lda = Hd; qz.B = wt_z; qz.ldb = Hd;
+      qz.C = dprev + D; qz.ldc = F; qz.flags = DM_GEMM_ACCUM; qz.row_zero = rz;
+      DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));
     }
   }
 
@@ -314,7 +331,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st));
     if (adist == 0)
       DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
-                                     act_idx ? act_idx + (size_t)i * M : nullptr, st));
+                                     act_idx ? act_idx + (size_t)i * M : nullptr, nullptr, nullptr, st));
     else
       DM_TRY(dm_sample_continuous_launch(adist, M, A, logits, u_act + (size_t)i * M * A, act, st));
     // cell.forward_prior(action, None, (h, z))                                          rssm.py:155-184
@@ -323,11 +340,12 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
     DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
-    DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, st));
+    DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
-    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, nullptr, st));
+    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, nullptr, nullptr,
+                                   nullptr, st));
   }
   return DM_OK;
 }
