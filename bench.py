@@ -90,7 +90,7 @@ def cpu_baseline_worker(sample_batch, threads):
         model.backward_clip_step(losses)
         n += 1
         el = time.perf_counter() - t0
-        if el >= 10.0 or n >= 4:
+        if el >= 15.0 or n >= 16:          # ~15 s of CPU work (bounded; the subprocess also has a hard timeout)
             break
     frac = sample_batch / full.batch_size
     print(json.dumps(dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port',
@@ -99,7 +99,7 @@ def cpu_baseline_worker(sample_batch, threads):
                                  f'included; scaled by {sample_batch}/{full.batch_size} to full-batch grad-steps/s')))
 
 
-def cpu_baseline(sample_batch=5, threads_cap=32, timeout_s=150):
+def cpu_baseline(sample_batch=10, threads_cap=32, timeout_s=150):
     """Oracle (test infrastructure, kind "port") as the CPU baseline on a bounded sample, in a subprocess with a hard
     timeout so a pathological host (thread oversubscription cost 889 s for one step in the first run of this round)
     can never stall the bench; returns a dict with value=None and the reason if it does not finish."""
@@ -217,23 +217,39 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
-        out = (ctypes.c_double * 36)()
+        out = (ctypes.c_double * 48)()
         n = hip.lib().dm_prof_end(out, 12)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
         tiles = ('128,128', '128,64', '64,64')
         for k in range(12):
-            cnt, fl, ms = out[3 * k], out[3 * k + 1], out[3 * k + 2]
+            cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
                 kinds.append(dict(kernel=f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>",
                                   layout=names[k & 3], launches_per_step=cnt / args.prof_steps,
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
-                                  ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12))
-        tot_fl = sum(out[3 * k + 1] for k in range(12))
-        tot_ms = sum(out[3 * k + 2] for k in range(12))
+                                  ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12,
+                                  alg_bytes_per_launch=by / cnt, alg_flops_per_launch=fl / cnt))
+        tot_fl = sum(out[4 * k + 1] for k in range(12))
+        tot_ms = sum(out[4 * k + 2] for k in range(12))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3
-        roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=None,
+        # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE
+        # and WRITE_SIZE cannot share a pass), summarised by scripts/pmc_traffic.py into profiles/ - read back here
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')) as f:
+                pmc = json.load(f)['kernels']
+            key = dom['kernel'].replace('>', '') + ','        # "gemm_f32_kernel<64,64,0,0" + remaining template args
+            hits = [v for k, v in pmc.items() if k.replace(' ', '').startswith(key.replace(' ', ''))]
+            if hits:
+                n = sum(h['launches'] for h in hits)
+                traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n, 1)
+        except (OSError, KeyError, ValueError):
+            traffic = None
+        roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=traffic,
+                    traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes; profiles/r01_pmc_traffic.json)',
+                    algorithmic_bytes_per_launch=dom.get('alg_bytes_per_launch'),
                     kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                   gflop_per_step=tot_fl / 1e9 / args.prof_steps, ms_per_step=tot_ms / args.prof_steps,

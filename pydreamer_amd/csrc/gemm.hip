@@ -303,14 +303,15 @@ struct GemmProf {
   bool on = false;
   size_t cap = 0, n = 0;
   std::vector<hipEvent_t> ev;      // 2 per slot
-  std::vector<double> flops;
+  std::vector<double> flops, bytes;
   std::vector<int> kind;
 };
 static GemmProf g_prof;
-static int prof_before(int kind, double flops, hipStream_t st) {
+static int prof_before(int kind, double flops, double bytes, hipStream_t st) {
   if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
   const int slot = (int)g_prof.n++;
   g_prof.flops[slot] = flops;
+  g_prof.bytes[slot] = bytes;
   g_prof.kind[slot] = kind;
   (void)hipEventRecord(g_prof.ev[2 * slot], st);
   return slot;
@@ -327,27 +328,30 @@ extern "C" int dm_prof_begin(int max_launches) {
       if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return dm_fail(DM_E_HIP, "prof_begin: hipEventCreate failed");
   }
   g_prof.flops.assign(max_launches, 0.0);
+  g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
   g_prof.cap = max_launches;
   g_prof.n = 0;
   g_prof.on = true;
   return DM_OK;
 }
-// out[kind*3 + {0,1,2}] = {launches, flops, milliseconds} for kind = (tile128 ? 4 : 0) + a_layout*2 + b_layout; returns
-// the number of recorded launches (negative on error).  Synchronises on the recorded events.
+// out[kind*4 + {0,1,2,3}] = {launches, flops, milliseconds, algorithmic bytes (4*(M*K + N*K + M*N))} for
+// kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64); returns the number of recorded launches
+// (negative on error).  Synchronises on the recorded events.
 extern "C" int dm_prof_end(double* out, int nkinds) {
   DM_REQUIRE(out && nkinds >= 12, DM_E_SHAPE, "prof_end: need room for 12 kinds");
   g_prof.on = false;
-  for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
+  for (int i = 0; i < nkinds * 4; ++i) out[i] = 0.0;
   for (size_t i = 0; i < g_prof.n; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return dm_fail(DM_E_HIP, "prof_end: event sync failed");
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
       return dm_fail(DM_E_HIP, "prof_end: hipEventElapsedTime failed");
     const int k = g_prof.kind[i];
-    out[k * 3 + 0] += 1.0;
-    out[k * 3 + 1] += g_prof.flops[i];
-    out[k * 3 + 2] += ms;
+    out[k * 4 + 0] += 1.0;
+    out[k * 4 + 1] += g_prof.flops[i];
+    out[k * 4 + 2] += ms;
+    out[k * 4 + 3] += g_prof.bytes[i];
   }
   return (int)g_prof.n;
 }
@@ -481,7 +485,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
   DM_REQUIRE(!(q.a_maj && q.b_maj), DM_E_SHAPE, "gemm: only one gathered operand per call");
   const int kind = tc * 4 + q.a_layout * 2 + q.b_layout;
-  const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K, stream);
+  const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K,
+                               4.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N), stream);
   int rc;
   const bool vec = a.a_vec && a.b_vec;
   if (vec) {

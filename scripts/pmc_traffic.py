@@ -1,0 +1,39 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
+
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/rNN_pmc_traffic.json
+
+Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KB; on gfx950 FETCH_SIZE
+reports half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled for the GEMM kernels (whose operand
+loads are all 16-byte); WRITE_SIZE is taken as is (uncalibrated).  Values are means per launch."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        name = re.sub(r'\(.*$', '', r['Kernel_Name']).replace('void ', '')
+        a = acc[name]
+        a[0] += float(r['Counter_Value'])
+        a[1] += 1
+    return acc
+
+
+fetch = load(sys.argv[1], 'FETCH_SIZE')
+write = load(sys.argv[2], 'WRITE_SIZE')
+out = {}
+for name in sorted(set(fetch) | set(write)):
+    f, nf = fetch.get(name, [0.0, 0])
+    w, nw = write.get(name, [0.0, 0])
+    fb = 1024.0 * f / max(nf, 1)
+    wb = 1024.0 * w / max(nw, 1)
+    out[name] = dict(launches=max(nf, nw), fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch=2.0 * fb,
+                     write_bytes_per_launch=wb, hbm_bytes_per_launch=2.0 * fb + wb)
+json.dump(dict(note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 2 '
+                    '--warmup 1 --no-overlap; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes', kernels=out),
+          sys.stdout, indent=1)
