@@ -146,6 +146,10 @@ int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim,
 int dm_head_loss(int kind, int rows, const float* out, const float* target, float scale, float loss_const,
                  float* loss, float* dout, float* mean_out, void* stream);
 
+/* uint8 ingest (preprocessing.py:21-29 to_image): src (n, h*w, c) uint8 HWC -> dst (n, c, h*w) float32,
+ * x/255 - 0.5.  Lets the trainer hand the replay's native uint8 frames to training_step(). */
+int dm_preprocess_image_u8(int64_t n, int hw, int c, const uint8_t* src, float* dst, void* stream);
+
 /* ConvEncoder (encoders.py:72-96): 4 x (Conv2d k4 s2 + ELU), Flatten.  w[i]: (Cout,Cin,4,4) torch layout. */
 typedef struct dm_conv_params { const float* w[5]; const float* b[5]; } dm_conv_params;
 typedef struct dm_conv_grads { float* w[5]; float* b[5]; } dm_conv_grads;

@@ -232,6 +232,30 @@ __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const flo
   if (threadIdx.x == 0 && loss) loss[i] = 0.5f * (red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---------------------------------------------------------------- uint8 ingest ---
+// preprocessing.py:21-29 `to_image`: uint8 (n, h*w, c) HWC frames -> float32 (n, c, h*w) CHW in [-0.5, 0.5], x/255 - 0.5 in
+// fp32 (correctly rounded division, same values as numpy's).  One pass: 1 byte read + 4 bytes written per element, so
+// a replay batch crosses PCIe and HBM as 31 MB instead of 123 MB and the host-side astype/transposes disappear.
+__global__ void __launch_bounds__(256) preprocess_u8_kernel(size_t n, int hw, int c, const uint8_t* __restrict__ src,
+                                                            float* __restrict__ dst) {
+  const size_t total = n * hw * c;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t i = e / ((size_t)hw * c);
+    const int rem = (int)(e % ((size_t)hw * c));
+    const int cc = rem / hw, pix = rem % hw;          // e indexes the CHW (output) side: coalesced writes
+    dst[e] = (float)src[i * hw * c + (size_t)pix * c + cc] / 255.0f - 0.5f;
+  }
+}
+extern "C" int dm_preprocess_image_u8(int64_t n, int hw, int c, const uint8_t* src, float* dst, void* stream) {
+  DM_REQUIRE(src && dst, DM_E_NULL, "preprocess_image_u8: null pointer");
+  DM_REQUIRE(n >= 0 && hw >= 1 && c >= 1, DM_E_SHAPE, "preprocess_image_u8: bad shape n=%lld hw=%d c=%d", (long long)n, hw, c);
+  if (n == 0) return DM_OK;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((size_t)n * hw * c)), dim3(256), 0, (hipStream_t)stream, (size_t)n,
+                     hw, c, src, dst);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // ---------------------------------------------------------------- geometry ----------------------
 struct EncGeom {
   int N, ch, d;

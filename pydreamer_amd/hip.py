@@ -91,6 +91,7 @@ _SIGNATURES = {
     'dm_mlp_head_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P,
                                 POINTER(dm_mlp_grads), _P, c_int, c_int, _P, c_size_t, _P]),
     'dm_head_loss': (c_int, [c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    'dm_preprocess_image_u8': (c_int, [c_int64, c_int, c_int, _P, _P, _P]),
     'dm_conv_encoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
     'dm_conv_encoder_fwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, _P, c_size_t, _P]),
     'dm_conv_encoder_fwd_rows': (c_int, [POINTER(dm_shape), c_int, c_int, c_int, _P, POINTER(dm_conv_params), _P, _P, _P,

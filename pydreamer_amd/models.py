@@ -549,6 +549,14 @@ class WorldModel(_Params):
         D_, Z, F_, E = c.deter_dim, c.stoch_dim * c.stoch_discrete, self.features_dim, self.encoder.out_dim
         shp = self.shape(T, B, imag_horizon)
         ws = self.workspace(shp, dev)
+        if image.dtype == torch.uint8:
+            # the replay's native frames (T,B,H,W,C) uint8: x/255-0.5 and HWC->CHW in one kernel (preprocessing.py:21-29)
+            if image.dim() != 5 or image.shape[-1] != c.image_channels:
+                raise ValueError(f'uint8 image must be (T,B,H,W,C) with C={c.image_channels}, got {tuple(image.shape)}')
+            src = image.contiguous()
+            image = torch.empty(T, B, c.image_channels, src.shape[2], src.shape[3], device=dev)
+            H.call('dm_preprocess_image_u8', T * B, src.shape[2] * src.shape[3], c.image_channels, H.ptr(src), H.fptr(image),
+                   H.stream())
         image = image.float().contiguous()
         action = action.float().contiguous()
         reset = obs['reset'].to(torch.uint8).contiguous()
@@ -656,7 +664,7 @@ class WorldModel(_Params):
                   dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws)
         tb = lambda x: x.view(T, B)
         pk['tensors'] = dict(loss_kl=tb(kl), entropy_prior=tb(ent_prior), entropy_post=tb(ent_post),
-                             loss_image=tb(loss_image), image_rec=image_rec.view(obs['image'].shape),
+                             loss_image=tb(loss_image), image_rec=image_rec.view(T, B, *image.shape[-3:]),
                              loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
                              loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
         pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],

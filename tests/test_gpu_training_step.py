@@ -503,3 +503,22 @@ def test_forward_time_chunk_pipeline_is_exact(hip):
         assert abs(x - y) <= 1e-5 * max(1.0, abs(x))
     _close(b['rec'], a['rec'], 1e-5, 1e-6, 'image_rec')
     assert _rel_l2(b['g'], a['g']) < 1e-5
+
+
+def test_uint8_ingest_matches_float_path(hip):
+    """training_step accepts the replay's native uint8 (T,B,H,W,C) frames; dm_preprocess_image_u8 equals
+    preprocessing.py:21-29 (x/255 - 0.5, HWC -> CHW) bit for bit, so the whole step is identical to the float path."""
+    oconf = O.tiny_conf()
+    raw = O.synthetic_batch(oconf, seed=21, first=True)
+    obs_f = _to_dev(O.preprocess(raw, oconf))
+    obs_u = dict(obs_f, image=torch.from_numpy(raw['image_u8']).to(DEV))
+    noise = _to_dev(O.make_noise(oconf, seed=22))
+    outs = []
+    for obs in (obs_f, obs_u):
+        model = _build(oconf, O.make_params(oconf, seed=2))
+        model.overlap_backward = False
+        losses, st, metrics, tensors, _ = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise)
+        outs.append(([float(x) for x in losses], tensors['image_rec'].cpu(), model.wm._last_pack['image'].cpu()))
+    assert torch.equal(outs[0][2].reshape(-1), outs[1][2].reshape(-1)), 'uint8 ingest differs from x/255-0.5'
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
