@@ -202,6 +202,13 @@ def make_noise(conf, seed=777):
     # which returns inf (and a NaN loss_actor) once a sampled action saturates in fp32 — a property of the reference
     # that parity data must avoid, not reproduce
     out['eps_act'] = torch.tensor(0.25 * rs.randn(H, M, conf.action_dim), dtype=torch.float32)
+    # logging variants (drawn AFTER everything above, so the streams of the plain step are unchanged):
+    #   do_image_pred: one prior sample per (t,b) (dreamer.py:383); do_dream_tensors: a (T-1)-step dream from the B first states
+    Bi = B * conf.iwae_samples
+    out['u_pred'] = torch.tensor(rs.rand(T, Bi, S), dtype=torch.float32)
+    out['u_act_log'] = torch.tensor(rs.rand(T - 1, Bi), dtype=torch.float32)
+    out['u_prior_log'] = torch.tensor(rs.rand(T - 1, Bi, S), dtype=torch.float32)
+    out['eps_act_log'] = torch.tensor(0.25 * rs.randn(T - 1, Bi, conf.action_dim), dtype=torch.float32)
     return out
 
 
@@ -323,7 +330,12 @@ def cell_forward_prior(p, conf, action, h, z, u):
 # ---------------------------------------------------------------------------------------------------------------
 # world model (dreamer.py:297-396)
 # ---------------------------------------------------------------------------------------------------------------
-def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None):
+def nanmean(x):
+    """functions.py:149-150."""
+    return torch.nansum(x) / (~torch.isnan(x)).sum()
+
+
+def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=None):
     assert conf.iwae_samples == 1, 'oracle restates the I=1 path'
     T, B = obs['action'].shape[:2]
     embed = conv_encoder(p, obs['image'])                                     # dreamer.py:307
@@ -379,6 +391,29 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None):
                        loss_image=tensors['loss_image'].mean(), loss_reward=tensors['loss_reward'].mean(),
                        loss_terminal=tensors['loss_terminal'].mean())
     extras = dict(post_idx=torch.stack(idxs), post=posts.detach(), prior=priors.detach(), embed=embed.detach())
+    if u_pred is not None:                                                    # do_image_pred, dreamer.py:381-394
+        with torch.no_grad():
+            z_prior, pred_idx = st_sample(conf, priors.detach(), u_pred)      # zdistr(prior).sample()
+            fp = torch.cat((hs, z_prior), -1).reshape(T, B, I, -1).detach()   # feature_replace_z
+            dec_p = conv_decoder(p, fp)
+            li = 0.5 * torch.square(dec_p - target).sum(dim=[-1, -2, -3]).squeeze(2)
+            mu_p = mlp(p, 'wm.decoder.reward.model.model', fp, conf.reward_decoder_layers)
+            lr = (-D.Normal(mu_p, torch.ones_like(mu_p) * std).log_prob(obs['reward'].unsqueeze(2)) * std ** 2).squeeze(2)
+            td = D.Bernoulli(logits=mlp(p, 'wm.decoder.terminal.model.model', fp, conf.terminal_decoder_layers).float())
+            lt = (-td.log_prob(obs['terminal'].unsqueeze(2))).squeeze(2)
+            tensors.update(logprob_image=li, logprob_reward=lr, logprob_terminal=lt, image_pred=dec_p.mean(2),
+                           reward_pred=mu_p.mean(2), terminal_pred=td.mean.mean(2))
+            metrics.update(logprob_image=li.mean(), logprob_reward=lr.mean(), logprob_terminal=lt.mean())
+            for sig in (-1, 1):                                               # decoders.py:94-100 (extra_metrics)
+                m = torch.sign(obs['reward']) == sig
+                lp = lr * m / m
+                metrics[f'logprob_reward{sig}'] = nanmean(lp)
+                tensors[f'logprob_reward{sig}'] = lp
+            m = obs['terminal'] > 0                                           # decoders.py:102-105
+            lp = lt * m / m
+            metrics['logprob_terminal1'] = nanmean(lp)
+            tensors['logprob_terminal1'] = lp
+            extras['pred_idx'] = pred_idx
     return loss, feat_tbi, (hs.reshape(T, B, I, -1), zs.reshape(T, B, I, -1)), out_state, metrics, tensors, extras
 
 
@@ -496,11 +531,11 @@ class OracleDreamer:
         c = self.conf
         return (torch.zeros(batch, c.deter_dim), torch.zeros(batch, c.stoch_dim * c.stoch_discrete))
 
-    def training_step(self, obs, in_state, noise, forced_idx=None):
+    def training_step(self, obs, in_state, noise, forced_idx=None, do_image_pred=False, do_dream_tensors=False):
         c, p = self.conf, self.p
         T, B = obs['action'].shape[:2]
         loss_model, features, states, out_state, metrics, tensors, extras = \
-            wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx)
+            wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx, noise['u_pred'] if do_image_pred else None)
         loss_probe = torch.square(p['probe_model.dummy'])                          # probes.py:146-150
         in_dream = tuple(x.detach().reshape(-1, x.shape[-1]) for x in states)      # dreamer.py:149
         if self.train_steps % c.target_interval == 0:                              # a2c.py:76-79
@@ -517,6 +552,16 @@ class OracleDreamer:
         tensors.update(policy_value=t_ac['value'][0].reshape(T, B, 1).mean(-1))    # dreamer.py:159
         extras.update(dx)
         extras.update(dream_features=feats, ac_tensors=t_ac)
+        if do_dream_tensors:                                                       # dreamer.py:163-180
+            with torch.no_grad():
+                first = tuple(x.detach()[0, :, 0] for x in states)                 # (T,B,I) => (B)
+                f2, a2, r2, t2, dx2 = dream(p, c, first, T - 1, noise['u_act_log'], noise['u_prior_log'],
+                                            noise.get('eps_act_log'))
+                image_dream = conv_decoder(p, f2)
+                _, _, t_ac2 = ac_training_step(p, c, f2, a2, r2, t2)               # log_only=True: same tensors
+                extras['dream_tensors'] = dict(action_pred=torch.cat([obs['action'][:1], a2]), reward_pred=r2,
+                                               terminal_pred=t2, image_pred=image_dream, **t_ac2)
+                extras['dream_log_idx'] = dx2
         return (loss_model, loss_probe, loss_actor, loss_critic), out_state, metrics, tensors, extras
 
     def backward_clip_step(self, losses):

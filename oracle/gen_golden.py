@@ -177,6 +177,70 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def run_eval(name, sections, overrides):
+    """Logging variants of training_step (train.py:353-359,380-385 call it with do_image_pred / do_dream_tensors):
+    one forward with both flags; inputs, extra uniforms and every extra output are stored."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REF)
+    from pydreamer.models import Dreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    rconf = reference_conf(sections, overrides)
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    model = Dreamer(rconf)
+    model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    T, B, S, H = rconf.batch_length, rconf.batch_size, rconf.stoch_dim, rconf.imag_horizon
+    raw = O.synthetic_batch(oconf, seed=4321, first=True)
+    obs = O.preprocess(raw, oconf)
+    noise = O.make_noise(oconf, seed=999)
+    onehot = rconf.actor_dist == 'onehot'
+    with MultinomialPatch() as mp:
+        mp.queue = [noise['u_post'][t] for t in range(T)] + [noise['u_pred'].reshape(-1, S)]
+        for i in range(H):
+            mp.queue += ([noise['u_act'][i]] if onehot else []) + [noise['u_prior'][i]]
+            if not onehot:
+                mp.eps_queue.append(noise['eps_act'][i])
+        for i in range(T - 1):
+            mp.queue += ([noise['u_act_log'][i]] if onehot else []) + [noise['u_prior_log'][i]]
+            if not onehot:
+                mp.eps_queue.append(noise['eps_act_log'][i])
+        with torch.no_grad():
+            losses, new_state, metrics, tensors, dream_tensors = model.training_step(
+                obs, model.init_state(B), do_image_pred=True, do_dream_tensors=True)
+        assert not mp.queue and not mp.eps_queue
+        pred_idx = mp.idx[T].reshape(T, B, S)
+        tail = mp.idx[T + 1 + (2 if onehot else 1) * H:]
+        log_act = torch.stack(tail[0::2]) if onehot else torch.zeros(T - 1, B, dtype=torch.long)
+        log_lat = torch.stack(tail[1::2] if onehot else tail).reshape(T - 1, B, S)
+    out = {'conf_json': np.array(repr(sorted(vars(oconf).items())))}
+    for k, v in raw.items():
+        out['in_' + k] = v
+    for k, v in noise.items():
+        out['in_' + k] = v.numpy()
+    out['losses'] = np.array([float(l) for l in losses], dtype=np.float64)
+    for k, v in metrics.items():
+        out['metric_' + k] = np.array(float(v), dtype=np.float64)
+    for k, v in tensors.items():
+        if k in ('image_rec', 'image_pred'):
+            out['tensor_' + k + '_sum'] = np.array(float(v.double().sum()))
+            out['tensor_' + k + '_frame'] = v[:1, :1].numpy()
+        else:
+            out['tensor_' + k] = v.detach().numpy()
+    for k, v in dream_tensors.items():
+        if k == 'image_pred':
+            out['dream_image_pred_sum'] = np.array(float(v.double().sum()))
+            out['dream_image_pred_frame'] = v[-1:, :1].numpy()
+        else:
+            out['dream_' + k] = v.detach().numpy()
+    out['idx_pred'] = pred_idx.numpy().astype(np.uint8)
+    out['idx_log_act'] = log_act.numpy().astype(np.uint8)
+    out['idx_log_lat'] = log_lat.numpy().astype(np.uint8)
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB', {k: float(v) for k, v in metrics.items() if 'logprob' in k})
+
+
 SMALL_GRADS = ('wm.core.cell.a_mlp.weight', 'wm.core.cell.gru.layers.0.bias_hh', 'wm.core.cell.post_norm.weight',
                'wm.core.cell.prior_mlp.bias', 'wm.encoder.encoder_image.model.0.weight',
                'wm.decoder.image.model.8.weight', 'ac.actor.model.12.weight', 'ac.critic.model.1.weight')
@@ -198,6 +262,12 @@ if __name__ == '__main__':
                  cnn_depth=t.cnn_depth, action_dim=4, batch_length=t.batch_length, batch_size=t.batch_size,
                  imag_horizon=t.imag_horizon, actor_grad='reinforce'), steps=1,
             full_grads=('ac.actor.model.12.weight', 'ac.actor.model.12.bias'))
+    if 'eval' in which:
+        t = O.tiny_conf()
+        run_eval('tiny_eval', ['defaults', 'atari'],
+                 dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                      cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                      imag_horizon=t.imag_horizon))
     if 'atari' in which:
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],

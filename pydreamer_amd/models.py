@@ -724,11 +724,57 @@ class WorldModel(_Params):
                H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
         return views, flat, direct
 
+    def _image_pred(self, pk, obs, u_pred):
+        """do_image_pred (dreamer.py:381-394): decode from a PRIOR sample instead of the posterior sample and report the
+        reconstruction losses as logprob_* / *_pred (decoders.py:50-108 with extra_metrics).  Logging variant, no grads.
+        The NaN-masked sign / terminal splits (decoders.py:94-105) are (T,B) torch expressions."""
+        c, dec = self.conf, self.decoder
+        T, B, feat, shp = pk['T'], pk['B'], pk['feat'], pk['shp']
+        N, dev = T * B, feat.device
+        D_, S, C, F_ = c.deter_dim, c.stoch_dim, c.stoch_discrete, self.features_dim
+        ws = self.workspace(shp, dev)
+        lib = H.lib()
+        with torch.no_grad():
+            if u_pred is None:
+                u_pred = torch.rand(N, S, device=dev)
+            u_pred = u_pred.reshape(N, S).contiguous()
+            fp = feat.clone()                                                 # feature_replace_z: [h | prior sample]
+            idx = torch.empty(N, S, dtype=torch.int32, device=dev)
+            H.call('dm_sample_onehot', N, S, C, H.fptr(pk['prior']), S * C, H.fptr(u_pred), None,
+                   ctypes.c_void_p(fp.data_ptr() + 4 * D_), F_, H.ptr(idx), H.stream())
+            dl = dec.image.layers()
+            dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+            acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
+            li = torch.empty(N, device=dev)
+            image_pred = torch.empty_like(pk['image'])
+            H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(fp), F_, H.fptr(pk['image']), ctypes.byref(dec_p),
+                   H.fptr(acts), H.fptr(li), H.fptr(image_pred), H.ptr(ws), ws.numel(), H.stream())
+            mu, _ = dec.reward.model.fwd(fp, F_, N, ws)
+            tl, _ = dec.terminal.model.fwd(fp, F_, N, ws)
+            lr, lt, rp, tp, scratch = (torch.empty(N, device=dev) for _ in range(5))
+            loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
+            H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(obs['reward'].float().contiguous()), 0.0, loss_const, H.fptr(lr),
+                   H.fptr(scratch), H.fptr(rp), H.stream())
+            H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(obs['terminal'].float().contiguous()), 0.0, 0.0, H.fptr(lt),
+                   H.fptr(scratch), H.fptr(tp), H.stream())
+            tb = lambda x: x.view(T, B)
+            tensors = dict(logprob_image=tb(li), logprob_reward=tb(lr), logprob_terminal=tb(lt),
+                           image_pred=image_pred.view(T, B, *image_pred.shape[-3:]), reward_pred=tb(rp), terminal_pred=tb(tp))
+            metrics = dict(logprob_image=li.mean(), logprob_reward=lr.mean(), logprob_terminal=lt.mean())
+            nan = torch.full((), float('nan'), device=dev)
+            nanmean = lambda x: torch.nansum(x) / (~torch.isnan(x)).sum()     # functions.py:149-150
+            for sig in (-1, 1):
+                lp = torch.where(torch.sign(obs['reward'].float()) == sig, tb(lr), nan)
+                metrics[f'logprob_reward{sig}'], tensors[f'logprob_reward{sig}'] = nanmean(lp), lp
+            lp = torch.where(obs['terminal'].float() > 0, tb(lt), nan)
+            metrics['logprob_terminal1'], tensors['logprob_terminal1'] = nanmean(lp), lp
+        return metrics, tensors, idx
+
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
-                      u_post=None, forced_idx=None, imag_horizon=1):
+                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
-        if iwae_samples != 1 or do_open_loop or do_image_pred:
-            raise NotImplementedError('iwae_samples>1 / do_open_loop / do_image_pred are evaluation variants not built yet')
+        if iwae_samples != 1 or do_open_loop:
+            raise NotImplementedError('iwae_samples>1 / do_open_loop are evaluation variants not built yet')
         T, B = obs['action'].shape[:2]
         if forward_only:
             feats, out_state = self.forward(obs, in_state)
@@ -740,6 +786,10 @@ class WorldModel(_Params):
         features = feat.view(T, B, 1, -1)
         states = (feat[:, :D_].view(T, B, 1, -1), feat[:, D_:].view(T, B, 1, -1))
         self._last_pack = pk
+        if do_image_pred:
+            m, t, pk['pred_idx'] = self._image_pred(pk, obs, u_pred)
+            pk['metrics'] = dict(pk['metrics'], **m)
+            pk['tensors'] = dict(pk['tensors'], **t)
         return loss, features, states, pk['out_state'], pk['metrics'], pk['tensors']
 
 
@@ -979,8 +1029,6 @@ class Dreamer(nn.Module):
             assert k in obs, f'`{k}` required in observation'
         iwae_samples = int(iwae_samples or self.iwae_samples)
         imag_horizon = int(imag_horizon or self.imag_horizon)
-        if do_dream_tensors:
-            raise NotImplementedError('do_dream_tensors is a logging variant not built yet')
         T, B = obs['action'].shape[:2]
         noise = noise or {}
         u_post = noise.get('u_post')
@@ -990,7 +1038,7 @@ class Dreamer(nn.Module):
         loss_model, features, states, out_state, metrics, tensors = \
             self.wm.training_step(obs, in_state, iwae_samples=iwae_samples, do_open_loop=do_open_loop,
                                   do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
-                                  imag_horizon=imag_horizon)
+                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'))
         pk = self.wm._last_pack
         ov = None
         if self.overlap_backward and torch.is_grad_enabled():
@@ -1032,9 +1080,32 @@ class Dreamer(nn.Module):
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,
                                 dream_features=features_dream,
-                                ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'])
+                                ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'], pred_idx=pk.get('pred_idx'))
+        # Dream for a log sample (dreamer.py:163-180): T-1 imagined steps from the B first states, decoded to images
+        dream_tensors = {}
+        if do_dream_tensors:
+            with torch.no_grad():
+                kind, dpk2 = self.ac.dist_kind, {}
+                f2, a2, r2, t2 = self._dream_from_features(
+                    pk['feat'][:B].contiguous(), T - 1,
+                    noise.get('u_act_log') if kind == 0 else noise.get('eps_act_log'), noise.get('u_prior_log'), _pack=dpk2)
+                dl = self.wm.decoder.image.layers()
+                dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+                shp, dev = pk['shp'], pk['feat'].device
+                acts = torch.empty(int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
+                image_dream = torch.empty_like(pk['image'])
+                ws = self.wm.workspace(shp, dev)
+                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(f2), self.wm.features_dim, H.fptr(pk['image']),
+                       ctypes.byref(dec_p), H.fptr(acts), None, H.fptr(image_dream), H.ptr(ws), ws.numel(), H.stream())
+                _, _, t_ac2 = self.ac.training_step(f2, a2, r2.mean, t2.mean, log_only=True, act_idx=dpk2['act_idx'],
+                                                    ws=dpk2['ws'], actor_acts=dpk2['actor_acts'],
+                                                    actor_logits=dpk2['actor_logits'])
+                dream_tensors = dict(action_pred=torch.cat([obs['action'][:1].float(), a2]), reward_pred=r2.mean,
+                                     terminal_pred=t2.mean, image_pred=image_dream.view(T, B, *image_dream.shape[-3:]),
+                                     **t_ac2)
+                self.last_extras.update(dream_log_act_idx=dpk2['act_idx'])
         losses = (loss_model, loss_probe, loss_actor, loss_critic)
-        return losses, out_state, metrics, tensors, {}
+        return losses, out_state, metrics, tensors, dream_tensors
 
     def __str__(self):
         count = lambda m: sum(p.numel() for p in m.parameters())

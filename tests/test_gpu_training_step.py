@@ -522,3 +522,36 @@ def test_uint8_ingest_matches_float_path(hip):
     assert torch.equal(outs[0][2].reshape(-1), outs[1][2].reshape(-1)), 'uint8 ingest differs from x/255-0.5'
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_logging_variants_match_reference_golden(hip):
+    """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394) through the HIP path against
+    tests/golden/tiny_eval.npz written by the real reference (called under no_grad like train.py:353-359)."""
+    g = np.load(os.path.join(GOLD, 'tiny_eval.npz'))
+    oconf = O.make_conf(**dict(eval(str(g['conf_json']))))
+    raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+    noise = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
+    model = _build(oconf, O.make_params(oconf, seed=0))
+    with torch.no_grad():
+        losses, st, metrics, tensors, dt = model.training_step(_to_dev(O.preprocess(raw, oconf)),
+                                                               model.init_state(oconf.batch_size), noise=noise,
+                                                               do_image_pred=True, do_dream_tensors=True)
+    T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
+    assert np.array_equal(model.last_extras['pred_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_pred'])
+    assert np.array_equal(model.last_extras['dream_log_act_idx'].cpu().numpy().astype(np.uint8), g['idx_log_act'])
+    for i, l in enumerate(losses):
+        assert _rel(l, g['losses'][i]) < 2e-5 or abs(float(l) - g['losses'][i]) < 2e-6
+    for k in [f[7:] for f in g.files if f.startswith('metric_')]:
+        ref = float(g['metric_' + k])
+        if np.isnan(ref):
+            assert torch.isnan(metrics[k]), k
+        else:
+            assert _rel(metrics[k], ref) < 1e-4 or abs(float(metrics[k]) - ref) < 5e-6, (k, float(metrics[k]), ref)
+    for k in [f[7:] for f in g.files if f.startswith('tensor_') and not f.endswith(('_sum', '_frame'))]:
+        np.testing.assert_allclose(tensors[k].cpu().numpy(), g['tensor_' + k], rtol=1e-4, atol=2e-5, equal_nan=True, err_msg=k)
+    assert _rel(tensors['image_pred'].double().sum(), g['tensor_image_pred_sum']) < 1e-5
+    np.testing.assert_allclose(tensors['image_pred'][:1, :1].cpu().numpy(), g['tensor_image_pred_frame'], rtol=0, atol=3e-5)
+    for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
+        np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
+    assert _rel(dt['image_pred'].double().sum(), g['dream_image_pred_sum']) < 1e-5
+    np.testing.assert_allclose(dt['image_pred'][-1:, :1].cpu().numpy(), g['dream_image_pred_frame'], rtol=0, atol=3e-5)

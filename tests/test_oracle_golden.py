@@ -161,3 +161,34 @@ def test_oracle_matches_reference_at_atari_literal():
         ref = float(g['s0_metric_' + k])
         tol = 2e-6 if k in wm_keys else 1e-2
         assert _rel(v, ref) < tol or abs(float(v) - ref) < 1e-3 * (k not in wm_keys) + 1e-7, (k, float(v), ref)
+
+
+def test_oracle_logging_variants_match_reference():
+    """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394; called by train.py:353-359,380-385) against
+    tests/golden/tiny_eval.npz written by the real reference."""
+    g = _load('tiny_eval')
+    conf = _conf_from(g)
+    raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+    noise = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
+    model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
+    with torch.no_grad():
+        losses, st, metrics, tensors, ex = model.training_step(O.preprocess(raw, conf), model.init_state(conf.batch_size),
+                                                               noise, do_image_pred=True, do_dream_tensors=True)
+    assert np.array_equal(ex['pred_idx'].numpy().astype(np.uint8).reshape(g['idx_pred'].shape), g['idx_pred'])
+    assert np.array_equal(ex['dream_log_idx']['act_idx'].numpy().astype(np.uint8), g['idx_log_act'])
+    assert np.array_equal(ex['dream_log_idx']['lat_idx'].numpy().astype(np.uint8), g['idx_log_lat'])
+    for k in [f[7:] for f in g.files if f.startswith('metric_')]:
+        ref = float(g['metric_' + k])
+        if np.isnan(ref):
+            assert torch.isnan(metrics[k]), k
+        else:
+            assert _rel(metrics[k], ref) < 5e-5 or abs(float(metrics[k]) - ref) < 2e-6, (k, float(metrics[k]), ref)
+    for k in [f[7:] for f in g.files if f.startswith('tensor_') and not f.endswith(('_sum', '_frame'))]:
+        np.testing.assert_allclose(tensors[k].numpy(), g['tensor_' + k], rtol=2e-5, atol=2e-5, equal_nan=True, err_msg=k)
+    assert _rel(tensors['image_pred'].double().sum(), g['tensor_image_pred_sum']) < 1e-5
+    np.testing.assert_allclose(tensors['image_pred'][:1, :1].numpy(), g['tensor_image_pred_frame'], rtol=0, atol=2e-5)
+    dt = ex['dream_tensors']
+    for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
+        np.testing.assert_allclose(dt[k].numpy(), g['dream_' + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    assert _rel(dt['image_pred'].double().sum(), g['dream_image_pred_sum']) < 1e-5
+    np.testing.assert_allclose(dt['image_pred'][-1:, :1].numpy(), g['dream_image_pred_frame'], rtol=0, atol=2e-5)
