@@ -319,8 +319,11 @@ def cell_forward(p, conf, embed, action, reset_mask, h, z, u, forced_idx=None):
     return post, h, sample, idx
 
 
-def cell_forward_prior(p, conf, action, h, z, u):
-    """RSSMCell.forward_prior with reset_mask=None, rssm.py:155-184."""
+def cell_forward_prior(p, conf, action, h, z, u, reset_mask=None):
+    """RSSMCell.forward_prior, rssm.py:155-184 (reset_mask=None in the dream; given in the open-loop sequence)."""
+    if reset_mask is not None:
+        h = h * reset_mask
+        z = z * reset_mask
     h = cell_trunk(p, action, h, z)
     prior = prior_head(p, h)
     sample, idx = st_sample(conf, prior, u)
@@ -335,7 +338,7 @@ def nanmean(x):
     return torch.nansum(x) / (~torch.isnan(x)).sum()
 
 
-def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=None):
+def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=None, do_open_loop=False):
     assert conf.iwae_samples == 1, 'oracle restates the I=1 path'
     T, B = obs['action'].shape[:2]
     embed = conv_encoder(p, obs['image'])                                     # dreamer.py:307
@@ -343,8 +346,11 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=Non
     reset_masks = (~obs['reset']).unsqueeze(-1).to(embed.dtype)               # rssm.py:41
     posts, hs, zs, idxs = [], [], [], []
     for t in range(T):                                                        # rssm.py:49-56
-        post, h, z, idx = cell_forward(p, conf, embed[t], obs['action'][t], reset_masks[t], h, z, u_post[t],
-                                       None if forced_idx is None else forced_idx[t])
+        if do_open_loop:                                                      # rssm.py:53: post = prior, no embed
+            post, h, z, idx = cell_forward_prior(p, conf, obs['action'][t], h, z, u_post[t], reset_masks[t])
+        else:
+            post, h, z, idx = cell_forward(p, conf, embed[t], obs['action'][t], reset_masks[t], h, z, u_post[t],
+                                           None if forced_idx is None else forced_idx[t])
         posts.append(post); hs.append(h); zs.append(z); idxs.append(idx)
     posts, hs, zs = torch.stack(posts), torch.stack(hs), torch.stack(zs)
     priors = prior_head(p, hs)                                                # rssm.py:61
@@ -531,11 +537,13 @@ class OracleDreamer:
         c = self.conf
         return (torch.zeros(batch, c.deter_dim), torch.zeros(batch, c.stoch_dim * c.stoch_discrete))
 
-    def training_step(self, obs, in_state, noise, forced_idx=None, do_image_pred=False, do_dream_tensors=False):
+    def training_step(self, obs, in_state, noise, forced_idx=None, do_image_pred=False, do_dream_tensors=False,
+                      do_open_loop=False):
         c, p = self.conf, self.p
         T, B = obs['action'].shape[:2]
         loss_model, features, states, out_state, metrics, tensors, extras = \
-            wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx, noise['u_pred'] if do_image_pred else None)
+            wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx, noise['u_pred'] if do_image_pred else None,
+                             do_open_loop)
         loss_probe = torch.square(p['probe_model.dummy'])                          # probes.py:146-150
         in_dream = tuple(x.detach().reshape(-1, x.shape[-1]) for x in states)      # dreamer.py:149
         if self.train_steps % c.target_interval == 0:                              # a2c.py:76-79

@@ -177,7 +177,7 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
-def run_eval(name, sections, overrides):
+def run_eval(name, sections, overrides, do_open_loop=False):
     """Logging variants of training_step (train.py:353-359,380-385 call it with do_image_pred / do_dream_tensors):
     one forward with both flags; inputs, extra uniforms and every extra output are stored."""
     torch.manual_seed(0)
@@ -207,7 +207,7 @@ def run_eval(name, sections, overrides):
                 mp.eps_queue.append(noise['eps_act_log'][i])
         with torch.no_grad():
             losses, new_state, metrics, tensors, dream_tensors = model.training_step(
-                obs, model.init_state(B), do_image_pred=True, do_dream_tensors=True)
+                obs, model.init_state(B), do_image_pred=True, do_dream_tensors=True, do_open_loop=do_open_loop)
         assert not mp.queue and not mp.eps_queue
         pred_idx = mp.idx[T].reshape(T, B, S)
         tail = mp.idx[T + 1 + (2 if onehot else 1) * H:]
@@ -233,6 +233,8 @@ def run_eval(name, sections, overrides):
             out['dream_image_pred_frame'] = v[-1:, :1].numpy()
         else:
             out['dream_' + k] = v.detach().numpy()
+    out['idx_post'] = torch.stack(mp.idx[:T]).reshape(T, B, S).numpy().astype(np.uint8)
+    out['out_state_h'] = new_state[0].numpy()
     out['idx_pred'] = pred_idx.numpy().astype(np.uint8)
     out['idx_log_act'] = log_act.numpy().astype(np.uint8)
     out['idx_log_lat'] = log_lat.numpy().astype(np.uint8)
@@ -268,6 +270,10 @@ if __name__ == '__main__':
                  dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
                       cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                       imag_horizon=t.imag_horizon))
+        run_eval('tiny_open_loop', ['defaults', 'atari'],
+                 dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                      cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                      imag_horizon=t.imag_horizon), do_open_loop=True)
     if 'atari' in which:
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],

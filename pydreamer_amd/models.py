@@ -540,7 +540,7 @@ class WorldModel(_Params):
         return pk['feat'].view(T, B, 1, -1), pk['out_state']
 
     # ---- forward through the C-ABI
-    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1):
+    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False):
         c = self.conf
         image, action = obs['image'], obs['action']
         _require_cuda(image, "obs['image']")
@@ -571,6 +571,17 @@ class WorldModel(_Params):
         embed = torch.empty(N, E, device=dev)
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
+        if open_loop:
+            # rssm.py:50-53: every step is RSSMCell.forward_prior - the same trunk, then the PRIOR head on h' with no
+            # embedding term.  That is dm_rssm_sequence_fwd with the posterior head's parameter slots pointing at the
+            # prior head and a zero embedding (its product with post_mlp_e is then an exact zero).  Forward only.
+            po = list(cell.ordered())
+            ix = {n: i for i, n in enumerate(H.RSSM_PARAM_ORDER)}
+            for dst, src in (('post_mlp_h.weight', 'prior_mlp_h.weight'), ('post_mlp_h.bias', 'prior_mlp_h.bias'),
+                             ('post_norm.weight', 'prior_norm.weight'), ('post_norm.bias', 'prior_norm.bias'),
+                             ('post_mlp.weight', 'prior_mlp.weight'), ('post_mlp.bias', 'prior_mlp.bias')):
+                po[ix[dst]] = po[ix[src]]
+            rssm_p = H.rssm_struct(po)
         rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp))), device=dev)
         feat = torch.empty(N, F_, device=dev)
         post = torch.empty(N, Z, device=dev)
@@ -587,11 +598,12 @@ class WorldModel(_Params):
             loss_image = torch.empty(N, device=dev)
             image_rec = torch.empty_like(image)
 
-        chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only) else 1
+        chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop) else 1
         if chunks <= 1:
             H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
                    H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
-            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0),
+            embed_rssm = torch.zeros_like(embed) if open_loop else embed
+            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed_rssm), H.fptr(action), H.ptr(reset), H.fptr(h0),
                    H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
             if not forward_only:
@@ -773,13 +785,16 @@ class WorldModel(_Params):
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
                       u_post=None, forced_idx=None, imag_horizon=1, u_pred=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
-        if iwae_samples != 1 or do_open_loop:
-            raise NotImplementedError('iwae_samples>1 / do_open_loop are evaluation variants not built yet')
+        if iwae_samples != 1:
+            raise NotImplementedError('iwae_samples>1 is an evaluation variant not built yet')
+        if do_open_loop and torch.is_grad_enabled():
+            raise NotImplementedError('do_open_loop is an evaluation variant: call it under torch.no_grad() like '
+                                      'train.py:353-359 does (its backward is not built)')
         T, B = obs['action'].shape[:2]
         if forward_only:
             feats, out_state = self.forward(obs, in_state)
             return torch.tensor(0.0), feats, None, out_state, {}, {}
-        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon)
+        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop)
         loss = _WMStep.apply(self, pk, *self._param_order())
         D_ = self.deter_dim
         feat = pk['feat']

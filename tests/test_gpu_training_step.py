@@ -555,3 +555,33 @@ def test_logging_variants_match_reference_golden(hip):
         np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
     assert _rel(dt['image_pred'].double().sum(), g['dream_image_pred_sum']) < 1e-5
     np.testing.assert_allclose(dt['image_pred'][-1:, :1].cpu().numpy(), g['dream_image_pred_frame'], rtol=0, atol=3e-5)
+
+
+def test_open_loop_matches_reference_golden(hip):
+    """do_open_loop (rssm.py:50-53: every step is forward_prior) + the logging variants, against
+    tests/golden/tiny_open_loop.npz written by the real reference; evaluation only (no_grad)."""
+    g = np.load(os.path.join(GOLD, 'tiny_open_loop.npz'))
+    oconf = O.make_conf(**dict(eval(str(g['conf_json']))))
+    raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+    noise = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
+    model = _build(oconf, O.make_params(oconf, seed=0))
+    obs = _to_dev(O.preprocess(raw, oconf))
+    with pytest.raises(NotImplementedError):
+        model.training_step(obs, model.init_state(oconf.batch_size), noise=noise, do_open_loop=True)
+    with torch.no_grad():
+        losses, st, metrics, tensors, dt = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise,
+                                                               do_image_pred=True, do_dream_tensors=True, do_open_loop=True)
+    T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
+    assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_post'])
+    assert np.array_equal(model.last_extras['pred_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_pred'])
+    np.testing.assert_allclose(st[0].cpu().numpy(), g['out_state_h'], rtol=0, atol=5e-6)
+    for i, l in enumerate(losses):
+        assert _rel(l, g['losses'][i]) < 2e-5 or abs(float(l) - g['losses'][i]) < 2e-6, (i, float(l), g['losses'][i])
+    for k in [f[7:] for f in g.files if f.startswith('metric_')]:
+        ref = float(g['metric_' + k])
+        if np.isnan(ref):
+            assert torch.isnan(metrics[k]), k
+        else:
+            assert _rel(metrics[k], ref) < 1e-4 or abs(float(metrics[k]) - ref) < 5e-6, (k, float(metrics[k]), ref)
+    for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
+        np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)

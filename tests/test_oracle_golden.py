@@ -163,17 +163,21 @@ def test_oracle_matches_reference_at_atari_literal():
         assert _rel(v, ref) < tol or abs(float(v) - ref) < 1e-3 * (k not in wm_keys) + 1e-7, (k, float(v), ref)
 
 
-def test_oracle_logging_variants_match_reference():
-    """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394; called by train.py:353-359,380-385) against
-    tests/golden/tiny_eval.npz written by the real reference."""
-    g = _load('tiny_eval')
+@pytest.mark.parametrize('name,open_loop', [('tiny_eval', False), ('tiny_open_loop', True)])
+def test_oracle_logging_variants_match_reference(name, open_loop):
+    """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394; called by train.py:353-359,380-385), without and
+    with do_open_loop (rssm.py:50-53), against the fixtures written by the real reference."""
+    g = _load(name)
     conf = _conf_from(g)
     raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
     noise = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
     model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
     with torch.no_grad():
         losses, st, metrics, tensors, ex = model.training_step(O.preprocess(raw, conf), model.init_state(conf.batch_size),
-                                                               noise, do_image_pred=True, do_dream_tensors=True)
+                                                               noise, do_image_pred=True, do_dream_tensors=True,
+                                                               do_open_loop=open_loop)
+    assert np.array_equal(ex['post_idx'].numpy().astype(np.uint8).reshape(g['idx_post'].shape), g['idx_post'])
+    np.testing.assert_allclose(st[0].numpy(), g['out_state_h'], rtol=0, atol=2e-6)
     assert np.array_equal(ex['pred_idx'].numpy().astype(np.uint8).reshape(g['idx_pred'].shape), g['idx_pred'])
     assert np.array_equal(ex['dream_log_idx']['act_idx'].numpy().astype(np.uint8), g['idx_log_act'])
     assert np.array_equal(ex['dream_log_idx']['lat_idx'].numpy().astype(np.uint8), g['idx_log_lat'])
