@@ -332,7 +332,7 @@ def _flat_views(plist, device, fused=None, scratch=False):
     if fused is not None and scratch:
         views = fused.scratch_views(plist)
         if views is not None:
-            return fused.scratch, views, False
+            return fused.scratch, views, ('scratch', fused.scratch_gen)
     if fused is not None and not scratch:
         views = fused.claim_fresh_grads(plist)
         if views is not None:
@@ -369,6 +369,10 @@ def _finish_backward(owner, grads, flat, direct, grad_loss):
     gl = grad_loss.detach().float().reshape(1).contiguous()
     fused = getattr(owner, '_fused', None)
     if fused is not None and flat is fused.scratch:
+        if not isinstance(direct, tuple) or direct[1] != fused.scratch_gen:
+            raise RuntimeError('the gradients pre-computed by this training_step() were overwritten by a later training_step() '
+                               'before backward() was called; call backward() after each training_step(), or set '
+                               'model.overlap_backward = False to compute gradients inside backward()')
         if fused.fresh:                      # zero_grad() since the last write: '=' semantics, one scale+copy kernel
             torch.mul(flat, gl, out=fused.flat_grad)
             fused.fresh = False

@@ -43,6 +43,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.dp = None                                    # set by dist.attach(): (process_group, weight)
         self.fresh = False                                # flat_grad is all zero and nobody has written to it yet
         self.scratch = None                               # same layout as flat_grad, for pre-launched backward passes
+        self.scratch_gen = 0                              # bumped every time the scratch buffer is handed out
         self._ids = {id(p) for p in params}
         with torch.no_grad():
             for p, off in zip(params, self._offsets):
@@ -85,6 +86,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.scratch is None:
             self.scratch = torch.zeros_like(self.flat_grad)
             self._off_of = {id(p): off for p, off in zip(self._plist, self._offsets)}
+        self.scratch_gen += 1
         return [self.scratch[self._off_of[id(p)]:self._off_of[id(p)] + p.numel()].view(p.shape) for p in plist]
 
     def claim_fresh_grads(self, plist):

@@ -585,3 +585,21 @@ def test_open_loop_matches_reference_golden(hip):
             assert _rel(metrics[k], ref) < 1e-4 or abs(float(metrics[k]) - ref) < 5e-6, (k, float(metrics[k]), ref)
     for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
         np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_stale_prelaunched_gradients_are_refused(hip):
+    """Pre-launched backward passes write into a per-optimizer scratch buffer; a backward() on losses of an OLDER
+    training_step() (its scratch was overwritten) must fail loudly instead of delivering the wrong gradients."""
+    oconf = O.tiny_conf()
+    model = _build(oconf, O.make_params(oconf, seed=1))
+    opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+    obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=3, first=True), oconf))
+    st = model.init_state(oconf.batch_size)
+    losses1, *_ = model.training_step(obs, st)
+    losses2, *_ = model.training_step(obs, st)
+    for opt in opts:
+        opt.zero_grad()
+    with pytest.raises(RuntimeError, match='overwritten'):
+        losses1[0].backward()
+    for loss in losses2:
+        loss.backward()
