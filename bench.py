@@ -221,12 +221,12 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
-        out = (ctypes.c_double * 48)()
-        n = hip.lib().dm_prof_end(out, 12)
+        out = (ctypes.c_double * 80)()
+        n = hip.lib().dm_prof_end(out, 20)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
-        tiles = ('128,128', '128,64', '64,64')
-        for k in range(12):
+        tiles = ('128,128', '128,64', '64,64', '128,96', '96,128')
+        for k in range(20):
             cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
                 kinds.append(dict(kernel=f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>",
@@ -234,8 +234,8 @@ def main():
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
                                   ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12,
                                   alg_bytes_per_launch=by / cnt, alg_flops_per_launch=fl / cnt))
-        tot_fl = sum(out[4 * k + 1] for k in range(12))
-        tot_ms = sum(out[4 * k + 2] for k in range(12))
+        tot_fl = sum(out[4 * k + 1] for k in range(20))
+        tot_ms = sum(out[4 * k + 2] for k in range(20))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE

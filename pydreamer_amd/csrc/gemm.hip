@@ -168,14 +168,17 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 // profiles/r01_gemm_persist_ab.txt.)
 // GA / GB: operand A / B is a separable gather (compile-time, so the plain instances keep their register budget).
 // VEC: both operands take the 16-byte load path (host-checked alignment and extents).
-template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false>
+// WGM x WGN: the 4 waves' grid over the block tile (2x2; 4x1 for the 128x96 tile, 1x4 for 96x128 - the conv stack is
+// full of 96-wide operands (cnn_depth 48), which 64/128-wide tiles pad by 25-33 %).
+template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false, int WGM = 2, int WGN = 2>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
+  static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
   constexpr int BK = 32;
   constexpr int LDK = 36;
   constexpr int LDMA = BM + 4, LDMB = BN + 4;
   constexpr int A_FLOATS = (AL == 0) ? BM * LDK : BK * LDMA;
   constexpr int B_FLOATS = (BL == 0) ? BN * LDK : BK * LDMB;
-  constexpr int MB = BM / 64, NB = BN / 64;
+  constexpr int MB = BM / (32 * WGM), NB = BN / (32 * WGN);
   constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
   __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
   float* As = smem;
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   const GemmItem cur = gemm_decode<BM, BN>(g, blockIdx.x);
 
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
       float a[MB][4], b[NB][4];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const int row = wm * (BM / 2) + mb * 32 + l31;
+        const int row = wm * (BM / WGM) + mb * 32 + l31;
         if (AL == 0) {
           const float4 t = *reinterpret_cast<const float4*>(&As[row * LDK + kg * 8 + half * 4]);
           a[mb][0] = t.x; a[mb][1] = t.y; a[mb][2] = t.z; a[mb][3] = t.w;
@@ -230,7 +233,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int row = wn * (BN / 2) + nb * 32 + l31;
+        const int row = wn * (BN / WGN) + nb * 32 + l31;
         if (BL == 0) {
           const float4 t = *reinterpret_cast<const float4*>(&Bs[row * LDK + kg * 8 + half * 4]);
           b[nb][0] = t.x; b[nb][1] = t.y; b[nb][2] = t.z; b[nb][3] = t.w;
@@ -255,10 +258,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const int col = cur.n0 + wn * (BN / 2) + nb * 32 + l31;
+      const int col = cur.n0 + wn * (BN / WGN) + nb * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = cur.m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = cur.m0 + wm * (BM / WGM) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < g.M && col < g.N) {
           float v = acc[mb][nb][r];
           if (g.nsplit > 1) {
@@ -336,10 +339,10 @@ extern "C" int dm_prof_begin(int max_launches) {
   return DM_OK;
 }
 // out[kind*4 + {0,1,2,3}] = {launches, flops, milliseconds, algorithmic bytes (4*(M*K + N*K + M*N))} for
-// kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64); returns the number of recorded launches
+// kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x96, 4: 96x128); returns the number of recorded launches
 // (negative on error).  Synchronises on the recorded events.
 extern "C" int dm_prof_end(double* out, int nkinds) {
-  DM_REQUIRE(out && nkinds >= 12, DM_E_SHAPE, "prof_end: need room for 12 kinds");
+  DM_REQUIRE(out && nkinds >= 20, DM_E_SHAPE, "prof_end: need room for 20 kinds");
   g_prof.on = false;
   for (int i = 0; i < nkinds * 4; ++i) out[i] = 0.0;
   for (size_t i = 0; i < g_prof.n; ++i) {
@@ -357,18 +360,18 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
 }
 
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
-template <int BM, int BN, bool V>
+template <int BM, int BN, bool V, int WGM = 2, int WGN = 2>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
     if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, true>), grid, dim3(256), 0, stream, a);
-  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, V>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, V>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, true, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
   return DM_OK;
 }
 
@@ -424,10 +427,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     else if ((size_t)max_split * per > ws_bytes) max_split = (int)(ws_bytes / per);
   }
   if (max_split < 1) max_split = 1;
-  static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-  static const double keq[3] = {150.0, 60.0, 45.0};
-  static const double rate[3] = {1.0, 0.9, 0.8};
-  static const double resid[3] = {3.0, 4.0, 7.0};
+  static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {96, 128}};
+  static const double keq[5] = {150.0, 60.0, 45.0, 100.0, 100.0};
+  static const double rate[5] = {1.0, 0.9, 0.8, 0.95, 0.95};
+  static const double resid[5] = {3.0, 4.0, 7.0, 4.0, 4.0};
   const double lat_macs = 1.0e6;
   // tuning overrides for scripts/gemm_bench.py only (unset in production): DM_GEMM_TILE=1|2|3 forces a candidate,
   // DM_GEMM_SPLIT=n forces the split count
@@ -436,7 +439,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   int BM = 64, BN = 64, nsplit = 1;
   double best_cost = -1.0;
   const int kt1 = ktiles > 0 ? ktiles : 1;
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < 5; ++c) {
     if (force_tile && c != force_tile - 1) continue;
     if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
     const int bm = cand[c][0], bn = cand[c][1];
@@ -480,7 +483,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.tiles_n = tiles_n;
   a.n_fast = tiles_n <= tiles_m ? 1 : 0;
   a.n_items = (int)(tiles * nsplit);
-  const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 ? 1 : 2);
+  const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 ? 2 : (BN == 96 ? 3 : 4));
   dim3 grid((unsigned)a.n_items);
   const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
   DM_REQUIRE(!(q.a_maj && q.b_maj), DM_E_SHAPE, "gemm: only one gathered operand per call");
@@ -492,6 +495,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   if (vec) {
     if (tc == 0) rc = gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 1) rc = gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 4) rc = gemm_dispatch<96, 128, true, 1, 4>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else rc = gemm_dispatch<64, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
   } else {      // rare shapes (K = action_dim = 18, single-row weight gradients): scalar loads, smallest tile only
     rc = gemm_dispatch<64, 64, false>(a, q.a_layout, q.b_layout, gather, grid, stream);
