@@ -407,7 +407,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
   // Cost model in MACs per CU, fitted offline (scripts/fit_gemm_model.py) to per-tile timings of 28 step shapes on
-  // MI355X (profiles/r01_gemm_shapes.txt; regret 43 us summed over all shapes vs the per-shape best tile):
+  // MI355X (profiles/r01_gemm_shapes_5tiles.txt; regret 140 us of 15.4 ms summed over all shapes vs the per-shape best
+  // tile):
   //   a CU holds `avg` = workgroups/256 of this launch, at most R of them resident (R = 3 / 4 / 7 by registers);
   //   per k-tile it needs max(conc * BM*BN*32 / rate, L): MFMA time of the `conc` co-resident workgroups, or the
   //   ~1 MMAC-equivalent load latency when too few workgroups are resident to cover it (long reductions on few
@@ -428,8 +429,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   }
   if (max_split < 1) max_split = 1;
   static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {96, 128}};
-  static const double keq[5] = {150.0, 60.0, 45.0, 100.0, 100.0};
-  static const double rate[5] = {1.0, 0.9, 0.8, 0.95, 0.95};
+  static const double keq[5] = {150.0, 60.0, 45.0, 45.0, 45.0};
+  static const double rate[5] = {1.0, 0.9, 0.8, 0.75, 0.75};
   static const double resid[5] = {3.0, 4.0, 7.0, 4.0, 4.0};
   const double lat_macs = 1.0e6;
   // tuning overrides for scripts/gemm_bench.py only (unset in production): DM_GEMM_TILE=1|2|3 forces a candidate,

@@ -14,8 +14,8 @@ def parse(path):
             out.setdefault(name, {})[tile] = us
     return out
 
-CAND = [(128, 128), (128, 64), (64, 64)]
-RESID = [3, 4, 7]
+CAND = [(128, 128), (128, 64), (64, 64), (128, 96), (96, 128)]
+RESID = [3, 4, 7, 4, 4]
 
 def choose(M, N, K, al, bl, P, force=None):
     keq, rate, Lm = P['keq'], P['rate'], P['Lm']
@@ -49,7 +49,7 @@ def choose(M, N, K, al, bl, P, force=None):
 def evaluate(P, meas, verbose=False):
     regret, tot = 0.0, 0.0
     for al, bl, M, N, K, name in SHAPES:
-        if name not in meas or len(meas[name]) < 3: continue
+        if name not in meas or len(meas[name]) < len(CAND) or M <= 64: continue     # <= 64 rows: skinny kernel
         cost, c, sp = choose(M, N, K, al, bl, P)
         t_best = min(meas[name].values())
         t_sel = meas[name][c + 1]
@@ -59,11 +59,13 @@ def evaluate(P, meas, verbose=False):
 
 if __name__ == '__main__':
     meas = parse(sys.argv[1])
-    base = dict(keq=[100, 60, 30], rate=[1.0, 0.93, 0.86], Lm=460e3)
-    print('base regret', evaluate(base, meas))
+    # tiles 0-2 keep the parameters fitted on the 3-tile data (r01_gemm_shapes.txt); the two 96-wide tiles are searched
+    base = dict(keq=[150, 60, 45, 45, 45], rate=[1.0, 0.9, 0.8, 0.75, 0.75], Lm=1000e3)
+    print('current regret', evaluate(base, meas))
     best = (1e18, None)
-    for k0, k1, k2, r1, r2, L in itertools.product([60, 100, 150], [40, 60, 90], [15, 30, 45], [0.9, 0.95, 1.0], [0.8, 0.86, 0.92, 0.98], [0, 250e3, 460e3, 700e3, 1000e3]):
-        P = dict(keq=[k0, k1, k2], rate=[1.0, r1, r2], Lm=L)
+    grid = [45, 60, 100, 150, 200, 300], [0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9]
+    for k3, k4, r3, r4 in itertools.product(grid[0], grid[0], grid[1], grid[1]):
+        P = dict(keq=[150, 60, 45, k3, k4], rate=[1.0, 0.9, 0.8, r3, r4], Lm=1000e3)
         r, t = evaluate(P, meas)
         if r < best[0]: best = (r, P)
     print('best', best)
