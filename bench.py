@@ -136,6 +136,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
                     'off by default: on ROCm 7.2 a graph with concurrent branches replays slower than the side streams run eagerly')
     ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
+                    'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
     args = ap.parse_args()
 
@@ -162,7 +164,7 @@ def main():
     lo, hi = DP.shard_bounds(B, world, rank)
     if args.emulate_world > 1 and world == 1:
         lo, hi = DP.shard_bounds(B, args.emulate_world, 0)
-    conf = config.atari_literal(batch_size=hi - lo)
+    conf = config.atari_literal(batch_size=hi - lo, amp=(args.dtype == 'bf16'))
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
     model.overlap_backward = not args.no_overlap
@@ -237,7 +239,7 @@ def main():
         tot_fl = sum(out[4 * k + 1] for k in range(20))
         tot_ms = sum(out[4 * k + 2] for k in range(20))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
-        peak = 157.3
+        peak = 157.3 if args.dtype == 'f32' else 2500.0       # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE
         # and WRITE_SIZE cannot share a pass), summarised by scripts/pmc_traffic.py into profiles/ - read back here
         traffic = None
@@ -268,9 +270,9 @@ def main():
         ms = 1e3 * elapsed / args.steps
         line = dict(metric=METRIC, value=args.steps / elapsed, unit='grad-steps/s', n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None,
-                    dtype='f32', data='synthetic',
+                    dtype='f32' if args.dtype == 'f32' else 'bf16 (MFMA operands; fp32 accumulate, fp32 storage and non-GEMM math)', data='synthetic',
                     config=dict(workload='atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
-                                         'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, fp32; '
+                                         'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ' + ('fp32' if args.dtype == 'f32' else 'amp/bf16') + '; '
                                          'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('; fwd+bwd section replayed as one hipGraph' if args.graph else ''),
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
@@ -278,6 +280,7 @@ def main():
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
+                    **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

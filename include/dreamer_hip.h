@@ -261,6 +261,11 @@ int dm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* clip_coef, void* stream);
 int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* critic_target <- critic, a2c.py:151-152 */
+/* GEMM operand precision of the whole library (process-wide): 0 = fp32 (default); 1 = operands rounded to bf16 (RNE) on
+ * their way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results and storage (BASELINE
+ * configs[2], the reference's `amp` switch).  The <= 64-row chain products stay fp32. */
+int dm_set_gemm_precision(int mode);
+int dm_get_gemm_precision(void);
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for

@@ -130,6 +130,44 @@ __device__ __forceinline__ void gemm_store_tile(const float4 (&rr)[NF4], unsigne
   }
 }
 
+// ---- bf16 operand path (BASELINE configs[2]: mixed precision).  Operands are loaded as fp32 exactly as above and
+// rounded to bf16 (round-to-nearest-even) on their way into LDS; products run on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation; results, activations and everything outside the GEMMs stay fp32.  The LDS image is [row][k] bf16
+// (row stride 40 elements = 80 bytes, 16-byte aligned) for BOTH source layouts - a row-contiguous source is transposed
+// by 2-byte stores - because the MFMA wants 8 consecutive k per lane: lane l feeds row l&31, k = 8*(l>>5) .. +7.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDKB = 40;
+__device__ __forceinline__ unsigned dm_f2bf(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+template <int ROWS, int LAYOUT, int NF4>
+__device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], unsigned mask, unsigned short* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const float x = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
+    const float y = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
+    const float z = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
+    const float w = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
+    const unsigned b0 = dm_f2bf(x), b1 = dm_f2bf(y), b2 = dm_f2bf(z), b3 = dm_f2bf(w);
+    const int f = tid + i * 256;
+    if (LAYOUT == 0) {
+      const int row = f >> 3;
+      const int kq = (f & 7) << 2;
+      *reinterpret_cast<uint2*>(&S[row * LDKB + kq]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+    } else {
+      constexpr int F4_PER_K = ROWS / 4;
+      const int kr = f / F4_PER_K;
+      const int r4 = (f % F4_PER_K) << 2;
+      S[(r4 + 0) * LDKB + kr] = (unsigned short)b0;
+      S[(r4 + 1) * LDKB + kr] = (unsigned short)b1;
+      S[(r4 + 2) * LDKB + kr] = (unsigned short)b2;
+      S[(r4 + 3) * LDKB + kr] = (unsigned short)b3;
+    }
+  }
+}
+
 // Work item -> (tile, split).  Workgroup b is observed to run on XCD b % 8 (used for L2 affinity only, never for
 // correctness): each XCD is given one CONTIGUOUS chunk of the item list, so the tiles an XCD's L2 sees share B panels
 // (tile_m runs fastest inside a chunk).  Bijective for any item count (q = n/8, r = n%8).
@@ -170,7 +208,8 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 // VEC: both operands take the 16-byte load path (host-checked alignment and extents).
 // WGM x WGN: the 4 waves' grid over the block tile (2x2; 4x1 for the 128x96 tile, 1x4 for 96x128 - the conv stack is
 // full of 96-wide operands (cnn_depth 48), which 64/128-wide tiles pad by 25-33 %).
-template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false, int WGM = 2, int WGN = 2,
+          bool BF = false>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
   constexpr int BK = 32;
@@ -208,8 +247,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
     gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_maj, g.b_min, tid, mb_);
   }
   for (int kt = 0; kt < cur.nkt; ++kt) {
-    gemm_store_tile<BM, AL, A_F4>(ra, ma, As, tid);
-    gemm_store_tile<BN, BL, B_F4>(rb, mb_, Bs, tid);
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Bh = Ah + BM * LDKB;
+    if (BF) {
+      gemm_store_tile_bf16<BM, AL, A_F4>(ra, ma, Ah, tid);
+      gemm_store_tile_bf16<BN, BL, B_F4>(rb, mb_, Bh, tid);
+    } else {
+      gemm_store_tile<BM, AL, A_F4>(ra, ma, As, tid);
+      gemm_store_tile<BN, BL, B_F4>(rb, mb_, Bs, tid);
+    }
     __syncthreads();
     if (kt + 1 < cur.nkt) {                                   // register prefetch under the MFMAs below
       const int k0 = cur.kbeg + (kt + 1) * BK;
@@ -217,6 +263,23 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
       gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_maj, g.b_min, tid, mb_);
     }
     __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
+    if (BF) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                        // two 16-k MFMA steps per 32-k tile
+        bf16x8 a8[MB], b8[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          a8[mb] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * (BM / WGM) + mb * 32 + l31) * LDKB + ks * 16 + half * 8]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          b8[nb] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / WGN) + nb * 32 + l31) * LDKB + ks * 16 + half * 8]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mb], b8[nb], acc[mb][nb], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       float a[MB][4], b[NB][4];
@@ -360,20 +423,29 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
 }
 
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
-template <int BM, int BN, bool V, int WGM = 2, int WGN = 2>
+template <int BM, int BN, bool V, int WGM = 2, int WGN = 2, bool BF = false>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
     if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, true, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, false, WGM, WGN>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, true, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, false, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 1, V, false, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 0, V, false, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 1, 1, V, false, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
   return DM_OK;
 }
+
+// process-wide GEMM operand precision: 0 = fp32 (default), 1 = bf16 operands / fp32 accumulate (see gemm_store_tile_bf16)
+static int g_gemm_bf16 = 0;
+extern "C" int dm_set_gemm_precision(int mode) {
+  DM_REQUIRE(mode == 0 || mode == 1, DM_E_SHAPE, "set_gemm_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+  g_gemm_bf16 = mode;
+  return DM_OK;
+}
+extern "C" int dm_get_gemm_precision(void) { return g_gemm_bf16; }
 
 int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
   DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1, DM_E_SHAPE, "gemm: bad dims M=%d N=%d K=%d (K must be >= 1)", q.M, q.N, q.K);
@@ -493,7 +565,13 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
                                4.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N), stream);
   int rc;
   const bool vec = a.a_vec && a.b_vec;
-  if (vec) {
+  if (vec && g_gemm_bf16) {
+    if (tc == 0) rc = gemm_dispatch<128, 128, true, 2, 2, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 1) rc = gemm_dispatch<128, 64, true, 2, 2, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else if (tc == 4) rc = gemm_dispatch<96, 128, true, 1, 4, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+    else rc = gemm_dispatch<64, 64, true, 2, 2, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
+  } else if (vec) {
     if (tc == 0) rc = gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 1) rc = gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);

@@ -126,6 +126,8 @@ _SIGNATURES = {
     'dm_adamw_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     'dm_copy_params': (c_int, [_P, _P, c_int64, _P]),
     'dm_axpby': (c_int, [c_int64, c_float, _P, c_float, _P, _P]),
+    'dm_set_gemm_precision': (c_int, [c_int]),
+    'dm_get_gemm_precision': (c_int, []),
     'dm_prof_begin': (c_int, [c_int]),
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
 }

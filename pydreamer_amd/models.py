@@ -950,6 +950,9 @@ class Dreamer(nn.Module):
         self.probe_model = NoProbeHead()
         self.probe_gradients = conf.probe_gradients
         self._groups = None
+        # conf.amp (defaults.yaml:55; train.py:166 runs the step under autocast): GEMM operands in bf16, fp32 accumulation,
+        # fp32 storage.  The switch is process-wide inside the library and is (re)asserted at the start of every step.
+        self.amp = bool(getattr(conf, 'amp', False))
         self._overlap = None
         self.overlap_backward = True      # pre-launch the three backward passes on side streams (see _Overlap)
 
@@ -1049,6 +1052,8 @@ class Dreamer(nn.Module):
         iwae_samples = int(iwae_samples or self.iwae_samples)
         imag_horizon = int(imag_horizon or self.imag_horizon)
         T, B = obs['action'].shape[:2]
+        if H.lib().dm_get_gemm_precision() != int(self.amp):
+            H.call('dm_set_gemm_precision', int(self.amp))
         noise = noise or {}
         u_post = noise.get('u_post')
         if u_post is not None:
