@@ -54,7 +54,10 @@ struct GemmKArgs {
 // tmin = offset of tap (ky,kx,c) inside it).
 // VEC (chosen on the host, grid-uniform): the minor extent is a multiple of 4 and rows are 16-byte aligned, so every
 // group of 4 minors is entirely inside or entirely outside and is one 16-byte load; otherwise 4 predicated scalar loads.
-template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool VEC>
+// KSEQ (bf16 path, row-contiguous sources with 256 % (ROWS/4) == 0): thread t owns NF4 CONSECUTIVE k of one 4-row group
+// (k = (t / F4_PER_K) * NF4 + i) instead of k strided by 256 / F4_PER_K, so the transposing bf16 store can pack them
+// into one 4/8-byte LDS write per row; global coalescing is unchanged (consecutive threads = consecutive row groups).
+template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool VEC, bool KSEQ = false>
 __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __restrict__ P, int ld, int row0,
                                                int nrows, int k0, int kend, const int* __restrict__ tmaj,
                                                const int* __restrict__ tmin, int tid, unsigned& mask) {
@@ -72,8 +75,13 @@ __device__ __forceinline__ void gemm_load_tile(float4 (&r)[NF4], const float* __
       minor_end = kend;
     } else {
       constexpr int F4_PER_K = ROWS / 4;
-      major = k0 + f / F4_PER_K;
-      minor = row0 + ((f % F4_PER_K) << 2);
+      if (KSEQ) {
+        major = k0 + (tid / F4_PER_K) * NF4 + i;
+        minor = row0 + ((tid % F4_PER_K) << 2);
+      } else {
+        major = k0 + f / F4_PER_K;
+        minor = row0 + ((f % F4_PER_K) << 2);
+      }
       major_end = kend;
       minor_end = nrows;
     }
@@ -142,8 +150,31 @@ __device__ __forceinline__ unsigned dm_f2bf(float x) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return u >> 16;
 }
-template <int ROWS, int LAYOUT, int NF4>
+template <int ROWS, int LAYOUT, int NF4, bool KSEQ = false>
 __device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], unsigned mask, unsigned short* S, int tid) {
+  if (LAYOUT == 1 && KSEQ) {      // rr[i] = rows r4..r4+3 at k = kq*NF4 + i: one packed write of NF4 bf16 per row
+    constexpr int F4_PER_K = ROWS / 4;
+    const int kq = (tid / F4_PER_K) * NF4;
+    const int r4 = (tid % F4_PER_K) << 2;
+    unsigned h[4][NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      h[0][i] = dm_f2bf((mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f);
+      h[1][i] = dm_f2bf((mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f);
+      h[2][i] = dm_f2bf((mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f);
+      h[3][i] = dm_f2bf((mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned short* d = &S[(r4 + j) * LDKB + kq];
+      if (NF4 == 4) *reinterpret_cast<uint2*>(d) = make_uint2(h[j][0] | (h[j][1] << 16), h[j][2] | (h[j][3] << 16));
+      else if (NF4 == 2) *reinterpret_cast<unsigned*>(d) = h[j][0] | (h[j][1] << 16);
+      else
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) d[i] = (unsigned short)h[j][i];
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const float x = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
@@ -219,6 +250,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int B_FLOATS = (BL == 0) ? BN * LDK : BK * LDMB;
   constexpr int MB = BM / (32 * WGM), NB = BN / (32 * WGN);
   constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
+  constexpr bool A_KSEQ = BF && AL == 1 && 256 % (BM / 4) == 0, B_KSEQ = BF && BL == 1 && 256 % (BN / 4) == 0;
   __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
   float* As = smem;
   float* Bs = smem + A_FLOATS;
@@ -243,15 +275,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   float4 ra[A_F4], rb[B_F4];
   unsigned ma = 0u, mb_ = 0u;
   if (cur.nkt > 0) {
-    gemm_load_tile<BM, AL, A_F4, GA, VEC>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_maj, g.a_min, tid, ma);
-    gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_maj, g.b_min, tid, mb_);
+    gemm_load_tile<BM, AL, A_F4, GA, VEC, A_KSEQ>(ra, g.A, g.lda, cur.m0, g.M, cur.kbeg, cur.kend, g.a_maj, g.a_min, tid, ma);
+    gemm_load_tile<BN, BL, B_F4, GB, VEC, B_KSEQ>(rb, g.B, g.ldb, cur.n0, g.N, cur.kbeg, cur.kend, g.b_maj, g.b_min, tid, mb_);
   }
   for (int kt = 0; kt < cur.nkt; ++kt) {
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
     unsigned short* Bh = Ah + BM * LDKB;
     if (BF) {
-      gemm_store_tile_bf16<BM, AL, A_F4>(ra, ma, Ah, tid);
-      gemm_store_tile_bf16<BN, BL, B_F4>(rb, mb_, Bh, tid);
+      gemm_store_tile_bf16<BM, AL, A_F4, A_KSEQ>(ra, ma, Ah, tid);
+      gemm_store_tile_bf16<BN, BL, B_F4, B_KSEQ>(rb, mb_, Bh, tid);
     } else {
       gemm_store_tile<BM, AL, A_F4>(ra, ma, As, tid);
       gemm_store_tile<BN, BL, B_F4>(rb, mb_, Bs, tid);
@@ -259,8 +291,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
     __syncthreads();
     if (kt + 1 < cur.nkt) {                                   // register prefetch under the MFMAs below
       const int k0 = cur.kbeg + (kt + 1) * BK;
-      gemm_load_tile<BM, AL, A_F4, GA, VEC>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_maj, g.a_min, tid, ma);
-      gemm_load_tile<BN, BL, B_F4, GB, VEC>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_maj, g.b_min, tid, mb_);
+      gemm_load_tile<BM, AL, A_F4, GA, VEC, A_KSEQ>(ra, g.A, g.lda, cur.m0, g.M, k0, cur.kend, g.a_maj, g.a_min, tid, ma);
+      gemm_load_tile<BN, BL, B_F4, GB, VEC, B_KSEQ>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_maj, g.b_min, tid, mb_);
     }
     __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
     if (BF) {
