@@ -428,6 +428,19 @@ class _Overlap:
         return self.pool.submit(job)
 
 
+def pack_metrics(*dicts):
+    """the trainer reads ~20 scalar metrics per logged step with one `.item()` (= one device sync) each
+    (train.py:204-214).  All metrics of this package are 0-d device tensors produced without a sync; this packs any
+    number of metric dicts into ONE 1-D device tensor so a single `.cpu()` / non-blocking copy replaces the syncs:
+        names, packed = pack_metrics(loss_metrics, grad_metrics);  values = dict(zip(names, packed.tolist()))"""
+    names, vals = [], []
+    for d in dicts:
+        for k, v in d.items():
+            names.append(k)
+            vals.append(v.detach().reshape(()).float())
+    return names, (torch.stack(vals) if vals else torch.empty(0))
+
+
 class _Done:
     def __init__(self, value):
         self.value = value

@@ -649,3 +649,11 @@ def test_amp_bf16_step_tracks_fp32(hip):
     cos = float((a @ b) / (a.norm() * b.norm()))
     print('bf16 vs fp32 oracle: loss_model', l1[0], float(lo[0]), 'wm grad cosine', cos)
     assert cos > 0.999
+
+
+def test_pack_metrics(hip):
+    from pydreamer_amd.models import pack_metrics
+    a = dict(x=torch.tensor(1.5, device=DEV), y=torch.tensor(-2.0, device=DEV))
+    b = dict(z=torch.tensor([3.0], device=DEV))
+    names, packed = pack_metrics(a, b)
+    assert names == ['x', 'y', 'z'] and packed.tolist() == [1.5, -2.0, 3.0] and packed.is_cuda
