@@ -177,6 +177,43 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def run_amp(name, sections, overrides):
+    """BASELINE configs[2] family: the reference's mixed-precision step (train.py:166 `autocast(enabled=conf.amp)`), run on
+    CPU under torch.autocast('cpu', bfloat16).  Forward losses / metrics only (a loose pin: the build's bf16 mode keeps fp32
+    storage, autocast also rounds layer outputs to bf16)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REF)
+    from pydreamer.models import Dreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    rconf = reference_conf(sections, overrides)
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    model = Dreamer(rconf)
+    model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    T, B, S, H = rconf.batch_length, rconf.batch_size, rconf.stoch_dim, rconf.imag_horizon
+    raw = O.synthetic_batch(oconf, seed=1234, first=True)
+    obs = O.preprocess(raw, oconf)
+    noise = O.make_noise(oconf, seed=777)
+    out = {'conf_json': np.array(repr(sorted(vars(oconf).items())))}
+    for tag, amp in (('fp32', False), ('bf16', True)):
+        with MultinomialPatch() as mp:
+            mp.queue = [noise['u_post'][t] for t in range(T)]
+            for i in range(H):
+                mp.queue += [noise['u_act'][i], noise['u_prior'][i]]
+            with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16, enabled=amp):
+                losses, _, metrics, _, _ = model.training_step(obs, model.init_state(B))
+            post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
+        out[tag + '_losses'] = np.array([float(l) for l in losses], dtype=np.float64)
+        for k, v in metrics.items():
+            out[tag + '_metric_' + k] = np.array(float(v), dtype=np.float64)
+        out[tag + '_idx_post'] = post_idx.numpy().astype(np.uint8)
+        print(f'[{name}] {tag}: losses', out[tag + '_losses'])
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def run_eval(name, sections, overrides, do_open_loop=False):
     """Logging variants of training_step (train.py:353-359,380-385 call it with do_image_pred / do_dream_tensors):
     one forward with both flags; inputs, extra uniforms and every extra output are stored."""
@@ -274,6 +311,12 @@ if __name__ == '__main__':
                  dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
                       cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                       imag_horizon=t.imag_horizon), do_open_loop=True)
+    if 'amp' in which:
+        t = O.tiny_conf()
+        run_amp('tiny_amp', ['defaults', 'atari'],
+                dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                     cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                     imag_horizon=t.imag_horizon))
     if 'atari' in which:
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],

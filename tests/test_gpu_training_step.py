@@ -657,3 +657,33 @@ def test_pack_metrics(hip):
     b = dict(z=torch.tensor([3.0], device=DEV))
     names, packed = pack_metrics(a, b)
     assert names == ['x', 'y', 'z'] and packed.tolist() == [1.5, -2.0, 3.0] and packed.is_cuda
+
+
+def test_amp_against_reference_autocast_golden(hip):
+    """tests/golden/tiny_amp.npz: the real reference's forward under torch.autocast('cpu', bfloat16) (its amp switch,
+    train.py:166) and in fp32 on the same batch.  The build's mixed-precision mode rounds GEMM operands only (autocast
+    also rounds layer outputs), so this is a loose pin: with the posterior indices teacher-forced to the reference's,
+    the world-model loss must sit within 1e-3 relative of the reference's bf16 value - and of its fp32 value."""
+    g = np.load(os.path.join(GOLD, 'tiny_amp.npz'))
+    oconf = O.make_conf(**dict(eval(str(g['conf_json']))))
+    obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=1234, first=True), oconf))
+    noise = _to_dev(O.make_noise(oconf, seed=777))
+    from pydreamer_amd import config
+    from pydreamer_amd.models import Dreamer
+    try:
+        conf = config.load_config('defaults', 'atari', **{**{k: getattr(oconf, k) for k in vars(oconf)}, 'amp': True})
+        model = Dreamer(conf)
+        model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+        model = model.to(DEV)
+        fidx = torch.from_numpy(g['bf16_idx_post'].astype(np.int64)).to(DEV)
+        with torch.no_grad():
+            losses, _, metrics, _, _ = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise,
+                                                           forced_idx=fidx)
+    finally:
+        hip.call('dm_set_gemm_precision', 0)
+    ref_bf16, ref_fp32 = float(g['bf16_losses'][0]), float(g['fp32_losses'][0])
+    print('loss_model: build amp', float(losses[0]), 'reference autocast', ref_bf16, 'reference fp32', ref_fp32)
+    assert abs(float(losses[0]) - ref_bf16) < 1e-3 * ref_bf16
+    assert abs(float(losses[0]) - ref_fp32) < 1e-3 * ref_fp32
+    for k in ('loss_image', 'loss_reward', 'loss_terminal', 'entropy_post'):
+        assert _rel(metrics[k], float(g['bf16_metric_' + k])) < 2e-2, k
