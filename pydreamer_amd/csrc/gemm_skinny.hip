@@ -24,15 +24,15 @@ struct SkinnyArgs {
 
 // Raw loads from clamped (always valid) addresses + a validity mask (bits 0-3: A row blocks, bit 4: B).  The zero-fill
 // select is applied where the chunk is CONSUMED, one iteration later, so the loads stay in flight under the MFMAs.
-template <int BL>
-__device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int n0, int c, int kend, int lane, float4 (&a)[4],
+template <int BL, int NRB>
+__device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int n0, int c, int kend, int lane, float4 (&a)[NRB],
                                             float4& b, unsigned& mask) {
   mask = 0u;
   const int l15 = lane & 15, q = lane >> 4;
   const int k = c + 4 * q;
   const bool kin = k < kend;                      // kend % 4 == 0 (host-checked K % 4): a group of 4 is all in or all out
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < NRB; ++mb) {
     const int m = mb * 16 + l15;
     const bool ok = kin && m < g.M;
     a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
@@ -53,8 +53,9 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int n0, int c, 
 constexpr int SK_DEPTH = 4;    // 16-k chunks loaded per round (all in flight before the first MFMA)
 constexpr int SK_WAVES = 16;   // waves per workgroup = K splits inside it (8 and 4 measured slower, also under contention)
 
-// One 64 x 16 output strip.
-template <int BL>
+// One (16*NRB) x 16 output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads a
+// quarter of the activation traffic of the 50-row case.
+template <int BL, int NRB>
 __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, float (*part)[64 * 16]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = strip * 16;
@@ -64,9 +65,9 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
   int c_end = c_beg + per * 16;
   if (c_end > chunks * 16) c_end = chunks * 16;
 
-  f32x4 acc[4];
+  f32x4 acc[NRB];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < NRB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // These products are latency bound (weights come from the MALL / HBM, ~1 us a round trip), so a round issues the
   // loads of SK_DEPTH chunks back to back and only then starts consuming them under counted waits; the 16 waves of
@@ -75,17 +76,17 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
   int kend = c_end < g.K ? c_end : g.K;
   if (kend < c_beg) kend = c_beg;
   for (int c = c_beg; c < c_end; c += 16 * SK_DEPTH) {
-    float4 a[SK_DEPTH][4], b[SK_DEPTH];
+    float4 a[SK_DEPTH][NRB], b[SK_DEPTH];
     unsigned mk[SK_DEPTH];
 #pragma unroll
-    for (int d = 0; d < SK_DEPTH; ++d) skinny_load<BL>(g, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
+    for (int d = 0; d < SK_DEPTH; ++d) skinny_load<BL, NRB>(g, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < SK_DEPTH; ++d) {
       const bool okb = (mk[d] & 16u) != 0u;
       const float bj[4] = {okb ? b[d].x : 0.f, okb ? b[d].y : 0.f, okb ? b[d].z : 0.f, okb ? b[d].w : 0.f};
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
+      for (int mb = 0; mb < NRB; ++mb) {
         const bool oka = ((mk[d] >> mb) & 1u) != 0u;
         const float aj[4] = {oka ? a[d][mb].x : 0.f, oka ? a[d][mb].y : 0.f, oka ? a[d][mb].z : 0.f,
                              oka ? a[d][mb].w : 0.f};
@@ -96,11 +97,11 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
   }
   // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+  for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][(mb * 16 + (lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[mb][r];
   __syncthreads();
-  for (int e = tid; e < 64 * 16; e += SK_WAVES * 64) {
+  for (int e = tid; e < NRB * 16 * 16; e += SK_WAVES * 64) {
     const int row = e >> 4, col = n0 + (e & 15);
     if (row < g.M && col < g.N) {
       float v = 0.f;
@@ -117,20 +118,21 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
   }
 }
 
-template <int BL>
+template <int BL, int NRB>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
   __shared__ float part[SK_WAVES][64 * 16];
-  skinny_strip<BL>(g, blockIdx.x, part);
+  skinny_strip<BL, NRB>(g, blockIdx.x, part);
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
 // feed step t-1's state gradient.  Workgroups [0, nb0) serve the first product, the rest the second.
 struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0; };
+template <int NRB>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
   __shared__ float part[SK_WAVES][64 * 16];
   const int b = blockIdx.x;
-  if (b < a.nb0) skinny_strip<0>(a.g[0], b, part);
-  else skinny_strip<0>(a.g[1], b - a.nb0, part);
+  if (b < a.nb0) skinny_strip<0, NRB>(a.g[0], b, part);
+  else skinny_strip<0, NRB>(a.g[1], b - a.nb0, part);
 }
 
 static bool skinny_ok(const DmGemm& q) {
@@ -153,8 +155,16 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   SkinnyArgs a;
   skinny_fill(q, a);
   const dim3 grid((unsigned)dm_cdiv(q.N, 16));
-  if (q.b_layout == 0) hipLaunchKernelGGL((skinny_gemm_kernel<0>), grid, dim3(SK_WAVES * 64), 0, stream, a);
-  else hipLaunchKernelGGL((skinny_gemm_kernel<1>), grid, dim3(SK_WAVES * 64), 0, stream, a);
+  const dim3 blk(SK_WAVES * 64);
+  if (q.b_layout == 0) {
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1>), grid, blk, 0, stream, a);
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4>), grid, blk, 0, stream, a);
+  } else {
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<1, 1>), grid, blk, 0, stream, a);
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 4>), grid, blk, 0, stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "skinny gemm: %s", hipGetErrorString(e));
   return 1;
@@ -166,7 +176,11 @@ int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
     a.nb0 = dm_cdiv(q0.N, 16);
-    hipLaunchKernelGGL(skinny_gemm_pair_kernel, dim3((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), dim3(SK_WAVES * 64), 0, stream, a);
+    const dim3 grid((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), blk(SK_WAVES * 64);
+    const int mmax = q0.M > q1.M ? q0.M : q1.M;
+    if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1>), grid, blk, 0, stream, a);
+    else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4>), grid, blk, 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
