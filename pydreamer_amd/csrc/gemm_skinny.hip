@@ -25,15 +25,15 @@ struct SkinnyArgs {
 // Raw loads from clamped (always valid) addresses + a validity mask (bits 0-3: A row blocks, bit 4: B).  The zero-fill
 // select is applied where the chunk is CONSUMED, one iteration later, so the loads stay in flight under the MFMAs.
 template <int BL, int NRB>
-__device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int n0, int c, int kend, int lane, float4 (&a)[NRB],
-                                            float4& b, unsigned& mask) {
+__device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0, int c, int kend, int lane,
+                                            float4 (&a)[NRB], float4& b, unsigned& mask) {
   mask = 0u;
   const int l15 = lane & 15, q = lane >> 4;
   const int k = c + 4 * q;
   const bool kin = k < kend;                      // kend % 4 == 0 (host-checked K % 4): a group of 4 is all in or all out
 #pragma unroll
   for (int mb = 0; mb < NRB; ++mb) {
-    const int m = mb * 16 + l15;
+    const int m = m0 + mb * 16 + l15;
     const bool ok = kin && m < g.M;
     a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
     mask |= ok ? (1u << mb) : 0u;
@@ -56,7 +56,7 @@ constexpr int SK_WAVES = 16;   // waves per workgroup = K splits inside it (8 an
 // One (16*NRB) x 16 output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads a
 // quarter of the activation traffic of the 50-row case.
 template <int BL, int NRB>
-__device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, float (*part)[64 * 16]) {
+__device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int m0, float (*part)[64 * 16]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = strip * 16;
   const int chunks = (g.K + 15) / 16;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
     float4 a[SK_DEPTH][NRB], b[SK_DEPTH];
     unsigned mk[SK_DEPTH];
 #pragma unroll
-    for (int d = 0; d < SK_DEPTH; ++d) skinny_load<BL, NRB>(g, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
+    for (int d = 0; d < SK_DEPTH; ++d) skinny_load<BL, NRB>(g, m0, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < SK_DEPTH; ++d) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
     for (int r = 0; r < 4; ++r) part[wave][(mb * 16 + (lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[mb][r];
   __syncthreads();
   for (int e = tid; e < NRB * 16 * 16; e += SK_WAVES * 64) {
-    const int row = e >> 4, col = n0 + (e & 15);
+    const int row = m0 + (e >> 4), col = n0 + (e & 15);
     if (row < g.M && col < g.N) {
       float v = 0.f;
 #pragma unroll
@@ -121,7 +121,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, flo
 template <int BL, int NRB>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
   __shared__ float part[SK_WAVES][64 * 16];
-  skinny_strip<BL, NRB>(g, blockIdx.x, part);
+  skinny_strip<BL, NRB>(g, blockIdx.x, blockIdx.y * 64, part);       // grid.y = 64-row chunks of M
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
@@ -131,12 +131,16 @@ template <int NRB>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
   __shared__ float part[SK_WAVES][64 * 16];
   const int b = blockIdx.x;
-  if (b < a.nb0) skinny_strip<0, NRB>(a.g[0], b, part);
-  else skinny_strip<0, NRB>(a.g[1], b - a.nb0, part);
+  if (b < a.nb0) skinny_strip<0, NRB>(a.g[0], b, 0, part);
+  else skinny_strip<0, NRB>(a.g[1], b - a.nb0, 0, part);
 }
 
-static bool skinny_ok(const DmGemm& q) {
-  if (q.M > 64 || q.M < 1 || q.N < 1 || q.K < 16) return false;
+// max_m: 64 for the pair kernel (one chunk); the single-product kernel walks M in 64-row chunks (grid.y) up to
+// g_skinny_max_m rows, where it still beats the tiled kernel's <= ~100 workgroups (imagination products of a
+// data-parallel shard: M = T*B/8 = 350)
+static const int g_skinny_max_m = getenv("DM_SKINNY_MAX_M") ? atoi(getenv("DM_SKINNY_MAX_M")) : 512;
+static bool skinny_ok(const DmGemm& q, int max_m) {
+  if (q.M > max_m || q.M < 1 || q.N < 1 || q.K < 16) return false;
   if (q.a_layout != 0 || q.a_maj || q.b_maj || q.mulref) return false;
   if ((q.K & 3) || (q.lda & 3) || ((uintptr_t)q.A & 15)) return false;
   if (q.b_layout == 0 && ((q.ldb & 3) || ((uintptr_t)q.B & 15))) return false;
@@ -151,10 +155,13 @@ static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      /
 
 // Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
 int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
-  if (g_skinny_disabled || !skinny_ok(q)) return 0;
+  if (g_skinny_disabled || !skinny_ok(q, g_skinny_max_m)) return 0;
+  // beyond one chunk it pays only for short reductions over small weight matrices (measured at M = 350: 1000x1024
+  // 31.9 -> 24.8 us, 400x400 15.1 -> 8.7 us; 1800x1000 equal; 400x1624 18.2 -> 19.9 us)
+  if (q.M > 64 && (q.K > 1024 || (int64_t)q.N * q.K > (int64_t)1100 * 1024)) return 0;
   SkinnyArgs a;
   skinny_fill(q, a);
-  const dim3 grid((unsigned)dm_cdiv(q.N, 16));
+  const dim3 grid((unsigned)dm_cdiv(q.N, 16), (unsigned)dm_cdiv(q.M, 64));
   const dim3 blk(SK_WAVES * 64);
   if (q.b_layout == 0) {
     if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1>), grid, blk, 0, stream, a);
@@ -171,7 +178,7 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
 }
 // Both products in one launch if both qualify (k-contiguous B); otherwise two ordinary launches.
 int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!g_skinny_disabled && skinny_ok(q0) && skinny_ok(q1) && q0.b_layout == 0 && q1.b_layout == 0) {
+  if (!g_skinny_disabled && skinny_ok(q0, 64) && skinny_ok(q1, 64) && q0.b_layout == 0 && q1.b_layout == 0) {
     SkinnyPairArgs a;
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
