@@ -1,15 +1,18 @@
-// Skinny fp32 GEMM for the sequential RSSM chains: M <= 64 rows (one batch of recurrent states), any N, any K.
+// Skinny fp32 GEMM for the sequential RSSM chains: M <= 64 rows (one batch of recurrent states), any N, any K - and, in
+// 64-row chunks, for the <= 512-row products of a data-parallel shard's imagination step.
 //
-//   C[m,n] = epi( sum_k A[m,k] * B(n,k) )          A row-major (k contiguous); B either [N][K] (weights, forward)
-//                                                  or [K][N] (weights, backward-data)
+//   C[m,n] = epi( sum_k A[m,k] * B(n,k) )          A row-major (k contiguous); B either [N][K] (weights, forward, and
+//                                                  the BPTT loop's transposed weights) or [K][N]
 //
 // The tiled kernel in gemm.hip needs split-K plus a second (reduce) launch to put more than ~20 workgroups on these
 // shapes, and each of the ~500 per-step GEMMs of the T / BPTT loops then costs ~11 us of mostly launch latency.
-// Here one launch does the whole product: a workgroup owns a 64 x 16 output strip (grid = N/16: 63-113 workgroups),
-// its 16 waves split K sixteen ways, each wave accumulates a full 64 x 16 partial on v_mfma_f32_16x16x4_f32 straight
+// Here one launch does the whole product: a workgroup owns a 64 x 16 output strip (grid = N/16 x M/64: 38-113
+// workgroups per chunk), its 16 waves split K sixteen ways, each wave accumulates a (16*NRB) x 16 partial (NRB =
+// populated 16-row blocks: a 7-row shard loads a quarter of the activation rows) on v_mfma_f32_16x16x4_f32 straight
 // from global memory (weights from MALL/HBM and a <= 64-row activation block from L2; no LDS staging, 4 chunks of
 // loads in flight per wave), and the 16 partials are summed through LDS in a fixed order (deterministic).
 // fp32-input MFMA is an exact fmaf chain, so numerics match the tiled kernel up to summation order.
+// skinny_gemm_pair_kernel runs two independent products in one launch (the loops are bound by the launch count).
 #include "common.h"
 #include <stdlib.h>
 
