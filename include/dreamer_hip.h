@@ -132,6 +132,12 @@ typedef struct dm_mlp_grads {
   float* ln_b[DM_MAX_MLP_LAYERS];
 } dm_mlp_grads;
 size_t dm_mlp_acts_floats(int rows, int hidden, int layers);
+/* scratch floats (incl. the split-K region) dm_mlp_head_fwd / dm_mlp_head_bwd need for `rows` rows */
+size_t dm_mlp_ws_floats(int rows, int hidden, int layers);
+/* acts may be NULL when no backward will follow (critic_target a2c.py:39,84; the dream's reward / terminal heads
+ * dreamer.py:205-206; inference dreamer.py:92-111): activations then ping-pong through `ws` and nothing is saved.
+ * For rows >= 16384 and hidden 400 each Linear -> LayerNorm -> ELU is ONE row-panel launch (csrc/panel.hip) and the output
+ * layer (out_dim <= 32) rides in the last one's epilogue. */
 int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim,
                     const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
                     void* ws, size_t ws_bytes, void* stream);

@@ -110,6 +110,18 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
                       void* ws, size_t ws_bytes, hipStream_t st);
 
+// row-panel Linear + LayerNorm/ELU kernels for the 400-wide MLP heads (panel.hip)
+bool dm_panel_ok(int rows, int hidden);
+int dm_panel_count(int rows);
+int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ldx, const float* W, const float* b,
+                           const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
+                           const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st);
+int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,
+                           const float* stats, const float* gamma, const float* beta, float* dx, float* colpart,
+                           hipStream_t st);
+int dm_panel_colsum_final_launch(int count, const float* const* part, float* const* out, int n, int npanels, int pstride,
+                                 hipStream_t st);
+
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;
 

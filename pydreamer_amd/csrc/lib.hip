@@ -62,7 +62,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D);    // + the transposed BPTT weights
   const size_t rows = (H + 1) * N;
-  const size_t mlp_bwd = SK + 2 * pad64(rows * Hm);
+  const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
                        2 * pad64(N * 3 * D) + pad64(N * Z);
   size_t m = enc_bwd;

@@ -23,35 +23,77 @@ extern "C" size_t dm_mlp_acts_floats(int rows, int hidden, int layers) {
   return mlp_carve(rows, hidden, layers, nullptr, nullptr);
 }
 
+// Scratch (floats) any MLP call may need beyond the split-K region: activation ping-pong for calls without an `acts`
+// buffer (3 x rows x hidden), backward ping-pong (2 x rows x hidden) and the panel kernels' column partials.
+static size_t mlp_ws_floats(int rows, int hidden, int layers) {
+  const size_t rh = dm_align_up((size_t)rows * hidden, 64);
+  return DM_SPLITK_FLOATS + 3 * rh + dm_align_up((size_t)layers * dm_panel_count(rows) * 3 * hidden, 64) + 256;
+}
+extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
+  if (rows < 0 || hidden < 0 || layers < 0 || layers > DM_MAX_MLP_LAYERS) return 0;
+  return mlp_ws_floats(rows, hidden, layers);
+}
+
 // `acts` is carved for acts_total_rows rows; this call fills rows [acts_row_off, acts_row_off + rows) of every
 // per-layer array (the imagination rollout writes one horizon step at a time into one (H*M)-row activation set).
+// acts == nullptr (heads nobody differentiates: critic_target, the dream's reward / terminal heads, inference): the
+// activations ping-pong through `ws` and no pre-activation / statistics are written at all.
+// Rows >= the panel threshold run each Linear -> LayerNorm -> ELU as ONE row-panel launch (panel.hip), with the output
+// layer folded into the last one's epilogue; smaller batches keep GEMM + LayerNorm launches (the 64-row panels would
+// leave most CUs idle there).
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
                       void* ws, size_t ws_bytes, hipStream_t st) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
-  DM_REQUIRE(acts_row_off >= 0 && acts_row_off + rows <= acts_total_rows, DM_E_SHAPE, "mlp_fwd: acts row window");
   MlpActs a;
-  mlp_carve(acts_total_rows, hidden, layers, acts, &a);
-  for (int l = 0; l < layers; ++l) {
-    a.xpre[l] += (size_t)acts_row_off * hidden;
-    a.stats[l] += (size_t)acts_row_off * 2;
-    a.y[l] += (size_t)acts_row_off * hidden;
+  if (acts) {
+    DM_REQUIRE(acts_row_off >= 0 && acts_row_off + rows <= acts_total_rows, DM_E_SHAPE, "mlp_fwd: acts row window");
+    mlp_carve(acts_total_rows, hidden, layers, acts, &a);
+    for (int l = 0; l < layers; ++l) {
+      a.xpre[l] += (size_t)acts_row_off * hidden;
+      a.stats[l] += (size_t)acts_row_off * 2;
+      a.y[l] += (size_t)acts_row_off * hidden;
+    }
+  } else {
+    DmArena ar(ws, ws_bytes);
+    ar.take(DM_SPLITK_FLOATS);
+    float* t0 = ar.take((size_t)rows * hidden);
+    float* t1 = ar.take((size_t)rows * hidden);
+    float* t2 = ar.take((size_t)rows * hidden);
+    float* t3 = ar.take((size_t)rows * 2);
+    DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "mlp_fwd: workspace too small for the activation ping-pong (need %zu floats)", ar.off);
+    for (int l = 0; l < layers; ++l) { a.xpre[l] = t2; a.stats[l] = t3; a.y[l] = (l & 1) ? t1 : t0; }
   }
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   const float* in = x;
   int ldin = ldx, kin = in_dim;
-  for (int l = 0; l < layers; ++l) {
-    DmGemm q;
-    q.M = rows; q.N = hidden; q.K = kin;
-    q.A = in; q.lda = ldin;
-    q.B = p->w[l]; q.ldb = kin;
-    q.C = a.xpre[l]; q.ldc = hidden;
-    q.bias = p->b[l];
-    DM_TRY(dm_gemm_launch(q, ws, skb, st));
-    DM_TRY(dm_ln_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, p->ln_g[l], p->ln_b[l], 1e-3f, a.y[l], hidden,
-                                a.stats[l], st));
-    in = a.y[l]; ldin = hidden; kin = hidden;
+  const bool panel = dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
+  if (panel) {
+    const bool fuse_out = out_dim <= 32;
+    for (int l = 0; l < layers; ++l) {
+      const bool last = l == layers - 1;
+      const bool fo = last && fuse_out;
+      DM_TRY(dm_panel_ln_fwd_launch(rows, hidden, kin, in, ldin, p->w[l], p->b[l], p->ln_g[l], p->ln_b[l], 1e-3f,
+                                    acts ? a.xpre[l] : nullptr, acts ? a.stats[l] : nullptr,
+                                    (fo && !acts) ? nullptr : a.y[l], fo ? p->w[layers] : nullptr,
+                                    fo ? p->b[layers] : nullptr, out, out_dim, ldout, st));
+      in = a.y[l]; ldin = hidden; kin = hidden;
+    }
+    if (fuse_out) return DM_OK;
+  } else {
+    for (int l = 0; l < layers; ++l) {
+      DmGemm q;
+      q.M = rows; q.N = hidden; q.K = kin;
+      q.A = in; q.lda = ldin;
+      q.B = p->w[l]; q.ldb = kin;
+      q.C = a.xpre[l]; q.ldc = hidden;
+      q.bias = p->b[l];
+      DM_TRY(dm_gemm_launch(q, ws, skb, st));
+      DM_TRY(dm_ln_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, p->ln_g[l], p->ln_b[l], 1e-3f, a.y[l], hidden,
+                                  a.stats[l], st));
+      in = a.y[l]; ldin = hidden; kin = hidden;
+    }
   }
   DmGemm q;
   q.M = rows; q.N = out_dim; q.K = hidden;
@@ -64,7 +106,7 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
 
 extern "C" int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                                const dm_mlp_params* p, float* acts, float* out, void* ws, size_t ws_bytes, void* stream) {
-  DM_REQUIRE(x && p && acts && out && ws, DM_E_NULL, "mlp_head_fwd: null pointer");
+  DM_REQUIRE(x && p && out && ws, DM_E_NULL, "mlp_head_fwd: null pointer");      // acts may be NULL (no backward)
   return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, rows, 0, out, out_dim, ws, ws_bytes,
                            (hipStream_t)stream);
 }
@@ -81,8 +123,66 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
   float* splitk = ar.take(DM_SPLITK_FLOATS);
   float* dy = ar.take((size_t)rows * hidden);
   float* dxp = ar.take((size_t)rows * hidden);
+  const bool panel = dm_panel_ok(rows, hidden) && ((uintptr_t)p->w[layers] & 15) == 0;
+  const int npanels = dm_panel_count(rows);
+  float* colpart = ar.take(panel ? (size_t)layers * npanels * 3 * hidden : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "mlp_head_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  if (panel) {
+    // Row-panel backward (panel.hip): the data-gradient product of layer l+1 and the LayerNorm/ELU backward of layer l
+    // are ONE launch that also leaves per-panel column sums for dbias / dgamma / dbeta; one final launch adds them up.
+    {
+      DmGemm q;   // dW_L[o][h] = sum_r dout[r][o] y[r][h]
+      q.a_layout = 1; q.b_layout = 1;
+      q.M = out_dim; q.N = hidden; q.K = rows;
+      q.A = dout; q.lda = out_dim;
+      q.B = a.y[layers - 1]; q.ldb = hidden;
+      q.C = g->w[layers]; q.ldc = hidden;
+      DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+      DM_TRY(dm_colsum_launch(rows, out_dim, dout, out_dim, g->b[layers], splitk, skb, st));
+    }
+    float* cur = dxp;
+    float* other = dy;
+    DM_TRY(dm_panel_ln_bwd_launch(rows, hidden, out_dim, dout, out_dim, p->w[layers], a.xpre[layers - 1],
+                                  a.stats[layers - 1], p->ln_g[layers - 1], p->ln_b[layers - 1], cur,
+                                  colpart + (size_t)(layers - 1) * npanels * 3 * hidden, st));
+    for (int l = layers - 1; l >= 0; --l) {
+      const float* in = l == 0 ? x : a.y[l - 1];
+      const int ldin = l == 0 ? ldx : hidden;
+      const int kin = l == 0 ? in_dim : hidden;
+      DmGemm q;   // dW_l[h][i] = sum_r dxp_l[r][h] in[r][i]
+      q.a_layout = 1; q.b_layout = 1;
+      q.M = hidden; q.N = kin; q.K = rows;
+      q.A = cur; q.lda = hidden;
+      q.B = in; q.ldb = ldin;
+      q.C = g->w[l]; q.ldc = kin;
+      DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+      if (l > 0) {
+        DM_TRY(dm_panel_ln_bwd_launch(rows, hidden, hidden, cur, hidden, p->w[l], a.xpre[l - 1], a.stats[l - 1],
+                                      p->ln_g[l - 1], p->ln_b[l - 1], other, colpart + (size_t)(l - 1) * npanels * 3 * hidden,
+                                      st));
+        float* t = cur; cur = other; other = t;
+      } else if (dx) {
+        DmGemm d;   // d(in)[r][i] = sum_h dxp_0[r][h] W_0[h][i]
+        d.a_layout = 0; d.b_layout = 1;
+        d.M = rows; d.N = kin; d.K = hidden;
+        d.A = cur; d.lda = hidden;
+        d.B = p->w[0]; d.ldb = kin;
+        d.C = dx; d.ldc = lddx; d.flags = dx_accum ? DM_GEMM_ACCUM : 0;
+        DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+      }
+    }
+    const float* parts[3 * DM_MAX_MLP_LAYERS];
+    float* outs[3 * DM_MAX_MLP_LAYERS];
+    for (int l = 0; l < layers; ++l) {
+      const float* base = colpart + (size_t)l * npanels * 3 * hidden;
+      parts[3 * l + 0] = base;              outs[3 * l + 0] = g->b[l];
+      parts[3 * l + 1] = base + hidden;     outs[3 * l + 1] = g->ln_g[l];
+      parts[3 * l + 2] = base + 2 * hidden; outs[3 * l + 2] = g->ln_b[l];
+    }
+    return dm_panel_colsum_final_launch(3 * layers, parts, outs, hidden, npanels, 3 * hidden, st);
+  }
 
   // output layer
   {

@@ -86,6 +86,7 @@ _SIGNATURES = {
     'dm_im2col_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     'dm_col2im_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
     'dm_mlp_acts_floats': (c_size_t, [c_int, c_int, c_int]),
+    'dm_mlp_ws_floats': (c_size_t, [c_int, c_int, c_int]),
     'dm_mlp_head_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P,
                                 c_size_t, _P]),
     'dm_mlp_head_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P,

@@ -128,10 +128,15 @@ class MLP(_Params):
     def acts_floats(self, rows):
         return int(H.lib().dm_mlp_acts_floats(rows, self.hidden_dim, self.hidden_layers))
 
-    def fwd(self, x2d, ldx, rows, ws, acts=None):
-        """x2d: device tensor whose rows (leading dim ldx floats) hold in_dim features. Returns (out, acts)."""
-        if acts is None:
+    def fwd(self, x2d, ldx, rows, ws, acts=None, save_acts=True):
+        """x2d: device tensor whose rows (leading dim ldx floats) hold in_dim features. Returns (out, acts).
+        save_acts=False (heads nobody differentiates: critic_target, the dream's reward / terminal heads, inference):
+        no activation buffer is allocated or written; the library ping-pongs through the workspace."""
+        if acts is None and save_acts:
             acts = torch.empty(self.acts_floats(rows), device=x2d.device)
+        need = 4 * int(H.lib().dm_mlp_ws_floats(rows, self.hidden_dim, self.hidden_layers))
+        if ws.numel() < need:
+            raise H.DreamerHipError(f'MLP.fwd: workspace of {ws.numel()} bytes, need {need} for {rows} rows')
         out = torch.empty(rows, self.out_dim, device=x2d.device)
         st = self.struct()
         H.call('dm_mlp_head_fwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
@@ -778,8 +783,8 @@ class WorldModel(_Params):
             image_pred = torch.empty_like(pk['image'])
             H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(fp), F_, H.fptr(pk['image']), ctypes.byref(dec_p),
                    H.fptr(acts), H.fptr(li), H.fptr(image_pred), H.ptr(ws), ws.numel(), H.stream())
-            mu, _ = dec.reward.model.fwd(fp, F_, N, ws)
-            tl, _ = dec.terminal.model.fwd(fp, F_, N, ws)
+            mu, _ = dec.reward.model.fwd(fp, F_, N, ws, save_acts=False)
+            tl, _ = dec.terminal.model.fwd(fp, F_, N, ws, save_acts=False)
             lr, lt, rp, tp, scratch = (torch.empty(N, device=dev) for _ in range(5))
             loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
             H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(obs['reward'].float().contiguous()), 0.0, loss_const, H.fptr(lr),
@@ -898,7 +903,7 @@ class ActorCritic(_Params):
         if ws is None:
             raise H.DreamerHipError('ActorCritic.training_step needs the model workspace (called through Dreamer.training_step)')
 
-        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws)
+        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws, save_acts=False)
         value, c_acts = self.critic.fwd(feats, F_, J * M, ws)
         if actor_acts is not None:
             logits, a_acts = actor_logits, actor_acts
@@ -1004,8 +1009,8 @@ class Dreamer(nn.Module):
         feat = features.reshape(B, -1)
         shp = self.wm.shape(1, B, 1)
         ws = self.wm.workspace(shp, feat.device)
-        logits, _ = self.ac.actor.fwd(feat, feat.shape[1], B, ws)
-        value, _ = self.ac.critic.fwd(feat, feat.shape[1], B, ws)
+        logits, _ = self.ac.actor.fwd(feat, feat.shape[1], B, ws, save_acts=False)
+        value, _ = self.ac.critic.fwd(feat, feat.shape[1], B, ws, save_acts=False)
         action_distr = _torch_actor_distribution(self.ac.actor_dist, logits.view(1, B, -1))
         return action_distr, out_state, dict(policy_value=value.mean())
 
@@ -1047,8 +1052,8 @@ class Dreamer(nn.Module):
                H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
         rows = (Hh + 1) * M
         f2 = feats.view(rows, F_)
-        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws)
-        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws)
+        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws, save_acts=False)
+        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws, save_acts=False)
         term = torch.empty(rows, device=dev)
         H.call('dm_head_loss', 1, rows, H.fptr(tl), None, 0.0, 0.0, None, None, H.fptr(term), H.stream())
         if _pack is not None:
@@ -1106,7 +1111,7 @@ class Dreamer(nn.Module):
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
                                   actor_logits=dpk['actor_logits'], overlap=ov)
         if ov is not None:
-            need = (int(H.DM_SPLITK_FLOATS) + 2 * ((imag_horizon + 1) * T * B * MLP_HIDDEN + 64) + 4096) * 4
+            need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B, MLP_HIDDEN, 4))
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
             ov.ev_fwd.record(torch.cuda.current_stream())

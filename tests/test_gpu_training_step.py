@@ -74,6 +74,38 @@ def test_mlp_head_fwd_bwd(hip):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
+@pytest.mark.parametrize('rows,in_dim,out_dim', [(16400, 136, 6), (16384, 1624, 1), (20000, 400, 18)])
+def test_mlp_head_panel_fwd_bwd(hip, rows, in_dim, out_dim):
+    """rows >= 16384: every Linear -> LayerNorm -> ELU is one row-panel launch (csrc/panel.hip), the output layer rides in
+    the last one's epilogue, and backward fuses dgrad + LayerNorm/ELU backward + the bias / gamma / beta column sums.
+    Ragged last panel (16400 = 256*64 + 16), K = 1 / 6 / 18 data-gradient products (unaligned scalar-load path).
+    Same tolerances as the GEMM + LayerNorm path's test above; also: the acts-free forward gives identical outputs."""
+    from pydreamer_amd.models import MLP
+    torch.manual_seed(1)
+    m = MLP(in_dim, out_dim, 400, 4).to(DEV)
+    with torch.no_grad():                      # non-trivial LayerNorm parameters
+        for i in range(4):
+            m.model[3 * i + 1].weight.uniform_(0.5, 1.5)
+            m.model[3 * i + 1].bias.uniform_(-0.5, 0.5)
+    x = torch.randn(rows, in_dim, device=DEV)
+    dout = torch.randn(rows, out_dim, device=DEV) / rows
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    out, acts = m.fwd(x, in_dim, rows, ws)
+    out2, none = m.fwd(x, in_dim, rows, ws, save_acts=False)
+    assert none is None and torch.equal(out, out2)
+    dx = torch.zeros(rows, in_dim, device=DEV)
+    grads, _, _ = m.bwd(x, in_dim, rows, acts, dout, ws, dx=dx, lddx=in_dim, dx_accum=False)
+    p = {f'h.{k}': v.detach().double().cpu().requires_grad_(True) for k, v in m.model.state_dict().items()}
+    xr = x.double().cpu().requires_grad_(True)
+    ref = O.mlp(p, 'h', xr, 4)
+    _close(out, ref.reshape(out.shape), 1e-4, 1e-5, 'panel mlp fwd')
+    ref.backward(dout.double().cpu().reshape(ref.shape))
+    assert _rel_l2(dx, xr.grad) < 1e-4, 'panel mlp dx'
+    for (name, _), g in zip(m.named_parameters(), grads):
+        key = 'h.' + name.replace('model.', '', 1)
+        assert _rel_l2(g, p[key].grad) < 1e-4, name
+
+
 def test_conv_encoder_fwd_bwd(hip):
     import ctypes
     from pydreamer_amd import hip as H
