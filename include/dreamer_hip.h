@@ -173,6 +173,9 @@ int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_p
 /* ConvDecoder + MSE (decoders.py:111-180): Linear F->32d, 4 x ConvTranspose2d (k 5,5,6,6; s2), ELU x3.
  * w[0],b[0] = Linear; w[1..4]: (Cin,Cout,k,k) torch layout.  loss_image[n] = 0.5*sum (pred-target)^2. */
 size_t dm_conv_decoder_acts_floats(const dm_shape* shp);
+/* float offset of the prediction (N, img, img, ch) NHWC inside `acts`: image_rec (decoders.py:177) is materialised by the
+ * caller only when somebody reads it (pass image_rec = NULL to the forward) */
+size_t dm_conv_decoder_pred_offset(const dm_shape* shp);
 int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
                             const dm_conv_params* p, float* acts, float* loss_image, float* image_rec /* nullable, NCHW */,
                             void* ws, size_t ws_bytes, void* stream);
@@ -249,9 +252,11 @@ int dm_critic_loss(int rows, const float* value, const float* value_target, cons
 /* out[i] = scale[i] * sum(x_i[0..n_i)) for up to 32 arrays in one launch (losses / metrics, dreamer.py:362-379, a2c.py:133-147). */
 typedef struct dm_reduce_item {
   const float* x; int64_t n; float scale;
-  int32_t mode;            /* 0: sum x ; 1: sum (x - *center)^2  (for reward1.std(), a2c.py:140) */
+  int32_t mode;            /* 0: sum x ; 1: sum (x - *center)^2 ; 2: sqrt(scale * sum (x - *center)^2)  (reward1.std(), a2c.py:140) */
   const float* center;     /* device scalar, mode 1 only */
 } dm_reduce_item;
+/* `out` is caller-provided: a step's losses and metrics are written side by side into ONE device buffer (Dreamer.metric_buffer),
+ * so the trainer's ~20 per-metric .item() syncs (train.py:204-214) become one copy. */
 int dm_multi_sum(int count, const dm_reduce_item* items /* host array */, float* out, void* stream);
 /* out[0] = sum_i w[i] * x[i]  (x device, w host; count <= 16): loss_model from its weighted terms (dreamer.py:362-365). */
 int dm_combine(int count, const float* x, const float* w, float* out, void* stream);

@@ -477,6 +477,20 @@ extern "C" size_t dm_conv_decoder_acts_floats(const dm_shape* shp) {
   return dec_carve(g, nullptr, 0, nullptr);
 }
 
+// Float offset, inside the `acts` buffer of dm_conv_decoder_mse_fwd, of the decoder's prediction (N, img, img, ch) NHWC:
+// lets the caller materialise `image_rec` (decoders.py:177) only when somebody reads it.
+extern "C" size_t dm_conv_decoder_pred_offset(const dm_shape* shp) {
+  if (!shp) return 0;
+  DecGeom g(shp);
+  size_t off = dm_align_up((size_t)g.N * g.cin[1], 64);                  // mirrors dec_carve
+  for (int l = 1; l <= 4; ++l) {
+    off += dm_align_up((size_t)g.cin[l] * g.k[l] * g.k[l] * g.cout[l], 64);
+    if (l == 4) break;
+    off += dm_align_up(g.rows_b[l] * g.cout[l], 64);
+  }
+  return off;
+}
+
 // Frames [n0, n0+n); buffers are the full-batch ones (see dm_conv_encoder_fwd_rows).  The patch-matrix workspace
 // scales with n, so a range stream needs only 1/chunks of the full-batch workspace.
 extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* feat, int ldf,

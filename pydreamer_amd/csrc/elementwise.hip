@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(256) multi_sum_kernel(const MultiSumArgs a, fl
   float s = 0.f;
   if (a.mode[item] == 0) {
     for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
-  } else {
+  } else {      // modes 1, 2: squared deviations from a device scalar
     const float c = a.center[item][0];
     for (long long i = threadIdx.x; i < n; i += 256) {
       const float d = x[i] - c;
@@ -966,7 +966,10 @@ __global__ void __launch_bounds__(256) multi_sum_kernel(const MultiSumArgs a, fl
   s = dm_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[item] = (red[0] + red[1] + red[2] + red[3]) * a.scale[item];
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1] + red[2] + red[3]) * a.scale[item];
+    out[item] = a.mode[item] == 2 ? sqrtf(v) : v;
+  }
 }
 extern "C" int dm_multi_sum(int count, const dm_reduce_item* items, float* out, void* stream) {
   DM_REQUIRE(items && out, DM_E_NULL, "multi_sum: null pointer");
@@ -974,7 +977,8 @@ extern "C" int dm_multi_sum(int count, const dm_reduce_item* items, float* out, 
   MultiSumArgs a;
   for (int i = 0; i < count; ++i) {
     DM_REQUIRE(items[i].x || items[i].n == 0, DM_E_NULL, "multi_sum: item %d null", i);
-    DM_REQUIRE(items[i].mode == 0 || (items[i].mode == 1 && items[i].center), DM_E_SHAPE, "multi_sum: item %d bad mode", i);
+    DM_REQUIRE(items[i].mode == 0 || ((items[i].mode == 1 || items[i].mode == 2) && items[i].center), DM_E_SHAPE,
+               "multi_sum: item %d bad mode", i);
     a.x[i] = items[i].x;
     a.center[i] = items[i].center;
     a.n[i] = items[i].n;

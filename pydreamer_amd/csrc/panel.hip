@@ -352,17 +352,30 @@ struct PanelFinalArgs {
   float* out[3 * DM_MAX_MLP_LAYERS];
   int count, n, npanels, pstride;
 };
-__global__ void __launch_bounds__(256) panel_colsum_final_kernel(const PanelFinalArgs a) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, cy = threadIdx.x >> 6;
+__global__ void __launch_bounds__(1024) panel_colsum_final_kernel(const PanelFinalArgs a) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, cy = threadIdx.x >> 6;      // 64 columns x 16 panel lanes, 4 loads in flight per lane
   const int col = blockIdx.x * 64 + cx;
-  const int t = blockIdx.y;
-  float s = 0.f;
-  if (col < a.n)
-    for (int p = cy; p < a.npanels; p += 4) s += a.part[t][(size_t)p * a.pstride + col];
-  red[cy][cx] = s;
+  const float* src = a.part[blockIdx.y] + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < a.n) {
+    int p = cy;
+    for (; p + 48 < a.npanels; p += 64) {
+      s0 += src[(size_t)p * a.pstride];
+      s1 += src[(size_t)(p + 16) * a.pstride];
+      s2 += src[(size_t)(p + 32) * a.pstride];
+      s3 += src[(size_t)(p + 48) * a.pstride];
+    }
+    for (; p < a.npanels; p += 16) s0 += src[(size_t)p * a.pstride];
+  }
+  red[cy][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (cy == 0 && col < a.n) a.out[t][col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (cy == 0 && col < a.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    a.out[blockIdx.y][col] = t;
+  }
 }
 
 // ---------------------------------------------------------------- host side ---------------------
@@ -423,7 +436,7 @@ int dm_panel_colsum_final_launch(int count, const float* const* part, float* con
   PanelFinalArgs a;
   for (int i = 0; i < count; ++i) { a.part[i] = part[i]; a.out[i] = out[i]; }
   a.count = count; a.n = n; a.npanels = npanels; a.pstride = pstride;
-  hipLaunchKernelGGL(panel_colsum_final_kernel, dim3(dm_cdiv(n, 64), count), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(panel_colsum_final_kernel, dim3(dm_cdiv(n, 64), count), dim3(1024), 0, st, a);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

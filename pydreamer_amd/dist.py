@@ -33,6 +33,19 @@ def attach(optimizers, local_batch, global_batch, group=None):
         opt.dp = (group, w)
 
 
+def allreduce_scratch_async(opt):
+    """Called on the side stream right after a pre-launched backward pass has been enqueued there (SURVEY.md 8(e):
+    "issued as soon as each backward finishes (wm first, overlapped with actor/critic backward)"): weights the rank's
+    gradient by B_r/B and starts the SUM all-reduce of the group's buffer; the handle is waited for in loss.backward()
+    (FusedAdamW.adopt_scratch), so grad_clip() finds the global-batch gradient already in place."""
+    if opt.dp is None:
+        return
+    group, w = opt.dp
+    if w != 1.0:
+        opt.scratch.mul_(w)
+    opt.early_reduce = dist.all_reduce(opt.scratch, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def allreduce_grads(opt):
     """grad <- sum_r (B_r/B) grad_r, in place on the flat buffer (one collective per optimizer group)."""
     group, w = opt.dp

@@ -60,14 +60,22 @@ class GraphedTrainStep:
             ac.train_steps = saved_steps
         losses, self.out_state, self.metrics, self.tensors, self.extra = out
         self.losses = tuple(x.detach() for x in losses)
+        # the captured graph bakes in raw pointers of lazily-grown buffers it does not own (workspaces of the
+        # world model and of the overlap streams, the optimizers' second gradient buffer).  Holding references here means a
+        # later, larger eager call allocates NEW buffers instead of freeing the captured ones under the graph's feet.
+        ov = model._overlap
+        self._keepalive = [model.wm._ws, getattr(ov, 'ws_wm', None), getattr(ov, 'ws_ac', None),
+                           (model.wm._pipe or {}).get('ws_chain'), (model.wm._pipe or {}).get('ws_dec'),
+                           [(o.flat_grad, o.scratch) for o in self.optimizers]]
 
     def __call__(self, obs, in_state, noise=None):
         """Same return value as Dreamer.training_step(); the four backward passes have already run (gradients are in the
         optimizers' flat buffers), so the caller continues with grad_clip() and optimizer.step()."""
         for k, dst in self.static_obs.items():
             src = obs[k]
-            if src.shape != dst.shape:
-                raise ValueError(f'obs[{k!r}] has shape {tuple(src.shape)}, the graph was captured for {tuple(dst.shape)}')
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError(f'obs[{k!r}] is {tuple(src.shape)} {src.dtype}, the graph was captured for '
+                                 f'{tuple(dst.shape)} {dst.dtype}')
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
         for dst, src in zip(self.static_state, in_state):
@@ -76,11 +84,20 @@ class GraphedTrainStep:
         if self.static_noise is not None:
             if noise is None:
                 raise ValueError('this graph was captured with explicit sampler noise: pass `noise` on every call')
+            missing = [k for k in self.static_noise if k not in noise]
+            if missing:
+                raise ValueError(f'noise is missing {missing} (the graph was captured with {sorted(self.static_noise)})')
             for k, dst in self.static_noise.items():
+                if noise[k].dtype != dst.dtype:
+                    raise ValueError(f'noise[{k!r}] is {noise[k].dtype}, the graph was captured with {dst.dtype}')
                 dst.copy_(noise[k].reshape(dst.shape), non_blocking=True)
+        elif noise is not None:
+            raise ValueError('this graph was captured WITHOUT explicit sampler noise (it draws its own): `noise` would be '
+                             'silently ignored - capture with an example `noise` dict to supply it per call')
         ac = self.model.ac
         if ac.train_steps % ac.target_interval == 0:        # a2c.py:68-70, host-side condition kept out of the graph
             ac.update_critic_target()
         ac.train_steps += 1
         self.graph.replay()
-        return self.losses, self.out_state, self.metrics, self.tensors, self.extra
+        tensors = self.tensors.copy() if hasattr(self.tensors, 'lazy') else self.tensors    # lazy entries re-read the new step
+        return self.losses, self.out_state, self.metrics, tensors, self.extra

@@ -100,6 +100,7 @@ _SIGNATURES = {
     'dm_conv_encoder_bwd': (c_int, [POINTER(dm_shape), _P, POINTER(dm_conv_params), _P, _P, POINTER(dm_conv_grads), _P,
                                     c_size_t, _P]),
     'dm_conv_decoder_acts_floats': (c_size_t, [POINTER(dm_shape)]),
+    'dm_conv_decoder_pred_offset': (c_size_t, [POINTER(dm_shape)]),
     'dm_conv_decoder_mse_fwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, _P, _P, _P,
                                         c_size_t, _P]),
     'dm_conv_decoder_mse_fwd_rows': (c_int, [POINTER(dm_shape), c_int, c_int, c_int, _P, c_int, _P, POINTER(dm_conv_params),

@@ -350,22 +350,32 @@ def _flat_views(plist, device, fused=None, scratch=False):
     return flat, views, False
 
 
-def _multi_sum(items, device):
-    """items: list of (tensor, scale) or (tensor, scale, center_tensor) -> 1-D tensor of results."""
+def _multi_sum(items, device, out=None):
+    """items: list of (tensor, scale) or (tensor, scale, center_tensor[, mode]) -> 1-D tensor of results (written into `out`,
+    a slice of the step's metric buffer, when given)."""
     arr = (H.dm_reduce_item * len(items))()
     for i, it in enumerate(items):
         arr[i].x = it[0].data_ptr()
         arr[i].n = it[0].numel()
         arr[i].scale = it[1]
         if len(it) > 2:
-            arr[i].mode = 1
+            arr[i].mode = it[3] if len(it) > 3 else 1
             arr[i].center = it[2].data_ptr()
         else:
             arr[i].mode = 0
             arr[i].center = None
-    out = torch.empty(len(items), device=device)
+    if out is None:
+        out = torch.empty(len(items), device=device)
+    assert out.numel() == len(items) and out.is_contiguous()
     H.call('dm_multi_sum', len(items), arr, H.fptr(out), H.stream())
     return out
+
+
+# One device buffer per step for every loss / metric scalar (SURVEY 8(f) N2): slot layout
+METRIC_SLOTS = dict(loss_kl=0, loss_image=1, loss_reward=2, loss_terminal=3, entropy_prior=4, entropy_post=5, loss_model=6,
+                    loss_critic=8, loss_actor=9, policy_entropy=10, policy_value=11, policy_value_im=12, policy_reward=13,
+                    policy_reward_std=14, grad_norm=16, grad_norm_probe=18, grad_norm_actor=20, grad_norm_critic=22)
+METRIC_BUF_FLOATS = 24
 
 
 def _finish_backward(owner, grads, flat, direct, grad_loss):
@@ -378,14 +388,21 @@ def _finish_backward(owner, grads, flat, direct, grad_loss):
             raise RuntimeError('the gradients pre-computed by this training_step() were overwritten by a later training_step() '
                                'before backward() was called; call backward() after each training_step(), or set '
                                'model.overlap_backward = False to compute gradients inside backward()')
-        if fused.fresh:                      # zero_grad() since the last write: '=' semantics, one scale+copy kernel
-            torch.mul(flat, gl, out=fused.flat_grad)
-            fused.fresh = False
-        else:                                # gradient accumulation
-            fused.flat_grad.addcmul_(flat, gl.expand_as(flat))
+        fused.adopt_scratch(gl)              # buffer swap ('=' semantics) or accumulation; see FusedAdamW.adopt_scratch
         return tuple(None for _ in grads)
     H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
     return tuple(None for _ in grads) if direct else tuple(grads)
+
+
+def _prelaunched(owner, fn):
+    """Runs a pre-launched backward pass (on its side stream, from the launcher thread) and, under data parallelism,
+    starts the all-reduce of its gradient buffer right behind it on the same stream."""
+    out = fn()
+    fused = getattr(owner, '_fused', None)
+    if fused is not None and fused.dp is not None and out[1] is fused.scratch:
+        from . import dist as D
+        D.allreduce_scratch_async(fused)
+    return out
 
 
 class _Overlap:
@@ -444,6 +461,61 @@ def pack_metrics(*dicts):
             names.append(k)
             vals.append(v.detach().reshape(()).float())
     return names, (torch.stack(vals) if vals else torch.empty(0))
+
+
+class _Thunk:
+    __slots__ = ('fn',)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
+class LazyTensors(dict):
+    """The `tensors` dict of training_step() (train.py:218-221 logs it only when `will_log_batch`): values may be thunks
+    that are computed - and cached - the first time somebody reads them.  `image_rec` (123 MB at Atari-literal,
+    decoders.py:177) is the one that matters: it is no longer written on the steps that never look at it."""
+
+    def _resolve(self, k, v):
+        if isinstance(v, _Thunk):
+            v = v.fn()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def lazy(self, k, fn):
+        dict.__setitem__(self, k, _Thunk(fn))
+
+    def __getitem__(self, k):
+        return self._resolve(k, dict.__getitem__(self, k))
+
+    def __iter__(self):                     # overriding __iter__ also keeps dict(x) / {**x} off CPython's raw-copy fast path
+        return iter(list(dict.keys(self)))
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def pop(self, k, *default):
+        if k in self:
+            v = self[k]
+            dict.__delitem__(self, k)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(k)
+
+    def copy(self):
+        new = LazyTensors()
+        for k in dict.keys(self):
+            dict.__setitem__(new, k, dict.__getitem__(self, k))      # thunks stay thunks
+        return new
+
+    def is_materialised(self, k):
+        return not isinstance(dict.__getitem__(self, k), _Thunk)
 
 
 class _Done:
@@ -562,7 +634,7 @@ class WorldModel(_Params):
         return pk['feat'].view(T, B, 1, -1), pk['out_state']
 
     # ---- forward through the C-ABI
-    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False):
+    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False, mbuf=None):
         c = self.conf
         image, action = obs['image'], obs['action']
         _require_cuda(image, "obs['image']")
@@ -583,6 +655,22 @@ class WorldModel(_Params):
         action = action.float().contiguous()
         reset = obs['reset'].to(torch.uint8).contiguous()
         h0, z0 = (x.float().contiguous() for x in in_state)
+        # the C side sizes every access from dm_shape alone: check what the caller handed over before packing pointers
+        want = dict(image=(T, B, c.image_channels, c.image_size, c.image_size), action=(T, B, c.action_dim), reset=(T, B))
+        got = dict(image=tuple(image.shape), action=tuple(action.shape), reset=tuple(reset.shape))
+        for k in ('reward', 'terminal'):
+            if not forward_only or k in obs:
+                if k in obs:
+                    want[k], got[k] = (T, B), tuple(obs[k].shape)
+        want['in_state[0]'], got['in_state[0]'] = (B, D_), tuple(h0.shape)
+        want['in_state[1]'], got['in_state[1]'] = (B, Z), tuple(z0.shape)
+        if u_post is not None:
+            want['u_post numel'], got['u_post numel'] = T * B * c.stoch_dim, u_post.numel()
+        if forced_idx is not None:
+            want['forced_idx'], got['forced_idx'] = (T, B, c.stoch_dim), tuple(forced_idx.shape)
+        bad = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+        if bad:
+            raise ValueError('training_step input shapes (got, expected): ' + ', '.join(f'{k}: {v[0]} != {v[1]}' for k, v in bad.items()))
         if u_post is None and forced_idx is None:
             u_post = torch.rand(T, B, c.stoch_dim, device=dev)
         lib = H.lib()
@@ -618,7 +706,7 @@ class WorldModel(_Params):
         if not forward_only:
             dec_acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
             loss_image = torch.empty(N, device=dev)
-            image_rec = torch.empty_like(image)
+            image_rec = None          # materialised lazily from the decoder's saved prediction (see LazyTensors)
 
         chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop) else 1
         if chunks <= 1:
@@ -630,7 +718,7 @@ class WorldModel(_Params):
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
             if not forward_only:
                 H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(image), ctypes.byref(dec_p),
-                       H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(), H.stream())
+                       H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(), H.stream())
         else:
             # Time-chunk pipeline over three streams: the posterior loop is a latency chain of T x ~10 small kernels
             # (rssm.py:38-58) that leaves most CUs idle, so the encoder of chunk i+1 and the decoder of chunk i-1 run
@@ -640,7 +728,7 @@ class WorldModel(_Params):
             H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(image), ctypes.byref(enc_p),
                    H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
             H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(feat), F_, H.fptr(image),
-                   ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec), H.ptr(ws), ws.numel(),
+                   ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(),
                    H.stream())
             pp['ev_prep'].record(main)
             pp['s_chain'].wait_event(pp['ev_prep'])
@@ -659,7 +747,7 @@ class WorldModel(_Params):
                 pp['s_dec'].wait_event(pp['ev_chain'][i])
                 with torch.cuda.stream(pp['s_dec']):
                     H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.fptr(feat), F_,
-                           H.fptr(image), ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), H.fptr(image_rec),
+                           H.fptr(image), ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), None,
                            H.ptr(pp['ws_dec']), pp['ws_dec'].numel(), H.stream())
             main.wait_stream(pp['s_chain'])
             main.wait_stream(pp['s_dec'])
@@ -688,19 +776,29 @@ class WorldModel(_Params):
         H.call('dm_kl_balance_fwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(post), H.fptr(prior), H.fptr(kl),
                H.fptr(ent_post), H.fptr(ent_prior), H.stream())
 
+        if mbuf is None:
+            mbuf = torch.zeros(METRIC_BUF_FLOATS, device=dev)
         means = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
-                            (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev)
-        loss = torch.empty((), device=dev)
+                            (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev, out=mbuf[0:6])
+        loss = mbuf[6]
         w = (ctypes.c_float * 4)(self.kl_weight, dec.image_weight, dec.reward_weight, dec.terminal_weight)
-        H.call('dm_combine', 4, H.fptr(means), w, H.fptr(loss), H.stream())     # dreamer.py:362-365
+        H.call('dm_combine', 4, H.fptr(means), w, ctypes.c_void_p(mbuf.data_ptr() + 24), H.stream())     # dreamer.py:362-365
 
         pk.update(loss=loss, image=image, action=action, reset=reset, enc_acts=enc_acts, rssm_acts=rssm_acts,
-                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws)
+                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws, mbuf=mbuf)
         tb = lambda x: x.view(T, B)
-        pk['tensors'] = dict(loss_kl=tb(kl), entropy_prior=tb(ent_prior), entropy_post=tb(ent_post),
-                             loss_image=tb(loss_image), image_rec=image_rec.view(T, B, *image.shape[-3:]),
-                             loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
-                             loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
+        pk['tensors'] = LazyTensors(loss_kl=tb(kl), entropy_prior=tb(ent_prior), entropy_post=tb(ent_post),
+                                    loss_image=tb(loss_image), image_rec=None,
+                                    loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
+                                    loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
+        Cc, hw = image.shape[-3], image.shape[-2] * image.shape[-1]
+        pred_off = int(lib.dm_conv_decoder_pred_offset(ctypes.byref(shp)))
+
+        def image_rec_thunk(acts=dec_acts):       # holds the decoder activations alive until the dict is dropped
+            with torch.no_grad():
+                pred = acts[pred_off:pred_off + N * hw * Cc].view(N, hw, Cc)                       # NHWC
+                return pred.transpose(1, 2).contiguous().view(T, B, Cc, *image.shape[-2:])         # -> (T,B,C,H,W)
+        pk['tensors'].lazy('image_rec', image_rec_thunk)
         pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
                              loss_image=means[1], loss_reward=means[2], loss_terminal=means[3])
         return pk
@@ -805,7 +903,7 @@ class WorldModel(_Params):
         return metrics, tensors, idx
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
-                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None):
+                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
         if iwae_samples != 1:
             raise NotImplementedError('iwae_samples>1 is an evaluation variant not built yet')
@@ -816,7 +914,7 @@ class WorldModel(_Params):
         if forward_only:
             feats, out_state = self.forward(obs, in_state)
             return torch.tensor(0.0), feats, None, out_state, {}, {}
-        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop)
+        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop, mbuf=mbuf)
         loss = _WMStep.apply(self, pk, *self._param_order())
         D_ = self.deter_dim
         feat = pk['feat']
@@ -826,7 +924,7 @@ class WorldModel(_Params):
         if do_image_pred:
             m, t, pk['pred_idx'] = self._image_pred(pk, obs, u_pred)
             pk['metrics'] = dict(pk['metrics'], **m)
-            pk['tensors'] = dict(pk['tensors'], **t)
+            pk['tensors'].update(t)
         return loss, features, states, pk['out_state'], pk['metrics'], pk['tensors']
 
 
@@ -883,7 +981,7 @@ class ActorCritic(_Params):
                 H.call('dm_copy_params', H.fptr(dst), H.fptr(src), dst.numel(), H.stream())
 
     def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None,
-                      actor_acts=None, actor_logits=None, overlap=None):
+                      actor_acts=None, actor_logits=None, overlap=None, mbuf=None):
         """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149.
         actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
         features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
@@ -928,9 +1026,11 @@ class ActorCritic(_Params):
                    H.stream())
         value2d = value.view(J, M)
         reward1 = rewards.view(J, M)[1:]
+        if mbuf is None:
+            mbuf = torch.zeros(METRIC_BUF_FLOATS, device=dev)
         s = _multi_sum([(lc, 1.0 / rows), (la, 1.0 / rows), (ent, 1.0 / rows), (value2d[0], 1.0 / M),
-                        (value2d[:-1], 1.0 / rows), (reward1, 1.0 / rows)], dev)
-        var = _multi_sum([(reward1, 1.0 / max(rows - 1, 1), s[5:6])], dev)
+                        (value2d[:-1], 1.0 / rows), (reward1, 1.0 / rows)], dev, out=mbuf[8:14])
+        std = _multi_sum([(reward1, 1.0 / max(rows - 1, 1), s[5:6], 2)], dev, out=mbuf[14:15])   # unbiased std (a2c.py:140)
         loss_critic_v, loss_actor_v = s[0], s[1]
         if log_only:
             loss_actor, loss_critic = loss_actor_v, loss_critic_v
@@ -942,7 +1042,7 @@ class ActorCritic(_Params):
             loss_critic = _HeadLoss.apply(self.critic, pc, *self.critic.param_list())
             self._last_packs = (pa, pc)
         metrics = dict(loss_critic=loss_critic_v, loss_actor=loss_actor_v, policy_entropy=s[2], policy_value=s[3],
-                       policy_value_im=s[4], policy_reward=s[5], policy_reward_std=var[0].sqrt())
+                       policy_value_im=s[4], policy_reward=s[5], policy_reward_std=std[0])
         tensors = dict(value=value2d, value_target=vtgt, value_advantage=adv, value_advantage_gae=agae, value_weight=wgt)
         return (loss_actor, loss_critic), metrics, tensors
 
@@ -992,9 +1092,23 @@ class Dreamer(nn.Module):
         if getattr(self, '_opt', None) is None:
             raise RuntimeError('call init_optimizers() before grad_clip(): clipping runs on the optimizers\' flat buffers')
         o = self._opt
-        return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip), grad_norm_probe=o['probe'].clip_grad_norm(grad_clip),
-                    grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip),
-                    grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip))
+        mb = getattr(self, 'metric_buffer', None)
+        if mb is not None and mb.device != o['wm'].flat_grad.device:
+            mb = None
+        out = lambda name: None if mb is None else mb[METRIC_SLOTS[name]:METRIC_SLOTS[name] + 2]   # [norm, clip coefficient]
+        return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip, out('grad_norm')),
+                    grad_norm_probe=o['probe'].clip_grad_norm(grad_clip, out('grad_norm_probe')),
+                    grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_actor')),
+                    grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_critic')))
+
+    def packed_metrics(self):
+        """(names, buffer): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
+        has run) as ONE 1-D device tensor - `dict(zip(names, buffer[idx].tolist()))` replaces the trainer's ~20 `.item()`
+        syncs per logged step (train.py:204-214) with a single copy.  No kernel runs here: the kernels of the step wrote
+        their results straight into this buffer."""
+        names = list(METRIC_SLOTS)
+        idx = torch.tensor([METRIC_SLOTS[n] for n in names])
+        return names, self.metric_buffer, idx
 
     def init_state(self, batch_size):
         return self.wm.init_state(batch_size)
@@ -1077,10 +1191,13 @@ class Dreamer(nn.Module):
         if u_post is not None:
             u_post = u_post.reshape(T, B, -1)
 
+        # every loss / metric scalar of this step lands in ONE device buffer (METRIC_SLOTS)
+        mbuf = torch.zeros(METRIC_BUF_FLOATS, device=obs['action'].device)
+        self.metric_buffer = mbuf
         loss_model, features, states, out_state, metrics, tensors = \
             self.wm.training_step(obs, in_state, iwae_samples=iwae_samples, do_open_loop=do_open_loop,
                                   do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
-                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'))
+                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf)
         pk = self.wm._last_pack
         ov = None
         if self.overlap_backward and torch.is_grad_enabled():
@@ -1089,13 +1206,17 @@ class Dreamer(nn.Module):
                 self._overlap = _Overlap(dev)
             ov = self._overlap
             pk['overlap'] = ov
+            for owner in (self.wm, self.ac.actor, self.ac.critic):      # main thread: zero_grad() may come before the
+                if getattr(owner, '_fused', None) is not None:          # launcher thread has claimed the buffers
+                    owner._fused._pending = True
             # world-model backward: on its own stream and workspace, concurrent with everything below
             need = pk['ws'].numel()
             if ov.ws_wm is None or ov.ws_wm.numel() < need:
                 ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
             ov.ev_wm_fwd.record(torch.cuda.current_stream())
-            pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: self.wm._backward(pk, ov.ws_wm, scratch=True))
-        metrics, tensors = dict(metrics), dict(tensors)
+            pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: _prelaunched(self.wm, lambda: self.wm._backward(
+                pk, ov.ws_wm, scratch=True)))
+        metrics, tensors = dict(metrics), tensors.copy()          # LazyTensors.copy(): image_rec stays a thunk
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)
         tensors.update(**tensors_probe)
@@ -1109,15 +1230,15 @@ class Dreamer(nn.Module):
         (loss_actor, loss_critic), metrics_ac, tensors_ac = \
             self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
-                                  actor_logits=dpk['actor_logits'], overlap=ov)
+                                  actor_logits=dpk['actor_logits'], overlap=ov, mbuf=mbuf)
         if ov is not None:
             need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B, MLP_HIDDEN, 4))
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
             ov.ev_fwd.record(torch.cuda.current_stream())
             for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
-                hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: mlp.bwd(
-                    hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True))
+                hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: _prelaunched(mlp, lambda: mlp.bwd(
+                    hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True)))
         metrics.update(**metrics_ac)
         tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
         self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,

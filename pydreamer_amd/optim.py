@@ -41,16 +41,46 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ws = torch.empty(4096, device=dev)
         self.step_count = 0
         self.dp = None                                    # set by dist.attach(): (process_group, weight)
-        self.fresh = False                                # flat_grad is all zero and nobody has written to it yet
-        self.scratch = None                               # same layout as flat_grad, for pre-launched backward passes
+        self.fresh = False                                # flat_grad is (logically) all zero and nobody has written to it yet
+        self._lazy_zero = False                           # ... but the memset was skipped (see zero_grad)
+        self.scratch = None                               # the OTHER gradient buffer: pre-launched backward passes write here
         self.scratch_gen = 0                              # bumped every time the scratch buffer is handed out
+        self._pending = False                             # a pre-launched backward result sits in `scratch`, not yet handed over
+        self.early_reduce = None                          # (work handle) all-reduce of `scratch` already in flight (dist.py)
+        self._reduced = False                             # flat_grad already holds the all-reduced gradient of this step
         self._ids = {id(p) for p in params}
         with torch.no_grad():
             for p, off in zip(params, self._offsets):
                 k = p.numel()
                 self.flat_param[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + k].view(p.shape)
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
+        self._grad_views = {}                             # buffer data_ptr -> per-parameter views of that buffer
+        self._point_grads(self.flat_grad)
+
+    def _views_of(self, buf):
+        v = self._grad_views.get(buf.data_ptr())
+        if v is None:
+            v = [buf[off:off + p.numel()].view(p.shape) for p, off in zip(self._plist, self._offsets)]
+            self._grad_views[buf.data_ptr()] = v
+        return v
+
+    def _point_grads(self, buf):
+        for p, g in zip(self._plist, self._views_of(buf)):
+            p.grad = g
+
+    def _check_params_are_views(self):
+        """anything that re-homes the parameters after init_optimizers() (model.to(...), .float(),
+        load_state_dict(assign=True), a second init_optimizers()) would leave step() updating a buffer nobody reads."""
+        base = self.flat_param.data_ptr()
+        for p, off in zip(self._plist, self._offsets):
+            if p.data_ptr() != base + 4 * off:
+                raise H.DreamerHipError('a parameter no longer aliases the optimizer\'s flat buffer (moved / cast / re-assigned '
+                                        'after init_optimizers()): call init_optimizers() again after moving the model')
+
+    def _ensure_zeroed(self):
+        if self._lazy_zero:
+            self.flat_grad.zero_()
+            self._lazy_zero = False
 
     def _grads_are_views(self):
         for p, off in zip(self._plist, self._offsets):
@@ -61,6 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _regather(self):
         """A caller replaced `.grad` (e.g. zero_grad(set_to_none=True) elsewhere): copy into the flat buffer and re-view."""
+        self._ensure_zeroed()
         with torch.no_grad():
             for p, off in zip(self._plist, self._offsets):
                 k = p.numel()
@@ -72,22 +103,61 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.grad = dst.view(p.shape)
 
     def zero_grad(self, set_to_none=False):
-        """Zeroes the flat gradient buffer and keeps the `.grad` views alive (set_to_none is ignored by design)."""
+        """Zeroes the flat gradient buffer and keeps the `.grad` views alive (set_to_none is ignored by design: the kernels
+        write into these views).  When a pre-launched backward result is waiting in the other buffer (the trainer's order is
+        training_step -> zero_grad -> backward, train.py:171-192) nothing is written at all: backward() will SWAP the two
+        buffers, so the 101 MB memset and the 2 x 101 MB hand-over copy of round 1 are gone; the memset is done lazily if
+        somebody needs real zeros first (clip / step / another backward path)."""
+        self._check_params_are_views()
         if not self._grads_are_views():
             self._regather()
-        self.flat_grad.zero_()
+        if self._pending and not torch.cuda.is_current_stream_capturing():
+            self._lazy_zero = True
+        else:
+            self.flat_grad.zero_()
+            self._lazy_zero = False
         self.fresh = True
+        self._reduced = False
 
     def scratch_views(self, plist):
-        """Per-parameter views of the persistent scratch gradient buffer (pad slots stay zero forever), or None if
-        `plist` is not exactly this group's parameter set."""
+        """Per-parameter views of the other gradient buffer (pad slots stay zero forever), or None if `plist` is not
+        exactly this group's parameter set."""
         if len(plist) != len(self._plist) or any(id(p) not in self._ids for p in plist):
             return None
         if self.scratch is None:
             self.scratch = torch.zeros_like(self.flat_grad)
-            self._off_of = {id(p): off for p, off in zip(self._plist, self._offsets)}
         self.scratch_gen += 1
-        return [self.scratch[self._off_of[id(p)]:self._off_of[id(p)] + p.numel()].view(p.shape) for p in plist]
+        self._pending = True
+        self.early_reduce = None
+        by_id = {id(p): v for p, v in zip(self._plist, self._views_of(self.scratch))}
+        return [by_id[id(p)] for p in plist]
+
+    def adopt_scratch(self, gl):
+        """Hand-over of a pre-launched backward result (called from loss.backward()): with '=' semantics (zero_grad since the
+        last write) the two buffers swap roles - no copy; otherwise (gradient accumulation) it is added.  `gl` is the
+        incoming scalar gradient as a 1-element device tensor (1.0 unless a GradScaler is active): the in-place scale
+        kernel returns at once when it is exactly 1."""
+        self._pending = False
+        work, self.early_reduce = self.early_reduce, None
+        if work is not None:
+            work.wait()                                   # the all-reduce of `scratch` issued right after its backward
+        if self.fresh and not torch.cuda.is_current_stream_capturing():
+            self.flat_grad, self.scratch = self.scratch, self.flat_grad
+            self._point_grads(self.flat_grad)
+            self._lazy_zero = False
+            H.call('dm_scale_inplace', H.fptr(self.flat_grad), self.numel, H.fptr(gl), H.stream())
+            self._reduced = work is not None
+        elif self.fresh:                                  # inside a graph capture: fixed addresses, so copy
+            self._ensure_zeroed()
+            torch.mul(self.scratch, gl, out=self.flat_grad)
+        else:                                             # accumulation onto gradients that are already there
+            self._ensure_zeroed()
+            if work is not None and self.dp is not None and not self._reduced:
+                from . import dist as D
+                D.allreduce_grads(self)                   # what is there has not been reduced yet; the addend has
+                self._reduced = True
+            self.flat_grad.addcmul_(self.scratch, gl.expand_as(self.scratch))
+        self.fresh = False
 
     def claim_fresh_grads(self, plist):
         """For a backward pass that produces the gradients of EXACTLY this group's parameters with '=' semantics: if the
@@ -96,28 +166,34 @@ class FusedAdamW(torch.optim.Optimizer):
             return None
         if not self._grads_are_views():
             return None
+        self._ensure_zeroed()
         self.fresh = False
         return [p.grad for p in plist]
 
-    def clip_grad_norm(self, max_norm):
-        """clip_grad_norm_ on the flat buffer: returns the pre-clip total norm as a 0-d device tensor (no host sync)."""
+    def clip_grad_norm(self, max_norm, out=None):
+        """clip_grad_norm_ on the flat buffer: returns the pre-clip total norm as a 0-d device tensor (no host sync).
+        out: optional 2-float device slice receiving [norm, clip coefficient] (the step's metric buffer)."""
         if not self._grads_are_views():
             self._regather()
-        if self.dp is not None:
+        self._ensure_zeroed()
+        if self.dp is not None and not self._reduced:
             from . import dist as D
             D.allreduce_grads(self)
-        H.call('dm_multi_tensor_norm_clip', H.fptr(self.flat_grad), self.numel, float(max_norm), H.fptr(self.norm_buf),
+        self._reduced = False
+        nb = self.norm_buf if out is None else out
+        H.call('dm_multi_tensor_norm_clip', H.fptr(self.flat_grad), self.numel, float(max_norm), H.fptr(nb),
                H.fptr(self._ws), self._ws.numel() * 4, H.stream())
-        H.call('dm_scale_inplace', H.fptr(self.flat_grad), self.numel, ctypes.c_void_p(self.norm_buf.data_ptr() + 4),
-               H.stream())
-        return self.norm_buf[0].clone()
+        H.call('dm_scale_inplace', H.fptr(self.flat_grad), self.numel, ctypes.c_void_p(nb.data_ptr() + 4), H.stream())
+        return nb[0].clone() if out is None else nb[0]
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError('closures are not used by the trainer section (train.py:193-198)')
+        self._check_params_are_views()
         if not self._grads_are_views():
             self._regather()
+        self._ensure_zeroed()
         g = self.param_groups[0]
         self.step_count += 1
         H.call('dm_adamw_step', H.fptr(self.flat_param), H.fptr(self.flat_grad), H.fptr(self.exp_avg),

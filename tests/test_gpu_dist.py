@@ -1,0 +1,118 @@
+"""-m gpu: the data-parallel step through the REAL optimizer path (FusedAdamW + pydreamer_amd.dist), two ranks.
+
+With >= 2 visible GPUs the ranks run one per GPU over RCCL ("nccl"); on a 1-GPU box both ranks share cuda:0 and talk
+over gloo (which all-reduces CUDA tensors through host staging) - the same FusedAdamW.clip_grad_norm / early
+all-reduce code runs either way.  Bars: posterior indices of every shard bit-identical to the matching
+columns of the 1-rank run (uniforms are sliced from the global layout); parameters after clip + AdamW within 1e-5."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _slice_noise(noise, T, B, S, Hh, lo, hi):
+    return dict(u_post=noise['u_post'][:, lo:hi].contiguous(),
+                u_act=noise['u_act'].view(Hh, T, B)[:, :, lo:hi].reshape(Hh, -1).contiguous(),
+                u_prior=noise['u_prior'].view(Hh, T, B, S)[:, :, lo:hi].reshape(Hh, -1, S).contiguous())
+
+
+def _one_step(model, conf, opts, obs, noise, steps=2):
+    out = None
+    state = model.init_state(obs['action'].shape[1])
+    for _ in range(steps):                          # 2 steps: the second one runs the steady-state buffer-swap path
+        losses, state, metrics, tensors, _ = model.training_step(obs, state, noise=noise)
+        for opt in opts:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
+        gm = model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+        for opt in opts:
+            opt.step()
+        out = (gm, model.last_extras['post_idx'].clone())
+    return out
+
+
+def _worker(rank, world, port, overlap, out):
+    import torch.distributed as dist
+    from oracle import dreamer_oracle as O
+    from pydreamer_amd import config
+    from pydreamer_amd import dist as DP
+    from pydreamer_amd.models import Dreamer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    ndev = torch.cuda.device_count()
+    backend = 'nccl' if ndev >= world else 'gloo'
+    dev = torch.device('cuda', rank % ndev)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        oconf = O.tiny_conf(batch_size=5, batch_length=4, imag_horizon=3)
+        T, B, S, Hh = oconf.batch_length, oconf.batch_size, oconf.stoch_dim, oconf.imag_horizon
+        params = O.make_params(oconf, seed=2)
+        obs = {k: v.to(dev) for k, v in O.preprocess(O.synthetic_batch(oconf), oconf).items()}
+        noise = {k: v.to(dev) for k, v in O.make_noise(oconf).items()}
+        lo, hi = DP.shard_bounds(B, world, rank)
+        c = O.make_conf(**{**vars(oconf), 'batch_size': hi - lo})
+        conf = config.load_config('defaults', 'atari', **{k: getattr(c, k) for k in vars(c)})
+        model = Dreamer(conf)
+        model.load_state_dict(params, strict=True)
+        model = model.to(dev)
+        model.overlap_backward = overlap
+        opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+        DP.attach(opts, hi - lo, B)
+        assert opts[0].dp is not None
+        shard, _ = DP.shard_obs(obs, world, rank)
+        gm, idx = _one_step(model, conf, opts, shard, _slice_noise(noise, T, B, S, Hh, lo, hi))
+        torch.cuda.synchronize()
+        out[rank] = dict(lo=lo, hi=hi, idx=idx.cpu(), params=[o.flat_param.cpu() for o in opts],
+                         norms={k: float(v) for k, v in gm.items()}, backend=backend)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_two_rank_step_equals_one_rank(hip, overlap):
+    import torch.multiprocessing as mp
+    from oracle import dreamer_oracle as O
+    from pydreamer_amd import config
+    from pydreamer_amd.models import Dreamer
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), overlap, out), nprocs=world, join=True)
+    res = dict(out)
+    assert set(res) == {0, 1}
+    # the single-process run of the whole batch
+    oconf = O.tiny_conf(batch_size=5, batch_length=4, imag_horizon=3)
+    conf = config.load_config('defaults', 'atari', **{k: getattr(oconf, k) for k in vars(oconf)})
+    model = Dreamer(conf)
+    model.load_state_dict(O.make_params(oconf, seed=2), strict=True)
+    model = model.to('cuda')
+    model.overlap_backward = overlap
+    opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+    obs = {k: v.to('cuda') for k, v in O.preprocess(O.synthetic_batch(oconf), oconf).items()}
+    noise = {k: v.to('cuda') for k, v in O.make_noise(oconf).items()}
+    gm, idx = _one_step(model, conf, opts, obs, noise)
+    torch.cuda.synchronize()
+    for r in (0, 1):
+        lo, hi = res[r]['lo'], res[r]['hi']
+        assert torch.equal(res[r]['idx'], idx[:, lo:hi].cpu()), f'rank {r}: posterior indices differ from the 1-rank run'
+        for i, (a, o) in enumerate(zip(res[r]['params'], opts)):
+            err = float((a - o.flat_param.cpu()).abs().max())
+            assert err < 1e-5, f'rank {r} group {i}: parameters after 2 steps differ by {err}'
+        for k, v in res[r]['norms'].items():
+            assert abs(v - float(gm[k])) <= 1e-4 * max(abs(float(gm[k])), 1e-6), (k, v, float(gm[k]))
+    # both ranks hold identical replicas
+    for a, b in zip(res[0]['params'], res[1]['params']):
+        assert torch.equal(a, b)

@@ -691,6 +691,59 @@ def test_pack_metrics(hip):
     assert names == ['x', 'y', 'z'] and packed.tolist() == [1.5, -2.0, 3.0] and packed.is_cuda
 
 
+def test_metric_buffer_and_lazy_tensors(hip):
+    """(1) every loss / metric scalar of a step, and the four gradient norms, sit in ONE device buffer
+    (Dreamer.packed_metrics) - parity of that buffer against the oracle's metrics at the loss tolerances; (2) `image_rec` is
+    not materialised unless somebody reads it, and when read it equals the oracle's reconstruction."""
+    from pydreamer_amd.models import METRIC_SLOTS
+    oconf = O.tiny_conf()
+    params = O.make_params(oconf)
+    model = _build(oconf, params)
+    conf = _hip_conf(oconf)
+    opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+    obs = O.preprocess(O.synthetic_batch(oconf), oconf)
+    noise = O.make_noise(oconf)
+    losses, _, metrics, tensors, _ = model.training_step(_to_dev(obs), model.init_state(oconf.batch_size), noise=_to_dev(noise))
+    assert not tensors.is_materialised('image_rec')
+    for opt in opts:
+        opt.zero_grad()
+    for loss in losses:
+        loss.backward()
+    gm = model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+    names, buf, idx = model.packed_metrics()
+    vals = dict(zip(names, buf[idx.to(buf.device)].tolist()))          # ONE device->host copy for everything
+    ora = O.OracleDreamer(oconf, params)
+    ora.init_optimizers()
+    lo, _, mo, to, _ = ora.training_step(obs, ora.init_state(oconf.batch_size), noise)
+    gmo, _ = ora.backward_clip_step(lo)
+    for k, v in mo.items():
+        assert k in vals, k
+        assert abs(vals[k] - float(v)) <= 2e-5 * abs(float(v)) + 2e-6, (k, vals[k], float(v))
+    for k, v in gmo.items():
+        assert abs(vals[k] - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, (k, vals[k], float(v))
+    for k, v in {**metrics, **gm}.items():                            # the dict views alias the same buffer
+        assert float(v) == vals[k], k
+    assert set(METRIC_SLOTS) == set(names)
+    rec = tensors['image_rec']
+    assert tensors.is_materialised('image_rec') and rec.shape == to['image_rec'].shape
+    _close(rec, to['image_rec'], 1e-4, 2e-5, 'lazy image_rec')
+    assert dict(tensors)['image_rec'] is rec                            # plain-dict conversion resolves, never leaks a thunk
+
+
+def test_optimizer_detects_rehomed_parameters(hip):
+    """moving / casting the model after init_optimizers() must fail loudly instead of training a dead copy."""
+    from pydreamer_amd.optim import FusedAdamW
+    w = torch.nn.Parameter(torch.randn(10, 7, device=DEV))
+    opt = FusedAdamW([w], lr=1e-3)
+    opt.zero_grad()
+    w.grad.add_(1.0)
+    opt.step()                                    # fine
+    w.data = w.data.clone()                       # what model.to(...) / .float() / load_state_dict(assign=True) do
+    with pytest.raises(Exception) as e:
+        opt.step()
+    assert 'flat buffer' in str(e.value)
+
+
 def test_amp_against_reference_autocast_golden(hip):
     """tests/golden/tiny_amp.npz: the real reference's forward under torch.autocast('cpu', bfloat16) (its amp switch,
     train.py:166) and in fp32 on the same batch.  The build's mixed-precision mode rounds GEMM operands only (autocast
