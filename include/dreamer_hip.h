@@ -49,8 +49,12 @@ typedef struct dm_shape {
   int32_t mlp_layers;       /* 4  (defaults.yaml:83,85; a2c.py:17) */
   int32_t cnn_depth;        /* 48 */
   int32_t img, img_ch;      /* 64, 3 */
-  int32_t flags;            /* bits 0-1: actor distribution, 0 = onehot, 1 = tanh_normal, 2 = normal_tanh (a2c.py:43-55) */
+  int32_t flags;            /* bits 0-1: actor distribution, 0 = onehot, 1 = tanh_normal, 2 = normal_tanh (a2c.py:43-55);
+                               bit 4 (DM_FLAG_IMAGE_U8): the `image` / `target` pointers of the conv encoder / decoder are the
+                               replay's native uint8 (N,H,W,C) frames; x/255-0.5 and HWC->CHW (preprocessing.py:21-29) happen
+                               inside the first conv's patch loader and the MSE kernel */
 } dm_shape;
+#define DM_FLAG_IMAGE_U8 16
 
 /* ---------------------------------------------------------------- library ---------------------- */
 int dm_version(void);                 /* ABI version, currently 1 */
@@ -183,7 +187,10 @@ int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, int ldf, con
 int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, int prepare, const float* feat, int ldf,
                                  const float* target, const dm_conv_params* p, float* acts, float* loss_image,
                                  float* image_rec, void* ws, size_t ws_bytes, void* stream);
-/* dfeat (N,F) accumulated (+=) ; scale = image_weight / (T*B). */
+/* dfeat (N,F) accumulated (+=) ; scale = image_weight / (T*B).  _rows: an optional per-frame factor on top (IWAE weights). */
+int dm_conv_decoder_mse_bwd_rows(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                 const dm_conv_params* p, const float* acts, float scale, const float* row_scale,
+                                 const dm_conv_grads* g, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream);
 int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
                             const dm_conv_params* p, const float* acts, float scale,
                             const dm_conv_grads* g, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream);

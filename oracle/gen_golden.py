@@ -321,6 +321,16 @@ if __name__ == '__main__':
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],
             dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18), steps=1, slim=True)
+    if 'dmc_native' in which:
+        # BASELINE.json configs[4] at its native width: defaults+dmc (deter_dim 2048, tanh_normal actor) with
+        # actor_grad=reinforce, action_dim 6, B=50, T=50, H=15; slim fixture (several minutes per step on 8 vCPU)
+        run('dmc_native', ['defaults', 'dmc'],
+            dict(batch_size=50, batch_length=50, imag_horizon=15, action_dim=6, actor_grad='reinforce'), steps=1, slim=True)
+    if 'atari_amp' in which:
+        # BASELINE.json configs[2]: Atari-literal forward under torch.autocast('cpu', bfloat16) and in fp32 (slim: scalars +
+        # posterior indices)
+        run_amp('atari_literal_amp', ['defaults', 'atari'],
+                dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18))
     if 'debug' in which:
         # BASELINE.json configs[0]: defaults+atari+debug on CPU, B=4,T=10,H=5, discrete(6)
         run('debug_literal', ['defaults', 'atari', 'debug'],

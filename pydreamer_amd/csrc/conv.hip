@@ -49,6 +49,24 @@ __global__ void __launch_bounds__(256) im2col_s2_nchw_kernel(int n, int hb, int 
   }
 }
 
+// the same patch matrix straight from the replay's native uint8 (T,B,H,W,C) frames (preprocessing.py:21-29 `to_image`:
+// x/255 - 0.5 and HWC -> CHW happen HERE, in the first conv's patch loader - SURVEY 8(f) N1): the float image is never
+// materialised, the frames cross HBM as 1 byte per element.  col[(i,ys,xs)][(cc,ky,kx)] = u8[i, 2ys+ky, 2xs+kx, cc]/255 - 0.5
+__global__ void __launch_bounds__(256) im2col_s2_u8hwc_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
+                                                              const uint8_t* __restrict__ big, float* __restrict__ col) {
+  const size_t total = (size_t)n * hs * ws * c * k * k;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int kx = (int)(t % k); t /= k;
+    const int ky = (int)(t % k); t /= k;
+    const int cc = (int)(t % c); t /= c;
+    const int xs = (int)(t % ws); t /= ws;
+    const int ys = (int)(t % hs); t /= hs;
+    const int i = (int)t;
+    col[e] = (float)big[(((size_t)i * hb + (2 * ys + ky)) * wb + (2 * xs + kx)) * c + cc] / 255.0f - 0.5f;
+  }
+}
+
 // big[i,y,x,cc] = epi( bias[cc] + sum_{ky,kx : (y-ky),(x-kx) even, in range} col[(i,(y-ky)/2,(x-kx)/2)][(ky,kx,cc)] )
 template <int VEC>
 __global__ void __launch_bounds__(256) col2im_s2_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
@@ -208,20 +226,28 @@ static int conv_tables_launch(int n, int hb, int wb, int c, int k, int* rowoff, 
 // ---------------------------------------------------------------- MSE (decoders.py:163-167) -----
 // pred NHWC (n,hw,c), target NCHW (n,c,hw).  loss[n] = 0.5*sum (pred-target)^2 ; dpred = scale*(pred-target) (NHWC);
 // rec = pred in NCHW.  One block per frame, fixed reduction order.
+// U8: the target is the replay's uint8 HWC frame, converted on the fly (x/255 - 0.5); it shares the prediction's NHWC
+// index, so both streams are coalesced.  tdiv: iwae_samples (decoders.py:163-167 expands the target over I: prediction
+// frame i compares with target frame i / I);  row_scale (optional): per-frame factor on dpred (IWAE importance weights).
+template <bool U8>
 __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const float* __restrict__ pred,
-                                                        const float* __restrict__ target, float scale,
+                                                        const void* __restrict__ target_, int tdiv, float scale,
+                                                        const float* __restrict__ row_scale,
                                                         float* __restrict__ loss, float* __restrict__ dpred,
                                                         float* __restrict__ rec) {
   __shared__ float red[4];
   const int i = blockIdx.x;
   const int per = hw * c;
   const float* pr = pred + (size_t)i * per;
-  const float* tg = target + (size_t)i * per;
+  const float* tg = (const float*)target_ + (size_t)(i / tdiv) * per;
+  const uint8_t* tg8 = (const uint8_t*)target_ + (size_t)(i / tdiv) * per;
+  if (row_scale) scale *= row_scale[i];
   float s = 0.f;
   for (int e = threadIdx.x; e < per; e += 256) {
     const int pix = e / c, cc = e % c;
     const float pv = pr[e];
-    const float d = pv - tg[(size_t)cc * hw + pix];
+    const float tv = U8 ? (float)tg8[e] / 255.0f - 0.5f : tg[(size_t)cc * hw + pix];
+    const float d = pv - tv;
     s += d * d;
     if (dpred) dpred[(size_t)i * per + e] = scale * d;
     if (rec) rec[(size_t)i * per + (size_t)cc * hw + pix] = pv;
@@ -252,6 +278,16 @@ extern "C" int dm_preprocess_image_u8(int64_t n, int hw, int c, const uint8_t* s
   if (n == 0) return DM_OK;
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((size_t)n * hw * c)), dim3(256), 0, (hipStream_t)stream, (size_t)n,
                      hw, c, src, dst);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dm_shape.flags bit 4: `image` / `target` pointers are uint8 (N, H, W, C) frames (the replay's native format)
+static inline bool shape_u8(const dm_shape* s) { return (s->flags & DM_FLAG_IMAGE_U8) != 0; }
+static int mse_launch(bool u8, int n, int hw, int c, const float* pred, const void* target, int tdiv, float scale,
+                      const float* row_scale, float* loss, float* dpred, float* rec, hipStream_t st) {
+  if (u8) hipLaunchKernelGGL((mse_image_kernel<true>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, rec);
+  else hipLaunchKernelGGL((mse_image_kernel<false>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, rec);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -371,9 +407,18 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
   if (n == 0) return DM_OK;
   for (int l = 0; l < 4; ++l) {
     const size_t r0 = (size_t)n0 * g.hs[l] * g.hs[l];          // first patch row of the range in layer l
-    if (l == 0)
-      DM_TRY(dm_im2col_s2_launch(n, g.hb[0], g.hb[0], g.cin[0], 4, image + (size_t)n0 * g.ch * g.hb[0] * g.hb[0], 1,
-                                 a.xcol[0] + r0 * g.kdim[0], st));
+    if (l == 0) {
+      const size_t frame = (size_t)g.ch * g.hb[0] * g.hb[0];
+      if (shape_u8(shp)) {
+        const size_t total = (size_t)n * g.hs[0] * g.hs[0] * g.kdim[0];
+        hipLaunchKernelGGL(im2col_s2_u8hwc_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, g.hb[0], g.hb[0], g.cin[0], 4,
+                           g.hs[0], g.hs[0], (const uint8_t*)image + (size_t)n0 * frame, a.xcol[0] + r0 * g.kdim[0]);
+        DM_LAUNCH_CHECK();
+      } else {
+        DM_TRY(dm_im2col_s2_launch(n, g.hb[0], g.hb[0], g.cin[0], 4, image + (size_t)n0 * frame, 1,
+                                   a.xcol[0] + r0 * g.kdim[0], st));
+      }
+    }
     DmGemm q;
     q.a_layout = 0; q.b_layout = 0;
     q.M = n * g.hs[l] * g.hs[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
@@ -542,11 +587,14 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
                                a.x[l] + (size_t)n0 * g.hbg[l] * g.hbg[l] * g.cout[l], st));
   }
   if (loss_image || image_rec) {
+    // targets are indexed by frame / I (I = iwae_samples, decoders.py:163-167), so the kernel gets the full target base
     const size_t per = (size_t)g.hbg[4] * g.hbg[4] * g.ch;
-    hipLaunchKernelGGL(mse_image_kernel, dim3(n), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4] + n0 * per,
-                       target + n0 * per, 0.f, loss_image ? loss_image + n0 : nullptr, nullptr,
-                       image_rec ? image_rec + n0 * per : nullptr);
-    DM_LAUNCH_CHECK();
+    const int I = shp->I > 0 ? shp->I : 1;
+    DM_REQUIRE(n0 % I == 0, DM_E_SHAPE, "conv_decoder_fwd: frame range must start on a multiple of iwae_samples");
+    const void* tbase = shape_u8(shp) ? (const void*)((const uint8_t*)target + (size_t)(n0 / I) * per)
+                                      : (const void*)(target + (size_t)(n0 / I) * per);
+    DM_TRY(mse_launch(shape_u8(shp), n, g.hbg[4] * g.hbg[4], g.ch, a.x[4] + n0 * per, tbase, I, 0.f, nullptr,
+                      loss_image ? loss_image + n0 : nullptr, nullptr, image_rec ? image_rec + n0 * per : nullptr, st));
   }
   return DM_OK;
 }
@@ -558,9 +606,25 @@ extern "C" int dm_conv_decoder_mse_fwd(const dm_shape* shp, const float* feat, i
                                       loss_image, image_rec, ws, ws_bytes, stream);
 }
 
+static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                     const dm_conv_params* p, const float* acts, float scale, const float* row_scale,
+                                     const dm_conv_grads* gr, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream);
 extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, int ldf, const float* target,
                                        const dm_conv_params* p, const float* acts, float scale, const dm_conv_grads* gr,
                                        float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream) {
+  return conv_decoder_mse_bwd_impl(shp, feat, ldf, target, p, acts, scale, nullptr, gr, dfeat, lddf, ws, ws_bytes, stream);
+}
+// row_scale (N floats, nullable): per-frame factor on the image-loss gradient - the IWAE importance weights of
+// loss_model = -logavgexp(-loss_tbi) (dreamer.py:362-365, functions.py:97-102)
+extern "C" int dm_conv_decoder_mse_bwd_rows(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                            const dm_conv_params* p, const float* acts, float scale, const float* row_scale,
+                                            const dm_conv_grads* gr, float* dfeat, int lddf, void* ws, size_t ws_bytes,
+                                            void* stream) {
+  return conv_decoder_mse_bwd_impl(shp, feat, ldf, target, p, acts, scale, row_scale, gr, dfeat, lddf, ws, ws_bytes, stream);
+}
+static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int ldf, const float* target,
+                                     const dm_conv_params* p, const float* acts, float scale, const float* row_scale,
+                                     const dm_conv_grads* gr, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && feat && target && p && acts && gr && ws, DM_E_NULL, "conv_decoder_bwd: null pointer");
   DecGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry");
@@ -594,9 +658,8 @@ extern "C" int dm_conv_decoder_mse_bwd(const dm_shape* shp, const float* feat, i
 
   // G4 = scale * (pred - target), NHWC
   float* G = ga;
-  hipLaunchKernelGGL(mse_image_kernel, dim3(g.N), dim3(256), 0, st, g.hbg[4] * g.hbg[4], g.ch, a.x[4], target, scale,
-                     nullptr, G, nullptr);
-  DM_LAUNCH_CHECK();
+  DM_TRY(mse_launch(shape_u8(shp), g.N, g.hbg[4] * g.hbg[4], g.ch, a.x[4], (const void*)target, shp->I > 0 ? shp->I : 1, scale,
+                    row_scale, nullptr, G, nullptr, st));
   for (int l = 4; l >= 1; --l) {
     const int kk = g.k[l] * g.k[l];
     const int ncol = kk * g.cout[l];

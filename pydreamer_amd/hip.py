@@ -18,6 +18,7 @@ DM_MAX_MLP_LAYERS = 8
 DM_GEMM_ACCUM = 1
 DM_GEMM_ELU = 2
 DM_C2I_ELU = 1
+DM_FLAG_IMAGE_U8 = 16
 DM_SPLITK_FLOATS = 16 * 1024 * 1024    # split-K partial region carved at the front of every operator workspace
 
 RSSM_PARAM_ORDER = [
@@ -107,6 +108,8 @@ _SIGNATURES = {
                                              _P, _P, _P, _P, c_size_t, _P]),
     'dm_conv_decoder_mse_bwd': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, c_float,
                                         POINTER(dm_conv_grads), _P, c_int, _P, c_size_t, _P]),
+    'dm_conv_decoder_mse_bwd_rows': (c_int, [POINTER(dm_shape), _P, c_int, _P, POINTER(dm_conv_params), _P, c_float, _P,
+                                             POINTER(dm_conv_grads), _P, c_int, _P, c_size_t, _P]),
     'dm_rssm_acts_floats': (c_size_t, [POINTER(dm_shape)]),
     'dm_rssm_sequence_fwd': (c_int, [POINTER(dm_shape), _P, _P, _P, _P, _P, _P, _P, POINTER(dm_rssm_params), _P, _P, _P,
                                      _P, _P, _P, c_size_t, _P]),

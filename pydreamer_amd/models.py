@@ -643,20 +643,23 @@ class WorldModel(_Params):
         D_, Z, F_, E = c.deter_dim, c.stoch_dim * c.stoch_discrete, self.features_dim, self.encoder.out_dim
         shp = self.shape(T, B, imag_horizon)
         ws = self.workspace(shp, dev)
-        if image.dtype == torch.uint8:
-            # the replay's native frames (T,B,H,W,C) uint8: x/255-0.5 and HWC->CHW in one kernel (preprocessing.py:21-29)
-            if image.dim() != 5 or image.shape[-1] != c.image_channels:
-                raise ValueError(f'uint8 image must be (T,B,H,W,C) with C={c.image_channels}, got {tuple(image.shape)}')
-            src = image.contiguous()
-            image = torch.empty(T, B, c.image_channels, src.shape[2], src.shape[3], device=dev)
-            H.call('dm_preprocess_image_u8', T * B, src.shape[2] * src.shape[3], c.image_channels, H.ptr(src), H.fptr(image),
-                   H.stream())
-        image = image.float().contiguous()
+        u8 = image.dtype == torch.uint8
+        if u8:
+            # the replay's native frames (T,B,H,W,C) uint8 are consumed AS THEY ARE: x/255-0.5 and HWC->CHW
+            # (preprocessing.py:21-29) happen inside the first conv's patch loader and inside the MSE kernel
+            # (dm_shape.flags bit DM_FLAG_IMAGE_U8); no float image is ever written
+            if image.dim() != 5 or tuple(image.shape[2:]) != (c.image_size, c.image_size, c.image_channels):
+                raise ValueError(f'uint8 image must be (T,B,{c.image_size},{c.image_size},{c.image_channels}), got {tuple(image.shape)}')
+            image = image.contiguous()
+            shp.flags |= H.DM_FLAG_IMAGE_U8
+        else:
+            image = image.float().contiguous()
         action = action.float().contiguous()
         reset = obs['reset'].to(torch.uint8).contiguous()
         h0, z0 = (x.float().contiguous() for x in in_state)
         # the C side sizes every access from dm_shape alone: check what the caller handed over before packing pointers
-        want = dict(image=(T, B, c.image_channels, c.image_size, c.image_size), action=(T, B, c.action_dim), reset=(T, B))
+        want = dict(image=(T, B, c.image_size, c.image_size, c.image_channels) if u8 else
+                    (T, B, c.image_channels, c.image_size, c.image_size), action=(T, B, c.action_dim), reset=(T, B))
         got = dict(image=tuple(image.shape), action=tuple(action.shape), reset=tuple(reset.shape))
         for k in ('reward', 'terminal'):
             if not forward_only or k in obs:
@@ -710,14 +713,14 @@ class WorldModel(_Params):
 
         chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop) else 1
         if chunks <= 1:
-            H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
+            H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.ptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
                    H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
             embed_rssm = torch.zeros_like(embed) if open_loop else embed
             H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed_rssm), H.fptr(action), H.ptr(reset), H.fptr(h0),
                    H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
             if not forward_only:
-                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(image), ctypes.byref(dec_p),
+                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(image), ctypes.byref(dec_p),
                        H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(), H.stream())
         else:
             # Time-chunk pipeline over three streams: the posterior loop is a latency chain of T x ~10 small kernels
@@ -725,16 +728,16 @@ class WorldModel(_Params):
             # beside the loop steps of chunk i.  Same kernels on the same rows as the single-stream path.
             pp = self._pipeline(shp, T, B, chunks, dev)
             main = torch.cuda.current_stream()
-            H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(image), ctypes.byref(enc_p),
+            H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.ptr(image), ctypes.byref(enc_p),
                    H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
-            H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(feat), F_, H.fptr(image),
+            H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), 0, 0, 1, H.fptr(feat), F_, H.ptr(image),
                    ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(),
                    H.stream())
             pp['ev_prep'].record(main)
             pp['s_chain'].wait_event(pp['ev_prep'])
             pp['s_dec'].wait_event(pp['ev_prep'])
             for i, (t0, t1) in enumerate(pp['ranges']):
-                H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.fptr(image),
+                H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.ptr(image),
                        ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
                 pp['ev_enc'][i].record(main)
                 pp['s_chain'].wait_event(pp['ev_enc'][i])
@@ -747,7 +750,7 @@ class WorldModel(_Params):
                 pp['s_dec'].wait_event(pp['ev_chain'][i])
                 with torch.cuda.stream(pp['s_dec']):
                     H.call('dm_conv_decoder_mse_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.fptr(feat), F_,
-                           H.fptr(image), ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), None,
+                           H.ptr(image), ctypes.byref(dec_p), H.fptr(dec_acts), H.fptr(loss_image), None,
                            H.ptr(pp['ws_dec']), pp['ws_dec'].numel(), H.stream())
             main.wait_stream(pp['s_chain'])
             main.wait_stream(pp['s_dec'])
@@ -791,13 +794,13 @@ class WorldModel(_Params):
                                     loss_image=tb(loss_image), image_rec=None,
                                     loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
                                     loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
-        Cc, hw = image.shape[-3], image.shape[-2] * image.shape[-1]
+        Cc, hw = c.image_channels, c.image_size * c.image_size
         pred_off = int(lib.dm_conv_decoder_pred_offset(ctypes.byref(shp)))
 
         def image_rec_thunk(acts=dec_acts):       # holds the decoder activations alive until the dict is dropped
             with torch.no_grad():
                 pred = acts[pred_off:pred_off + N * hw * Cc].view(N, hw, Cc)                       # NHWC
-                return pred.transpose(1, 2).contiguous().view(T, B, Cc, *image.shape[-2:])         # -> (T,B,C,H,W)
+                return pred.transpose(1, 2).contiguous().view(T, B, Cc, c.image_size, c.image_size)    # -> (T,B,C,H,W)
         pk['tensors'].lazy('image_rec', image_rec_thunk)
         pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
                              loss_image=means[1], loss_reward=means[2], loss_terminal=means[3])
@@ -827,7 +830,7 @@ class WorldModel(_Params):
         dl = dec.image.layers()
         dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
         dec_g = H.conv_struct([gof[id(m.weight)] for m in dl], [gof[id(m.bias)] for m in dl], cls=H.dm_conv_grads)
-        H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(pk['image']), ctypes.byref(dec_p),
+        H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
                H.fptr(pk['dec_acts']), dec.image_weight / N, ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws), ws.numel(),
                H.stream())
         # KL (dreamer.py:334-339)
@@ -852,7 +855,7 @@ class WorldModel(_Params):
         enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
         enc_g = H.conv_struct([gof[id(m.weight)] for m in enc.convs()], [gof[id(m.bias)] for m in enc.convs()],
                               cls=H.dm_conv_grads)
-        H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
+        H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.ptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
                H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
         return views, flat, direct
 
@@ -878,8 +881,8 @@ class WorldModel(_Params):
             dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
             acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
             li = torch.empty(N, device=dev)
-            image_pred = torch.empty_like(pk['image'])
-            H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(fp), F_, H.fptr(pk['image']), ctypes.byref(dec_p),
+            image_pred = torch.empty(T, B, c.image_channels, c.image_size, c.image_size, device=dev)
+            H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(fp), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
                    H.fptr(acts), H.fptr(li), H.fptr(image_pred), H.ptr(ws), ws.numel(), H.stream())
             mu, _ = dec.reward.model.fwd(fp, F_, N, ws, save_acts=False)
             tl, _ = dec.terminal.model.fwd(fp, F_, N, ws, save_acts=False)
@@ -1256,9 +1259,9 @@ class Dreamer(nn.Module):
                 dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
                 shp, dev = pk['shp'], pk['feat'].device
                 acts = torch.empty(int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
-                image_dream = torch.empty_like(pk['image'])
+                image_dream = torch.empty(T, B, self.conf.image_channels, self.conf.image_size, self.conf.image_size, device=dev)
                 ws = self.wm.workspace(shp, dev)
-                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(f2), self.wm.features_dim, H.fptr(pk['image']),
+                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(f2), self.wm.features_dim, H.ptr(pk['image']),
                        ctypes.byref(dec_p), H.fptr(acts), None, H.fptr(image_dream), H.ptr(ws), ws.numel(), H.stream())
                 _, _, t_ac2 = self.ac.training_step(f2, a2, r2.mean, t2.mean, log_only=True, act_idx=dpk2['act_idx'],
                                                     ws=dpk2['ws'], actor_acts=dpk2['actor_acts'],

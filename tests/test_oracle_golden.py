@@ -5,6 +5,7 @@ Bars: sampled indices (posterior / actor / imagined latents) bit-exact; losses a
 (fp32, same torch CPU kernels, different op grouping); per-parameter gradient norms within 1e-4 relative (+1e-7 abs);
 stored full gradients within 1e-4 of the tensor's max; post-AdamW parameter checksums within 1e-6 relative.
 """
+import ast
 import os
 
 import numpy as np
@@ -21,7 +22,7 @@ def _load(name):
 
 
 def _conf_from(g):
-    items = eval(str(g['conf_json']))      # repr of a sorted (key, value) list written by gen_golden.py
+    items = ast.literal_eval(str(g['conf_json']))      # repr of a sorted (key, value) list written by gen_golden.py
     return O.make_conf(**dict(items))
 
 
@@ -161,6 +162,30 @@ def test_oracle_matches_reference_at_atari_literal():
         ref = float(g['s0_metric_' + k])
         tol = 2e-6 if k in wm_keys else 1e-2
         assert _rel(v, ref) < tol or abs(float(v) - ref) < 1e-3 * (k not in wm_keys) + 1e-7, (k, float(v), ref)
+
+
+def test_oracle_matches_reference_at_dmc_native():
+    """BASELINE.json configs[4] at its native width (defaults+dmc: deter_dim 2048, tanh_normal actor, action_dim 6,
+    actor_grad=reinforce, B=50, T=50, H=15) against the slim golden written by the real reference.  Forward only here
+    (the backward of the 2048-wide model costs minutes on CPU; the GPU test covers the gradients against this fixture)."""
+    g = _load('dmc_native')
+    conf = _conf_from(g)
+    assert conf.deter_dim == 2048 and conf.actor_dist == 'tanh_normal' and conf.action_dim == 6
+    raw = O.synthetic_batch(conf, seed=1234, first=True)
+    noise = O.make_noise(conf, seed=777)
+    assert int(raw['image_u8'].astype(np.int64).sum()) == int(g['s0_in_image_sum'])
+    model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
+    with torch.no_grad():
+        losses, new_state, metrics, tensors, extras = model.training_step(O.preprocess(raw, conf),
+                                                                          model.init_state(conf.batch_size), noise)
+    T, B, S = conf.batch_length, conf.batch_size, conf.stoch_dim
+    same = extras['post_idx'].reshape(T, B, S).numpy().astype(np.uint8) == g['s0_idx_post']
+    assert same[:10].all() and same.mean() > 0.999, same.mean()
+    assert _rel(losses[0], g['s0_losses'][0]) < 2e-5
+    for i in (2, 3):
+        assert _rel(losses[i], g['s0_losses'][i]) < 2e-2 or abs(float(losses[i]) - g['s0_losses'][i]) < 2e-3, i
+    for k in ('loss_kl', 'entropy_prior', 'entropy_post', 'loss_image', 'loss_reward', 'loss_terminal'):
+        assert _rel(metrics[k], float(g['s0_metric_' + k])) < 2e-5, k
 
 
 @pytest.mark.parametrize('name,open_loop', [('tiny_eval', False), ('tiny_open_loop', True)])
