@@ -59,7 +59,18 @@ struct DmGemm {
   const int* a_maj = nullptr; const int* a_min = nullptr; int a_tab_vec = 0;
   const int* b_maj = nullptr; const int* b_min = nullptr; int b_tab_vec = 0;
   int flags = 0;
+  // LayerNorm+ELU prologue on A (A holds pre-activations; the product uses ELU(LN(A))): <= 64-row skinny products only
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-3f;
 };
+// categorical sampler riding in the epilogue of a <= 64-row logits product (gemm_skinny.hip)
+struct DmSample {
+  const float* u = nullptr; const int32_t* forced = nullptr;   // uniforms (rows, groups) or forced indices
+  float* onehot = nullptr; int ldo = 0;                        // one-hot sample rows (leading dim ldo)
+  int32_t* idx = nullptr;                                      // optional (rows, groups)
+  float* z_next = nullptr; const uint8_t* next_reset = nullptr;   // optional: next step's reset-masked sample input (dense rows)
+};
+bool dm_skinny_ln_ok(int M, int N, int K);
+int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t stream);
 int dm_gemm_launch(const DmGemm& g, void* ws, size_t ws_bytes, hipStream_t stream);
 int dm_gemm_skinny_try(const DmGemm& g, hipStream_t stream);   // gemm_skinny.hip: 1 = handled, 0 = not applicable, <0 error
 // two independent products; one launch when both are <= 64-row skinny products, else two ordinary launches

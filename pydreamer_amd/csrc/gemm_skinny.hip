@@ -23,13 +23,19 @@ struct SkinnyArgs {
   const float* bias; const float* add;
   const uint8_t* row_zero;
   int M, N, K, lda, ldb, ldc, ldadd, flags;
+  // LNA: A holds PRE-activations x; the product uses ELU(LayerNorm(x; ln_g, ln_b, eps)) (rssm.py:138-146: in_norm /
+  // post_norm + ELU feeding the GRU / the posterior head).  Row statistics are computed by the consuming workgroup.
+  const float* ln_g; const float* ln_b; float ln_eps;
+  // SAMPLE: the strip is one categorical group of 32 logits; the epilogue draws the straight-through sample
+  // (rssm.py:147-148) with the sampler contract of elementwise.hip and writes one-hot z, the next step's masked z and idx
+  const float* u; const int32_t* forced; float* onehot; int ldo; int32_t* idx; float* z_next; const uint8_t* next_reset;
 };
 
 // Raw loads from clamped (always valid) addresses + a validity mask (bits 0-3: A row blocks, bit 4: B).  The zero-fill
 // select is applied where the chunk is CONSUMED, one iteration later, so the loads stay in flight under the MFMAs.
-template <int BL, int NRB>
+template <int BL, int NRB, int NCB>
 __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0, int c, int kend, int lane,
-                                            float4 (&a)[NRB], float4& b, unsigned& mask) {
+                                            float4 (&a)[NRB], float4 (&b)[NCB], unsigned& mask) {
   mask = 0u;
   const int l15 = lane & 15, q = lane >> 4;
   const int k = c + 4 * q;
@@ -41,75 +47,151 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0,
     a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
     mask |= ok ? (1u << mb) : 0u;
   }
-  const int n = n0 + l15;
-  const bool okb = kin && n < g.N;
-  if (BL == 0) {
-    b = *reinterpret_cast<const float4*>(g.B + (okb ? (size_t)n * g.ldb + k : 0));
-  } else {
-    const float* p = g.B + (okb ? (size_t)k * g.ldb + n : 0);
-    const size_t st = okb ? (size_t)g.ldb : 0;
-    b = make_float4(p[0], p[st], p[2 * st], p[3 * st]);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int n = n0 + cb * 16 + l15;
+    const bool okb = kin && n < g.N;
+    if (BL == 0) {
+      b[cb] = *reinterpret_cast<const float4*>(g.B + (okb ? (size_t)n * g.ldb + k : 0));
+    } else {
+      const float* p = g.B + (okb ? (size_t)k * g.ldb + n : 0);
+      const size_t st = okb ? (size_t)g.ldb : 0;
+      b[cb] = make_float4(p[0], p[st], p[2 * st], p[3 * st]);
+    }
+    mask |= okb ? (16u << cb) : 0u;
   }
-  mask |= okb ? 16u : 0u;
 }
 
-constexpr int SK_DEPTH = 4;    // 16-k chunks loaded per round (all in flight before the first MFMA)
 constexpr int SK_WAVES = 16;   // waves per workgroup = K splits inside it (8 and 4 measured slower, also under contention)
+constexpr int SK_LN_MAXK = 1024;
 
-// One (16*NRB) x 16 output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads a
-// quarter of the activation traffic of the 50-row case.
-template <int BL, int NRB>
-__device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int m0, float (*part)[64 * 16]) {
+// ELU for the LayerNorm prologue: exp(v) - 1 on the hardware exp (absolute error ~1e-7 near 0, where expm1f's relative
+// accuracy buys nothing for an O(1) activation); every workgroup of the launch redoes this transform for its 64 x K
+// operand, so it has to be cheap.
+__device__ __forceinline__ float skinny_elu(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
+
+struct SkinnyShared {
+  float lnstat[64][2];
+  float lng[SK_LN_MAXK];
+  float lnb[SK_LN_MAXK];
+};
+
+// One (16*NRB) x (16*NCB) output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads
+// a quarter of the activation traffic of the 50-row case.  DEPTH = 16-k chunks loaded per round (all in flight before
+// the first MFMA).
+template <int BL, int NRB, int NCB, bool LNA, bool SAMPLE, int DEPTH>
+__device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int m0, float* part, SkinnyShared* sh,
+                                             float* tile) {
+  constexpr int PW = 16 * NCB;                    // strip width
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = strip * 16;
+  const int n0 = strip * PW;
   const int chunks = (g.K + 15) / 16;
   const int per = (chunks + SK_WAVES - 1) / SK_WAVES;
   const int c_beg = wave * per * 16;
   int c_end = c_beg + per * 16;
   if (c_end > chunks * 16) c_end = chunks * 16;
 
-  f32x4 acc[NRB];
+  f32x4 acc[NRB][NCB];
 #pragma unroll
-  for (int mb = 0; mb < NRB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < NRB; ++mb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (LNA) {
+    // row statistics of this strip's A rows (two-pass, the row cached in registers: K <= 1024), gamma / beta staged in LDS
+    for (int e = tid; e < g.K; e += SK_WAVES * 64) { sh->lng[e] = g.ln_g[e]; sh->lnb[e] = g.ln_b[e]; }
+    for (int rr = wave; rr < 16 * NRB; rr += SK_WAVES) {
+      const int row = m0 + rr;
+      const float* xr = g.A + (size_t)(row < g.M ? row : 0) * g.lda;
+      float xc[SK_LN_MAXK / 64];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < SK_LN_MAXK / 64; ++j) {
+        const int cidx = lane + 64 * j;
+        xc[j] = cidx < g.K ? xr[cidx] : 0.f;
+        s += xc[j];
+      }
+      const float mean = dm_wave_sum(s) / (float)g.K;
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < SK_LN_MAXK / 64; ++j) {
+        const float d = (lane + 64 * j < g.K) ? xc[j] - mean : 0.f;
+        v += d * d;
+      }
+      const float rstd = 1.0f / sqrtf(dm_wave_sum(v) / (float)g.K + g.ln_eps);
+      if (lane == 0) { sh->lnstat[rr][0] = mean; sh->lnstat[rr][1] = rstd; }
+    }
+    __syncthreads();
+  }
 
   // These products are latency bound (weights come from the MALL / HBM, ~1 us a round trip), so a round issues the
-  // loads of SK_DEPTH chunks back to back and only then starts consuming them under counted waits; the 16 waves of
+  // loads of DEPTH chunks back to back and only then starts consuming them under counted waits; the 16 waves of
   // the workgroup (4 per SIMD) overlap each other's rounds.  With K <= 1024 a wave's whole K range is ONE round.
   // A chunk past the wave's range loads clamped addresses under an all-zero mask and contributes exact zeros.
   int kend = c_end < g.K ? c_end : g.K;
   if (kend < c_beg) kend = c_beg;
-  for (int c = c_beg; c < c_end; c += 16 * SK_DEPTH) {
-    float4 a[SK_DEPTH][NRB], b[SK_DEPTH];
-    unsigned mk[SK_DEPTH];
+  for (int c = c_beg; c < c_end; c += 16 * DEPTH) {
+    float4 a[DEPTH][NRB], b[DEPTH][NCB];
+    unsigned mk[DEPTH];
 #pragma unroll
-    for (int d = 0; d < SK_DEPTH; ++d) skinny_load<BL, NRB>(g, m0, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
+    for (int d = 0; d < DEPTH; ++d) skinny_load<BL, NRB, NCB>(g, m0, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < SK_DEPTH; ++d) {
-      const bool okb = (mk[d] & 16u) != 0u;
-      const float bj[4] = {okb ? b[d].x : 0.f, okb ? b[d].y : 0.f, okb ? b[d].z : 0.f, okb ? b[d].w : 0.f};
+    for (int d = 0; d < DEPTH; ++d) {
+      float bj[NCB][4];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const bool okb = ((mk[d] >> (4 + cb)) & 1u) != 0u;
+        bj[cb][0] = okb ? b[d][cb].x : 0.f; bj[cb][1] = okb ? b[d][cb].y : 0.f;
+        bj[cb][2] = okb ? b[d][cb].z : 0.f; bj[cb][3] = okb ? b[d][cb].w : 0.f;
+      }
+      float gq[4] = {1.f, 1.f, 1.f, 1.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (LNA) {
+        const int k = c + 16 * d + 4 * (lane >> 4);
+        const int kk = k < SK_LN_MAXK - 3 ? k : 0;          // past-the-range chunks are masked below; keep the read in bounds
+        const float4 g4 = *reinterpret_cast<const float4*>(&sh->lng[kk]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&sh->lnb[kk]);
+        gq[0] = g4.x; gq[1] = g4.y; gq[2] = g4.z; gq[3] = g4.w;
+        bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+      }
 #pragma unroll
       for (int mb = 0; mb < NRB; ++mb) {
         const bool oka = ((mk[d] >> mb) & 1u) != 0u;
-        const float aj[4] = {oka ? a[d][mb].x : 0.f, oka ? a[d][mb].y : 0.f, oka ? a[d][mb].z : 0.f,
-                             oka ? a[d][mb].w : 0.f};
+        float aj[4] = {a[d][mb].x, a[d][mb].y, a[d][mb].z, a[d][mb].w};
+        float lmean = 0.f, lrstd = 0.f;
+        if (LNA) {        // row statistics straight from LDS (keeping them in registers spills the NRB = 4 instance)
+          const float2 st2 = *reinterpret_cast<const float2*>(&sh->lnstat[mb * 16 + (lane & 15)][0]);
+          lmean = st2.x; lrstd = st2.y;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bj[j], acc[mb], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          if (LNA) aj[j] = skinny_elu((aj[j] - lmean) * lrstd * gq[j] + bq[j]);
+          aj[j] = oka ? aj[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bj[cb][j], acc[mb][cb], 0, 0, 0);
       }
     }
   }
   // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+  float* mypart = part + (size_t)wave * (64 * PW);
 #pragma unroll
   for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave][(mb * 16 + (lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[mb][r];
-  __syncthreads();
-  for (int e = tid; e < NRB * 16 * 16; e += SK_WAVES * 64) {
-    const int row = m0 + (e >> 4), col = n0 + (e & 15);
-    if (row < g.M && col < g.N) {
-      float v = 0.f;
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) v += part[w][e];
+      for (int r = 0; r < 4; ++r) mypart[(mb * 16 + (lane >> 4) * 4 + r) * PW + cb * 16 + (lane & 15)] = acc[mb][cb][r];
+  __syncthreads();
+  for (int e = tid; e < NRB * 16 * PW; e += SK_WAVES * 64) {
+    const int lr = e / PW, lc = e % PW;
+    const int row = m0 + lr, col = n0 + lc;
+    float v = 0.f;
+    if (row < g.M && col < g.N) {
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += part[(size_t)w * (64 * PW) + e];
       if (g.row_zero && g.row_zero[row]) v = 0.f;
       if (g.bias) v += g.bias[col];
       if (g.add) v += g.add[(size_t)row * g.ldadd + col];
@@ -118,24 +200,88 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
       *cp = v;
     }
+    if (SAMPLE) tile[lr * 33 + lc] = v;
+  }
+  if (SAMPLE) {
+    // One lane per row: the strip IS the row's categorical group `strip` (32 logits).  Same operation order as
+    // sample_onehot_lane32_kernel (elementwise.hip), so the drawn indices are bit-identical to the stand-alone sampler.
+    __syncthreads();
+    const int row = m0 + tid;
+    if (tid < 16 * NRB && row < g.M) {
+      constexpr int C = 32;
+      const int groups = g.N / C;
+      const size_t i = (size_t)row * groups + strip;
+      int idx;
+      if (g.forced) {
+        idx = g.forced[i];
+      } else {
+        float x[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) x[k] = tile[tid * 33 + k];
+        float mx = x[0];
+#pragma unroll
+        for (int k = 1; k < C; ++k) mx = fmaxf(mx, x[k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) { x[k] = expf(x[k] - mx); sum += x[k]; }
+        float total_p = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) { x[k] = x[k] / sum; total_p += x[k]; }
+        const float target = g.u[i] * total_p;
+        float cdf = 0.f;
+        idx = 0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          cdf += x[k];
+          idx += (cdf <= target) ? 1 : 0;
+        }
+        if (idx > C - 1) idx = C - 1;
+      }
+      float4* dst = reinterpret_cast<float4*>(g.onehot + (size_t)row * g.ldo + (size_t)strip * C);
+#pragma unroll
+      for (int q4 = 0; q4 < C / 4; ++q4)
+        dst[q4] = make_float4(idx == 4 * q4 ? 1.f : 0.f, idx == 4 * q4 + 1 ? 1.f : 0.f, idx == 4 * q4 + 2 ? 1.f : 0.f,
+                              idx == 4 * q4 + 3 ? 1.f : 0.f);
+      if (g.z_next) {
+        const int keep = (g.next_reset && g.next_reset[row]) ? -1 : idx;
+        float4* dn = reinterpret_cast<float4*>(g.z_next + ((size_t)row * groups + strip) * C);
+#pragma unroll
+        for (int q4 = 0; q4 < C / 4; ++q4)
+          dn[q4] = make_float4(keep == 4 * q4 ? 1.f : 0.f, keep == 4 * q4 + 1 ? 1.f : 0.f, keep == 4 * q4 + 2 ? 1.f : 0.f,
+                               keep == 4 * q4 + 3 ? 1.f : 0.f);
+      }
+      if (g.idx) g.idx[i] = idx;
+    }
   }
 }
 
-template <int BL, int NRB>
+template <int BL, int NRB, bool LNA>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
-  __shared__ float part[SK_WAVES][64 * 16];
-  skinny_strip<BL, NRB>(g, blockIdx.x, blockIdx.y * 64, part);       // grid.y = 64-row chunks of M
+  __shared__ float part[SK_WAVES * 64 * 16];
+  __shared__ SkinnyShared sh;
+  skinny_strip<BL, NRB, 1, LNA, false, 4>(g, blockIdx.x, blockIdx.y * 64, part, &sh, nullptr);   // grid.y = 64-row chunks of M
+}
+// Posterior / prior head with the sampler in the epilogue: LayerNorm+ELU prologue, 32-wide strips (one categorical group
+// per workgroup), M <= 64.
+template <int NRB>
+__global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const SkinnyArgs g) {
+  __shared__ float part[SK_WAVES * 64 * 32];
+  __shared__ SkinnyShared sh;
+  __shared__ float tile[64 * 33];
+  skinny_strip<0, NRB, 2, true, true, 2>(g, blockIdx.x, 0, part, &sh, tile);
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
 // feed step t-1's state gradient.  Workgroups [0, nb0) serve the first product, the rest the second.
+// LNA0: the FIRST product's A operand goes through the LayerNorm+ELU prologue (gi = ELU(in_norm(x)) W_ih^T).
 struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0; };
-template <int NRB>
+template <int NRB, bool LNA0>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
-  __shared__ float part[SK_WAVES][64 * 16];
+  __shared__ float part[SK_WAVES * 64 * 16];
+  __shared__ SkinnyShared sh;
   const int b = blockIdx.x;
-  if (b < a.nb0) skinny_strip<0, NRB>(a.g[0], b, 0, part);
-  else skinny_strip<0, NRB>(a.g[1], b - a.nb0, 0, part);
+  if (b < a.nb0) skinny_strip<0, NRB, 1, LNA0, false, 4>(a.g[0], b, 0, part, &sh, nullptr);
+  else skinny_strip<0, NRB, 1, false, false, 4>(a.g[1], b - a.nb0, 0, part, &sh, nullptr);
 }
 
 // max_m: 64 for the pair kernel (one chunk); the single-product kernel walks M in 64-row chunks (grid.y) up to
@@ -153,8 +299,18 @@ static bool skinny_ok(const DmGemm& q, int max_m) {
 static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.row_zero = q.row_zero;
   a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.flags = q.flags;
+  a.ln_g = q.ln_g; a.ln_b = q.ln_b; a.ln_eps = q.ln_eps;
+  a.u = nullptr; a.forced = nullptr; a.onehot = nullptr; a.ldo = 0; a.idx = nullptr; a.z_next = nullptr; a.next_reset = nullptr;
 }
 static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
+static const int g_skinny_nofuse = getenv("DM_SKINNY_NO_FUSE") ? 1 : 0;        // A/B switch: keep LayerNorm / sampler launches
+
+// Can a <= 64-row product with reduction length K take the LayerNorm+ELU prologue (and, for N % 32 == 0, the sampler
+// epilogue)?  Shape-only test: rssm.hip picks the fused or the unfused schedule of the T loop with it.
+bool dm_skinny_ln_ok(int M, int N, int K) {
+  return !g_skinny_disabled && !g_skinny_nofuse && M >= 1 && M <= 64 && K >= 16 && K <= SK_LN_MAXK && (K & 3) == 0 &&
+         (int64_t)N * K >= (int64_t)64 * 1024;
+}
 
 // Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
 int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
@@ -162,38 +318,76 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   // beyond one chunk it pays only for short reductions over small weight matrices (measured at M = 350: 1000x1024
   // 31.9 -> 24.8 us, 400x400 15.1 -> 8.7 us; 1800x1000 equal; 400x1624 18.2 -> 19.9 us)
   if (q.M > 64 && (q.K > 1024 || (int64_t)q.N * q.K > (int64_t)1100 * 1024)) return 0;
+  const bool ln = q.ln_g != nullptr;
+  if (ln && (q.K > SK_LN_MAXK || q.b_layout != 0 || !q.ln_b)) return 0;
   SkinnyArgs a;
   skinny_fill(q, a);
   const dim3 grid((unsigned)dm_cdiv(q.N, 16), (unsigned)dm_cdiv(q.M, 64));
   const dim3 blk(SK_WAVES * 64);
-  if (q.b_layout == 0) {
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1>), grid, blk, 0, stream, a);
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4>), grid, blk, 0, stream, a);
+  if (ln) {
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1, true>), grid, blk, 0, stream, a);
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4, true>), grid, blk, 0, stream, a);
+  } else if (q.b_layout == 0) {
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1, false>), grid, blk, 0, stream, a);
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2, false>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4, false>), grid, blk, 0, stream, a);
   } else {
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<1, 1>), grid, blk, 0, stream, a);
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 4>), grid, blk, 0, stream, a);
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<1, 1, false>), grid, blk, 0, stream, a);
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, false>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, false>), grid, blk, 0, stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "skinny gemm: %s", hipGetErrorString(e));
   return 1;
 }
 // Both products in one launch if both qualify (k-contiguous B); otherwise two ordinary launches.
+// q0 may carry a LayerNorm+ELU prologue (ln_g / ln_b): then the one-launch path is mandatory (callers check
+// dm_skinny_ln_ok first).
 int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!g_skinny_disabled && skinny_ok(q0, 64) && skinny_ok(q1, 64) && q0.b_layout == 0 && q1.b_layout == 0) {
+  const bool ln0 = q0.ln_g != nullptr;
+  DM_REQUIRE(!q1.ln_g, DM_E_SHAPE, "gemm pair: only the first product may carry a LayerNorm prologue");
+  if (!g_skinny_disabled && skinny_ok(q0, 64) && skinny_ok(q1, 64) && q0.b_layout == 0 && q1.b_layout == 0 &&
+      (!ln0 || (q0.K <= SK_LN_MAXK && q0.ln_b))) {
     SkinnyPairArgs a;
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
     a.nb0 = dm_cdiv(q0.N, 16);
     const dim3 grid((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), blk(SK_WAVES * 64);
     const int mmax = q0.M > q1.M ? q0.M : q1.M;
-    if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1>), grid, blk, 0, stream, a);
-    else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4>), grid, blk, 0, stream, a);
+    if (ln0) {
+      if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, true>), grid, blk, 0, stream, a);
+      else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, true>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, true>), grid, blk, 0, stream, a);
+    } else {
+      if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, false>), grid, blk, 0, stream, a);
+      else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, false>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, false>), grid, blk, 0, stream, a);
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
+  DM_REQUIRE(!ln0, DM_E_SHAPE, "gemm pair: LayerNorm prologue requested but the one-launch skinny path does not apply");
   DM_TRY(dm_gemm_launch(q0, ws, ws_bytes, stream));
   return dm_gemm_launch(q1, ws, ws_bytes, stream);
+}
+
+// logits = ELU(LN(x)) W^T + b for M <= 64 rows, N = groups*32, then one straight-through categorical draw per 32-logit
+// group in the epilogue (rssm.py:143-148 posterior head + sample; rssm.py:174-179 prior head + sample): ONE launch.
+int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t stream) {
+  DM_REQUIRE(q.ln_g && q.ln_b && dm_skinny_ln_ok(q.M, q.N, q.K) && skinny_ok(q, 64) && q.b_layout == 0 && (q.N & 31) == 0,
+             DM_E_SHAPE, "gemm_sample: shape M=%d N=%d K=%d does not qualify", q.M, q.N, q.K);
+  DM_REQUIRE(sm.onehot && (sm.u || sm.forced) && (sm.ldo & 3) == 0 &&
+                 (((uintptr_t)sm.onehot | (uintptr_t)sm.z_next) & 15) == 0,
+             DM_E_SHAPE, "gemm_sample: sampler outputs must be 16-byte aligned");
+  SkinnyArgs a;
+  skinny_fill(q, a);
+  a.u = sm.u; a.forced = sm.forced; a.onehot = sm.onehot; a.ldo = sm.ldo; a.idx = sm.idx; a.z_next = sm.z_next;
+  a.next_reset = sm.next_reset;
+  const dim3 grid((unsigned)(q.N / 32)), blk(SK_WAVES * 64);
+  if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_sample_kernel<1>), grid, blk, 0, stream, a);
+  else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_sample_kernel<2>), grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL((skinny_gemm_sample_kernel<4>), grid, blk, 0, stream, a);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
 }

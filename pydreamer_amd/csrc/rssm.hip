@@ -122,8 +122,16 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DM_TRY(linear(st, ws, skb, N, Hd, A, action + q0 * A, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea + q0 * Hd, Hd));
   DM_TRY(linear(st, ws, skb, N, Hd, E, embed + q0 * E, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee + q0 * Hd, Hd));
 
-  // 8 launches per step: the reset masks of step t+1 are applied by the kernels that produce h_t and z_t (only the
-  // first step of a range needs the stand-alone mask kernel), and the GRU's two gate products share one launch.
+  // Fused schedule (5 launches per step instead of 8) when the <= 64-row products qualify: the two LayerNorm+ELU stages
+  // ride in the PROLOGUE of the product that consumes them (each workgroup recomputes the row statistics of its <= 64
+  // rows from L2) and the straight-through sampler rides in the EPILOGUE of the posterior-logits product (one 32-logit
+  // group per workgroup).  The post-LayerNorm activations `za` / `pin` that only the backward pass needs (weight
+  // gradients, ELU') are then produced for ALL rows of the range by two batched launches after the loop.
+  const bool fuse_ln = dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
+  const bool fuse_sample = fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
+                           (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
+  // 8 launches per step otherwise: the reset masks of step t+1 are applied by the kernels that produce h_t and z_t (only
+  // the first step of a range needs the stand-alone mask kernel), and the GRU's two gate products share one launch.
   for (int t = t0; t < t1; ++t) {
     const size_t r0 = (size_t)t * B;
     float* hin = a.hin + r0 * D;
@@ -140,12 +148,14 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     const uint8_t* reset_next = more ? reset + r0 + B : nullptr;
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
     DM_TRY(linear(st, ws, skb, B, Hd, Z, zin, Z, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd, a.x1 + r0 * Hd, Hd));
-    DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
-                                a.st1 + r0 * 2, st));
+    if (!fuse_ln)
+      DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
+                                  a.st1 + r0 * 2, st));
     // h = GRUCell(za, h_in)                                                             rssm.py:141
     {
       DmGemm gi_q, gh_q;
       gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
+      if (fuse_ln) { gi_q.A = a.x1 + r0 * Hd; gi_q.ln_g = p[DM_RSSM_IN_G]; gi_q.ln_b = p[DM_RSSM_IN_B]; gi_q.ln_eps = 1e-3f; }
       gi_q.C = a.gi + r0 * 3 * D; gi_q.ldc = 3 * D; gi_q.bias = p[DM_RSSM_GRU_BIH];
       gh_q.M = B; gh_q.N = 3 * D; gh_q.K = D; gh_q.A = hin; gh_q.lda = D; gh_q.B = p[DM_RSSM_GRU_WHH]; gh_q.ldb = D;
       gh_q.C = a.gh + r0 * 3 * D; gh_q.ldc = 3 * D; gh_q.bias = p[DM_RSSM_GRU_BHH];
@@ -156,14 +166,36 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     // post = post_mlp(ELU(post_norm(post_mlp_h(h) + post_mlp_e(embed))))               rssm.py:143-146
     DM_TRY(linear(st, ws, skb, B, Hd, D, feat + r0 * F, F, p[DM_RSSM_POST_H_W], p[DM_RSSM_POST_H_B], a.ee + r0 * Hd, Hd,
                   a.x2 + r0 * Hd, Hd));
-    DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
-                                Hd, a.st2 + r0 * 2, st));
-    DM_TRY(linear(st, ws, skb, B, Z, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
-                  post + r0 * Z, Z));
+    if (fuse_ln) {
+      DmGemm pq;      // post = post_mlp(ELU(post_norm(x2))), LayerNorm in the prologue
+      pq.M = B; pq.N = Z; pq.K = Hd; pq.A = a.x2 + r0 * Hd; pq.lda = Hd; pq.B = p[DM_RSSM_POST_W]; pq.ldb = Hd;
+      pq.C = post + r0 * Z; pq.ldc = Z; pq.bias = p[DM_RSSM_POST_OB];
+      pq.ln_g = p[DM_RSSM_POST_G]; pq.ln_b = p[DM_RSSM_POST_B]; pq.ln_eps = 1e-3f;
+      if (fuse_sample) {   // ... and z ~ OneHotCategoricalStraightThrough(post) in the epilogue        rssm.py:147-148
+        DmSample sm;
+        sm.u = u ? u + r0 * S : nullptr; sm.forced = forced_idx ? forced_idx + r0 * S : nullptr;
+        sm.onehot = feat + r0 * F + D; sm.ldo = F; sm.idx = idx ? idx + r0 * S : nullptr;
+        sm.z_next = zin_next; sm.next_reset = reset_next;
+        DM_TRY(dm_gemm_sample_launch(pq, sm, st));
+        continue;
+      }
+      DM_TRY(dm_gemm_launch(pq, ws, skb, st));
+    } else {
+      DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
+                                  Hd, a.st2 + r0 * 2, st));
+      DM_TRY(linear(st, ws, skb, B, Z, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
+                    post + r0 * Z, Z));
+    }
     // z ~ OneHotCategoricalStraightThrough(post)                                       rssm.py:147-148
     DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * Z, Z, u ? u + r0 * S : nullptr,
                                    forced_idx ? forced_idx + r0 * S : nullptr, feat + r0 * F + D, F,
                                    idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
+  }
+  if (fuse_ln) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
+    DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,
+                                a.st1 + q0 * 2, st));
+    DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x2 + q0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + q0 * Hd, Hd,
+                                a.st2 + q0 * 2, st));
   }
   // batch_prior over all (T*B) rows                                                    rssm.py:61,186-193
   DM_TRY(linear(st, ws, skb, N, Hd, D, feat + q0 * F, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0,

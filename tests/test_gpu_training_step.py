@@ -329,6 +329,82 @@ def test_dream_rollout_vs_oracle(hip):
     _close(th.mean, to, 1e-4, 1e-5, 'dream terminals')
 
 
+@pytest.mark.parametrize('B', [7, 50])
+def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B):
+    """dm_rssm_sequence_fwd / dm_rssm_sequence_bwd stand-alone through the C-ABI at the Atari-literal cell width (deter 600,
+    hidden 1000, stoch 32x32) for a 7-column data-parallel shard and the full 50 columns: at these sizes the T loop runs its
+    FUSED schedule (LayerNorm+ELU in the prologue of the consuming <= 64-row product, sampler in the epilogue of the
+    posterior-logits product).  Oracle = rssm.py:21-78,125-153,186-193 restated in fp64 (oracle.cell_forward /
+    prior_head) with autograd; the loss is a random projection of (features, post, prior).
+    Bars: indices identical (a uniform within 1e-6 of a CDF edge excepted), states / logits 2e-5, every parameter
+    gradient and dembed within 2e-4 relative L2 (posterior indices forced to the HIP draw in the oracle)."""
+    import ctypes
+    from pydreamer_amd import config, hip as H
+    from pydreamer_amd.models import Dreamer
+    T, D_, Hd, S, C, A, depth = 4, 600, 1000, 32, 32, 18, 8
+    oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
+                        batch_size=B, batch_length=T)
+    params = O.make_params(oconf, seed=4)
+    model = _build(oconf, params)
+    cell = model.wm.core.cell
+    E, Z, F_ = 32 * depth, S * C, D_ + S * C
+    g = torch.Generator().manual_seed(11)
+    embed = torch.randn(T, B, E, generator=g)
+    action = F.one_hot(torch.randint(0, A, (T, B), generator=g), A).float()
+    reset = torch.zeros(T, B, dtype=torch.bool)
+    reset[0, 0] = True
+    reset[2, B - 1] = True
+    h0 = torch.tanh(torch.randn(B, D_, generator=g))
+    z0 = F.one_hot(torch.randint(0, C, (B, S), generator=g), C).float().reshape(B, Z)
+    u = torch.rand(T, B, S, generator=g)
+    Gf, Gp, Gq = (torch.randn(T * B, n, generator=g) / (T * B) for n in (F_, Z, Z))
+    shp = model.wm.shape(T, B, 1)
+    ws = model.wm.workspace(shp, torch.device(DEV, 0))
+    N = T * B
+    dev = lambda x: x.to(DEV).contiguous()
+    acts = torch.empty(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
+    feat, post, prior = torch.empty(N, F_, device=DEV), torch.empty(N, Z, device=DEV), torch.empty(N, Z, device=DEV)
+    idx = torch.empty(N, S, dtype=torch.int32, device=DEV)
+    e_d, a_d, r_d, u_d = dev(embed.view(N, E)), dev(action.view(N, A)), dev(reset.view(N).to(torch.uint8)), dev(u.view(N, S))
+    P = H.rssm_struct(cell.ordered())
+    H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), H.fptr(dev(h0)), H.fptr(dev(z0)),
+           H.fptr(u_d), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(ws),
+           ws.numel(), H.stream())
+    # oracle, fp64, posterior indices forced to the HIP draw (compared separately below)
+    pd = {k: v.double().requires_grad_(True) for k, v in params.items() if k.startswith('wm.core.')}
+    emb64 = embed.double().requires_grad_(True)
+    h, z = h0.double(), z0.double()
+    hs, zs, posts, idx_o = [], [], [], []
+    for t in range(T):
+        mask = (~reset[t]).double().unsqueeze(-1)
+        po, h, z, _ = O.cell_forward(pd, oconf, emb64[t], action[t].double(), mask, h, z, u[t].double(),
+                                     forced_idx=idx.view(T, B, S)[t].cpu())
+        with torch.no_grad():
+            lg = po.detach().float().reshape(B, S, C)
+            idx_o.append(O.sample_inverse_cdf(torch.softmax(lg - lg.logsumexp(-1, keepdim=True), -1), u[t]))
+        hs.append(h); zs.append(z); posts.append(po)
+    hs, zs, posts = torch.stack(hs), torch.stack(zs), torch.stack(posts)
+    priors = O.prior_head(pd, hs)
+    feat_o = torch.cat((hs, zs), -1).reshape(N, F_)
+    same = torch.stack(idx_o).reshape(N, S) == idx.cpu().long()
+    assert same.float().mean() > 0.999, float(same.float().mean())
+    _close(feat, feat_o, 0, 2e-5, 'rssm features')
+    _close(post, posts.reshape(N, Z), 1e-5, 2e-5, 'rssm post logits')
+    _close(prior, priors.reshape(N, Z), 1e-5, 2e-5, 'rssm prior logits')
+    loss = (feat_o * Gf.double()).sum() + (posts.reshape(N, Z) * Gp.double()).sum() + (priors.reshape(N, Z) * Gq.double()).sum()
+    loss.backward()
+    grads = [torch.zeros_like(p_) for p_ in cell.ordered()]
+    Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
+    dembed = torch.empty(N, E, device=DEV)
+    dfeat, dpost, dprior = dev(Gf), dev(Gp), dev(Gq)
+    H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), ctypes.byref(P), H.fptr(acts),
+           H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
+           H.ptr(ws), ws.numel(), H.stream())
+    for name, gh in zip(H.RSSM_PARAM_ORDER, grads):
+        assert _rel_l2(gh, pd['wm.core.cell.' + name].grad) < 2e-4, name
+    assert _rel_l2(dembed, emb64.grad.reshape(N, E)) < 2e-4, 'dembed'
+
+
 # ------------------------------------------------------------------------------------------- size-independent properties
 def test_properties_at_atari_literal(hip):
     """BASELINE.json configs[1] (B=50,T=50,H=15,deter=600): too large for the CPU oracle inside a test, so check
