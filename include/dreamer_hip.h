@@ -39,7 +39,7 @@ extern "C" {
 
 /* model / batch geometry: the config/defaults.yaml keys the hot path reads (dreamer.py:23-58,237-277) */
 typedef struct dm_shape {
-  int32_t T, B, I;          /* batch_length, batch_size, iwae_samples (I must be 1) */
+  int32_t T, B, I;          /* batch_length, batch_size, iwae_samples (conv decoder: N = T*B*I frames; RSSM calls take B*I as B, I = 1) */
   int32_t H;                /* imag_horizon */
   int32_t D, Hd;            /* deter_dim, hidden_dim */
   int32_t S, C;             /* stoch_dim, stoch_discrete (Z = S*C) */
@@ -108,6 +108,20 @@ int dm_kl_balance_bwd(int rows, int S, int C, const float* post, const float* pr
 /* straight-through backward: dlogits (+)= softmax-jacobian(logits)^T dz per group (accumulate if accum). */
 int dm_st_softmax_bwd(int rows, int groups, int C, const float* logits, int ldl, const float* dz, int lddz,
                       float* dlogits, int lddl, int accum, void* stream);
+
+/* IWAE (iwae_samples = I > 1).  Row index n = (t*B + b)*I + i everywhere (rssm.py:35-41).
+ * Sampled KL (dreamer.py:340-343): out[n] = log q(z_n) - log p(z_n), z given by its indices (rows,S). */
+int dm_kl_sampled_fwd(int rows, int S, int C, const float* post, const float* prior, const int32_t* idx, float* out, void* stream);
+/* dpost = scale*row_w[n]*(onehot - softmax(post)), dprior = -scale*row_w[n]*(onehot - softmax(prior)); row_w nullable. */
+int dm_kl_sampled_bwd(int rows, int S, int C, const float* post, const float* prior, const int32_t* idx, float scale,
+                      const float* row_w, float* dpost, float* dprior, void* stream);
+/* x (TB,I,W) -> out (TB,W): mode 0 mean over I, mode 2 sum, mode 1 (W = 1) -logavgexp(-x) (functions.py:97-102) with the
+ * optional importance weights w_out (TB,I) = softmax_i(-x) = d out/d x_i. */
+int dm_reduce_i(int TB, int I, int W, const float* x, int mode, float* out, float* w_out, void* stream);
+/* out[r] = sum_j w[j]*x_j[r], j < count <= 8 (x: host array of device pointers, w: host floats): dreamer.py:362. */
+int dm_combine_rows(int count, int64_t n, const float* const* x, const float* w, float* out, void* stream);
+/* x[r, 0..n) *= w[r]*scale (ldx leading dim): per-sample importance weights on row gradients. */
+int dm_scale_rows(int64_t rows, int n, float* x, int ldx, const float* w, float scale, void* stream);
 
 /* rows of h and z multiplied by (1-reset[r]) (rssm.py:41,134-135). */
 int dm_mask_rows(int rows, int n, const float* x, int ldx, const uint8_t* reset, float* y, int ldy, void* stream);

@@ -338,25 +338,36 @@ def nanmean(x):
     return torch.nansum(x) / (~torch.isnan(x)).sum()
 
 
-def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=None, do_open_loop=False):
-    assert conf.iwae_samples == 1, 'oracle restates the I=1 path'
+def logavgexp(x, dim):
+    """functions.py:97-102."""
+    if x.size(dim) > 1:
+        return x.logsumexp(dim=dim) - math.log(x.size(dim))
+    return x.squeeze(dim)
+
+
+def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=None, do_open_loop=False, iwae_samples=None):
+    """WorldModel.training_step (dreamer.py:297-396) with RSSMCore.forward (rssm.py:21-78) inlined.  iwae_samples = I > 1:
+    the batch is multiplied by I (rssm.py:35-41: row b*I + i), the KL term becomes the sampled one (dreamer.py:340-343) and
+    loss_model = -logavgexp(-loss_tbi) over I (dreamer.py:362-365).  u_post is (T, B*I, S); in_state is (B*I, .)."""
+    I = int(iwae_samples or conf.iwae_samples)
     T, B = obs['action'].shape[:2]
     embed = conv_encoder(p, obs['image'])                                     # dreamer.py:307
     h, z = in_state
-    reset_masks = (~obs['reset']).unsqueeze(-1).to(embed.dtype)               # rssm.py:41
+    expand = lambda x: x.unsqueeze(2).expand(T, B, I, x.shape[-1]).reshape(T, B * I, x.shape[-1])      # rssm.py:35-37
+    embeds, actions = expand(embed), expand(obs['action'])
+    reset_masks = expand((~obs['reset']).unsqueeze(-1).to(embed.dtype))       # rssm.py:41
     posts, hs, zs, idxs = [], [], [], []
     for t in range(T):                                                        # rssm.py:49-56
         if do_open_loop:                                                      # rssm.py:53: post = prior, no embed
-            post, h, z, idx = cell_forward_prior(p, conf, obs['action'][t], h, z, u_post[t], reset_masks[t])
+            post, h, z, idx = cell_forward_prior(p, conf, actions[t], h, z, u_post[t], reset_masks[t])
         else:
-            post, h, z, idx = cell_forward(p, conf, embed[t], obs['action'][t], reset_masks[t], h, z, u_post[t],
+            post, h, z, idx = cell_forward(p, conf, embeds[t], actions[t], reset_masks[t], h, z, u_post[t],
                                            None if forced_idx is None else forced_idx[t])
         posts.append(post); hs.append(h); zs.append(z); idxs.append(idx)
     posts, hs, zs = torch.stack(posts), torch.stack(hs), torch.stack(zs)
     priors = prior_head(p, hs)                                                # rssm.py:61
     features = torch.cat((hs, zs), -1)                                        # rssm.py:62,83-84
     out_state = (h.detach(), z.detach())                                      # rssm.py:77
-    I = 1
     feat_tbi = features.reshape(T, B, I, -1)
 
     # decoders (decoders.py:50-108)
@@ -375,29 +386,34 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=Non
     prior_tbi, post_tbi = priors.reshape(T, B, I, -1), posts.reshape(T, B, I, -1)
     dprior, dpost = zdistr(conf, prior_tbi), zdistr(conf, post_tbi)
     loss_kl_exact = D.kl_divergence(dpost, dprior)
-    if conf.kl_balance == 0.5:
+    if I > 1:                                                                 # sampled KL for IWAE, dreamer.py:340-343
+        zs_tbi = zs.reshape(dpost.batch_shape + dpost.event_shape)
+        loss_kl = dpost.log_prob(zs_tbi) - dprior.log_prob(zs_tbi)
+    elif conf.kl_balance == 0.5:
         loss_kl = loss_kl_exact
     else:
         postgrad = D.kl_divergence(dpost, zdistr(conf, prior_tbi.detach()))
         priograd = D.kl_divergence(zdistr(conf, post_tbi.detach()), dprior)
         loss_kl = (1 - conf.kl_balance) * postgrad + conf.kl_balance * priograd
     loss_model_tbi = conf.kl_weight * loss_kl + loss_reconstr                 # dreamer.py:362-365
-    loss_model_tb = loss_model_tbi.squeeze(2)
+    loss_model_tb = -logavgexp(-loss_model_tbi, 2)
     loss = loss_model_tb.mean()
 
     with torch.no_grad():
         ent_prior = dprior.entropy().mean(2)
         ent_post = dpost.entropy().mean(2)
-        tensors = dict(loss_kl=loss_kl_exact.squeeze(2).detach(), entropy_prior=ent_prior, entropy_post=ent_post,
-                       loss_image=loss_image.squeeze(2).detach(), image_rec=decoded.mean(2).detach(),
-                       loss_reward=loss_reward.squeeze(2).detach(), reward_rec=mu.mean(2).detach(),
-                       loss_terminal=loss_terminal.squeeze(2).detach(), terminal_rec=tdist.mean.mean(2).detach())
+        lae = lambda x: (-logavgexp(-x, 2)).detach()                          # decoders.py:170,277,312: TBI => TB
+        tensors = dict(loss_kl=lae(loss_kl_exact), entropy_prior=ent_prior, entropy_post=ent_post,
+                       loss_image=lae(loss_image), image_rec=decoded.mean(2).detach(),
+                       loss_reward=lae(loss_reward), reward_rec=mu.mean(2).detach(),
+                       loss_terminal=lae(loss_terminal), terminal_rec=tdist.mean.mean(2).detach())
         metrics = dict(loss_model=loss_model_tb.mean(), loss_kl=tensors['loss_kl'].mean(),
                        entropy_prior=ent_prior.mean(), entropy_post=ent_post.mean(),
                        loss_image=tensors['loss_image'].mean(), loss_reward=tensors['loss_reward'].mean(),
                        loss_terminal=tensors['loss_terminal'].mean())
     extras = dict(post_idx=torch.stack(idxs), post=posts.detach(), prior=priors.detach(), embed=embed.detach())
     if u_pred is not None:                                                    # do_image_pred, dreamer.py:381-394
+        assert I == 1, 'the oracle restates do_image_pred for iwae_samples = 1'
         with torch.no_grad():
             z_prior, pred_idx = st_sample(conf, priors.detach(), u_pred)      # zdistr(prior).sample()
             fp = torch.cat((hs, z_prior), -1).reshape(T, B, I, -1).detach()   # feature_replace_z
@@ -538,12 +554,13 @@ class OracleDreamer:
         return (torch.zeros(batch, c.deter_dim), torch.zeros(batch, c.stoch_dim * c.stoch_discrete))
 
     def training_step(self, obs, in_state, noise, forced_idx=None, do_image_pred=False, do_dream_tensors=False,
-                      do_open_loop=False):
+                      do_open_loop=False, iwae_samples=None):
         c, p = self.conf, self.p
         T, B = obs['action'].shape[:2]
+        I = int(iwae_samples or c.iwae_samples)
         loss_model, features, states, out_state, metrics, tensors, extras = \
             wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx, noise['u_pred'] if do_image_pred else None,
-                             do_open_loop)
+                             do_open_loop, iwae_samples=I)
         loss_probe = torch.square(p['probe_model.dummy'])                          # probes.py:146-150
         in_dream = tuple(x.detach().reshape(-1, x.shape[-1]) for x in states)      # dreamer.py:149
         if self.train_steps % c.target_interval == 0:                              # a2c.py:76-79
@@ -557,7 +574,7 @@ class OracleDreamer:
         dx['actions'] = actions
         (loss_actor, loss_critic), m_ac, t_ac = ac_training_step(p, c, feats, actions, rewards, terminals)
         metrics.update(m_ac)
-        tensors.update(policy_value=t_ac['value'][0].reshape(T, B, 1).mean(-1))    # dreamer.py:159
+        tensors.update(policy_value=t_ac['value'][0].reshape(T, B, I).mean(-1))    # dreamer.py:159
         extras.update(dx)
         extras.update(dream_features=feats, ac_tensors=t_ac)
         if do_dream_tensors:                                                       # dreamer.py:163-180

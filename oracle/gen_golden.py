@@ -115,7 +115,7 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
             losses, new_state, metrics, tensors, _ = model.training_step(obs, state)
             assert not mp.queue and not mp.eps_queue, f'{len(mp.queue)} uniforms / {len(mp.eps_queue)} normals unused'
             M = T * B * rconf.iwae_samples
-            post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
+            post_idx = torch.stack(mp.idx[:T]).reshape(T, B * rconf.iwae_samples, S)
             if onehot:
                 act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
                 lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
@@ -321,6 +321,14 @@ if __name__ == '__main__':
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],
             dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18), steps=1, slim=True)
+    if 'iwae' in which:
+        # iwae_samples > 1 (rssm.py:35-41 batch expansion, dreamer.py:340-343 sampled KL,
+        # functions.py:97-102 logavgexp), as a TRAINING step (gradients included), tiny dims, I = 3
+        t = O.tiny_conf()
+        run('tiny_iwae', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, iwae_samples=3), steps=2, full_grads=SMALL_GRADS)
     if 'dmc_native' in which:
         # BASELINE.json configs[4] at its native width: defaults+dmc (deter_dim 2048, tanh_normal actor) with
         # actor_grad=reinforce, action_dim 6, B=50, T=50, H=15; slim fixture (several minutes per step on 8 vCPU)

@@ -664,6 +664,143 @@ __global__ void __launch_bounds__(256) kl_bwd_kernel(int rows, int S, int C, con
   }
 }
 
+// ---- IWAE (iwae_samples = I > 1; dreamer.py:340-343,362-365, functions.py:97-102, rssm.py:35-41) ------------------
+// Sampled KL term: loss_kl[n] = log q(z_n) - log p(z_n) with z the drawn one-hot sample.  OneHotCategorical.log_prob
+// goes through value.max(-1) (indices), so no gradient flows through z itself:
+//   d/dpost_k = 1[k = idx] - softmax(post)_k ,  d/dprior_k = -(1[k = idx] - softmax(prior)_k).
+__global__ void __launch_bounds__(256) kl_sampled_fwd_kernel(int rows, int S, int C, const float* __restrict__ post,
+                                                             const float* __restrict__ prior, const int32_t* __restrict__ idx,
+                                                             float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float* a = post + ((size_t)row * S + s) * C;
+    const float* b = prior + ((size_t)row * S + s) * C;
+    const int k = idx[(size_t)row * S + s];
+    acc += (a[k] - dm_group_lse(a, C)) - (b[k] - dm_group_lse(b, C));
+  }
+  acc = dm_wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+__global__ void __launch_bounds__(256) kl_sampled_bwd_kernel(int rows, int S, int C, const float* __restrict__ post,
+                                                             const float* __restrict__ prior, const int32_t* __restrict__ idx,
+                                                             float scale, const float* __restrict__ row_w,
+                                                             float* __restrict__ dpost, float* __restrict__ dprior) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const float* a = post + (size_t)i * C;
+    const float* b = prior + (size_t)i * C;
+    const float la = dm_group_lse(a, C), lb = dm_group_lse(b, C);
+    const float w = scale * (row_w ? row_w[i / S] : 1.f);
+    const int kk = idx[i];
+    for (int k = 0; k < C; ++k) {
+      const float hot = k == kk ? 1.f : 0.f;
+      dpost[(size_t)i * C + k] = w * (hot - expf(a[k] - la));
+      dprior[(size_t)i * C + k] = -w * (hot - expf(b[k] - lb));
+    }
+  }
+}
+extern "C" int dm_kl_sampled_fwd(int rows, int S, int C, const float* post, const float* prior, const int32_t* idx,
+                                 float* out, void* stream) {
+  DM_REQUIRE(post && prior && idx && out, DM_E_NULL, "kl_sampled_fwd: null pointer");
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(kl_sampled_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, S, C, post, prior,
+                     idx, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_kl_sampled_bwd(int rows, int S, int C, const float* post, const float* prior, const int32_t* idx,
+                                 float scale, const float* row_w, float* dpost, float* dprior, void* stream) {
+  DM_REQUIRE(post && prior && idx && dpost && dprior, DM_E_NULL, "kl_sampled_bwd: null pointer");
+  if (rows <= 0) return DM_OK;
+  int blocks = dm_cdiv((size_t)rows * S, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(kl_sampled_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, S, C, post, prior, idx,
+                     scale, row_w, dpost, dprior);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// Reductions over the I samples of every (t,b): x (TB, I, W) -> out (TB, W).
+//   mode 0: mean_i x        mode 2: sum_i x
+//   mode 1 (W = 1): -logavgexp_i(-x) = -(logsumexp_i(-x) - log I)  (functions.py:97-102), and optionally the importance
+//           weights w[tb,i] = softmax_i(-x) = d out / d x_i  (the factor every per-sample gradient of loss_model carries)
+__global__ void __launch_bounds__(256) reduce_i_kernel(int TB, int I, int W, const float* __restrict__ x, int mode,
+                                                       float* __restrict__ out, float* __restrict__ w_out) {
+  const size_t total = (size_t)TB * W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t tb = e / W;
+    const int c = (int)(e % W);
+    const float* p = x + (tb * I) * W + c;
+    if (mode == 1) {
+      float mx = -p[0];
+      for (int i = 1; i < I; ++i) mx = fmaxf(mx, -p[(size_t)i * W]);
+      float s = 0.f;
+      for (int i = 0; i < I; ++i) s += expf(-p[(size_t)i * W] - mx);
+      out[e] = -(mx + logf(s) - logf((float)I));
+      if (w_out)
+        for (int i = 0; i < I; ++i) w_out[tb * I + i] = expf(-p[(size_t)i * W] - mx) / s;
+    } else {
+      float s = 0.f;
+      for (int i = 0; i < I; ++i) s += p[(size_t)i * W];
+      out[e] = mode == 0 ? s / (float)I : s;
+    }
+  }
+}
+extern "C" int dm_reduce_i(int TB, int I, int W, const float* x, int mode, float* out, float* w_out, void* stream) {
+  DM_REQUIRE(x && out, DM_E_NULL, "reduce_i: null pointer");
+  DM_REQUIRE(I >= 1 && W >= 1 && (unsigned)mode <= 2 && (mode != 1 || W == 1), DM_E_SHAPE, "reduce_i: I=%d W=%d mode=%d", I, W, mode);
+  if (TB <= 0) return DM_OK;
+  int blocks = dm_cdiv((size_t)TB * W, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_i_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, TB, I, W, x, mode, out, w_out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// out[r] = sum_j w[j] * x_j[r]  (j < count <= 8): the per-sample model loss kl_weight*KL + image_w*.. (dreamer.py:362)
+struct RowCombineArgs { const float* x[8]; float w[8]; };
+__global__ void __launch_bounds__(256) combine_rows_kernel(int count, long long n, const RowCombineArgs a, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int j = 0; j < count; ++j) s += a.w[j] * a.x[j][i];
+    out[i] = s;
+  }
+}
+extern "C" int dm_combine_rows(int count, int64_t n, const float* const* x, const float* w, float* out, void* stream) {
+  DM_REQUIRE(x && w && out, DM_E_NULL, "combine_rows: null pointer");
+  DM_REQUIRE(count >= 1 && count <= 8, DM_E_SHAPE, "combine_rows: count %d not in [1,8]", count);
+  if (n <= 0) return DM_OK;
+  RowCombineArgs a;
+  for (int j = 0; j < count; ++j) { a.x[j] = x[j]; a.w[j] = w[j]; }
+  int blocks = dm_cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(combine_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, count, (long long)n, a, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// x[r, 0..n) *= w[r] * scale
+__global__ void __launch_bounds__(256) scale_rows_kernel(long long rows, int n, float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ w, float scale) {
+  const long long total = rows * n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / n;
+    x[r * ldx + e % n] *= w[r] * scale;
+  }
+}
+extern "C" int dm_scale_rows(int64_t rows, int n, float* x, int ldx, const float* w, float scale, void* stream) {
+  DM_REQUIRE(x && w, DM_E_NULL, "scale_rows: null pointer");
+  if (rows <= 0 || n <= 0) return DM_OK;
+  int blocks = dm_cdiv(rows * n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)rows, n, x, ldx, w, scale);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // straight-through: sample = onehot + (p - sg(p)) => dlogits_k = p_k (g_k - sum_j p_j g_j)
 // LPG lanes per group (power of two >= C, <= 64): lane k of a group owns category k; reductions are xor-shuffles
 // inside the group's lanes, so the 50-row RSSM steps cost one short wave each instead of a 96-expf serial chain.

@@ -84,6 +84,11 @@ _SIGNATURES = {
     'dm_kl_balance_bwd': (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
     'dm_st_softmax_bwd': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P]),
     'dm_mask_rows': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_int, _P]),
+    'dm_kl_sampled_fwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'dm_kl_sampled_bwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P]),
+    'dm_reduce_i': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    'dm_combine_rows': (c_int, [c_int, c_int64, POINTER(c_void_p), POINTER(c_float), _P, _P]),
+    'dm_scale_rows': (c_int, [c_int64, c_int, _P, c_int, _P, c_float, _P]),
     'dm_im2col_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     'dm_col2im_s2': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
     'dm_mlp_acts_floats': (c_size_t, [c_int, c_int, c_int]),

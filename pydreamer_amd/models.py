@@ -7,7 +7,7 @@ calls the C-ABI of libdreamer_hip.so (pydreamer_amd/hip.py) through three `torch
 model, actor, critic — so each of the 4 returned losses supports an independent `.backward()` exactly like the
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
-Supported configuration (everything else raises NotImplementedError): iwae_samples=1, gru_type='gru', gru_layers=1,
+Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type='gru', gru_layers=1,
 stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh},
 actor_grad='reinforce',
 probe_model='none', no aux critic / vecobs / reward_input.
@@ -564,8 +564,8 @@ class WorldModel(_Params):
 
     def __init__(self, conf):
         super().__init__()
-        if conf.iwae_samples != 1 or conf.aux_critic:
-            raise NotImplementedError('iwae_samples>1 / aux_critic are not built in the HIP path')
+        if conf.aux_critic:
+            raise NotImplementedError('aux_critic is not built in the HIP path')
         if conf.image_size != 64:
             raise NotImplementedError('conv geometry is built for 64x64 observations')
         self.conf = conf
@@ -634,14 +634,21 @@ class WorldModel(_Params):
         return pk['feat'].view(T, B, 1, -1), pk['out_state']
 
     # ---- forward through the C-ABI
-    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False, mbuf=None):
+    def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False, mbuf=None,
+                 iwae=1):
+        """iwae = I > 1 (rssm.py:35-41): every row-wise stage runs on T*B*I rows, row n = (t*B + b)*I + i; only the conv
+        encoder sees the T*B frames once.  Three geometry structs: `shp` (T,B,I: conv decoder + workspace), `shp_e`
+        (T,B,1: encoder), `shp_r` (T, B*I, 1: the RSSM calls take the expanded batch as their batch)."""
         c = self.conf
         image, action = obs['image'], obs['action']
         _require_cuda(image, "obs['image']")
         T, B = action.shape[:2]
-        N, dev = T * B, image.device
+        I = int(iwae)
+        BI, NE = B * I, T * B
+        N, dev = T * B * I, image.device
         D_, Z, F_, E = c.deter_dim, c.stoch_dim * c.stoch_discrete, self.features_dim, self.encoder.out_dim
         shp = self.shape(T, B, imag_horizon)
+        shp.I = I
         ws = self.workspace(shp, dev)
         u8 = image.dtype == torch.uint8
         if u8:
@@ -665,23 +672,29 @@ class WorldModel(_Params):
             if not forward_only or k in obs:
                 if k in obs:
                     want[k], got[k] = (T, B), tuple(obs[k].shape)
-        want['in_state[0]'], got['in_state[0]'] = (B, D_), tuple(h0.shape)
-        want['in_state[1]'], got['in_state[1]'] = (B, Z), tuple(z0.shape)
+        want['in_state[0]'], got['in_state[0]'] = (BI, D_), tuple(h0.shape)
+        want['in_state[1]'], got['in_state[1]'] = (BI, Z), tuple(z0.shape)
         if u_post is not None:
-            want['u_post numel'], got['u_post numel'] = T * B * c.stoch_dim, u_post.numel()
+            want['u_post numel'], got['u_post numel'] = T * BI * c.stoch_dim, u_post.numel()
         if forced_idx is not None:
-            want['forced_idx'], got['forced_idx'] = (T, B, c.stoch_dim), tuple(forced_idx.shape)
+            want['forced_idx'], got['forced_idx'] = (T, BI, c.stoch_dim), tuple(forced_idx.shape)
         bad = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
         if bad:
             raise ValueError('training_step input shapes (got, expected): ' + ', '.join(f'{k}: {v[0]} != {v[1]}' for k, v in bad.items()))
         if u_post is None and forced_idx is None:
-            u_post = torch.rand(T, B, c.stoch_dim, device=dev)
+            u_post = torch.rand(T, BI, c.stoch_dim, device=dev)
         lib = H.lib()
+        shp_e = shp_r = shp
+        if I > 1:
+            shp_e = H.dm_shape.from_buffer_copy(shp)
+            shp_e.I = 1
+            shp_r = H.dm_shape.from_buffer_copy(shp)
+            shp_r.B, shp_r.I = BI, 1
 
         enc = self.encoder.encoder_image
         enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
-        enc_acts = torch.empty(int(lib.dm_conv_encoder_acts_floats(ctypes.byref(shp))), device=dev)
-        embed = torch.empty(N, E, device=dev)
+        enc_acts = torch.empty(int(lib.dm_conv_encoder_acts_floats(ctypes.byref(shp_e))), device=dev)
+        embed = torch.empty(NE, E, device=dev)
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         if open_loop:
@@ -695,7 +708,7 @@ class WorldModel(_Params):
                              ('post_mlp.weight', 'prior_mlp.weight'), ('post_mlp.bias', 'prior_mlp.bias')):
                 po[ix[dst]] = po[ix[src]]
             rssm_p = H.rssm_struct(po)
-        rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp))), device=dev)
+        rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp_r))), device=dev)
         feat = torch.empty(N, F_, device=dev)
         post = torch.empty(N, Z, device=dev)
         prior = torch.empty(N, Z, device=dev)
@@ -711,12 +724,17 @@ class WorldModel(_Params):
             loss_image = torch.empty(N, device=dev)
             image_rec = None          # materialised lazily from the decoder's saved prediction (see LazyTensors)
 
-        chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop) else 1
+        chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop and I == 1) else 1
+        embed_x, action_x, reset_x = embed, action, reset
         if chunks <= 1:
-            H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.ptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
+            H.call('dm_conv_encoder_fwd', ctypes.byref(shp_e), H.ptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
                    H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
-            embed_rssm = torch.zeros_like(embed) if open_loop else embed
-            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed_rssm), H.fptr(action), H.ptr(reset), H.fptr(h0),
+            if I > 1:       # rssm.py:35-41: (T,B,X) -> (T,B*I,X); pure data movement
+                embed_x = embed.view(T, B, E).repeat_interleave(I, dim=1).contiguous().view(N, E)
+                action_x = action.repeat_interleave(I, dim=1).contiguous()
+                reset_x = reset.repeat_interleave(I, dim=1).contiguous()
+            embed_rssm = torch.zeros_like(embed_x) if open_loop else embed_x
+            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp_r), H.fptr(embed_rssm), H.fptr(action_x), H.ptr(reset_x), H.fptr(h0),
                    H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
             if not forward_only:
@@ -755,23 +773,27 @@ class WorldModel(_Params):
             main.wait_stream(pp['s_chain'])
             main.wait_stream(pp['s_dec'])
 
-        last = feat[(T - 1) * B:]
+        last = feat[(T - 1) * BI:]
         out_state = (last[:, :D_].clone(), last[:, D_:].clone())                  # detached by construction (rssm.py:77)
-        pk = dict(shp=shp, T=T, B=B, feat=feat, post=post, prior=prior, idx=idx, out_state=out_state, embed=embed)
+        pk = dict(shp=shp, shp_e=shp_e, shp_r=shp_r, T=T, B=B, I=I, feat=feat, post=post, prior=prior, idx=idx,
+                  out_state=out_state, embed=embed, embed_x=embed_x, action_x=action_x, reset_x=reset_x)
         if forward_only:
             return pk
 
         reward_t = obs['reward'].float().contiguous()
         terminal_t = obs['terminal'].float().contiguous()
+        if I > 1:                                  # targets expanded over I (decoders.py:270,305: insert_dim)
+            reward_t = reward_t.repeat_interleave(I, dim=1).contiguous()
+            terminal_t = terminal_t.repeat_interleave(I, dim=1).contiguous()
         mu, r_acts = dec.reward.model.fwd(feat, F_, N, ws)
         tl, t_acts = dec.terminal.model.fwd(feat, F_, N, ws)
         loss_reward, dmu, reward_rec = (torch.empty(N, device=dev) for _ in range(3))
         loss_terminal, dtl, terminal_rec = (torch.empty(N, device=dev) for _ in range(3))
         # -Normal(mu, std).log_prob(y) * std^2 = 0.5 (mu-y)^2 + std^2 (log std + log sqrt(2 pi))   (decoders.py:296-304)
         loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
-        H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), dec.reward_weight / N, loss_const, H.fptr(loss_reward),
+        H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), dec.reward_weight / NE, loss_const, H.fptr(loss_reward),
                H.fptr(dmu), H.fptr(reward_rec), H.stream())
-        H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), dec.terminal_weight / N, 0.0, H.fptr(loss_terminal),
+        H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), dec.terminal_weight / NE, 0.0, H.fptr(loss_terminal),
                H.fptr(dtl), H.fptr(terminal_rec), H.stream())
 
         # KL + entropies (dreamer.py:326-343,369-379)
@@ -781,26 +803,52 @@ class WorldModel(_Params):
 
         if mbuf is None:
             mbuf = torch.zeros(METRIC_BUF_FLOATS, device=dev)
-        means = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
-                            (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev, out=mbuf[0:6])
         loss = mbuf[6]
         w = (ctypes.c_float * 4)(self.kl_weight, dec.image_weight, dec.reward_weight, dec.terminal_weight)
-        H.call('dm_combine', 4, H.fptr(means), w, ctypes.c_void_p(mbuf.data_ptr() + 24), H.stream())     # dreamer.py:362-365
+        iw = None
+        if I == 1:
+            means = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
+                                (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev, out=mbuf[0:6])
+            H.call('dm_combine', 4, H.fptr(means), w, ctypes.c_void_p(mbuf.data_ptr() + 24), H.stream())   # dreamer.py:362-365
+            tb = lambda x: x.view(T, B)
+            t_kl, t_ep, t_eq, t_li, t_lr, t_lt, t_rr, t_tr = (tb(x) for x in (kl, ent_prior, ent_post, loss_image, loss_reward,
+                                                                              loss_terminal, reward_rec, terminal_rec))
+        else:
+            # IWAE: sampled KL (dreamer.py:340-343); loss_model = mean_tb -logavgexp_i(-loss_tbi) (dreamer.py:362-365);
+            # the logged tensors are -logavgexp_i(-x) of the per-sample losses (decoders.py:170,277,312), means over I for the
+            # entropies and the reconstructions (dreamer.py:371-372, decoders.py:171,278,313)
+            kl_s = torch.empty(N, device=dev)
+            H.call('dm_kl_sampled_fwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(post), H.fptr(prior), H.ptr(idx), H.fptr(kl_s),
+                   H.stream())
+            l_tbi = torch.empty(N, device=dev)
+            ptrs = (ctypes.c_void_p * 4)(kl_s.data_ptr(), loss_image.data_ptr(), loss_reward.data_ptr(), loss_terminal.data_ptr())
+            H.call('dm_combine_rows', 4, N, ptrs, w, H.fptr(l_tbi), H.stream())
+            iw = torch.empty(N, device=dev)                   # importance weights softmax_i(-loss_tbi) = d loss_tb / d loss_tbi
+            red = torch.empty(9, NE, device=dev)
+            H.call('dm_reduce_i', NE, I, 1, H.fptr(l_tbi), 1, H.fptr(red[0]), H.fptr(iw), H.stream())
+            for j, (x, mode) in enumerate(((kl, 1), (loss_image, 1), (loss_reward, 1), (loss_terminal, 1), (ent_prior, 0),
+                                           (ent_post, 0), (reward_rec, 0), (terminal_rec, 0))):
+                H.call('dm_reduce_i', NE, I, 1, H.fptr(x), mode, H.fptr(red[j + 1]), None, H.stream())
+            _multi_sum([(red[1], 1.0 / NE), (red[2], 1.0 / NE), (red[3], 1.0 / NE), (red[4], 1.0 / NE), (red[5], 1.0 / NE),
+                        (red[6], 1.0 / NE), (red[0], 1.0 / NE)], dev, out=mbuf[0:7])
+            means = mbuf[0:6]
+            tb = lambda x: x.view(T, B)
+            t_kl, t_li, t_lr, t_lt, t_ep, t_eq, t_rr, t_tr = (tb(red[j]) for j in range(1, 9))
 
         pk.update(loss=loss, image=image, action=action, reset=reset, enc_acts=enc_acts, rssm_acts=rssm_acts,
-                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws, mbuf=mbuf)
-        tb = lambda x: x.view(T, B)
-        pk['tensors'] = LazyTensors(loss_kl=tb(kl), entropy_prior=tb(ent_prior), entropy_post=tb(ent_post),
-                                    loss_image=tb(loss_image), image_rec=None,
-                                    loss_reward=tb(loss_reward), reward_rec=tb(reward_rec),
-                                    loss_terminal=tb(loss_terminal), terminal_rec=tb(terminal_rec))
+                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws, mbuf=mbuf, iw=iw)
+        pk['tensors'] = LazyTensors(loss_kl=t_kl, entropy_prior=t_ep, entropy_post=t_eq,
+                                    loss_image=t_li, image_rec=None,
+                                    loss_reward=t_lr, reward_rec=t_rr,
+                                    loss_terminal=t_lt, terminal_rec=t_tr)
         Cc, hw = c.image_channels, c.image_size * c.image_size
         pred_off = int(lib.dm_conv_decoder_pred_offset(ctypes.byref(shp)))
 
         def image_rec_thunk(acts=dec_acts):       # holds the decoder activations alive until the dict is dropped
             with torch.no_grad():
                 pred = acts[pred_off:pred_off + N * hw * Cc].view(N, hw, Cc)                       # NHWC
-                return pred.transpose(1, 2).contiguous().view(T, B, Cc, c.image_size, c.image_size)    # -> (T,B,C,H,W)
+                rec = pred.transpose(1, 2).contiguous().view(T, B, I, Cc, c.image_size, c.image_size)   # -> (T,B,I,C,H,W)
+                return rec[:, :, 0] if I == 1 else rec.mean(2)       # decoded.mean(dim=2), decoders.py:171 (logging only)
         pk['tensors'].lazy('image_rec', image_rec_thunk)
         pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
                              loss_image=means[1], loss_reward=means[2], loss_terminal=means[3])
@@ -811,8 +859,9 @@ class WorldModel(_Params):
 
     def _backward(self, pk, ws, scratch=False):
         c = self.conf
-        shp, T, B = pk['shp'], pk['T'], pk['B']
-        N = T * B
+        shp, T, B, I = pk['shp'], pk['T'], pk['B'], pk.get('I', 1)
+        NE, N = T * B, T * B * I
+        iw = pk.get('iw')          # IWAE importance weights (N,) or None: every per-sample gradient of loss_model carries them
         feat, dev = pk['feat'], pk['feat'].device
         F_, Z, E = self.features_dim, c.stoch_dim * c.stoch_discrete, self.encoder.out_dim
         plist = self._param_order()
@@ -822,6 +871,10 @@ class WorldModel(_Params):
 
         dfeat = torch.zeros(N, F_, device=dev)
         # dense heads (decoders.py:73-83)
+        if iw is not None and not pk.get('iw_applied'):
+            for dout in (pk['dmu'], pk['dtl']):
+                H.call('dm_scale_rows', N, 1, H.fptr(dout), 1, H.fptr(iw), 1.0, H.stream())
+            pk['iw_applied'] = True
         for head, acts, dout in ((dec.reward.model, pk['r_acts'], pk['dmu']), (dec.terminal.model, pk['t_acts'], pk['dtl'])):
             st, gs = head.struct(), head.grad_struct(gof)
             H.call('dm_mlp_head_bwd', N, F_, head.hidden_dim, head.hidden_layers, 1, H.fptr(feat), F_, ctypes.byref(st),
@@ -830,33 +883,42 @@ class WorldModel(_Params):
         dl = dec.image.layers()
         dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
         dec_g = H.conv_struct([gof[id(m.weight)] for m in dl], [gof[id(m.bias)] for m in dl], cls=H.dm_conv_grads)
-        H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
-               H.fptr(pk['dec_acts']), dec.image_weight / N, ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws), ws.numel(),
-               H.stream())
-        # KL (dreamer.py:334-339)
+        H.call('dm_conv_decoder_mse_bwd_rows', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
+               H.fptr(pk['dec_acts']), dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws),
+               ws.numel(), H.stream())
+        # KL (dreamer.py:334-343)
         dpost = torch.empty(N, Z, device=dev)
         dprior = torch.empty(N, Z, device=dev)
-        if self.kl_balance is None:
-            sp = sq = self.kl_weight / N
+        if iw is not None:         # sampled KL of the IWAE bound
+            H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
+                   H.ptr(pk['idx']), self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
         else:
-            sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
-        H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
-               H.fptr(dpost), H.fptr(dprior), H.stream())
+            if self.kl_balance is None:
+                sp = sq = self.kl_weight / N
+            else:
+                sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
+            H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
+                   H.fptr(dpost), H.fptr(dprior), H.stream())
         # RSSM BPTT
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
         dembed = torch.empty(N, E, device=dev)
-        H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(pk['embed']), H.fptr(pk['action']), H.ptr(pk['reset']),
-               ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']), H.fptr(dfeat), H.fptr(dpost),
-               H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(), H.stream())
+        H.call('dm_rssm_sequence_bwd', ctypes.byref(pk['shp_r']), H.fptr(pk['embed_x']), H.fptr(pk['action_x']),
+               H.ptr(pk['reset_x']), ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']),
+               H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(),
+               H.stream())
+        if I > 1:                  # the I samples of a (t,b) share one embedding row: their gradients add up
+            dsum = torch.empty(NE, E, device=dev)
+            H.call('dm_reduce_i', NE, I, E, H.fptr(dembed), 2, H.fptr(dsum), None, H.stream())
+            dembed = dsum
         # encoder
         enc = self.encoder.encoder_image
         enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
         enc_g = H.conv_struct([gof[id(m.weight)] for m in enc.convs()], [gof[id(m.bias)] for m in enc.convs()],
                               cls=H.dm_conv_grads)
-        H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.ptr(pk['image']), ctypes.byref(enc_p), H.fptr(pk['enc_acts']),
-               H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
+        H.call('dm_conv_encoder_bwd', ctypes.byref(pk['shp_e']), H.ptr(pk['image']), ctypes.byref(enc_p),
+               H.fptr(pk['enc_acts']), H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
         return views, flat, direct
 
     def _image_pred(self, pk, obs, u_pred):
@@ -908,8 +970,9 @@ class WorldModel(_Params):
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
                       u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
-        if iwae_samples != 1:
-            raise NotImplementedError('iwae_samples>1 is an evaluation variant not built yet')
+        I = int(iwae_samples)
+        if I > 1 and (do_image_pred or do_open_loop):
+            raise NotImplementedError('do_image_pred / do_open_loop are built for iwae_samples = 1')
         if do_open_loop and torch.is_grad_enabled():
             raise NotImplementedError('do_open_loop is an evaluation variant: call it under torch.no_grad() like '
                                       'train.py:353-359 does (its backward is not built)')
@@ -917,12 +980,13 @@ class WorldModel(_Params):
         if forward_only:
             feats, out_state = self.forward(obs, in_state)
             return torch.tensor(0.0), feats, None, out_state, {}, {}
-        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop, mbuf=mbuf)
+        pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop, mbuf=mbuf,
+                           iwae=I)
         loss = _WMStep.apply(self, pk, *self._param_order())
         D_ = self.deter_dim
         feat = pk['feat']
-        features = feat.view(T, B, 1, -1)
-        states = (feat[:, :D_].view(T, B, 1, -1), feat[:, D_:].view(T, B, 1, -1))
+        features = feat.view(T, B, I, -1)
+        states = (feat[:, :D_].view(T, B, I, -1), feat[:, D_:].view(T, B, I, -1))
         self._last_pack = pk
         if do_image_pred:
             m, t, pk['pred_idx'] = self._image_pred(pk, obs, u_pred)
@@ -1190,9 +1254,12 @@ class Dreamer(nn.Module):
         if H.lib().dm_get_gemm_precision() != int(self.amp):
             H.call('dm_set_gemm_precision', int(self.amp))
         noise = noise or {}
+        I = iwae_samples
+        if I > 1 and do_dream_tensors:
+            raise NotImplementedError('do_dream_tensors is built for iwae_samples = 1')
         u_post = noise.get('u_post')
         if u_post is not None:
-            u_post = u_post.reshape(T, B, -1)
+            u_post = u_post.reshape(T, B * I, -1)
 
         # every loss / metric scalar of this step lands in ONE device buffer (METRIC_SLOTS)
         mbuf = torch.zeros(METRIC_BUF_FLOATS, device=obs['action'].device)
@@ -1235,7 +1302,7 @@ class Dreamer(nn.Module):
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
                                   actor_logits=dpk['actor_logits'], overlap=ov, mbuf=mbuf)
         if ov is not None:
-            need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B, MLP_HIDDEN, 4))
+            need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B * I, MLP_HIDDEN, 4))
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
             ov.ev_fwd.record(torch.cuda.current_stream())
@@ -1243,8 +1310,13 @@ class Dreamer(nn.Module):
                 hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: _prelaunched(mlp, lambda: mlp.bwd(
                     hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True)))
         metrics.update(**metrics_ac)
-        tensors.update(policy_value=tensors_ac['value'][0].view(T, B, 1).mean(-1))
-        self.last_extras = dict(post_idx=pk['idx'].view(T, B, -1), act_idx=dpk['act_idx'], actions=actions_dream,
+        if I == 1:
+            tensors.update(policy_value=tensors_ac['value'][0].view(T, B))
+        else:                        # unflatten_batch(value[0], (T,B,I)).mean(-1), dreamer.py:159
+            pv = torch.empty(T, B, device=pk['feat'].device)
+            H.call('dm_reduce_i', T * B, I, 1, H.fptr(tensors_ac['value'][0].contiguous()), 0, H.fptr(pv), None, H.stream())
+            tensors.update(policy_value=pv)
+        self.last_extras = dict(post_idx=pk['idx'].view(T, B * I, -1), act_idx=dpk['act_idx'], actions=actions_dream,
                                 dream_features=features_dream,
                                 ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'], pred_idx=pk.get('pred_idx'))
         # Dream for a log sample (dreamer.py:163-180): T-1 imagined steps from the B first states, decoded to images

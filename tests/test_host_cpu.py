@@ -75,7 +75,7 @@ def test_state_dict_keys_match_reference_table():
 
 def test_unsupported_configs_fail_loudly():
     from pydreamer_amd.models import Dreamer
-    for kw in (dict(iwae_samples=3), dict(gru_type='gru_layernorm'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
+    for kw in (dict(aux_critic=True), dict(gru_type='gru_layernorm'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
                dict(image_size=32), dict(stoch_discrete=0), dict(layer_norm=False)):
         conf = config.load_config('defaults', 'atari', **kw)
         with pytest.raises(NotImplementedError):

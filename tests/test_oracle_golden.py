@@ -32,7 +32,7 @@ def _replay(name, steps):
     torch.manual_seed(0)
     model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
     model.init_optimizers()
-    state = model.init_state(conf.batch_size)
+    state = model.init_state(conf.batch_size * conf.iwae_samples)
     results = []
     for s in range(steps):
         pre = f's{s}_'
@@ -58,7 +58,7 @@ def _check_step(g, conf, res):
     pre, losses, new_state, metrics, tensors, extras, grad_metrics, grads, (sums, abss) = res
     T, B, S, H = conf.batch_length, conf.batch_size, conf.stoch_dim, conf.imag_horizon
     # integer outputs: bit-exact
-    assert np.array_equal(extras['post_idx'].reshape(T, B, S).numpy().astype(np.uint8), g[pre + 'idx_post'])
+    assert np.array_equal(extras['post_idx'].reshape(T, B * conf.iwae_samples, S).numpy().astype(np.uint8), g[pre + 'idx_post'])
     assert np.array_equal(extras['act_idx'].numpy().astype(np.uint8), g[pre + 'idx_act'])
     assert np.array_equal(extras['lat_idx'].numpy().astype(np.uint8), g[pre + 'idx_lat'])
     # losses / metrics
@@ -105,6 +105,15 @@ def test_param_table_matches_reference_state_dict():
 
 def test_oracle_matches_reference_tiny_two_steps():
     g, conf, results = _replay('tiny', 2)
+    for res in results:
+        _check_step(g, conf, res)
+
+
+def test_oracle_matches_reference_iwae():
+    """iwae_samples = 3 as a training step (two consecutive steps): batch expansion by I (rssm.py:35-41),
+    sampled KL (dreamer.py:340-343), loss_model = -logavgexp(-loss_tbi) (functions.py:97-102), gradients included."""
+    g, conf, results = _replay('tiny_iwae', 2)
+    assert conf.iwae_samples == 3
     for res in results:
         _check_step(g, conf, res)
 
