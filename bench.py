@@ -74,7 +74,8 @@ def _effective_cores():
 
 
 def cpu_baseline_worker(sample_batch, threads):
-    """Runs in a subprocess (see cpu_baseline): oracle grad steps on `sample_batch` of the 50 batch columns."""
+    """Runs in a subprocess (see cpu_baseline): oracle grad steps on the FULL workload (all 50 batch columns, T=50, H=15),
+    one warm-up step excluded, >= 3 timed steps or ~25 s of CPU work, whichever comes first."""
     from oracle import dreamer_oracle as O
     torch.set_num_threads(threads)
     full = O.atari_literal_conf()
@@ -84,25 +85,35 @@ def cpu_baseline_worker(sample_batch, threads):
     state = model.init_state(conf.batch_size)
     obs = O.preprocess(O.synthetic_batch(conf), conf)
     noise = O.make_noise(conf)
-    n, t0 = 0, time.perf_counter()
-    while True:
+
+    def one(state):
         losses, state, *_ = model.training_step(obs, state, noise)
         model.backward_clip_step(losses)
+        return state
+    tw = time.perf_counter()
+    state = one(state)                       # warm-up (allocator, thread pools, first-touch) - excluded
+    warm = time.perf_counter() - tw
+    n, t0 = 0, time.perf_counter()
+    while True:
+        state = one(state)
         n += 1
         el = time.perf_counter() - t0
-        if el >= 15.0 or n >= 16:          # ~15 s of CPU work (bounded; the subprocess also has a hard timeout)
+        if n >= 3 and (el >= 15.0 or n >= 8):
+            break
+        if el >= 40.0:
             break
     frac = sample_batch / full.batch_size
     print(json.dumps(dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port',
-                          sample=f'{n} grad step(s) (fwd + 4 bwd + clip + 4 AdamW) on {sample_batch} of the {full.batch_size} batch '
-                                 f'columns (T=50, H=15, same model) in {el:.1f} s with {threads} torch threads, first step '
-                                 f'included; scaled by {sample_batch}/{full.batch_size} to full-batch grad-steps/s')))
+                          sample=f'{n} timed grad step(s) (fwd + 4 bwd + clip + 4 AdamW) of oracle/dreamer_oracle.py on {sample_batch} of the '
+                                 f'{full.batch_size} batch columns (T=50, H=15, same model) in {el:.1f} s with {threads} torch threads; one '
+                                 f'warm-up step ({warm:.1f} s) excluded' +
+                                 ('' if frac == 1.0 else f'; scaled by {sample_batch}/{full.batch_size} to full-batch grad-steps/s'))))
 
 
-def cpu_baseline(sample_batch=10, threads_cap=32, timeout_s=150):
-    """Oracle (test infrastructure, kind "port") as the CPU baseline on a bounded sample, in a subprocess with a hard
-    timeout so a pathological host (thread oversubscription cost 889 s for one step in the first run of this round)
-    can never stall the bench; returns a dict with value=None and the reason if it does not finish."""
+def cpu_baseline(sample_batch=50, threads_cap=32, timeout_s=200):
+    """Oracle (test infrastructure, kind "port") as the CPU baseline, in a subprocess with a hard timeout so a pathological
+    host (thread oversubscription cost 889 s for one step in the first run of round 1) can never stall the bench; returns a
+    dict with value=None and the reason if it does not finish."""
     import subprocess
     cores = _effective_cores()
     threads = max(1, min(cores, threads_cap))
@@ -113,26 +124,51 @@ def cpu_baseline(sample_batch=10, threads_cap=32, timeout_s=150):
         line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
         res = json.loads(line)
         res['host_cores'] = cores
-        # measured in the build container (8 threads, 10 batch columns, 4 steps each): the oracle needs 0.79x the wall time
-        # of the real reference per grad step (the reference re-runs the actor and goes through torch.distributions),
-        # i.e. this baseline is ~1.27x FASTER than the reference's own CPU path would be on the same cores
-        res['oracle_over_reference_time'] = 0.79
+        # representativeness of the port: oracle / reference wall time per grad step, MEASURED in the build
+        # container by oracle/time_vs_reference.py against the reference's own loop and committed under profiles/
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r02_oracle_vs_reference.json')) as f:
+                m = json.load(f)
+            res['oracle_over_reference_time'] = m['oracle_over_reference_time']
+            res['oracle_over_reference_source'] = (f"profiles/r02_oracle_vs_reference.json: oracle {m['oracle_s_per_step']:.2f} s vs reference "
+                                                   f"{m['reference_s_per_step']:.2f} s per step, {m['batch_columns']} columns, {m['threads']} threads, "
+                                                   f"build container")
+        except (OSError, KeyError, ValueError):
+            res['oracle_over_reference_time'] = None
         return res
     except Exception as e:       # timeout or crash: report, never hang
         return dict(value=None, unit='grad-steps/s', cores=threads, kind='port', host_cores=cores,
                     sample=f'oracle sample of {sample_batch}/50 batch columns did not finish within {timeout_s} s ({type(e).__name__})')
 
 
+def csrc_sha():
+    """Fingerprint of the kernel sources: PMC traffic files carry it, so a stale file is refused instead of silently reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'pydreamer_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h')):
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == '--cpu-baseline-worker':
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+    if len(sys.argv) >= 2 and sys.argv[1] == '--csrc-sha':
+        return print(csrc_sha())
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pmc-json', default=os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'),
+                    help='per-kernel HBM traffic from two rocprofv3 PMC passes of THIS command (scripts/pmc_traffic.py); it carries a '
+                         'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
     ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
                     'off by default: on ROCm 7.2 a graph with concurrent branches replays slower than the side streams run eagerly')
     ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
@@ -223,38 +259,48 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
-        out = (ctypes.c_double * 80)()
-        n = hip.lib().dm_prof_end(out, 20)
+        out = (ctypes.c_double * 88)()
+        n = hip.lib().dm_prof_end(out, 22)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
         tiles = ('128,128', '128,64', '64,64', '128,96', '96,128')
-        for k in range(20):
+        for k in range(22):
             cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
-                kinds.append(dict(kernel=f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>",
-                                  layout=names[k & 3], launches_per_step=cnt / args.prof_steps,
+                kname = (f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>" if k < 20 else
+                         ('panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2'))
+                kinds.append(dict(kernel=kname,
+                                  layout=names[k & 3] if k < 20 else ('row panel fwd' if k == 20 else 'row panel bwd'), launches_per_step=cnt / args.prof_steps,
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
                                   ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12,
                                   alg_bytes_per_launch=by / cnt, alg_flops_per_launch=fl / cnt))
-        tot_fl = sum(out[4 * k + 1] for k in range(20))
-        tot_ms = sum(out[4 * k + 2] for k in range(20))
+        tot_fl = sum(out[4 * k + 1] for k in range(22))
+        tot_ms = sum(out[4 * k + 2] for k in range(22))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3 if args.dtype == 'f32' else 2500.0       # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE
         # and WRITE_SIZE cannot share a pass), summarised by scripts/pmc_traffic.py into profiles/ - read back here
-        traffic = None
+        traffic, traffic_note = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')) as f:
-                pmc = json.load(f)['kernels']
-            key = dom['kernel'].replace('>', '') + ','        # "gemm_f32_kernel<64,64,0,0" + remaining template args
-            hits = [v for k, v in pmc.items() if k.replace(' ', '').startswith(key.replace(' ', ''))]
-            if hits:
-                n = sum(h['launches'] for h in hits)
-                traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n, 1)
-        except (OSError, KeyError, ValueError):
-            traffic = None
+            with open(args.pmc_json) as f:
+                pj = json.load(f)
+            if pj.get('csrc_sha') != csrc_sha():
+                traffic_note = (f"{os.path.relpath(args.pmc_json, ROOT)} was collected for kernel sources {pj.get('csrc_sha')}, the tree is "
+                                f"{csrc_sha()}: stale, refused")
+            else:
+                pmc = pj['kernels']
+                key = dom['kernel'].replace('>', '') + ','        # "gemm_f32_kernel<64,64,0,0" + remaining template args
+                hits = [v for k, v in pmc.items() if k.replace(' ', '').startswith(key.replace(' ', ''))]
+                if hits:
+                    n = sum(h['launches'] for h in hits)
+                    traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n, 1)
+                    traffic_note = (f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE in separate rocprofv3 passes of this command "
+                                    f"({os.path.relpath(args.pmc_json, ROOT)}, kernel sources {pj['csrc_sha']}); whole step "
+                                    f"{pj.get('total_gb_per_step')} GB")
+        except (OSError, KeyError, ValueError) as e:
+            traffic_note = f'no PMC file ({type(e).__name__})' 
         roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=traffic,
-                    traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes; profiles/r01_pmc_traffic.json)',
+                    traffic_unit=traffic_note,
                     algorithmic_bytes_per_launch=dom.get('alg_bytes_per_launch'),
                     kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,

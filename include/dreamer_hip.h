@@ -301,8 +301,9 @@ int dm_get_gemm_precision(void);
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for
- * kind = tile*4 + a_layout*2 + b_layout with tile 0..4 = 128x128 / 128x64 / 64x64 / 128x96 / 96x128 (20 kinds; nkinds >= 20; `out` holds
- * 4*nkinds doubles) and returns the number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
+ * kind = tile*4 + a_layout*2 + b_layout with tile 0..4 = 128x128 / 128x64 / 64x64 / 128x96 / 96x128, kind 20 = row-panel
+ * Linear+LayerNorm+ELU forward, 21 = row-panel backward (22 kinds; nkinds >= 22; `out` holds 4*nkinds doubles) and returns the
+ * number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
 /* y = a*x + b*y */

@@ -280,6 +280,43 @@ def run_eval(name, sections, overrides, do_open_loop=False):
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB', {k: float(v) for k, v in metrics.items() if 'logprob' in k})
 
 
+def run_inference(name, sections, overrides):
+    """Dreamer.inference (dreamer.py:92-111) as the acting process calls it (generator.py:317-331): one step, (1,B,...) obs,
+    the posterior draw pinned by the same multinomial patch.  Stores inputs, uniforms, action probabilities, the new state
+    and policy_value - what an actor running the reference would see when it loads a checkpoint written by the build."""
+    torch.manual_seed(0)
+    sys.path.insert(0, REF)
+    from pydreamer.models import Dreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    rconf = reference_conf(sections, overrides)
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    model = Dreamer(rconf)
+    model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    B, S, C, A = 3, rconf.stoch_dim, rconf.stoch_discrete, rconf.action_dim
+    g = torch.Generator().manual_seed(31)
+    image_u8 = torch.randint(0, 256, (1, B, 64, 64, 3), generator=g, dtype=torch.uint8)
+    image = (image_u8.float() / 255.0 - 0.5).permute(0, 1, 4, 2, 3).contiguous()
+    action = torch.nn.functional.one_hot(torch.randint(0, A, (1, B), generator=g), A).float()
+    reset = torch.tensor([[True, False, False]])
+    h = torch.tanh(torch.randn(B, rconf.deter_dim, generator=g))
+    z = torch.nn.functional.one_hot(torch.randint(0, C, (B, S), generator=g), C).float().reshape(B, S * C)
+    u = torch.rand(1, B, S, generator=g)
+    obs = dict(image=image, action=action, reset=reset, reward=torch.zeros(1, B), terminal=torch.zeros(1, B))
+    with MultinomialPatch() as mp, torch.no_grad():
+        mp.queue = [u[0]]
+        dist, (h1, z1), metrics = model.inference(obs, (h, z))
+        assert not mp.queue
+        probs = dist.probs if hasattr(dist, 'probs') else None
+    out = dict(conf_json=np.array(repr(sorted(vars(oconf).items()))), in_image_u8=image_u8.numpy(), in_action=action.numpy(),
+               in_reset=reset.numpy(), in_h=h.numpy(), in_z=z.numpy(), in_u=u.numpy(), action_probs=probs.numpy(),
+               out_h=h1.numpy(), out_z=z1.numpy(), policy_value=np.array(float(metrics['policy_value'])),
+               state_dict_keys=np.array(list(model.state_dict().keys())))
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB', 'policy_value', float(metrics['policy_value']))
+
+
 SMALL_GRADS = ('wm.core.cell.a_mlp.weight', 'wm.core.cell.gru.layers.0.bias_hh', 'wm.core.cell.post_norm.weight',
                'wm.core.cell.prior_mlp.bias', 'wm.encoder.encoder_image.model.0.weight',
                'wm.decoder.image.model.8.weight', 'ac.actor.model.12.weight', 'ac.critic.model.1.weight')
@@ -321,6 +358,11 @@ if __name__ == '__main__':
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],
             dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18), steps=1, slim=True)
+    if 'inference' in which:
+        t = O.tiny_conf()
+        run_inference('tiny_inference', ['defaults', 'atari'],
+                      dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                           cnn_depth=t.cnn_depth, action_dim=t.action_dim))
     if 'iwae' in which:
         # iwae_samples > 1 (rssm.py:35-41 batch expansion, dreamer.py:340-343 sampled KL,
         # functions.py:97-102 logavgexp), as a TRAINING step (gradients included), tiny dims, I = 3

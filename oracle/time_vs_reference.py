@@ -1,0 +1,79 @@
+"""Wall-time ratio oracle / reference for one gradient step (build container only: imports /root/reference).
+
+    python oracle/time_vs_reference.py [batch_columns=10] [steps=3]  ->  profiles/r02_oracle_vs_reference.json
+
+SURVEY 8(d): the CPU baseline that bench.py times on the GPU box is the oracle (kind "port"; the reference's Python never
+travels).  Its representativeness is established HERE by running the reference's own loop (train.py:165-198: forward under
+its nn.Modules and torch.distributions, 4 x backward, clip, 4 x AdamW) and the oracle's on the same synthetic
+Atari-literal batch (same model size, T=50, H=15; `batch_columns` of the 50 columns), one warm-up step excluded.
+bench.py reads the JSON and reports the ratio with its provenance instead of a hard-coded constant."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import dreamer_oracle as O          # noqa: E402
+from oracle import gen_golden as G              # noqa: E402
+
+
+def main():
+    cols = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    threads = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    rconf = G.reference_conf(['defaults', 'atari'], dict(batch_size=cols, batch_length=50, imag_horizon=15, deter_dim=600,
+                                                         action_dim=18))
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    obs = O.preprocess(O.synthetic_batch(oconf), oconf)
+    noise = O.make_noise(oconf)
+    params = O.make_params(oconf, seed=0)
+
+    # oracle
+    model = O.OracleDreamer(oconf, params)
+    model.init_optimizers()
+    state = model.init_state(cols)
+    t_or = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        losses, state, *_ = model.training_step(obs, state, noise)
+        model.backward_clip_step(losses)
+        t_or.append(time.perf_counter() - t0)
+
+    # reference (its own modules; torch.multinomial / torch.normal unpatched: it draws its own samples)
+    sys.path.insert(0, G.REF)
+    from pydreamer.models import Dreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    ref = Dreamer(rconf)
+    ref.load_state_dict(params, strict=True)
+    opts = ref.init_optimizers(rconf.adam_lr, rconf.adam_lr_actor, rconf.adam_lr_critic, rconf.adam_eps)
+    rstate = ref.init_state(cols)
+    t_ref = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        losses, rstate, metrics, tensors, _ = ref.training_step(obs, rstate)
+        for opt in opts:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
+        ref.grad_clip(rconf.grad_clip, rconf.grad_clip_ac)
+        for opt in opts:
+            opt.step()
+        t_ref.append(time.perf_counter() - t0)
+    o, r = sum(t_or[1:]) / steps, sum(t_ref[1:]) / steps
+    out = dict(oracle_s_per_step=o, reference_s_per_step=r, oracle_over_reference_time=o / r, batch_columns=cols, steps=steps,
+               threads=threads, host='build container (no GPU)', warmup_steps_excluded=1,
+               note='reference = /root/reference pydreamer.models.Dreamer driven by the train.py:165-198 section; same batch, '
+                    'same weights, same torch build; within +-10 % means the oracle is a representative CPU baseline (SURVEY 8(d))')
+    path = os.path.join(ROOT, 'profiles', 'r02_oracle_vs_reference.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -133,6 +133,9 @@ int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int 
 int dm_panel_colsum_final_launch(int count, const float* const* part, float* const* out, int n, int npanels, int pstride,
                                  hipStream_t st);
 
+int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
+void dm_prof_slot_end(int slot, hipStream_t st);
+
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;
 

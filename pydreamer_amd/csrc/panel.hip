@@ -401,8 +401,11 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
   a.xpre = xpre; a.stats = stats; a.y = y; a.ldy = hidden;
   a.wout = wout; a.bout = bout; a.out = out; a.out_dim = out_dim; a.ldout = ldout;
   const dim3 grid((unsigned)dm_panel_count(rows)), blk(256);
+  const int slot = dm_prof_slot_begin(20, 2.0 * rows * hidden * ((double)kin + (wout ? out_dim : 0)),
+                                      4.0 * ((double)rows * kin + (double)hidden * kin + (double)rows * hidden * (xpre ? 2 : 1)), st);
   if ((ldx & 3) == 0 && al16(x)) hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, false>), grid, blk, 0, st, a);
+  dm_prof_slot_end(slot, st);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -421,10 +424,13 @@ int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int 
   a.gamma = gamma; a.beta = beta;
   a.xin = xpre; a.stin = stats; a.dx = dx; a.lddx = hidden; a.colpart = colpart;
   const dim3 grid((unsigned)dm_panel_count(rows)), blk(256);
+  const int slot = dm_prof_slot_begin(21, 2.0 * rows * hidden * (double)kup,
+                                      4.0 * ((double)rows * kup + (double)hidden * kup + 2.0 * rows * hidden), st);
   if ((kup & 3) == 0 && (lddup & 3) == 0 && al16(dup))
     hipLaunchKernelGGL((panel_linear_kernel<25, 1, PANEL_EPI_LN_BWD, true>), grid, blk, 0, st, a);
   else
     hipLaunchKernelGGL((panel_linear_kernel<25, 1, PANEL_EPI_LN_BWD, false>), grid, blk, 0, st, a);
+  dm_prof_slot_end(slot, st);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

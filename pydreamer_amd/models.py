@@ -626,10 +626,10 @@ class WorldModel(_Params):
             self._pipe = pp
         return pp
 
-    def forward(self, obs, in_state):
+    def forward(self, obs, in_state, u_post=None):
         """dreamer.py:289-295: features and out_state only (used by Dreamer.inference)."""
         with torch.no_grad():
-            pk = self._forward(obs, in_state, None, None, forward_only=True)
+            pk = self._forward(obs, in_state, u_post, None, forward_only=True)
         T, B = obs['action'].shape[:2]
         return pk['feat'].view(T, B, 1, -1), pk['out_state']
 
@@ -1181,11 +1181,12 @@ class Dreamer(nn.Module):
         return self.wm.init_state(batch_size)
 
     # ---- inference (dreamer.py:92-111)
-    def inference(self, obs, in_state):
+    def inference(self, obs, in_state, noise=None):
+        """`noise` (beyond the reference signature): dict(u_post (1,B,S)) of explicit uniforms for the posterior draw."""
         assert 'action' in obs, 'Observation should contain previous action'
         act_shape = obs['action'].shape
         assert len(act_shape) == 3 and act_shape[0] == 1, f'Expected shape (1,B,A), got {act_shape}'
-        features, out_state = self.wm.forward(obs, in_state)
+        features, out_state = self.wm.forward(obs, in_state, None if noise is None else noise['u_post'])
         B = act_shape[1]
         feat = features.reshape(B, -1)
         shp = self.wm.shape(1, B, 1)

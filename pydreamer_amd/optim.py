@@ -200,15 +200,52 @@ class FusedAdamW(torch.optim.Optimizer):
                H.fptr(self.exp_avg_sq), self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
                self.step_count, None, H.stream())
 
-    # checkpoint format: same top-level keys as torch optimizers ('state', 'param_groups') with flat moments
+    # ---- checkpoint format: EXACTLY torch.optim.AdamW's (per-parameter 'state' entries, 'params' index lists), so that
+    # tools.mlflow_save_checkpoint / mlflow_load_checkpoint (tools.py:164-197) move `optimizer_{i}_state_dict` between a
+    # reference run and this build in both directions.  The flat moments are sliced at the parameter offsets.
     def state_dict(self):
-        return dict(state=dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone()),
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != 'params'}])
+        g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        for k, v in dict(amsgrad=False, foreach=None, maximize=False, capturable=False, differentiable=False, fused=None).items():
+            g.setdefault(k, v)
+        g['params'] = list(range(len(self._plist)))
+        state = {}
+        if self.step_count > 0:                      # torch creates the per-parameter state lazily at the first step
+            for i, (p, off) in enumerate(zip(self._plist, self._offsets)):
+                k = p.numel()
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[off:off + k].view(p.shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape).clone())
+        return dict(state=state, param_groups=[g])
 
     def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1:
+            raise ValueError(f'FusedAdamW holds one parameter group, the state dict has {len(groups)}')
         st = sd['state']
-        self.step_count = int(st['step'])
-        self.exp_avg.copy_(st['exp_avg'])
-        self.exp_avg_sq.copy_(st['exp_avg_sq'])
-        for k, v in sd['param_groups'][0].items():
-            self.param_groups[0][k] = v
+        if 'exp_avg' in st and not any(isinstance(k, int) for k in st):      # round-1 flat format of this package
+            self.step_count = int(st['step'])
+            self.exp_avg.copy_(st['exp_avg'])
+            self.exp_avg_sq.copy_(st['exp_avg_sq'])
+        else:
+            ids = groups[0].get('params', list(range(len(self._plist))))
+            if len(ids) != len(self._plist):
+                raise ValueError(f'optimizer state has {len(ids)} parameters, this group has {len(self._plist)}')
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = set()
+            for pid, p, off in zip(ids, self._plist, self._offsets):
+                e = st.get(pid, st.get(str(pid)))
+                if e is None:
+                    continue
+                if tuple(e['exp_avg'].shape) != tuple(p.shape):
+                    raise ValueError(f'optimizer state entry {pid} has shape {tuple(e["exp_avg"].shape)}, parameter has {tuple(p.shape)}')
+                k = p.numel()
+                self.exp_avg[off:off + k].copy_(e['exp_avg'].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(e['exp_avg_sq'].reshape(-1))
+                steps.add(int(float(e['step'])))
+            if len(steps) > 1:
+                raise ValueError(f'per-parameter step counts differ ({sorted(steps)}); one flat AdamW step count is kept')
+            self.step_count = steps.pop() if steps else 0
+        for k, v in groups[0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v

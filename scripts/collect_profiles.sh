@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round profile set, run on the GPU box from the repo root:  bash scripts/collect_profiles.sh r02
+#   1. rocprofv3 --kernel-trace --stats of the default bench command's workload (short run) -> <tag>_kernel_stats.csv
+#   2. two PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass; counters only, no tracing domains besides
+#      --kernel-trace) of a 3-step single-stream run -> <tag>_pmc_traffic.json (carries the kernel-source fingerprint)
+#   3. the bench line itself, reading the fresh PMC file -> <tag>_bench.json
+# Everything lands in gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/.
+set -u
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+SHA=$(python bench.py --csrc-sha)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --prof-steps 0 > $OUT/ks_bench.json 2> $OUT/ks.err
+cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python $REPO/scripts/trace_timeline.py $(find /tmp/prof_ks -name "*kernel_trace.csv" | head -1) 2 > $OUT/${TAG}_timeline.txt 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --prof-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+done
+python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/prof_WRITE_SIZE -name "*counter_collection.csv" | head -1) 3 $SHA > $OUT/${TAG}_pmc_traffic.json
+cd $REPO
+python bench.py --pmc-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
+python - << PY
+import json
+d = json.load(open('$OUT/${TAG}_bench.json'))
+print('ms/step', d['ms_per_step'], 'value', d['value'], 'roofline', {k: d['roofline'][k] for k in ('kernel', 'achieved', 'frac', 'traffic', 'launches_per_step')})
+print('cpu', d['cpu_baseline'])
+p = json.load(open('$OUT/${TAG}_pmc_traffic.json'))
+print('HBM GB/step', p['total_gb_per_step'])
+s = json.load(open('$OUT/${TAG}_bench_shard7of50.json'))
+print('shard 7 of 50:', s['ms_per_step'])
+PY
+head -3 $OUT/${TAG}_timeline.txt

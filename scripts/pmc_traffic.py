@@ -1,6 +1,6 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
 
-    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/rNN_pmc_traffic.json
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <csrc_sha> > profiles/rNN_pmc_traffic.json
 
 Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KB; on gfx950 FETCH_SIZE
 reports half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled for the GEMM kernels (whose operand
@@ -34,6 +34,10 @@ for name in sorted(set(fetch) | set(write)):
     wb = 1024.0 * w / max(nw, 1)
     out[name] = dict(launches=max(nf, nw), fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch=2.0 * fb,
                      write_bytes_per_launch=wb, hbm_bytes_per_launch=2.0 * fb + wb)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3        # bench.py --steps S --warmup W --prof-steps 0: S + W steps in total
+sha = sys.argv[4] if len(sys.argv) > 4 else None            # `python bench.py --csrc-sha`: fingerprint of the kernel sources
+total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values()) / steps / 1e9
 json.dump(dict(note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 2 '
-                    '--warmup 1 --no-overlap; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes', kernels=out),
+                    '--warmup 1 --no-overlap --prof-steps 0; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes',
+               csrc_sha=sha, steps_profiled=steps, total_gb_per_step=round(total, 2), kernels=out),
           sys.stdout, indent=1)

@@ -940,6 +940,81 @@ def test_optimizer_detects_rehomed_parameters(hip):
 
 
 @pytest.mark.parametrize('fixture', ['tiny_amp', 'atari_literal_amp'])
+def test_optimizer_state_dict_is_torch_adamw_format(hip):
+    """Checkpoint interop (tools.py:164-197 saves `optimizer_{i}_state_dict` = torch.optim.AdamW.state_dict()): FusedAdamW
+    emits and accepts exactly that per-parameter layout.  (a) a torch AdamW loads the dict written by FusedAdamW and takes the
+    same next step; (b) FusedAdamW loads the dict written by torch AdamW and takes the same next step; (c) round trip."""
+    from pydreamer_amd.optim import FusedAdamW
+    torch.manual_seed(5)
+    shapes = [(7, 5), (13,), (3, 4, 2), (1,)]
+    gen = lambda: [torch.randn(*s_) for s_ in shapes]
+    init, grads = gen(), [gen() for _ in range(4)]
+    pf = [torch.nn.Parameter(x.clone().to(DEV)) for x in init]
+    pt = [torch.nn.Parameter(x.clone()) for x in init]
+    fused = FusedAdamW(pf, lr=3e-3, eps=1e-5)
+    ref = torch.optim.AdamW(pt, lr=3e-3, eps=1e-5)
+
+    def step(opt, params, gs, dev):
+        opt.zero_grad()
+        for p_, g_ in zip(params, gs):
+            if p_.grad is None:
+                p_.grad = g_.to(dev).clone()
+            else:
+                p_.grad.copy_(g_.to(dev))
+        opt.step()
+    for i in range(2):
+        step(fused, pf, grads[i], DEV)
+        step(ref, pt, grads[i], 'cpu')
+    sd = fused.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and sd['param_groups'][0]['params'] == [0, 1, 2, 3]
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 2.0
+    # (a) torch loads ours
+    pt2 = [torch.nn.Parameter(p_.detach().cpu().clone()) for p_ in pf]
+    ref2 = torch.optim.AdamW(pt2, lr=1.0)
+    ref2.load_state_dict({'state': {k: {kk: vv.cpu() if torch.is_tensor(vv) else vv for kk, vv in v.items()}
+                                    for k, v in sd['state'].items()}, 'param_groups': sd['param_groups']})
+    assert ref2.param_groups[0]['lr'] == 3e-3
+    step(ref2, pt2, grads[2], 'cpu')
+    step(ref, pt, grads[2], 'cpu')
+    for a, b in zip(pt2, pt):
+        assert float((a - b).abs().max()) < 2e-6
+    # (b) ours loads torch's
+    pf2 = [torch.nn.Parameter(p_.detach().clone().to(DEV)) for p_ in pt]
+    fused2 = FusedAdamW(pf2, lr=1.0)
+    fused2.load_state_dict(ref.state_dict())
+    assert fused2.step_count == 3 and fused2.param_groups[0]['lr'] == 3e-3
+    step(fused2, pf2, grads[3], DEV)
+    step(ref, pt, grads[3], 'cpu')
+    for a, b in zip(pf2, pt):
+        assert float((a.cpu() - b).abs().max()) < 2e-6
+    # (c) round trip through our own format is exact
+    fused3 = FusedAdamW([torch.nn.Parameter(p_.detach().clone()) for p_ in pf2], lr=1.0)
+    fused3.load_state_dict(fused2.state_dict())
+    assert torch.equal(fused3.exp_avg, fused2.exp_avg) and torch.equal(fused3.exp_avg_sq, fused2.exp_avg_sq)
+    assert fused3.step_count == fused2.step_count
+
+
+def test_inference_matches_reference_golden(hip):
+    """Dreamer.inference (dreamer.py:92-111; what generator.py:317-331 calls in the acting process) against
+    tests/golden/tiny_inference.npz written by the real reference: action probabilities 2e-5, new state, policy_value.
+    Together with tests/test_host_cpu.py::test_reference_loads_build_state_dict (build container only) this is the
+    checkpoint path between a learner on this build and actors on the reference."""
+    g = np.load(os.path.join(GOLD, 'tiny_inference.npz'))
+    oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
+    model = _build(oconf, O.make_params(oconf, seed=0))
+    assert list(model.state_dict().keys()) == [str(k) for k in g['state_dict_keys']]
+    u8 = torch.from_numpy(g['in_image_u8'])
+    obs = dict(image=(u8.float() / 255.0 - 0.5).permute(0, 1, 4, 2, 3).contiguous().to(DEV), action=torch.from_numpy(g['in_action']).to(DEV),
+               reset=torch.from_numpy(g['in_reset']).to(DEV))
+    state = (torch.from_numpy(g['in_h']).to(DEV), torch.from_numpy(g['in_z']).to(DEV))
+    with torch.no_grad():
+        dist, (h1, z1), metrics = model.inference(obs, state, noise=dict(u_post=torch.from_numpy(g['in_u']).to(DEV)))
+    _close(dist.probs, torch.from_numpy(g['action_probs']), 1e-4, 2e-6, 'action probabilities')
+    _close(h1, torch.from_numpy(g['out_h']), 0, 2e-6, 'out_state h')
+    assert torch.equal(z1.cpu(), torch.from_numpy(g['out_z']))
+    assert abs(float(metrics['policy_value']) - float(g['policy_value'])) < 2e-6
+
+
 def test_amp_against_reference_autocast_golden(hip, fixture):
     """tests/golden/tiny_amp.npz and atari_literal_amp.npz (BASELINE configs[2] at FULL size: B=50, T=50, H=15, deter 600):
     the real reference's forward under torch.autocast('cpu', bfloat16) (its amp switch, train.py:166) and in fp32 on the

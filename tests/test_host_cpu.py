@@ -162,3 +162,44 @@ def test_init_weights_tf2_matches_reference_rule():
         assert float(lin.weight.data.abs().max()) <= bound + 1e-7
         assert float(lin.bias.data.abs().max()) > 0.0 and float(lin.bias.data.abs().max()) <= bound + 1e-7
     assert not any(p.requires_grad for p in m.ac.critic_target.parameters())
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/pydreamer'), reason='the reference exists in the build container only')
+def test_reference_loads_build_state_dict():
+    """Checkpoint interop, model side (tools.py:164-197, generator.py:109): the REAL reference Dreamer loads the state_dict
+    written by this package (strict: identical keys and shapes) and, with those weights, reproduces the inference golden;
+    and this package loads the reference's state_dict.  Runs only where /root/reference exists; nothing is read from it on
+    the GPU box."""
+    import ast
+    import sys
+    import numpy as np
+    import torch
+    import yaml
+    from argparse import Namespace
+    from oracle import dreamer_oracle as O
+    from oracle.gen_golden import MultinomialPatch, reference_conf
+    from pydreamer_amd.models import Dreamer
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tiny_inference.npz'))
+    oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
+    conf = config.load_config('defaults', 'atari', **{k: getattr(oconf, k) for k in vars(oconf)})
+    ours = Dreamer(conf)                                     # parameters on CPU: holding and exchanging them needs no GPU
+    ours.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    sys.path.insert(0, '/root/reference')
+    from pydreamer.models import Dreamer as RefDreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    t = O.tiny_conf()
+    rconf = reference_conf(['defaults', 'atari'], dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim,
+                                                       stoch_discrete=t.stoch_discrete, cnn_depth=t.cnn_depth,
+                                                       action_dim=t.action_dim))
+    ref = RefDreamer(rconf)
+    ref.load_state_dict(ours.state_dict(), strict=True)      # the reference accepts the build's checkpoint as is
+    ours.load_state_dict(ref.state_dict(), strict=True)      # ... and the other way round
+    u8 = torch.from_numpy(g['in_image_u8'])
+    obs = dict(image=(u8.float() / 255.0 - 0.5).permute(0, 1, 4, 2, 3).contiguous(), action=torch.from_numpy(g['in_action']),
+               reset=torch.from_numpy(g['in_reset']), reward=torch.zeros(1, 3), terminal=torch.zeros(1, 3))
+    with MultinomialPatch() as mp, torch.no_grad():
+        mp.queue = [torch.from_numpy(g['in_u'])[0]]
+        dist, (h1, z1), metrics = ref.inference(obs, (torch.from_numpy(g['in_h']), torch.from_numpy(g['in_z'])))
+    np.testing.assert_allclose(dist.probs.numpy(), g['action_probs'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(h1.numpy(), g['out_h'], rtol=0, atol=1e-7)
