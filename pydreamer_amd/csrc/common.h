@@ -59,6 +59,9 @@ struct DmGemm {
   const int* a_maj = nullptr; const int* a_min = nullptr; int a_tab_vec = 0;
   const int* b_maj = nullptr; const int* b_min = nullptr; int b_tab_vec = 0;
   int flags = 0;
+  // scatter epilogue of the class-concatenated transposed convolution (see gemm.hip SC / conv.hip): c_tab[row] = {float
+  // offset of the row's class-(0,0) output pixel, bit 1: odd output row exists, bit 0: odd output column exists}
+  const int2* c_tab = nullptr; int sc_cout = 0, sc_wpitch = 0;
   // LayerNorm+ELU prologue on A (A holds pre-activations; the product uses ELU(LN(A))): <= 64-row skinny products only
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-3f;
 };

@@ -8,6 +8,7 @@
 // The backward passes are the same two gathers with the roles swapped (convT backward-data is a conv).
 // All kernels here are HBM-streaming; the contractions run in gemm.hip on the matrix cores.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- patch gather ------------------
 // col[(i,ys,xs)][(ky,kx,cc)] = big[i, 2ys+ky, 2xs+kx, cc]      (NHWC, VEC floats of c per thread)
@@ -221,6 +222,67 @@ static int conv_tables_launch(int n, int hb, int wb, int c, int k, int* rowoff, 
   hipLaunchKernelGGL(conv_tables_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, rowoff, koff);
   DM_LAUNCH_CHECK();
   return DM_OK;
+}
+
+// ---------------------------------------------------------------- gather-form transposed convolution ----------
+// ConvTranspose2d(k even, stride 2) WITHOUT a column matrix (decoders.py:144-161; the same identity gives the data
+// gradient of a stride-2 Conv2d).  out[n, 2yy+py, 2xx+px, o] = b[o] + sum_{a,b,i} X[n, yy-a, xx-b, i] W[i][o][py+2a][px+2b]
+// with a, b in [0, k/2): every parity class (py,px) reads the SAME input patch, so the layer is ONE GEMM
+//   M = n*Hc*Wc class pixels (Hc = hs + k/2 - 1),  K = (k/2)^2 * cin (gathered from a zero-padded copy of X),
+//   N = 4*cout (the four classes side by side), result scattered straight into the NHWC big image (gemm.hip SC epilogue).
+// vs. the column-matrix form: no Ycol write + col2im read (2 x 2.9 GB for decoder layer 3 at Atari-literal), at the price
+// of (Hc/hs)^2 more MACs (the zero border is multiplied too: 1.33x for 13 -> 30).
+__global__ void __launch_bounds__(256) convt_pad_kernel(int n, int hs, int ws, int c4, int P, const float4* __restrict__ x,
+                                                        float4* __restrict__ xp) {
+  const int hp = hs + 2 * P, wp = ws + 2 * P;
+  const size_t total = (size_t)n * hp * wp * c4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int cc = (int)(t % c4); t /= c4;
+    const int xx = (int)(t % wp) - P; t /= wp;
+    const int yy = (int)(t % hp) - P; t /= hp;
+    const int i = (int)t;
+    const bool in = yy >= 0 && yy < hs && xx >= 0 && xx < ws;
+    xp[e] = in ? x[(((size_t)i * hs + yy) * ws + xx) * c4 + cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// rowoff[(n,yy,xx)] = offset of padded pixel (yy+P, xx+P);  koff[(a,b,i)] = -(a*wp + b)*cin + i;
+// ctab[(n,yy,xx)] = {offset of big[n, 2yy, 2xx, 0], bit 1: 2yy+1 < hb, bit 0: 2xx+1 < wb}
+__global__ void __launch_bounds__(256) convt_tables_kernel(int n, int hs, int ws, int cin, int ta, int hb, int wb, int cout,
+                                                           int* __restrict__ rowoff, int* __restrict__ koff,
+                                                           int2* __restrict__ ctab) {
+  const int P = ta - 1, hp = hs + 2 * P, wp = ws + 2 * P;
+  const int Hc = hs + ta - 1, Wc = ws + ta - 1;
+  const int rows = n * Hc * Wc, kdim = ta * ta * cin;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < rows + kdim; e += gridDim.x * 256) {
+    if (e < rows) {
+      const int xx = e % Wc, yy = (e / Wc) % Hc, i = e / (Wc * Hc);
+      rowoff[e] = ((i * hp + yy + P) * wp + xx + P) * cin;
+      ctab[e] = make_int2(((i * hb + 2 * yy) * wb + 2 * xx) * cout, ((2 * yy + 1 < hb) ? 2 : 0) | ((2 * xx + 1 < wb) ? 1 : 0));
+    } else {
+      const int q = e - rows;
+      const int ci = q % cin, b = (q / cin) % ta, a = q / (cin * ta);
+      koff[q] = -(a * wp + b) * cin + ci;
+    }
+  }
+}
+// Wcat[(py,px,o)][(a,b,i)] = W[i][o][py+2a][px+2b]      (W: torch ConvTranspose2d layout (cin, cout, k, k))
+__global__ void __launch_bounds__(256) convt_repack_kernel(int cin, int cout, int k, const float* __restrict__ w,
+                                                           float* __restrict__ wcat) {
+  const int ta = k / 2, kdim = ta * ta * cin;
+  const int total = 4 * cout * kdim;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int kk = e % kdim, nn = e / kdim;
+    const int ci = kk % cin, b = (kk / cin) % ta, a = kk / (cin * ta);
+    const int o = nn % cout, cls = nn / cout, py = cls >> 1, px = cls & 1;
+    wcat[e] = w[(((size_t)ci * cout + o) * k + (py + 2 * a)) * k + (px + 2 * b)];
+  }
+}
+static const int g_convt_gather_off = getenv("DM_CONVT_COLUMN") ? 1 : 0;       // A/B switch: keep the column-matrix form
+// layers this form is used for: even kernel, 16-byte gathers, and enough output channels that N = 4*cout fills MFMA tiles
+static bool convt_gather_ok(int k, int cin, int cout, int hs, size_t n) {
+  return !g_convt_gather_off && (k & 1) == 0 && (cin & 3) == 0 && cout >= 16 && hs >= 2 &&
+         n * (size_t)(2 * (hs - 1) + k) * (2 * (hs - 1) + k) * cout < ((size_t)1 << 31);
 }
 
 // ---------------------------------------------------------------- MSE (decoders.py:163-167) -----
@@ -561,6 +623,21 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
     if (c > colmax) colmax = c;
   }
   float* ycol = ar.take(colmax);
+  // gather-form layers: zero-padded input copy, gather / scatter tables, class-concatenated weights
+  size_t padmax = 0, tabmax = 0, wcmax = 0;
+  for (int l = 1; l <= 4; ++l)
+    if (convt_gather_ok(g.k[l], g.cin[l], g.cout[l], g.hsm[l], (size_t)n)) {
+      const int ta = g.k[l] / 2, hp = g.hsm[l] + 2 * (ta - 1), Hc = g.hsm[l] + ta - 1;
+      const size_t pad = (size_t)n * hp * hp * g.cin[l], tab = (size_t)n * Hc * Hc, wc = (size_t)4 * g.cout[l] * ta * ta * g.cin[l];
+      if (pad > padmax) padmax = pad;
+      if (tab > tabmax) tabmax = tab;
+      if (wc > wcmax) wcmax = wc;
+    }
+  float* xpad = ar.take(padmax);
+  int* t_rowoff = (int*)ar.take(tabmax);
+  int2* t_ctab = (int2*)ar.take(2 * tabmax);
+  int* t_koff = (int*)ar.take(wcmax ? 9 * 1024 : 0);
+  float* wcat = ar.take(wcmax);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_fwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   {
@@ -576,6 +653,30 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
     const int kk = g.k[l] * g.k[l];
     const float* xin = l == 1 ? a.x[0] + (size_t)n0 * g.cin[1]
                               : a.x[l - 1] + (size_t)n0 * g.hbg[l - 1] * g.hbg[l - 1] * g.cout[l - 1];
+    if (convt_gather_ok(g.k[l], g.cin[l], g.cout[l], g.hsm[l], (size_t)n)) {
+      const int ta = g.k[l] / 2, hs = g.hsm[l], hb = g.hbg[l], Hc = hs + ta - 1, kdim = ta * ta * g.cin[l];
+      DM_REQUIRE(kdim <= 9 * 1024, DM_E_SHAPE, "conv_decoder_fwd: gather-form K %d exceeds the offset table", kdim);
+      const size_t padn = (size_t)n * (hs + 2 * (ta - 1)) * (hs + 2 * (ta - 1)) * (g.cin[l] / 4);
+      hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, n, hs, hs, g.cin[l] / 4, ta - 1,
+                         (const float4*)xin, (float4*)xpad);
+      DM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(convt_tables_kernel, dim3(grid_for((size_t)n * Hc * Hc + kdim)), dim3(256), 0, st, n, hs, hs, g.cin[l],
+                         ta, hb, hb, g.cout[l], t_rowoff, t_koff, t_ctab);
+      DM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(convt_repack_kernel, dim3(grid_for((size_t)4 * g.cout[l] * kdim)), dim3(256), 0, st, g.cin[l], g.cout[l],
+                         g.k[l], p->w[l], wcat);
+      DM_LAUNCH_CHECK();
+      DmGemm q;   // big[n, 2yy+py, 2xx+px, o] = act( b[o] + patch(n,yy,xx) . Wcat[(py,px,o)] )
+      q.M = n * Hc * Hc; q.N = 4 * g.cout[l]; q.K = kdim;
+      q.A = xpad; q.a_maj = t_rowoff; q.a_min = t_koff; q.a_tab_vec = 1;
+      q.B = wcat; q.ldb = kdim;
+      q.C = a.x[l] + (size_t)n0 * hb * hb * g.cout[l];
+      q.c_tab = t_ctab; q.sc_cout = g.cout[l]; q.sc_wpitch = hb * g.cout[l];
+      q.bias = p->b[l];
+      q.flags = l < 4 ? DM_GEMM_ELU : 0;
+      DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+      continue;
+    }
     DmGemm q;   // Ycol[(n,ys,xs)][(ky,kx,o)] = X[(n,ys,xs)][i] * Wr[i][(ky,kx,o)]
     q.a_layout = 0; q.b_layout = 1;
     q.M = n * g.hsm[l] * g.hsm[l]; q.N = kk * g.cout[l]; q.K = g.cin[l];

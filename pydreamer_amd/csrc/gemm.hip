@@ -35,6 +35,8 @@ struct GemmKArgs {
   const int* a_maj; const int* a_min;   // optional separable-gather tables: element = A[a_maj[major] + a_min[minor]]
   const int* b_maj; const int* b_min;
   float* partial;
+  const int2* c_tab;          // SC (scatter) epilogue: per output row {float offset of its class-(0,0) pixel, validity bits}
+  int sc_cout, sc_wpitch;     // channels per parity class; floats between two output rows of the big image (wb * cout)
   int M, N, K;
   int lda, ldb, ldc, ldadd, ldmul;
   int flags;
@@ -239,8 +241,12 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 // VEC: both operands take the 16-byte load path (host-checked alignment and extents).
 // WGM x WGN: the 4 waves' grid over the block tile (2x2; 4x1 for the 128x96 tile, 1x4 for 96x128 - the conv stack is
 // full of 96-wide operands (cnn_depth 48), which 64/128-wide tiles pad by 25-33 %).
+// SC: stride-2 transposed-convolution output scatter.  The GEMM row is a class pixel (n, yy, xx), the column is
+// (parity class (py,px), channel o): the result lands at big[n, 2yy+py, 2xx+px, o] (NHWC) - the four parity classes of a
+// k = 4 / k = 6 transposed convolution share ONE gathered A operand (the input patch (yy-a, xx-b)), so the whole layer is
+// one GEMM with N = 4*cout that writes the big image directly: no column matrix, no col2im pass (conv.hip).
 template <int BM, int BN, int AL, int BL, bool VEC, bool GA = false, bool GB = false, int WGM = 2, int WGN = 2,
-          bool BF = false>
+          bool BF = false, bool SC = false>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
   constexpr int BK = 32;
@@ -354,12 +360,28 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int col = cur.n0 + wn * (BN / WGN) + nb * 32 + l31;
+      int sc_off = 0, sc_need = 0, sc_o = 0;
+      if (SC) {
+        const int cls = col / g.sc_cout;
+        sc_o = col - cls * g.sc_cout;
+        sc_off = (cls >> 1) * g.sc_wpitch + (cls & 1) * g.sc_cout + sc_o;
+        sc_need = cls;                                  // bit 1: odd output row needed, bit 0: odd output column needed
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = cur.m0 + wm * (BM / WGM) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < g.M && col < g.N) {
           float v = acc[mb][nb][r];
-          if (g.nsplit > 1) {
+          if (SC) {
+            const int2 ct = g.c_tab[row];
+            if ((sc_need & ~ct.y) == 0) {               // the odd row / column of this class pixel exists in the big image
+              const size_t at = (size_t)ct.x + sc_off;
+              if (g.bias) v += g.bias[sc_o];
+              if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
+              if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[at]);
+              g.C[at] = v;
+            }
+          } else if (g.nsplit > 1) {
             g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
           } else {
             if (g.row_zero && g.row_zero[row]) v = 0.f;
@@ -460,7 +482,10 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
 template <int BM, int BN, bool V, int WGM = 2, int WGN = 2, bool BF = false>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
-  if (gather == 1) {
+  if (a.c_tab) {
+    if (gather != 1 || al != 0 || bl != 0 || !V) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0), 16-byte loads");
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, true, true, false, WGM, WGN, BF, true>), grid, dim3(256), 0, stream, a);
+  } else if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, V, true, false, WGM, WGN, BF>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
@@ -491,7 +516,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   DM_REQUIRE(q.b_maj || q.ldb >= (q.b_layout == 0 ? q.K : q.N), DM_E_SHAPE, "gemm: ldb %d too small", q.ldb);
   DM_REQUIRE((q.a_maj == nullptr) == (q.a_min == nullptr) && (q.b_maj == nullptr) == (q.b_min == nullptr), DM_E_NULL,
              "gemm: gather tables must come in (major, minor) pairs");
-  DM_REQUIRE(q.ldc >= q.N, DM_E_SHAPE, "gemm: ldc %d < N %d", q.ldc, q.N);
+  DM_REQUIRE(q.c_tab || q.ldc >= q.N, DM_E_SHAPE, "gemm: ldc %d < N %d", q.ldc, q.N);
   DM_REQUIRE(!q.add || q.ldadd >= q.N, DM_E_SHAPE, "gemm: ldadd %d < N %d", q.ldadd, q.N);
 
   {   // <= 64-row products of the sequential RSSM chains: one-launch skinny kernel (gemm_skinny.hip)
@@ -506,6 +531,9 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
   a.flags = q.flags;
   a.a_maj = q.a_maj; a.a_min = q.a_min; a.b_maj = q.b_maj; a.b_min = q.b_min;
+  a.c_tab = q.c_tab; a.sc_cout = q.sc_cout; a.sc_wpitch = q.sc_wpitch;
+  DM_REQUIRE(!q.c_tab || (q.sc_cout > 0 && q.N % q.sc_cout == 0 && q.N / q.sc_cout == 4 && !q.add && !(q.flags & DM_GEMM_ACCUM)),
+             DM_E_SHAPE, "gemm: scatter epilogue needs N = 4 * sc_cout, no addend, no accumulate");
   // 16-byte load path: aligned base, rows a multiple of 4 floats apart, and the vectorised (minor) extent a multiple
   // of 4 so that no group of 4 straddles the edge.  Minor extent: K for layout 0, M (resp. N) for layout 1.
   a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0) &&
@@ -532,7 +560,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   if (max_split > 512) max_split = 512;
   {
     const size_t per = (size_t)q.M * q.N * sizeof(float);
-    if (ws == nullptr) max_split = 1;
+    if (ws == nullptr || q.c_tab) max_split = 1;        // the scatter epilogue writes its result directly
     else if ((size_t)max_split * per > ws_bytes) max_split = (int)(ws_bytes / per);
   }
   if (max_split < 1) max_split = 1;

@@ -57,7 +57,12 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (4 * d * 25 * 2 * d > wmax) wmax = 4 * d * 25 * 2 * d;
   if (2 * d * 36 * d > wmax) wmax = 2 * d * 36 * d;
   if (d * 36 * ch > wmax) wmax = d * 36 * ch;
-  const size_t dec_fwd = SK + pad64(col);
+  // + gather-form transposed convolution (conv.hip): zero-padded input copy, tables, class-concatenated weights; bounded by the
+  //   k = 6 layers: inputs 13x13x2d -> 17x17, 30x30xd -> 34x34, class pixels 15x15 / 32x32
+  size_t gpad = N * 17 * 17 * 2 * d;
+  if (N * 34 * 34 * d > gpad) gpad = N * 34 * 34 * d;
+  const size_t gtab = N * 32 * 32;
+  const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) + 1024;
   const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax) + pad64(N * 900) + pad64(100 * d + 36 * ch);   // + gather tables
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D);    // + the transposed BPTT weights

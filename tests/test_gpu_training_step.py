@@ -939,7 +939,6 @@ def test_optimizer_detects_rehomed_parameters(hip):
     assert 'flat buffer' in str(e.value)
 
 
-@pytest.mark.parametrize('fixture', ['tiny_amp', 'atari_literal_amp'])
 def test_optimizer_state_dict_is_torch_adamw_format(hip):
     """Checkpoint interop (tools.py:164-197 saves `optimizer_{i}_state_dict` = torch.optim.AdamW.state_dict()): FusedAdamW
     emits and accepts exactly that per-parameter layout.  (a) a torch AdamW loads the dict written by FusedAdamW and takes the
@@ -1015,6 +1014,7 @@ def test_inference_matches_reference_golden(hip):
     assert abs(float(metrics['policy_value']) - float(g['policy_value'])) < 2e-6
 
 
+@pytest.mark.parametrize('fixture', ['tiny_amp', 'atari_literal_amp'])
 def test_amp_against_reference_autocast_golden(hip, fixture):
     """tests/golden/tiny_amp.npz and atari_literal_amp.npz (BASELINE configs[2] at FULL size: B=50, T=50, H=15, deter 600):
     the real reference's forward under torch.autocast('cpu', bfloat16) (its amp switch, train.py:166) and in fp32 on the
