@@ -62,6 +62,7 @@ struct DmGemm {
   // scatter epilogue of the class-concatenated transposed convolution (see gemm.hip SC / conv.hip): c_tab[row] = {float
   // offset of the row's class-(0,0) output pixel, bit 1: odd output row exists, bit 0: odd output column exists}
   const int2* c_tab = nullptr; int sc_cout = 0, sc_wpitch = 0;
+  int bias_mod = 0;                               // > 0: the bias is indexed by col % bias_mod
   // LayerNorm+ELU prologue on A (A holds pre-activations; the product uses ELU(LN(A))): <= 64-row skinny products only
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-3f;
 };

@@ -280,9 +280,12 @@ __global__ void __launch_bounds__(256) convt_repack_kernel(int cin, int cout, in
 }
 static const int g_convt_gather_off = getenv("DM_CONVT_COLUMN") ? 1 : 0;       // A/B switch: keep the column-matrix form
 // layers this form is used for: even kernel, 16-byte gathers, and enough output channels that N = 4*cout fills MFMA tiles
+// (and an input large enough that the multiplied zero border stays under 40 % extra MACs: (Hc/hs)^2 <= 1.4, i.e. hs >= 6 for
+// k = 4 and hs >= 11 for k = 6)
 static bool convt_gather_ok(int k, int cin, int cout, int hs, size_t n) {
-  return !g_convt_gather_off && (k & 1) == 0 && (cin & 3) == 0 && cout >= 16 && hs >= 2 &&
-         n * (size_t)(2 * (hs - 1) + k) * (2 * (hs - 1) + k) * cout < ((size_t)1 << 31);
+  const int Hc = hs + k / 2 - 1;
+  return !g_convt_gather_off && (k & 1) == 0 && (cin & 3) == 0 && cout >= 16 && 10 * Hc * Hc <= 14 * hs * hs &&
+         n * (size_t)(2 * (hs - 1) + k + 1) * (2 * (hs - 1) + k + 1) * cout < ((size_t)1 << 31);
 }
 
 // ---------------------------------------------------------------- MSE (decoders.py:163-167) -----
@@ -295,7 +298,7 @@ template <bool U8>
 __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const float* __restrict__ pred,
                                                         const void* __restrict__ target_, int tdiv, float scale,
                                                         const float* __restrict__ row_scale,
-                                                        float* __restrict__ loss, float* __restrict__ dpred,
+                                                        float* __restrict__ loss, float* __restrict__ dpred, int dpad,
                                                         float* __restrict__ rec) {
   __shared__ float red[4];
   const int i = blockIdx.x;
@@ -311,7 +314,12 @@ __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const flo
     const float tv = U8 ? (float)tg8[e] / 255.0f - 0.5f : tg[(size_t)cc * hw + pix];
     const float d = pv - tv;
     s += d * d;
-    if (dpred) dpred[(size_t)i * per + e] = scale * d;
+    if (dpred) {        // dpad >= c channels per pixel; the pad channels are written as zeros (see the 4-channel trick in backward)
+      float* dp = dpred + ((size_t)i * hw + pix) * dpad;
+      dp[cc] = scale * d;
+      if (cc == c - 1)
+        for (int q = c; q < dpad; ++q) dp[q] = 0.f;
+    }
     if (rec) rec[(size_t)i * per + (size_t)cc * hw + pix] = pv;
   }
   s = dm_wave_sum(s);
@@ -347,9 +355,9 @@ extern "C" int dm_preprocess_image_u8(int64_t n, int hw, int c, const uint8_t* s
 // dm_shape.flags bit 4: `image` / `target` pointers are uint8 (N, H, W, C) frames (the replay's native format)
 static inline bool shape_u8(const dm_shape* s) { return (s->flags & DM_FLAG_IMAGE_U8) != 0; }
 static int mse_launch(bool u8, int n, int hw, int c, const float* pred, const void* target, int tdiv, float scale,
-                      const float* row_scale, float* loss, float* dpred, float* rec, hipStream_t st) {
-  if (u8) hipLaunchKernelGGL((mse_image_kernel<true>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, rec);
-  else hipLaunchKernelGGL((mse_image_kernel<false>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, rec);
+                      const float* row_scale, float* loss, float* dpred, int dpad, float* rec, hipStream_t st) {
+  if (u8) hipLaunchKernelGGL((mse_image_kernel<true>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec);
+  else hipLaunchKernelGGL((mse_image_kernel<false>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -523,6 +531,20 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
   size_t xcmax = 0;
   for (int l = 1; l < 4; ++l) if (g.rows[l] * g.kdim[l] > xcmax) xcmax = g.rows[l] * g.kdim[l];
   float* dxcol = ar.take(xcmax);
+  // gather-form data gradient (see convt_* above: the data gradient of a stride-2 convolution IS a transposed convolution)
+  size_t padmax = 0, tabmax = 0, wcmax = 0;
+  for (int l = 1; l < 4; ++l)
+    if (convt_gather_ok(4, g.cout[l], g.cin[l], g.hs[l], (size_t)g.N)) {
+      const size_t hp = g.hs[l] + 2, Hc = g.hs[l] + 1;
+      if ((size_t)g.N * hp * hp * g.cout[l] > padmax) padmax = (size_t)g.N * hp * hp * g.cout[l];
+      if ((size_t)g.N * Hc * Hc > tabmax) tabmax = (size_t)g.N * Hc * Hc;
+      if ((size_t)16 * g.cin[l] * g.cout[l] > wcmax) wcmax = (size_t)16 * g.cin[l] * g.cout[l];
+    }
+  float* gpad = ar.take(padmax);
+  int* t_rowoff = (int*)ar.take(tabmax);
+  int2* t_ctab = (int2*)ar.take(2 * tabmax);
+  int* t_koff = (int*)ar.take(wcmax ? 4 * 1024 : 0);
+  float* wcat = ar.take(wcmax);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_encoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -544,7 +566,37 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
     else { q.B = a.y[l - 1]; q.b_maj = a.rowoff[l]; q.b_min = a.koff[l]; q.b_tab_vec = (g.cin[l] & 3) == 0; }
     q.C = (l == 0) ? gr->w[0] : dwr; q.ldc = kd;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
-    if (l > 0) {
+    if (l > 0 && convt_gather_ok(4, co, g.cin[l], g.hs[l], (size_t)g.N)) {
+      // dX[n, 2yy+py, 2xx+px, i] = ELU'(Y_{l-1}) * sum_{a,b,o} G[n, yy-a, xx-b, o] W[o][i][py+2a][px+2b]: one implicit GEMM
+      // over a zero-padded copy of G, scattered straight into the NHWC gradient of layer l-1 (no dXcol, no col2im)
+      DM_TRY(dm_permute4_launch(dwr, gr->w[l], co, 4, 4, g.cin[l], 0, 3, 1, 2, st));
+      const int hs = g.hs[l], hb = g.hb[l], Hc = hs + 1, kdim4 = 4 * co, ci = g.cin[l];
+      DM_REQUIRE(kdim4 <= 4 * 1024, DM_E_SHAPE, "conv_encoder_bwd: gather-form K %d exceeds the offset table", kdim4);
+      float* Gn = (G == ga) ? gb : ga;
+      if (l == 1) Gn = ga;   // layer-0 output grads are the largest buffer
+      const size_t padn = (size_t)g.N * (hs + 2) * (hs + 2) * (co / 4);
+      hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, g.N, hs, hs, co / 4, 1, (const float4*)G,
+                         (float4*)gpad);
+      DM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(convt_tables_kernel, dim3(grid_for((size_t)g.N * Hc * Hc + kdim4)), dim3(256), 0, st, g.N, hs, hs, co, 2,
+                         hb, hb, ci, t_rowoff, t_koff, t_ctab);
+      DM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(convt_repack_kernel, dim3(grid_for((size_t)4 * ci * kdim4)), dim3(256), 0, st, co, ci, 4, p->w[l], wcat);
+      DM_LAUNCH_CHECK();
+      if (2 * Hc != hb) {      // odd input extent (31): the last row / column is reached by no window - its gradient is zero
+        hipError_t e = hipMemsetAsync(Gn, 0, (size_t)g.N * hb * hb * ci * sizeof(float), st);
+        if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_encoder_bwd: %s", hipGetErrorString(e));
+      }
+      DmGemm d;
+      d.M = g.N * Hc * Hc; d.N = 4 * ci; d.K = kdim4;
+      d.A = gpad; d.a_maj = t_rowoff; d.a_min = t_koff; d.a_tab_vec = 1;
+      d.B = wcat; d.ldb = kdim4;
+      d.C = Gn;
+      d.c_tab = t_ctab; d.sc_cout = ci; d.sc_wpitch = hb * ci;
+      d.mulref = a.y[l - 1];
+      DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+      G = Gn;
+    } else if (l > 0) {
       DM_TRY(dm_permute4_launch(dwr, gr->w[l], co, 4, 4, g.cin[l], 0, 3, 1, 2, st));
       DmGemm d;   // dXcol[row][kidx] = sum_o G[row][o] * Wr[o][kidx]
       d.a_layout = 0; d.b_layout = 1;
@@ -560,6 +612,28 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
     }
   }
   return DM_OK;
+}
+
+// 4-channel trick for the image layer's backward (cout = 3): the output gradient is written with 4 channels per pixel (the
+// 4th = 0) and the weights are padded to match, so its patches are 16-byte gathers like every other layer's and the
+// explicit patch matrix of the 3-channel gradient (972 MB written + read at Atari-literal) is never built.
+// dst (I, k, k, O4) <- src (I, O, k, k)  (torch ConvTranspose2d layout), zero for o >= O
+__global__ void __launch_bounds__(256) convt_pad_cout_kernel(int I, int O, int O4, int k, const float* __restrict__ src,
+                                                             float* __restrict__ dst) {
+  const int total = I * k * k * O4;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int o = e % O4, kx = (e / O4) % k, ky = (e / (O4 * k)) % k, i = e / (O4 * k * k);
+    dst[e] = o < O ? src[(((size_t)i * O + o) * k + ky) * k + kx] : 0.f;
+  }
+}
+// dst (I, O, k, k) <- src (I, k, k, O4), dropping the pad channels
+__global__ void __launch_bounds__(256) convt_unpad_cout_kernel(int I, int O, int O4, int k, const float* __restrict__ src,
+                                                               float* __restrict__ dst) {
+  const int total = I * O * k * k;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int kx = e % k, ky = (e / k) % k, o = (e / (k * k)) % O, i = e / (k * k * O);
+    dst[e] = src[(((size_t)i * k + ky) * k + kx) * O4 + o];
+  }
 }
 
 // ---------------------------------------------------------------- decoder -----------------------
@@ -683,6 +757,13 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
     q.A = xin; q.lda = q.K;
     q.B = a.wr[l]; q.ldb = q.N;
     q.C = ycol; q.ldc = q.N;
+    if (g.hsm[l] == 1) {     // a 1x1 input: no windows overlap, the column matrix IS the NHWC output - bias + ELU in the epilogue
+      q.C = a.x[l] + (size_t)n0 * g.hbg[l] * g.hbg[l] * g.cout[l];
+      q.bias = p->b[l]; q.bias_mod = g.cout[l];
+      q.flags = l < 4 ? DM_GEMM_ELU : 0;
+      DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+      continue;
+    }
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
     DM_TRY(dm_col2im_s2_launch(n, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], ycol, p->b[l], l < 4 ? DM_C2I_ELU : 0, nullptr,
                                a.x[l] + (size_t)n0 * g.hbg[l] * g.hbg[l] * g.cout[l], st));
@@ -695,7 +776,7 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
     const void* tbase = shape_u8(shp) ? (const void*)((const uint8_t*)target + (size_t)(n0 / I) * per)
                                       : (const void*)(target + (size_t)(n0 / I) * per);
     DM_TRY(mse_launch(shape_u8(shp), n, g.hbg[4] * g.hbg[4], g.ch, a.x[4] + n0 * per, tbase, I, 0.f, nullptr,
-                      loss_image ? loss_image + n0 : nullptr, nullptr, image_rec ? image_rec + n0 * per : nullptr, st));
+                      loss_image ? loss_image + n0 : nullptr, nullptr, g.ch, image_rec ? image_rec + n0 * per : nullptr, st));
   }
   return DM_OK;
 }
@@ -734,59 +815,75 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
   dec_carve(g, const_cast<float*>(acts), (size_t)1 << 60, &a);
   DmArena ar(ws, ws_bytes);
   float* splitk = ar.take(DM_SPLITK_FLOATS);
-  size_t colmax = 0, gmax = 0, wmax = 0;
+  // every layer's output gradient is gathered implicitly: channel counts that are not a multiple of 4 (the 3-channel image
+  // layer) are padded to 4 (co4) in the gradient buffer and in a padded copy of the weights
+  int co4[5] = {0, 0, 0, 0, 0};
+  size_t gmax = 0, wmax = 0, wpadmax = 0;
   for (int l = 1; l <= 4; ++l) {
-    const size_t c = g.rows_s[l] * g.k[l] * g.k[l] * g.cout[l];
-    if (c > colmax) colmax = c;
-    if (g.rows_b[l] * g.cout[l] > gmax) gmax = g.rows_b[l] * g.cout[l];
-    const size_t w = (size_t)g.cin[l] * g.k[l] * g.k[l] * g.cout[l];
+    co4[l] = (g.cout[l] + 3) & ~3;
+    if (g.rows_b[l] * co4[l] > gmax) gmax = g.rows_b[l] * co4[l];
+    const size_t w = (size_t)g.cin[l] * g.k[l] * g.k[l] * co4[l];
     if (w > wmax) wmax = w;
+    if (co4[l] != g.cout[l] && w > wpadmax) wpadmax = w;
   }
   if ((size_t)g.N * g.cin[1] > gmax) gmax = (size_t)g.N * g.cin[1];
-  float* dycol = ar.take(colmax);
   float* ga = ar.take(gmax);
   float* gb = ar.take(gmax);
   float* dwr = ar.take(wmax);
+  float* wpad = ar.take(wpadmax);
+  float* bsum = ar.take(64);
   size_t romax = 0, komax = 0;
   for (int l = 1; l <= 4; ++l) {
     if (g.rows_s[l] > romax) romax = g.rows_s[l];
-    if ((size_t)g.k[l] * g.k[l] * g.cout[l] > komax) komax = (size_t)g.k[l] * g.k[l] * g.cout[l];
+    if ((size_t)g.k[l] * g.k[l] * co4[l] > komax) komax = (size_t)g.k[l] * g.k[l] * co4[l];
   }
   int* rowoff = (int*)ar.take(romax);
   int* koff = (int*)ar.take(komax);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
-  // G4 = scale * (pred - target), NHWC
+  // G4 = scale * (pred - target), NHWC with co4[4] channels per pixel
   float* G = ga;
   DM_TRY(mse_launch(shape_u8(shp), g.N, g.hbg[4] * g.hbg[4], g.ch, a.x[4], (const void*)target, shp->I > 0 ? shp->I : 1, scale,
-                    row_scale, nullptr, G, nullptr, st));
+                    row_scale, nullptr, G, co4[4], nullptr, st));
   for (int l = 4; l >= 1; --l) {
     const int kk = g.k[l] * g.k[l];
-    const int ncol = kk * g.cout[l];
+    const int co = co4[l];
+    const bool padded = co != g.cout[l];
+    const int ncol = kk * co;
     const int rows_s = (int)g.rows_s[l];
-    DM_TRY(dm_colsum_launch((int)g.rows_b[l], g.cout[l], G, g.cout[l], gr->b[l], splitk, skb, st));
-    // patches of the output gradient: implicit (gather tables) when the channel count allows 16-byte gathers,
-    // else (the 3-channel image layer) an explicit patch matrix
-    const bool implicit = (g.cout[l] & 3) == 0;
-    if (implicit) DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], rowoff, koff, st));
-    else DM_TRY(dm_im2col_s2_launch(g.N, g.hbg[l], g.hbg[l], g.cout[l], g.k[l], G, 0, dycol, st));
+    if (padded) {
+      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, bsum, splitk, skb, st));
+      hipError_t e = hipMemcpyAsync(gr->b[l], bsum, (size_t)g.cout[l] * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_decoder_bwd: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL(convt_pad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * ncol)), dim3(256), 0, st, g.cin[l], g.cout[l], co,
+                         g.k[l], p->w[l], wpad);
+      DM_LAUNCH_CHECK();
+    } else {
+      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, gr->b[l], splitk, skb, st));
+    }
+    // patches of the output gradient, gathered implicitly (16-byte gathers: co is a multiple of 4)
+    DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], co, g.k[l], rowoff, koff, st));
     DmGemm q;   // dWr[i][(ky,kx,o)] = sum_rows X[row][i] * dYcol[row][(ky,kx,o)]
     q.a_layout = 1; q.b_layout = 1;
     q.M = g.cin[l]; q.N = ncol; q.K = rows_s;
     q.A = a.x[l - 1]; q.lda = g.cin[l];
-    if (implicit) { q.B = G; q.b_maj = rowoff; q.b_min = koff; q.b_tab_vec = 1; }
-    else { q.B = dycol; q.ldb = ncol; }
+    q.B = G; q.b_maj = rowoff; q.b_min = koff; q.b_tab_vec = 1;
     q.C = dwr; q.ldc = ncol;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
-    DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, st));
+    if (padded) {
+      hipLaunchKernelGGL(convt_unpad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * kk * g.cout[l])), dim3(256), 0, st, g.cin[l],
+                         g.cout[l], co, g.k[l], dwr, gr->w[l]);
+      DM_LAUNCH_CHECK();
+    } else {
+      DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, st));
+    }
     float* Gn = (G == ga) ? gb : ga;
     DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
     d.a_layout = 0; d.b_layout = 0;
     d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
-    if (implicit) { d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1; }
-    else { d.A = dycol; d.lda = ncol; }
-    d.B = a.wr[l]; d.ldb = ncol;
+    d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1;
+    d.B = padded ? wpad : a.wr[l]; d.ldb = ncol;
     d.C = Gn; d.ldc = g.cin[l];
     if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }
     DM_TRY(dm_gemm_launch(d, splitk, skb, st));

@@ -37,6 +37,7 @@ struct GemmKArgs {
   float* partial;
   const int2* c_tab;          // SC (scatter) epilogue: per output row {float offset of its class-(0,0) pixel, validity bits}
   int sc_cout, sc_wpitch;     // channels per parity class; floats between two output rows of the big image (wb * cout)
+  int bias_mod;               // > 0: bias[col % bias_mod] (a 1x1 -> kxk transposed convolution: columns are (ky,kx,o))
   int M, N, K;
   int lda, ldb, ldc, ldadd, ldmul;
   int flags;
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
             g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
           } else {
             if (g.row_zero && g.row_zero[row]) v = 0.f;
-            if (g.bias) v += g.bias[col];
+            if (g.bias) v += g.bias[g.bias_mod > 0 ? col % g.bias_mod : col];
             if (g.add) v += g.add[(size_t)row * g.ldadd + col];
             float* c = g.C + (size_t)row * g.ldc + col;
             if (g.flags & DM_GEMM_ACCUM) v += *c;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs
     float v = 0.f;
     for (int s = 0; s < g.nsplit; ++s) v += g.partial[(size_t)s * total + i];
     if (g.row_zero && g.row_zero[row]) v = 0.f;
-    if (g.bias) v += g.bias[col];
+    if (g.bias) v += g.bias[g.bias_mod > 0 ? col % g.bias_mod : col];
     if (g.add) v += g.add[(size_t)row * g.ldadd + col];
     float* c = g.C + (size_t)row * g.ldc + col;
     if (g.flags & DM_GEMM_ACCUM) v += *c;
@@ -531,7 +532,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
   a.flags = q.flags;
   a.a_maj = q.a_maj; a.a_min = q.a_min; a.b_maj = q.b_maj; a.b_min = q.b_min;
-  a.c_tab = q.c_tab; a.sc_cout = q.sc_cout; a.sc_wpitch = q.sc_wpitch;
+  a.c_tab = q.c_tab; a.sc_cout = q.sc_cout; a.sc_wpitch = q.sc_wpitch; a.bias_mod = q.bias_mod;
   DM_REQUIRE(!q.c_tab || (q.sc_cout > 0 && q.N % q.sc_cout == 0 && q.N / q.sc_cout == 4 && !q.add && !(q.flags & DM_GEMM_ACCUM)),
              DM_E_SHAPE, "gemm: scatter epilogue needs N = 4 * sc_cout, no addend, no accumulate");
   // 16-byte load path: aligned base, rows a multiple of 4 floats apart, and the vectorised (minor) extent a multiple

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const S
 static const int g_skinny_max_m = getenv("DM_SKINNY_MAX_M") ? atoi(getenv("DM_SKINNY_MAX_M")) : 512;
 static bool skinny_ok(const DmGemm& q, int max_m) {
   if (q.M > max_m || q.M < 1 || q.N < 1 || q.K < 16) return false;
-  if (q.a_layout != 0 || q.a_maj || q.b_maj || q.mulref) return false;
+  if (q.a_layout != 0 || q.a_maj || q.b_maj || q.mulref || q.c_tab || q.bias_mod) return false;
   if ((q.K & 3) || (q.lda & 3) || ((uintptr_t)q.A & 15)) return false;
   if (q.b_layout == 0 && ((q.ldb & 3) || ((uintptr_t)q.B & 15))) return false;
   if ((int64_t)q.N * q.K < (int64_t)64 * 1024) return false;             // tiny products: one tiled workgroup is fine

@@ -42,7 +42,11 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   size_t xc = N * 196 * 16 * d;
   if (N * 36 * 32 * d > xc) xc = N * 36 * 32 * d;
   if (N * 4 * 64 * d > xc) xc = N * 4 * 64 * d;
-  const size_t enc_bwd = SK + pad64(N * 961 * d) + pad64(N * 196 * 2 * d) + pad64(8 * d * 64 * d) + pad64(xc);
+  // + gather-form data gradient: zero-padded copies of the 14x14x2d / 6x6x4d gradients, tables, class-concatenated weights
+  size_t epad = N * 16 * 16 * 2 * d;
+  if (N * 8 * 8 * 4 * d > epad) epad = N * 8 * 8 * 4 * d;
+  const size_t enc_bwd = SK + pad64(N * 961 * d) + pad64(N * 196 * 2 * d) + pad64(8 * d * 64 * d) + pad64(xc) + pad64(epad) +
+                         3 * pad64(N * 225) + pad64(4 * 1024) + pad64(16 * 2 * d * 4 * d) + 1024;
   // decoder: column matrices rows_small * k*k*cout for layers 1..4
   size_t col = N * 25 * 4 * d;
   if (N * 25 * 25 * 2 * d > col) col = N * 25 * 25 * 2 * d;
@@ -51,7 +55,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   size_t gmax = N * 25 * 4 * d;
   if (N * 169 * 2 * d > gmax) gmax = N * 169 * 2 * d;
   if (N * 900 * d > gmax) gmax = N * 900 * d;
-  if (N * 4096 * ch > gmax) gmax = N * 4096 * ch;
+  if (N * 4096 * ((ch + 3) / 4 * 4) > gmax) gmax = N * 4096 * ((ch + 3) / 4 * 4);   // image-layer gradient padded to 4 channels
   if (N * 32 * d > gmax) gmax = N * 32 * d;
   size_t wmax = 32 * d * 25 * 4 * d;
   if (4 * d * 25 * 2 * d > wmax) wmax = 4 * d * 25 * 2 * d;
@@ -63,7 +67,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (N * 34 * 34 * d > gpad) gpad = N * 34 * 34 * d;
   const size_t gtab = N * 32 * 32;
   const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) + 1024;
-  const size_t dec_bwd = SK + pad64(col) + 2 * pad64(gmax) + pad64(wmax) + pad64(N * 900) + pad64(100 * d + 36 * ch);   // + gather tables
+  const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024;   // + gather tables, padded image-layer weights
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D);    // + the transposed BPTT weights
   const size_t rows = (H + 1) * N;
