@@ -44,6 +44,7 @@ struct DmArena {
 };
 
 // ---- internal (C++) entry points shared between translation units -------------------------------
+struct DmGatesBwd;
 struct DmGemm {
   int a_layout = 0, b_layout = 0;
   int M = 0, N = 0, K = 0;
@@ -65,6 +66,13 @@ struct DmGemm {
   int bias_mod = 0;                               // > 0: the bias is indexed by col % bias_mod
   // LayerNorm+ELU prologue on A (A holds pre-activations; the product uses ELU(LN(A))): <= 64-row skinny products only
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-3f;
+  // LayerNorm+ELU BACKWARD prologue on A (A holds dy; the product uses dx): lnb_x = pre-activations, lnb_stats = (mean, rstd)
+  const float* lnb_x = nullptr; int lnb_ldx = 0; const float* lnb_stats = nullptr;
+  const struct DmGatesBwd* gates = nullptr;       // GRU gates backward in the epilogue (C = dh', N = D), skinny products only
+};
+struct DmGatesBwd {
+  const float* gi; const float* gh; const float* h_in; int ldh, D;
+  float* dgi; float* dgh; float* dprev; int ldp; const uint8_t* row_zero;   // dprev (nullable) += mask * dh' * u
 };
 // categorical sampler riding in the epilogue of a <= 64-row logits product (gemm_skinny.hip)
 struct DmSample {

@@ -525,7 +525,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     if (sk < 0) return sk;
     if (sk == 1) return DM_OK;
   }
-  DM_REQUIRE(!q.ln_g, DM_E_SHAPE, "gemm: a LayerNorm prologue is built for the <= 64-row skinny products only (M=%d K=%d)", q.M, q.K);
+  DM_REQUIRE(!q.ln_g && !q.lnb_x && !q.gates, DM_E_SHAPE,
+             "gemm: LayerNorm prologues / the gates epilogue are built for the <= 64-row skinny products only (M=%d K=%d)", q.M, q.K);
   GemmKArgs a;
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.mulref = q.mulref; a.row_zero = q.row_zero; a.partial = nullptr;
   a.M = q.M; a.N = q.N; a.K = q.K;

@@ -29,6 +29,13 @@ struct SkinnyArgs {
   // SAMPLE: the strip is one categorical group of 32 logits; the epilogue draws the straight-through sample
   // (rssm.py:147-148) with the sampler contract of elementwise.hip and writes one-hot z, the next step's masked z and idx
   const float* u; const int32_t* forced; float* onehot; int ldo; int32_t* idx; float* z_next; const uint8_t* next_reset;
+  // MODE 2 (LayerNorm+ELU BACKWARD prologue): A holds dy, the gradient w.r.t. y = ELU(LN(x)); the product uses
+  //   dx = rstd * (g - mean_row(g) - xhat * mean_row(g xhat)),  g = dy * ELU'(pre) * gamma,  pre = xhat * gamma + beta
+  // with x (pre-activations, leading dim ldx2) and the saved statistics (mean, rstd per row)
+  const float* lnb_x; int lnb_ldx; const float* lnb_stats;
+  // EPI 2 (GRU gates backward in the epilogue; the strip holds 16 hidden units of dh' = C): see skinny_gates_bwd
+  const float* gb_gi; const float* gb_gh; const float* gb_hin; int gb_ldh, gb_D;
+  float* gb_dgi; float* gb_dgh; float* gb_dprev; int gb_ldp; const uint8_t* gb_rz;
 };
 
 // Raw loads from clamped (always valid) addresses + a validity mask (bits 0-3: A row blocks, bit 4: B).  The zero-fill
@@ -70,8 +77,8 @@ constexpr int SK_LN_MAXK = 1024;
 // operand, so it has to be cheap.
 __device__ __forceinline__ float skinny_elu(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
 
-struct SkinnyShared {
-  float lnstat[64][2];
+struct __attribute__((aligned(16))) SkinnyShared {
+  float lnstat[64][4];      // mean, rstd (+ MODE 2: mean(g), mean(g xhat))
   float lng[SK_LN_MAXK];
   float lnb[SK_LN_MAXK];
 };
@@ -79,9 +86,10 @@ struct SkinnyShared {
 // One (16*NRB) x (16*NCB) output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads
 // a quarter of the activation traffic of the 50-row case.  DEPTH = 16-k chunks loaded per round (all in flight before
 // the first MFMA).
-template <int BL, int NRB, int NCB, bool LNA, bool SAMPLE, int DEPTH>
+template <int BL, int NRB, int NCB, int MODE, int EPI, int DEPTH>
 __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int m0, float* part, SkinnyShared* sh,
                                              float* tile) {
+  constexpr bool LNA = MODE == 1, LNB = MODE == 2, SAMPLE = EPI == 1, GATESB = EPI == 2;
   constexpr int PW = 16 * NCB;                    // strip width
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = strip * PW;
@@ -123,6 +131,34 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
     }
     __syncthreads();
   }
+  if (LNB) {
+    // row terms of the LayerNorm backward: mean / rstd from the forward's statistics, mean(g) and mean(g xhat) over the row
+    for (int e = tid; e < g.K; e += SK_WAVES * 64) { sh->lng[e] = g.ln_g[e]; sh->lnb[e] = g.ln_b[e]; }
+    for (int rr = wave; rr < 16 * NRB; rr += SK_WAVES) {
+      const int row = m0 + rr;
+      const bool rok = row < g.M;
+      const float* dr = g.A + (size_t)(rok ? row : 0) * g.lda;
+      const float* xr = g.lnb_x + (size_t)(rok ? row : 0) * g.lnb_ldx;
+      const float mean = g.lnb_stats[2 * (size_t)(rok ? row : 0)], rstd = g.lnb_stats[2 * (size_t)(rok ? row : 0) + 1];
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < SK_LN_MAXK / 64; ++j) {
+        const int cidx = lane + 64 * j;
+        if (cidx < g.K) {
+          const float ga = g.ln_g[cidx];
+          const float xh = (xr[cidx] - mean) * rstd;
+          const float pre = xh * ga + g.ln_b[cidx];
+          const float gg = dr[cidx] * (pre > 0.f ? 1.f : __expf(pre)) * ga;
+          sg += gg;
+          sgx += gg * xh;
+        }
+      }
+      sg = dm_wave_sum(sg) / (float)g.K;
+      sgx = dm_wave_sum(sgx) / (float)g.K;
+      if (lane == 0) { sh->lnstat[rr][0] = mean; sh->lnstat[rr][1] = rstd; sh->lnstat[rr][2] = sg; sh->lnstat[rr][3] = sgx; }
+    }
+    __syncthreads();
+  }
 
   // These products are latency bound (weights come from the MALL / HBM, ~1 us a round trip), so a round issues the
   // loads of DEPTH chunks back to back and only then starts consuming them under counted waits; the 16 waves of
@@ -131,10 +167,21 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
   int kend = c_end < g.K ? c_end : g.K;
   if (kend < c_beg) kend = c_beg;
   for (int c = c_beg; c < c_end; c += 16 * DEPTH) {
-    float4 a[DEPTH][NRB], b[DEPTH][NCB];
+    float4 a[DEPTH][NRB], b[DEPTH][NCB], ax[LNB ? DEPTH : 1][NRB];
     unsigned mk[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) skinny_load<BL, NRB, NCB>(g, m0, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
+    for (int d = 0; d < DEPTH; ++d) {
+      skinny_load<BL, NRB, NCB>(g, m0, n0, c + 16 * d, kend, lane, a[d], b[d], mk[d]);
+      if (LNB) {          // the pre-activations x at the same (row, k) positions as dy
+        const int k = c + 16 * d + 4 * (lane >> 4);
+#pragma unroll
+        for (int mb = 0; mb < NRB; ++mb) {
+          const int m = m0 + mb * 16 + (lane & 15);
+          const bool ok = k < kend && m < g.M;
+          ax[d][mb] = *reinterpret_cast<const float4*>(g.lnb_x + (ok ? (size_t)m * g.lnb_ldx + k : 0));
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -146,7 +193,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
         bj[cb][2] = okb ? b[d][cb].z : 0.f; bj[cb][3] = okb ? b[d][cb].w : 0.f;
       }
       float gq[4] = {1.f, 1.f, 1.f, 1.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
-      if (LNA) {
+      if (LNA || LNB) {
         const int k = c + 16 * d + 4 * (lane >> 4);
         const int kk = k < SK_LN_MAXK - 3 ? k : 0;          // past-the-range chunks are masked below; keep the read in bounds
         const float4 g4 = *reinterpret_cast<const float4*>(&sh->lng[kk]);
@@ -158,14 +205,22 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       for (int mb = 0; mb < NRB; ++mb) {
         const bool oka = ((mk[d] >> mb) & 1u) != 0u;
         float aj[4] = {a[d][mb].x, a[d][mb].y, a[d][mb].z, a[d][mb].w};
-        float lmean = 0.f, lrstd = 0.f;
-        if (LNA) {        // row statistics straight from LDS (keeping them in registers spills the NRB = 4 instance)
-          const float2 st2 = *reinterpret_cast<const float2*>(&sh->lnstat[mb * 16 + (lane & 15)][0]);
-          lmean = st2.x; lrstd = st2.y;
+        float lmean = 0.f, lrstd = 0.f, lc1 = 0.f, lc2 = 0.f;
+        if (LNA || LNB) {   // row statistics straight from LDS (keeping them in registers spills the NRB = 4 instance)
+          const float4 st4 = *reinterpret_cast<const float4*>(&sh->lnstat[mb * 16 + (lane & 15)][0]);
+          lmean = st4.x; lrstd = st4.y; lc1 = st4.z; lc2 = st4.w;
         }
+        float xj[4] = {0.f, 0.f, 0.f, 0.f};
+        if (LNB) { const float4 x4 = ax[LNB ? d : 0][mb]; xj[0] = x4.x; xj[1] = x4.y; xj[2] = x4.z; xj[3] = x4.w; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (LNA) aj[j] = skinny_elu((aj[j] - lmean) * lrstd * gq[j] + bq[j]);
+          if (LNB) {
+            const float xh = (xj[j] - lmean) * lrstd;
+            const float pre = xh * gq[j] + bq[j];
+            const float gg = aj[j] * (pre > 0.f ? 1.f : __expf(pre)) * gq[j];
+            aj[j] = lrstd * (gg - lc1 - xh * lc2);
+          }
           aj[j] = oka ? aj[j] : 0.f;
         }
 #pragma unroll
@@ -199,6 +254,28 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       if (g.flags & DM_GEMM_ACCUM) v += *cp;
       if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
       *cp = v;
+      if (GATESB) {
+        // v = dh'[row][d] (complete): GRU gates backward for hidden unit d = col (rnn.py:48-49 / nn.GRUCell, gates recomputed
+        // from the saved products), the same arithmetic as gru_gates_bwd_kernel (elementwise.hip)
+        const int D = g.gb_D;
+        const size_t g0 = (size_t)row * 3 * D;
+        const float ghn = g.gb_gh[g0 + 2 * D + col];
+        const float rg = 1.0f / (1.0f + expf(-(g.gb_gi[g0 + col] + g.gb_gh[g0 + col])));
+        const float ug = 1.0f / (1.0f + expf(-(g.gb_gi[g0 + D + col] + g.gb_gh[g0 + D + col])));
+        const float ng = tanhf(g.gb_gi[g0 + 2 * D + col] + rg * ghn);
+        const float h = g.gb_hin[(size_t)row * g.gb_ldh + col];
+        const float dn = v * (1.f - ug);
+        const float du = v * (h - ng);
+        const float dpn = dn * (1.f - ng * ng);
+        const float dpr = dpn * ghn * rg * (1.f - rg);
+        const float dpu = du * ug * (1.f - ug);
+        g.gb_dgi[g0 + col] = dpr; g.gb_dgi[g0 + D + col] = dpu; g.gb_dgi[g0 + 2 * D + col] = dpn;
+        g.gb_dgh[g0 + col] = dpr; g.gb_dgh[g0 + D + col] = dpu; g.gb_dgh[g0 + 2 * D + col] = dpn * rg;
+        if (g.gb_dprev) {
+          const float dv = (g.gb_rz && g.gb_rz[row]) ? 0.f : v * ug;
+          g.gb_dprev[(size_t)row * g.gb_ldp + col] += dv;
+        }
+      }
     }
     if (SAMPLE) tile[lr * 33 + lc] = v;
   }
@@ -255,11 +332,11 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
   }
 }
 
-template <int BL, int NRB, bool LNA>
+template <int BL, int NRB, int MODE, int EPI = 0>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
   __shared__ float part[SK_WAVES * 64 * 16];
   __shared__ SkinnyShared sh;
-  skinny_strip<BL, NRB, 1, LNA, false, 4>(g, blockIdx.x, blockIdx.y * 64, part, &sh, nullptr);   // grid.y = 64-row chunks of M
+  skinny_strip<BL, NRB, 1, MODE, EPI, MODE == 2 ? 2 : 4>(g, blockIdx.x, blockIdx.y * 64, part, &sh, nullptr);   // grid.y = 64-row chunks of M
 }
 // Posterior / prior head with the sampler in the epilogue: LayerNorm+ELU prologue, 32-wide strips (one categorical group
 // per workgroup), M <= 64.
@@ -268,20 +345,21 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const
   __shared__ float part[SK_WAVES * 64 * 32];
   __shared__ SkinnyShared sh;
   __shared__ float tile[64 * 33];
-  skinny_strip<0, NRB, 2, true, true, 2>(g, blockIdx.x, 0, part, &sh, tile);
+  skinny_strip<0, NRB, 2, 1, 1, 2>(g, blockIdx.x, 0, part, &sh, tile);
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
 // feed step t-1's state gradient.  Workgroups [0, nb0) serve the first product, the rest the second.
 // LNA0: the FIRST product's A operand goes through the LayerNorm+ELU prologue (gi = ELU(in_norm(x)) W_ih^T).
 struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0; };
-template <int NRB, bool LNA0>
+// MODE0 / MODE1: prologue of the first / second product (0 none, 1 LayerNorm+ELU forward, 2 LayerNorm+ELU backward)
+template <int NRB, int MODE0, int MODE1>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
   __shared__ float part[SK_WAVES * 64 * 16];
   __shared__ SkinnyShared sh;
   const int b = blockIdx.x;
-  if (b < a.nb0) skinny_strip<0, NRB, 1, LNA0, false, 4>(a.g[0], b, 0, part, &sh, nullptr);
-  else skinny_strip<0, NRB, 1, false, false, 4>(a.g[1], b - a.nb0, 0, part, &sh, nullptr);
+  if (b < a.nb0) skinny_strip<0, NRB, 1, MODE0, 0, MODE0 == 2 ? 2 : 4>(a.g[0], b, 0, part, &sh, nullptr);
+  else skinny_strip<0, NRB, 1, MODE1, 0, MODE1 == 2 ? 2 : 4>(a.g[1], b - a.nb0, 0, part, &sh, nullptr);
 }
 
 // max_m: 64 for the pair kernel (one chunk); the single-product kernel walks M in 64-row chunks (grid.y) up to
@@ -300,6 +378,13 @@ static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.row_zero = q.row_zero;
   a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.flags = q.flags;
   a.ln_g = q.ln_g; a.ln_b = q.ln_b; a.ln_eps = q.ln_eps;
+  a.lnb_x = q.lnb_x; a.lnb_ldx = q.lnb_ldx; a.lnb_stats = q.lnb_stats;
+  a.gb_gi = nullptr; a.gb_gh = nullptr; a.gb_hin = nullptr; a.gb_ldh = 0; a.gb_D = 0; a.gb_dgi = nullptr; a.gb_dgh = nullptr;
+  a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr;
+  if (q.gates) {
+    a.gb_gi = q.gates->gi; a.gb_gh = q.gates->gh; a.gb_hin = q.gates->h_in; a.gb_ldh = q.gates->ldh; a.gb_D = q.gates->D;
+    a.gb_dgi = q.gates->dgi; a.gb_dgh = q.gates->dgh; a.gb_dprev = q.gates->dprev; a.gb_ldp = q.gates->ldp; a.gb_rz = q.gates->row_zero;
+  }
   a.u = nullptr; a.forced = nullptr; a.onehot = nullptr; a.ldo = 0; a.idx = nullptr; a.z_next = nullptr; a.next_reset = nullptr;
 }
 static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
@@ -318,25 +403,26 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   // beyond one chunk it pays only for short reductions over small weight matrices (measured at M = 350: 1000x1024
   // 31.9 -> 24.8 us, 400x400 15.1 -> 8.7 us; 1800x1000 equal; 400x1624 18.2 -> 19.9 us)
   if (q.M > 64 && (q.K > 1024 || (int64_t)q.N * q.K > (int64_t)1100 * 1024)) return 0;
-  const bool ln = q.ln_g != nullptr;
-  if (ln && (q.K > SK_LN_MAXK || q.b_layout != 0 || !q.ln_b)) return 0;
+  const bool lnb = q.lnb_x != nullptr, ln = q.ln_g != nullptr && !lnb;
+  if ((ln || lnb) && (q.K > SK_LN_MAXK || q.b_layout != 0 || !q.ln_b || !q.ln_g || q.M > 64)) return 0;
+  if (lnb && (!q.lnb_stats || (q.lnb_ldx & 3) || ((uintptr_t)q.lnb_x & 15))) return 0;
+  if (q.gates && (!lnb || q.N != q.gates->D)) return 0;
   SkinnyArgs a;
   skinny_fill(q, a);
   const dim3 grid((unsigned)dm_cdiv(q.N, 16), (unsigned)dm_cdiv(q.M, 64));
   const dim3 blk(SK_WAVES * 64);
-  if (ln) {
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1, true>), grid, blk, 0, stream, a);
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2, true>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4, true>), grid, blk, 0, stream, a);
-  } else if (q.b_layout == 0) {
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<0, 1, false>), grid, blk, 0, stream, a);
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<0, 2, false>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<0, 4, false>), grid, blk, 0, stream, a);
-  } else {
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<1, 1, false>), grid, blk, 0, stream, a);
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, false>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, false>), grid, blk, 0, stream, a);
-  }
+#define SK_LAUNCH(BL_, MODE_, EPI_)                                                                                     \
+  do {                                                                                                                  \
+    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 1, MODE_, EPI_>), grid, blk, 0, stream, a);              \
+    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 2, MODE_, EPI_>), grid, blk, 0, stream, a);         \
+    else hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 4, MODE_, EPI_>), grid, blk, 0, stream, a);                        \
+  } while (0)
+  if (lnb && q.gates) SK_LAUNCH(0, 2, 2);
+  else if (lnb) SK_LAUNCH(0, 2, 0);
+  else if (ln) SK_LAUNCH(0, 1, 0);
+  else if (q.b_layout == 0) SK_LAUNCH(0, 0, 0);
+  else SK_LAUNCH(1, 0, 0);
+#undef SK_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "skinny gemm: %s", hipGetErrorString(e));
   return 1;
@@ -345,29 +431,34 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
 // q0 may carry a LayerNorm+ELU prologue (ln_g / ln_b): then the one-launch path is mandatory (callers check
 // dm_skinny_ln_ok first).
 int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_bytes, hipStream_t stream) {
-  const bool ln0 = q0.ln_g != nullptr;
-  DM_REQUIRE(!q1.ln_g, DM_E_SHAPE, "gemm pair: only the first product may carry a LayerNorm prologue");
+  const bool ln0 = q0.ln_g != nullptr && !q0.lnb_x, lnb1 = q1.lnb_x != nullptr;
+  DM_REQUIRE(!q0.lnb_x && !(q1.ln_g && !q1.lnb_x) && !q0.gates && !q1.gates, DM_E_SHAPE,
+             "gemm pair: built for a forward LayerNorm prologue on the first product or a backward one on the second");
+  const bool fused = ln0 || lnb1;
   if (!g_skinny_disabled && skinny_ok(q0, 64) && skinny_ok(q1, 64) && q0.b_layout == 0 && q1.b_layout == 0 &&
-      (!ln0 || (q0.K <= SK_LN_MAXK && q0.ln_b))) {
+      (!ln0 || (q0.K <= SK_LN_MAXK && q0.ln_b)) &&
+      (!lnb1 || (q1.K <= SK_LN_MAXK && q1.ln_g && q1.ln_b && q1.lnb_stats && (q1.lnb_ldx & 3) == 0 && ((uintptr_t)q1.lnb_x & 15) == 0))) {
     SkinnyPairArgs a;
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
     a.nb0 = dm_cdiv(q0.N, 16);
     const dim3 grid((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), blk(SK_WAVES * 64);
     const int mmax = q0.M > q1.M ? q0.M : q1.M;
-    if (ln0) {
-      if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, true>), grid, blk, 0, stream, a);
-      else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, true>), grid, blk, 0, stream, a);
-      else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, true>), grid, blk, 0, stream, a);
-    } else {
-      if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, false>), grid, blk, 0, stream, a);
-      else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, false>), grid, blk, 0, stream, a);
-      else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, false>), grid, blk, 0, stream, a);
-    }
+#define SKP_LAUNCH(M0_, M1_)                                                                                            \
+  do {                                                                                                                  \
+    if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, M0_, M1_>), grid, blk, 0, stream, a);                \
+    else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, M0_, M1_>), grid, blk, 0, stream, a);           \
+    else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, M0_, M1_>), grid, blk, 0, stream, a);                           \
+  } while (0)
+    if (ln0 && !lnb1) SKP_LAUNCH(1, 0);
+    else if (lnb1 && !ln0) SKP_LAUNCH(0, 2);
+    else if (!ln0 && !lnb1) SKP_LAUNCH(0, 0);
+    else return dm_fail(DM_E_SHAPE, "gemm pair: forward and backward LayerNorm prologues in one launch are not built");
+#undef SKP_LAUNCH
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
-  DM_REQUIRE(!ln0, DM_E_SHAPE, "gemm pair: LayerNorm prologue requested but the one-launch skinny path does not apply");
+  DM_REQUIRE(!fused, DM_E_SHAPE, "gemm pair: LayerNorm prologue requested but the one-launch skinny path does not apply");
   DM_TRY(dm_gemm_launch(q0, ws, ws_bytes, stream));
   return dm_gemm_launch(q1, ws, ws_bytes, stream);
 }
