@@ -232,6 +232,9 @@ def main():
             opt.step()
         return metrics
 
+    main_prio = os.environ.get('DM_MAIN_PRIO')            # experiment switch: run the caller's stream at another priority
+    if main_prio is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(main_prio)))
     for i in range(args.warmup):
         step(i)
     if world > 1:

@@ -55,9 +55,13 @@ typedef struct dm_shape {
                                inside the first conv's patch loader and the MSE kernel */
 } dm_shape;
 #define DM_FLAG_IMAGE_U8 16
+/* bits 5-6: recurrent cell (rnn.py:40-67 `gru_type`): 0 = gru (nn.GRUCell), 1 = gru_layernorm (NormGRUCell, rnn.py:95-114),
+ * 2 = gru_layernorm_dv2 (NormGRUCellLateReset, rnn.py:117-138) */
+#define DM_FLAG_GRU_SHIFT 5
+#define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 1 */
+int dm_version(void);                 /* ABI version, currently 2 (round 2: dm_rssm_params grew by the LayerNorm-GRU slots) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -215,6 +219,10 @@ enum {
   DM_RSSM_GRU_WIH, DM_RSSM_GRU_WHH, DM_RSSM_GRU_BIH, DM_RSSM_GRU_BHH,
   DM_RSSM_PRIOR_H_W, DM_RSSM_PRIOR_H_B, DM_RSSM_PRIOR_G, DM_RSSM_PRIOR_B, DM_RSSM_PRIOR_W, DM_RSSM_PRIOR_OB,
   DM_RSSM_POST_H_W, DM_RSSM_POST_H_B, DM_RSSM_POST_E_W, DM_RSSM_POST_G, DM_RSSM_POST_B, DM_RSSM_POST_W, DM_RSSM_POST_OB,
+  /* LayerNorm GRU cells only (NULL for gru; then GRU_BIH / GRU_BHH are NULL instead - these cells have no biases):
+   * gru_layernorm: (G0,B0) = ln_reset, (G1,B1) = ln_update, (G2,B2) = ln_newval, D floats each;
+   * gru_layernorm_dv2: (G0,B0) = lnorm, 3D floats */
+  DM_RSSM_GRU_LN_G0, DM_RSSM_GRU_LN_B0, DM_RSSM_GRU_LN_G1, DM_RSSM_GRU_LN_B1, DM_RSSM_GRU_LN_G2, DM_RSSM_GRU_LN_B2,
   DM_RSSM_NPARAMS
 };
 typedef struct dm_rssm_params { const float* p[DM_RSSM_NPARAMS]; } dm_rssm_params;

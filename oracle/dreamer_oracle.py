@@ -109,8 +109,19 @@ def param_shapes(conf):
     s[f'{c}.z_mlp.weight'] = (Hd, Z); s[f'{c}.z_mlp.bias'] = (Hd,)
     s[f'{c}.a_mlp.weight'] = (Hd, A)
     s[f'{c}.in_norm.weight'] = (Hd,); s[f'{c}.in_norm.bias'] = (Hd,)
-    s[f'{c}.gru.layers.0.weight_ih'] = (3 * D_, Hd); s[f'{c}.gru.layers.0.weight_hh'] = (3 * D_, D_)
-    s[f'{c}.gru.layers.0.bias_ih'] = (3 * D_,); s[f'{c}.gru.layers.0.bias_hh'] = (3 * D_,)
+    gl = f'{c}.gru.layers.0'
+    if conf.gru_type == 'gru':                                                             # nn.GRUCell, rnn.py:47-48
+        s[f'{gl}.weight_ih'] = (3 * D_, Hd); s[f'{gl}.weight_hh'] = (3 * D_, D_)
+        s[f'{gl}.bias_ih'] = (3 * D_,); s[f'{gl}.bias_hh'] = (3 * D_,)
+    elif conf.gru_type == 'gru_layernorm':                                                 # NormGRUCell, rnn.py:95-104
+        s[f'{gl}.weight_ih.weight'] = (3 * D_, Hd); s[f'{gl}.weight_hh.weight'] = (3 * D_, D_)
+        for n in ('ln_reset', 'ln_update', 'ln_newval'):
+            s[f'{gl}.{n}.weight'] = (D_,); s[f'{gl}.{n}.bias'] = (D_,)
+    elif conf.gru_type == 'gru_layernorm_dv2':                                             # NormGRUCellLateReset, rnn.py:117-125
+        s[f'{gl}.weight_ih.weight'] = (3 * D_, Hd); s[f'{gl}.weight_hh.weight'] = (3 * D_, D_)
+        s[f'{gl}.lnorm.weight'] = (3 * D_,); s[f'{gl}.lnorm.bias'] = (3 * D_,)
+    else:
+        raise ValueError(conf.gru_type)
     s[f'{c}.prior_mlp_h.weight'] = (Hd, D_); s[f'{c}.prior_mlp_h.bias'] = (Hd,)
     s[f'{c}.prior_norm.weight'] = (Hd,); s[f'{c}.prior_norm.bias'] = (Hd,)
     s[f'{c}.prior_mlp.weight'] = (Z, Hd); s[f'{c}.prior_mlp.bias'] = (Z,)
@@ -261,8 +272,24 @@ def conv_decoder(p, features):
 
 
 def gru_cell(p, x, h):
-    """nn.GRUCell via GRUCellStack (rnn.py:40-67); gate order r,z,n."""
+    """GRUCellStack with one layer (rnn.py:40-67): nn.GRUCell (gate order r,z,n), NormGRUCell (rnn.py:95-114) or
+    NormGRUCellLateReset (rnn.py:117-138), told apart by the parameter names of the cell."""
     c = 'wm.core.cell.gru.layers.0'
+    ln = lambda v, n: F.layer_norm(v, (v.shape[-1],), p[f'{c}.{n}.weight'], p[f'{c}.{n}.bias'], 1e-3)
+    if f'{c}.lnorm.weight' in p:                               # gru_layernorm_dv2
+        gates = ln(F.linear(x, p[f'{c}.weight_ih.weight']) + F.linear(h, p[f'{c}.weight_hh.weight']), 'lnorm')
+        reset, update, newval = gates.chunk(3, -1)
+        reset = torch.sigmoid(reset)
+        update = torch.sigmoid(update - 1)                     # update_bias = -1
+        newval = torch.tanh(reset * newval)                    # late reset
+        return update * newval + (1 - update) * h
+    if f'{c}.ln_reset.weight' in p:                            # gru_layernorm
+        i_r, i_u, i_n = F.linear(x, p[f'{c}.weight_ih.weight']).chunk(3, -1)
+        h_r, h_u, h_n = F.linear(h, p[f'{c}.weight_hh.weight']).chunk(3, -1)
+        reset = torch.sigmoid(ln(i_r + h_r, 'ln_reset'))
+        update = torch.sigmoid(ln(i_u + h_u, 'ln_update'))
+        newval = torch.tanh(ln(i_n + reset * h_n, 'ln_newval'))
+        return update * newval + (1 - update) * h
     gi = F.linear(x, p[f'{c}.weight_ih'], p[f'{c}.bias_ih'])
     gh = F.linear(h, p[f'{c}.weight_hh'], p[f'{c}.bias_hh'])
     i_r, i_z, i_n = gi.chunk(3, -1)

@@ -358,6 +358,15 @@ if __name__ == '__main__':
         # BASELINE.json configs[1]: Atari-literal at full size (B=50,T=50,H=15,deter 600); ~1 min per step on 8 vCPU
         run('atari_literal', ['defaults', 'atari'],
             dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18), steps=1, slim=True)
+    for gt in ('gru_layernorm', 'gru_layernorm_dv2'):
+        if gt in which or 'grucells' in which:
+            # the LayerNorm GRU cells (rnn.py:95-138), tiny dims, 2 training steps incl. gradients
+            t = O.tiny_conf()
+            run('tiny_' + gt, ['defaults', 'atari'],
+                dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                     cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                     imag_horizon=t.imag_horizon, gru_type=gt), steps=2,
+                full_grads=('wm.core.cell.post_norm.weight', 'wm.core.cell.a_mlp.weight', 'ac.actor.model.12.weight'))
     if 'inference' in which:
         t = O.tiny_conf()
         run_inference('tiny_inference', ['defaults', 'atari'],

@@ -380,6 +380,245 @@ __global__ void __launch_bounds__(256) gru_gates_bwd_kernel(int rows, int D, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LayerNorm GRU cells (rnn.py:95-138), one wave per row.  h' = u n + (1-u) h in both.
+//   KIND 1 gru_layernorm     : r = sig(LN_r(gi_r+gh_r)), u = sig(LN_u(gi_u+gh_u)), n = tanh(LN_n(gi_n + r gh_n))
+//   KIND 2 gru_layernorm_dv2 : g = LN_3D(gi+gh); r = sig(g_r), u = sig(g_u - 1), n = tanh(r g_n)        (late reset)
+// gs (rows,3D): the pre-LayerNorm sums [s_r | s_u | s_n] (KIND 1) / s (KIND 2), saved for backward;
+// gst (rows,6): (mean, rstd) of LN_r, LN_u, LN_n (KIND 1) / of the one LayerNorm in slots 0,1 (KIND 2).  eps = 1e-3.
+// ------------------------------------------------------------------------------------------------
+struct GruLnParams { const float* g[3]; const float* b[3]; };
+
+template <int KIND>
+__global__ void __launch_bounds__(256) gru_norm_fwd_kernel(int rows, int D, const float* __restrict__ gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ h_in,
+                                                           int ldh, const GruLnParams lp, float* __restrict__ h_out, int ldo,
+                                                           float* __restrict__ gs, float* __restrict__ gst,
+                                                           float* __restrict__ h_next, const uint8_t* __restrict__ next_reset) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float eps = 1e-3f;
+  const float* gir = gi + (size_t)row * 3 * D;
+  const float* ghr = gh + (size_t)row * 3 * D;
+  float* sr = gs + (size_t)row * 3 * D;
+  const float* hr = h_in + (size_t)row * ldh;
+  float st[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (KIND == 2) {
+    float sum = 0.f;
+    for (int j = lane; j < 3 * D; j += 64) { const float v = gir[j] + ghr[j]; sr[j] = v; sum += v; }
+    const float mean = dm_wave_sum(sum) / (float)(3 * D);
+    float var = 0.f;
+    for (int j = lane; j < 3 * D; j += 64) { const float d = (gir[j] + ghr[j]) - mean; var += d * d; }
+    const float rstd = 1.0f / sqrtf(dm_wave_sum(var) / (float)(3 * D) + eps);
+    st[0] = mean; st[1] = rstd;
+    for (int d = lane; d < D; d += 64) {
+      const float g_r = ((gir[d] + ghr[d]) - mean) * rstd * lp.g[0][d] + lp.b[0][d];
+      const float g_u = ((gir[D + d] + ghr[D + d]) - mean) * rstd * lp.g[0][D + d] + lp.b[0][D + d];
+      const float g_n = ((gir[2 * D + d] + ghr[2 * D + d]) - mean) * rstd * lp.g[0][2 * D + d] + lp.b[0][2 * D + d];
+      const float r = dm_sigmoid(g_r), u = dm_sigmoid(g_u - 1.0f), n = tanhf(r * g_n);
+      const float ho = u * n + (1.f - u) * hr[d];
+      h_out[(size_t)row * ldo + d] = ho;
+      if (h_next) h_next[(size_t)row * D + d] = (next_reset && next_reset[row]) ? 0.f : ho;
+    }
+  } else {
+    float s0 = 0.f, s1 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float a = gir[d] + ghr[d], b = gir[D + d] + ghr[D + d];
+      sr[d] = a; sr[D + d] = b;
+      s0 += a; s1 += b;
+    }
+    const float m0 = dm_wave_sum(s0) / (float)D, m1 = dm_wave_sum(s1) / (float)D;
+    float v0 = 0.f, v1 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float a = (gir[d] + ghr[d]) - m0, b = (gir[D + d] + ghr[D + d]) - m1;
+      v0 += a * a; v1 += b * b;
+    }
+    const float r0 = 1.0f / sqrtf(dm_wave_sum(v0) / (float)D + eps), r1 = 1.0f / sqrtf(dm_wave_sum(v1) / (float)D + eps);
+    float s2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float r = dm_sigmoid(((gir[d] + ghr[d]) - m0) * r0 * lp.g[0][d] + lp.b[0][d]);
+      const float c = gir[2 * D + d] + r * ghr[2 * D + d];
+      sr[2 * D + d] = c;
+      s2 += c;
+    }
+    const float m2 = dm_wave_sum(s2) / (float)D;
+    float v2 = 0.f;
+    for (int d = lane; d < D; d += 64) { const float c = sr[2 * D + d] - m2; v2 += c * c; }     // own writes: same lane, same address
+    const float r2 = 1.0f / sqrtf(dm_wave_sum(v2) / (float)D + eps);
+    st[0] = m0; st[1] = r0; st[2] = m1; st[3] = r1; st[4] = m2; st[5] = r2;
+    for (int d = lane; d < D; d += 64) {
+      const float u = dm_sigmoid(((gir[D + d] + ghr[D + d]) - m1) * r1 * lp.g[1][d] + lp.b[1][d]);
+      const float n = tanhf((sr[2 * D + d] - m2) * r2 * lp.g[2][d] + lp.b[2][d]);
+      const float ho = u * n + (1.f - u) * hr[d];
+      h_out[(size_t)row * ldo + d] = ho;
+      if (h_next) h_next[(size_t)row * D + d] = (next_reset && next_reset[row]) ? 0.f : ho;
+    }
+  }
+  if (lane < 6) gst[(size_t)row * 6 + lane] = st[lane];
+}
+
+// dgi, dgh (rows,3D): gradients w.r.t. the two gate products; dg (rows,3D): gradients w.r.t. the LayerNorm OUTPUTS (for
+// the batched gamma / beta gradients); dh_in (nullable) += mask * dh' * (1 - u).
+template <int KIND>
+__global__ void __launch_bounds__(256) gru_norm_bwd_kernel(int rows, int D, const float* __restrict__ gh,
+                                                           const float* __restrict__ h_in, int ldh,
+                                                           const float* __restrict__ gs, const float* __restrict__ gst,
+                                                           const GruLnParams lp, const float* __restrict__ dh_out, int lddh,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh,
+                                                           float* __restrict__ dg, float* __restrict__ dh_in, int lddi,
+                                                           const uint8_t* __restrict__ row_zero) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = gs + (size_t)row * 3 * D;
+  const float* ghr = gh + (size_t)row * 3 * D;
+  const float* hr = h_in + (size_t)row * ldh;
+  const float* dhr = dh_out + (size_t)row * lddh;
+  float* dgr = dg + (size_t)row * 3 * D;
+  float* dgir = dgi + (size_t)row * 3 * D;
+  float* dghr = dgh + (size_t)row * 3 * D;
+  const float* st = gst + (size_t)row * 6;
+  const bool rz = row_zero && row_zero[row];
+  if (KIND == 2) {
+    const float mean = st[0], rstd = st[1];
+    const float inv = 1.0f / (float)(3 * D);
+    float c1 = 0.f, c2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float x_r = (sr[d] - mean) * rstd, x_u = (sr[D + d] - mean) * rstd, x_n = (sr[2 * D + d] - mean) * rstd;
+      const float g_n = x_n * lp.g[0][2 * D + d] + lp.b[0][2 * D + d];
+      const float r = dm_sigmoid(x_r * lp.g[0][d] + lp.b[0][d]);
+      const float u = dm_sigmoid(x_u * lp.g[0][D + d] + lp.b[0][D + d] - 1.0f);
+      const float n = tanhf(r * g_n);
+      const float dh = dhr[d];
+      const float dpn = dh * u * (1.f - n * n);
+      const float d_r = dpn * g_n * r * (1.f - r), d_u = dh * (n - hr[d]) * u * (1.f - u), d_n = dpn * r;
+      dgr[d] = d_r; dgr[D + d] = d_u; dgr[2 * D + d] = d_n;
+      const float a = d_r * lp.g[0][d], b = d_u * lp.g[0][D + d], c = d_n * lp.g[0][2 * D + d];
+      c1 += a + b + c;
+      c2 += a * x_r + b * x_u + c * x_n;
+      if (dh_in) dh_in[(size_t)row * lddi + d] += rz ? 0.f : dh * (1.f - u);
+    }
+    c1 = dm_wave_sum(c1) * inv;
+    c2 = dm_wave_sum(c2) * inv;
+    for (int d = lane; d < D; d += 64)          // every lane re-reads only its OWN dg writes (d, D+d, 2D+d)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = q * D + d;
+        const float xh = (sr[j] - mean) * rstd;
+        const float v = rstd * (dgr[j] * lp.g[0][j] - c1 - xh * c2);
+        dgir[j] = v;
+        dghr[j] = v;
+      }
+  } else {
+    const float m0 = st[0], r0 = st[1], m1 = st[2], r1 = st[3], m2 = st[4], r2 = st[5];
+    const float inv = 1.0f / (float)D;
+    // pass A: LN_n backward needs the row means of dg_n gamma_n (and x xhat)
+    float a1 = 0.f, a2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float xn = (sr[2 * D + d] - m2) * r2;
+      const float u = dm_sigmoid((sr[D + d] - m1) * r1 * lp.g[1][d] + lp.b[1][d]);
+      const float n = tanhf(xn * lp.g[2][d] + lp.b[2][d]);
+      const float dh = dhr[d];
+      const float d_n = dh * u * (1.f - n * n);
+      dgr[2 * D + d] = d_n;
+      const float gg = d_n * lp.g[2][d];
+      a1 += gg; a2 += gg * xn;
+      dgr[D + d] = dh * (n - hr[d]) * u * (1.f - u);
+      if (dh_in) dh_in[(size_t)row * lddi + d] += rz ? 0.f : dh * (1.f - u);
+    }
+    a1 = dm_wave_sum(a1) * inv; a2 = dm_wave_sum(a2) * inv;
+    // pass B: ds_n -> dgi_n, dgh_n = ds_n r, dr = ds_n gh_n -> dg_r ; row means for LN_r and LN_u
+    float b1 = 0.f, b2 = 0.f, u1 = 0.f, u2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float xn = (sr[2 * D + d] - m2) * r2, xr = (sr[d] - m0) * r0, xu = (sr[D + d] - m1) * r1;
+      const float ds_n = r2 * (dgr[2 * D + d] * lp.g[2][d] - a1 - xn * a2);
+      const float r = dm_sigmoid(xr * lp.g[0][d] + lp.b[0][d]);
+      dgir[2 * D + d] = ds_n;
+      dghr[2 * D + d] = ds_n * r;
+      const float d_r = ds_n * ghr[2 * D + d] * r * (1.f - r);
+      dgr[d] = d_r;
+      const float gr_ = d_r * lp.g[0][d], gu_ = dgr[D + d] * lp.g[1][d];
+      b1 += gr_; b2 += gr_ * xr;
+      u1 += gu_; u2 += gu_ * xu;
+    }
+    b1 = dm_wave_sum(b1) * inv; b2 = dm_wave_sum(b2) * inv;
+    u1 = dm_wave_sum(u1) * inv; u2 = dm_wave_sum(u2) * inv;
+    for (int d = lane; d < D; d += 64) {
+      const float xr = (sr[d] - m0) * r0, xu = (sr[D + d] - m1) * r1;
+      const float ds_r = r0 * (dgr[d] * lp.g[0][d] - b1 - xr * b2);
+      const float ds_u = r1 * (dgr[D + d] * lp.g[1][d] - u1 - xu * u2);
+      dgir[d] = ds_r; dghr[d] = ds_r;
+      dgir[D + d] = ds_u; dghr[D + d] = ds_u;
+    }
+  }
+}
+
+// dgamma_q[c] = sum_rows dg[r][c] * xhat[r][c], dbeta_q[c] = sum_rows dg[r][c]  over the 3D columns; the statistics of column
+// c are gst[r][2*(c / D)] (KIND 1: one LayerNorm per third) or gst[r][0] (KIND 2).  64 columns x 4 row lanes per block.
+__global__ void __launch_bounds__(256) gru_norm_param_grads_kernel(int kind, int rows, int D, const float* __restrict__ gs,
+                                                                   const float* __restrict__ gst, const float* __restrict__ dg,
+                                                                   float* __restrict__ dgam, float* __restrict__ dbet) {
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  float a = 0.f, b = 0.f;
+  if (col < 3 * D) {
+    const int q = kind == 1 ? col / D : 0;
+    for (int r = ry; r < rows; r += 4) {
+      const float v = dg[(size_t)r * 3 * D + col];
+      const float xh = (gs[(size_t)r * 3 * D + col] - gst[(size_t)r * 6 + 2 * q]) * gst[(size_t)r * 6 + 2 * q + 1];
+      a += v * xh;
+      b += v;
+    }
+  }
+  red[0][ry][cx] = a; red[1][ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && col < 3 * D) {
+    dgam[col] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+    dbet[col] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+  }
+}
+
+int dm_gru_norm_fwd_launch(int kind, int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
+                           const float* const* ln_g, const float* const* ln_b, float* h_out, int ldo, float* gs, float* gst,
+                           float* h_next, const uint8_t* next_reset, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  GruLnParams lp;
+  for (int i = 0; i < 3; ++i) { lp.g[i] = ln_g[i]; lp.b[i] = ln_b[i]; }
+  if (kind == 1)
+    hipLaunchKernelGGL((gru_norm_fwd_kernel<1>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gi, gh, h_in, ldh, lp, h_out,
+                       ldo, gs, gst, h_next, next_reset);
+  else
+    hipLaunchKernelGGL((gru_norm_fwd_kernel<2>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gi, gh, h_in, ldh, lp, h_out,
+                       ldo, gs, gst, h_next, next_reset);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_gru_norm_bwd_launch(int kind, int rows, int D, const float* gh, const float* h_in, int ldh, const float* gs,
+                           const float* gst, const float* const* ln_g, const float* const* ln_b, const float* dh_out, int lddh,
+                           float* dgi, float* dgh, float* dg, float* dh_in, int lddi, const uint8_t* row_zero, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  GruLnParams lp;
+  for (int i = 0; i < 3; ++i) { lp.g[i] = ln_g[i]; lp.b[i] = ln_b[i]; }
+  if (kind == 1)
+    hipLaunchKernelGGL((gru_norm_bwd_kernel<1>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gh, h_in, ldh, gs, gst, lp,
+                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero);
+  else
+    hipLaunchKernelGGL((gru_norm_bwd_kernel<2>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gh, h_in, ldh, gs, gst, lp,
+                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+// dgam / dbet: 3D-float vectors laid out like the LayerNorm outputs ([reset | update | newval] thirds)
+int dm_gru_norm_param_grads_launch(int kind, int rows, int D, const float* gs, const float* gst, const float* dg, float* dgam,
+                                   float* dbet, hipStream_t st) {
+  hipLaunchKernelGGL(gru_norm_param_grads_kernel, dim3(dm_cdiv(3 * D, 64)), dim3(256), 0, st, kind, rows, D, gs, gst, dg, dgam,
+                     dbet);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 static inline int ew_blocks(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 4096) b = 4096;

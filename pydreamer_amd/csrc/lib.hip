@@ -14,7 +14,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 1; }
+extern "C" int dm_version(void) { return 2; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -68,12 +68,12 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t gtab = N * 32 * 32;
   const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) + 1024;
   const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024;   // + gather tables, padded image-layer weights
-  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 2 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
-                          pad64(3 * D * Hd) + pad64(3 * D * D);    // + the transposed BPTT weights
+  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
+                          pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D);    // + the transposed BPTT weights, LN-GRU dg
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
-                       2 * pad64(N * 3 * D) + pad64(N * Z);
+                       3 * pad64(N * 3 * D) + pad64(N * 6) + pad64(N * Z);
   size_t m = enc_bwd;
   if (dec_fwd > m) m = dec_fwd;
   if (dec_bwd > m) m = dec_bwd;

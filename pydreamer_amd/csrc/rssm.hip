@@ -14,7 +14,9 @@
 
 struct RssmActs {
   float *ea, *ee, *hin, *zin, *x1, *st1, *za, *gi, *gh, *x2, *st2, *pin, *x3, *st3, *prin;
+  float *gs, *gst;      // LayerNorm GRU cells: pre-LayerNorm gate sums (N,3D) and their statistics (N,6)
 };
+static inline int rssm_gru_kind(const dm_shape* s) { return (s->flags & DM_FLAG_GRU_MASK) >> DM_FLAG_GRU_SHIFT; }
 static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
   const size_t N = (size_t)s->T * s->B, Hd = s->Hd, D = s->D, Z = (size_t)s->S * s->C;
   DmArena ar(base, (size_t)1 << 62);
@@ -25,6 +27,8 @@ static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
   t.gi = ar.take(N * 3 * D); t.gh = ar.take(N * 3 * D);
   t.x2 = ar.take(N * Hd); t.st2 = ar.take(N * 2); t.pin = ar.take(N * Hd);
   t.x3 = ar.take(N * Hd); t.st3 = ar.take(N * 2); t.prin = ar.take(N * Hd);
+  const bool lncell = rssm_gru_kind(s) != 0;
+  t.gs = ar.take(lncell ? N * 3 * D : 0); t.gst = ar.take(lncell ? N * 6 : 0);
   if (a) *a = t;
   return ar.off;
 }
@@ -38,6 +42,7 @@ static int rssm_check(const dm_shape* s) {
   DM_REQUIRE(s->T >= 1 && s->B >= 1 && s->D >= 4 && s->Hd >= 4 && s->S >= 1 && s->C >= 2 && s->A >= 1 && s->E >= 1,
              DM_E_SHAPE, "rssm: bad shape");
   DM_REQUIRE((s->D & 3) == 0, DM_E_SHAPE, "rssm: deter_dim must be a multiple of 4 (got %d)", s->D);
+  DM_REQUIRE(rssm_gru_kind(s) <= 2, DM_E_SHAPE, "rssm: unknown recurrent cell kind %d", rssm_gru_kind(s));
   return DM_OK;
 }
 
@@ -127,6 +132,11 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   // rows from L2) and the straight-through sampler rides in the EPILOGUE of the posterior-logits product (one 32-logit
   // group per workgroup).  The post-LayerNorm activations `za` / `pin` that only the backward pass needs (weight
   // gradients, ELU') are then produced for ALL rows of the range by two batched launches after the loop.
+  const int kind = rssm_gru_kind(s);
+  const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
+  const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
+  DM_REQUIRE(kind == 0 || (lng[0] && lnb[0] && (kind == 2 || (lng[1] && lnb[1] && lng[2] && lnb[2]))), DM_E_NULL,
+             "rssm_sequence_fwd: LayerNorm GRU cell without its LayerNorm parameters");
   const bool fuse_ln = dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
   const bool fuse_sample = fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
@@ -161,8 +171,12 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       gh_q.C = a.gh + r0 * 3 * D; gh_q.ldc = 3 * D; gh_q.bias = p[DM_RSSM_GRU_BHH];
       DM_TRY(dm_gemm_pair_launch(gi_q, gh_q, ws, skb, st));
     }
-    DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, hin_next,
-                                   reset_next, st));
+    if (kind == 0)
+      DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, hin_next,
+                                     reset_next, st));
+    else
+      DM_TRY(dm_gru_norm_fwd_launch(kind, B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, lng, lnb, feat + r0 * F, F,
+                                    a.gs + r0 * 3 * D, a.gst + r0 * 6, hin_next, reset_next, st));
     // post = post_mlp(ELU(post_norm(post_mlp_h(h) + post_mlp_e(embed))))               rssm.py:143-146
     DM_TRY(linear(st, ws, skb, B, Hd, D, feat + r0 * F, F, p[DM_RSSM_POST_H_W], p[DM_RSSM_POST_H_B], a.ee + r0 * Hd, Hd,
                   a.x2 + r0 * Hd, Hd));
@@ -245,6 +259,12 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   float* wt_ih = ar.take((size_t)3 * D * Hd);
   float* wt_hh = ar.take((size_t)3 * D * D);
   float* wt_z = ar.take((size_t)Hd * Z);
+  const int kind = rssm_gru_kind(s);
+  float* dgl = ar.take(kind ? (size_t)N * 3 * D : 0);       // LayerNorm GRU cells: gradients w.r.t. the LayerNorm outputs
+  float* lnpg = ar.take(kind ? (size_t)3 * D : 0);
+  float* lnpb = ar.take(kind ? (size_t)3 * D : 0);
+  const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
+  const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -270,7 +290,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  const bool fuse_b = kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
   for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
@@ -310,8 +330,12 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     // GRU gates; the direct path dh'*u goes (masked) straight into step t-1's dh'
     const uint8_t* rz = reset + r0;
     float* dprev = t > 0 ? dfeat + (r0 - B) * F : nullptr;
-    DM_TRY(dm_gru_gates_bwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, dft, F,
-                                   dgi + r0 * 3 * D, dgh + r0 * 3 * D, dprev, F, 1, rz, st));
+    if (kind == 0)
+      DM_TRY(dm_gru_gates_bwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, dft, F,
+                                     dgi + r0 * 3 * D, dgh + r0 * 3 * D, dprev, F, 1, rz, st));
+    else
+      DM_TRY(dm_gru_norm_bwd_launch(kind, B, D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, a.gs + r0 * 3 * D, a.gst + r0 * 6, lng,
+                                    lnb, dft, F, dgi + r0 * 3 * D, dgh + r0 * 3 * D, dgl + r0 * 3 * D, dprev, F, rz, st));
     DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, wt_ih, dza + r0 * Hd, Hd, 0, nullptr));
     DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
                                    dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
@@ -339,9 +363,23 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(wgrad(st, sk, skb, N, Hd, E, dx2, Hd, embed, E, g[DM_RSSM_POST_E_W]));
   if (dembed) DM_TRY(dgrad(st, sk, skb, N, Hd, E, dx2, Hd, p[DM_RSSM_POST_E_W], dembed, E, 0, nullptr));
   DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
-  DM_TRY(dm_colsum_launch(N, 3 * D, dgi, 3 * D, g[DM_RSSM_GRU_BIH], sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, 3 * D, D, dgh, 3 * D, a.hin, D, g[DM_RSSM_GRU_WHH]));
-  DM_TRY(dm_colsum_launch(N, 3 * D, dgh, 3 * D, g[DM_RSSM_GRU_BHH], sk, skb, st));
+  if (kind == 0) {
+    DM_TRY(dm_colsum_launch(N, 3 * D, dgi, 3 * D, g[DM_RSSM_GRU_BIH], sk, skb, st));
+    DM_TRY(dm_colsum_launch(N, 3 * D, dgh, 3 * D, g[DM_RSSM_GRU_BHH], sk, skb, st));
+  } else {      // LayerNorm parameters of the cell: one batched column pass over all rows, then split into the thirds
+    DM_TRY(dm_gru_norm_param_grads_launch(kind, N, D, a.gs, a.gst, dgl, lnpg, lnpb, st));
+    const int parts = kind == 1 ? 3 : 1;
+    const size_t len = (kind == 1 ? (size_t)D : (size_t)3 * D) * sizeof(float);
+    float* const gdst[3] = {g[DM_RSSM_GRU_LN_G0], g[DM_RSSM_GRU_LN_G1], g[DM_RSSM_GRU_LN_G2]};
+    float* const bdst[3] = {g[DM_RSSM_GRU_LN_B0], g[DM_RSSM_GRU_LN_B1], g[DM_RSSM_GRU_LN_B2]};
+    for (int q = 0; q < parts; ++q) {
+      DM_REQUIRE(gdst[q] && bdst[q], DM_E_NULL, "rssm_sequence_bwd: missing LayerNorm-GRU gradient slot %d", q);
+      if (hipMemcpyAsync(gdst[q], lnpg + (size_t)q * D, len, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(bdst[q], lnpb + (size_t)q * D, len, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return dm_fail(DM_E_HIP, "rssm_sequence_bwd: gradient copy failed");
+    }
+  }
   DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x1, Hd, a.za, Hd, a.st1, dza, Hd, g[DM_RSSM_IN_G], g[DM_RSSM_IN_B], sk, skb,
                                      st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
@@ -380,6 +418,11 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   float* gi = ar.take((size_t)M * 3 * D);
   float* gh = ar.take((size_t)M * 3 * D);
   float* prior = ar.take((size_t)M * Z);
+  const int kind = rssm_gru_kind(s);
+  float* gsw = ar.take(kind ? (size_t)M * 3 * D : 0);
+  float* gstw = ar.take(kind ? (size_t)M * 6 : 0);
+  const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
+  const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -406,7 +449,8 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
     DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
-    DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, st));
+    if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, st));
+    else DM_TRY(dm_gru_norm_fwd_launch(kind, M, D, gi, gh, cur, F, lng, lnb, nxt, F, gsw, gstw, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));

@@ -28,7 +28,28 @@ RSSM_PARAM_ORDER = [
     'post_mlp_h.weight', 'post_mlp_h.bias', 'post_mlp_e.weight', 'post_norm.weight', 'post_norm.bias',
     'post_mlp.weight', 'post_mlp.bias',
 ]
-DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER)
+# the LayerNorm GRU cells (rnn.py:95-138): no gate biases, LayerNorm parameters in the 6 extra slots (include/dreamer_hip.h)
+GRU_KINDS = {'gru': 0, 'gru_layernorm': 1, 'gru_layernorm_dv2': 2}
+DM_FLAG_GRU_SHIFT = 5
+_LN_SLOTS = {
+    'gru': [None] * 6,
+    'gru_layernorm': ['gru.layers.0.ln_reset.weight', 'gru.layers.0.ln_reset.bias', 'gru.layers.0.ln_update.weight',
+                      'gru.layers.0.ln_update.bias', 'gru.layers.0.ln_newval.weight', 'gru.layers.0.ln_newval.bias'],
+    'gru_layernorm_dv2': ['gru.layers.0.lnorm.weight', 'gru.layers.0.lnorm.bias', None, None, None, None],
+}
+
+
+def rssm_param_names(gru_type='gru'):
+    """Parameter name (relative to wm.core.cell) of every dm_rssm_params slot, None for slots the cell does not have."""
+    names = list(RSSM_PARAM_ORDER)
+    if gru_type != 'gru':
+        ren = {'gru.layers.0.weight_ih': 'gru.layers.0.weight_ih.weight', 'gru.layers.0.weight_hh': 'gru.layers.0.weight_hh.weight',
+               'gru.layers.0.bias_ih': None, 'gru.layers.0.bias_hh': None}
+        names = [ren.get(n, n) for n in names]
+    return names + _LN_SLOTS[gru_type]
+
+
+DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER) + 6
 
 
 class DreamerHipError(RuntimeError):
@@ -231,8 +252,10 @@ def conv_struct(ws, bs, cls=dm_conv_params):
 
 
 def rssm_struct(tensors, cls=dm_rssm_params):
+    """tensors: one per slot (rssm_param_names order); the 6 LayerNorm-GRU slots may be omitted, absent slots are None."""
+    tensors = list(tensors) + [None] * (DM_RSSM_NPARAMS - len(tensors))
     assert len(tensors) == DM_RSSM_NPARAMS
     s = cls()
     for i, t in enumerate(tensors):
-        s.p[i] = t.data_ptr()
+        s.p[i] = None if t is None else t.data_ptr()
     return s

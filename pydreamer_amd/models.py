@@ -7,7 +7,8 @@ calls the C-ABI of libdreamer_hip.so (pydreamer_amd/hip.py) through three `torch
 model, actor, critic — so each of the 4 returned losses supports an independent `.backward()` exactly like the
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
-Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type='gru', gru_layers=1,
+Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type in {gru, gru_layernorm,
+gru_layernorm_dv2}, gru_layers=1,
 stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh},
 actor_grad='reinforce',
 probe_model='none', no aux critic / vecobs / reward_input.
@@ -236,14 +237,38 @@ class MultiDecoder(_Params):
         self.terminal = DenseBernoulliDecoder(features_dim, conf.terminal_decoder_layers, conf.layer_norm)
 
 
+class NormGRUCellP(_Params):
+    """rnn.py:95-104 (gru_layernorm): bias-free gate products, one LayerNorm(eps 1e-3) per gate."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.weight_ih = LinearP(input_size, 3 * hidden_size, bias=False)
+        self.weight_hh = LinearP(hidden_size, 3 * hidden_size, bias=False)
+        self.ln_reset = LayerNormP(hidden_size)
+        self.ln_update = LayerNormP(hidden_size)
+        self.ln_newval = LayerNormP(hidden_size)
+
+
+class NormGRUCellLateResetP(_Params):
+    """rnn.py:117-125 (gru_layernorm_dv2): one LayerNorm over all three gates, update bias -1, late reset."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.weight_ih = LinearP(input_size, 3 * hidden_size, bias=False)
+        self.weight_hh = LinearP(hidden_size, 3 * hidden_size, bias=False)
+        self.lnorm = LayerNormP(3 * hidden_size)
+
+
 class GRUCellStack(_Params):
-    """rnn.py:40-67 with cell_type='gru', num_layers=1."""
+    """rnn.py:40-67 with num_layers=1; cell_type in {gru, gru_layernorm, gru_layernorm_dv2}."""
 
     def __init__(self, input_size, hidden_size, num_layers, cell_type):
         super().__init__()
-        if cell_type != 'gru' or num_layers != 1:
+        cells = dict(gru=GRUCellP, gru_layernorm=NormGRUCellP, gru_layernorm_dv2=NormGRUCellLateResetP)
+        if cell_type not in cells or num_layers != 1:
             raise NotImplementedError(f'gru_type={cell_type!r}, gru_layers={num_layers} not built in the HIP path')
-        self.layers = nn.ModuleList([GRUCellP(input_size, hidden_size)])
+        self.cell_type = cell_type
+        self.layers = nn.ModuleList([cells[cell_type](input_size, hidden_size)])
 
 
 class RSSMCell(_Params):
@@ -268,9 +293,9 @@ class RSSMCell(_Params):
         self.post_mlp = LinearP(hidden_dim, Z)
 
     def ordered(self):
-        """Tensors in the DM_RSSM_* order of include/dreamer_hip.h."""
+        """Tensors in the DM_RSSM_* order of include/dreamer_hip.h (None for slots this cell type does not have)."""
         named = dict(self.named_parameters())
-        return [named[n] for n in H.RSSM_PARAM_ORDER]
+        return [None if n is None else named[n] for n in H.rssm_param_names(self.gru.cell_type)]
 
     def init_state(self, batch_size):
         dev = self.z_mlp.weight.device
@@ -419,8 +444,8 @@ class _Overlap:
     def __init__(self, device):
         # the latency-bound chain gets the high-priority queue: its 40-110-workgroup kernels must be dispatched ahead of
         # the thousands of queued GEMM workgroups of the concurrent work, or the chain just slows down
-        self.s_wm = torch.cuda.Stream(device, priority=-1)
-        self.s_ac = torch.cuda.Stream(device, priority=0)
+        self.s_wm = torch.cuda.Stream(device, priority=int(os.environ.get('DM_WM_PRIO', '-1')))
+        self.s_ac = torch.cuda.Stream(device, priority=int(os.environ.get('DM_AC_PRIO', '0')))
         self.ev_wm_fwd = torch.cuda.Event()
         self.ev_fwd = torch.cuda.Event()
         self.ws_wm = None
@@ -600,7 +625,7 @@ class WorldModel(_Params):
         return H.make_shape(T=T, B=B, I=1, H=H_, D=c.deter_dim, Hd=c.hidden_dim, S=c.stoch_dim, C=c.stoch_discrete,
                             E=self.encoder.out_dim, A=c.action_dim, mlp_hidden=MLP_HIDDEN, mlp_layers=4,
                             cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels,
-                            flags=ACTOR_KINDS.get(c.actor_dist, 0))
+                            flags=ACTOR_KINDS.get(c.actor_dist, 0) | (H.GRU_KINDS[c.gru_type] << H.DM_FLAG_GRU_SHIFT))
 
     def workspace(self, shp, device):
         need = H.workspace_bytes(shp)
@@ -902,7 +927,7 @@ class WorldModel(_Params):
         # RSSM BPTT
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
-        rssm_g = H.rssm_struct([gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
+        rssm_g = H.rssm_struct([None if p is None else gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
         dembed = torch.empty(N, E, device=dev)
         H.call('dm_rssm_sequence_bwd', ctypes.byref(pk['shp_r']), H.fptr(pk['embed_x']), H.fptr(pk['action_x']),
                H.ptr(pk['reset_x']), ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']),

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
     lib = hip.lib()
-    assert lib.dm_version() == 1
+    assert lib.dm_version() == 2
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
@@ -63,7 +63,8 @@ def test_config_surface():
 def test_state_dict_keys_match_reference_table():
     """oracle.param_shapes was asserted key-for-key against the reference's state_dict by gen_golden.py."""
     from pydreamer_amd.models import Dreamer
-    for oconf in (O.tiny_conf(), O.atari_literal_conf()):
+    for oconf in (O.tiny_conf(), O.atari_literal_conf(), O.tiny_conf(gru_type='gru_layernorm'),
+                  O.tiny_conf(gru_type='gru_layernorm_dv2')):
         shapes = O.param_shapes(oconf)
         conf = config.load_config('defaults', 'atari', **vars(oconf))
         with torch.device('meta'):
@@ -75,7 +76,7 @@ def test_state_dict_keys_match_reference_table():
 
 def test_unsupported_configs_fail_loudly():
     from pydreamer_amd.models import Dreamer
-    for kw in (dict(aux_critic=True), dict(gru_type='gru_layernorm'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
+    for kw in (dict(aux_critic=True), dict(gru_layers=2), dict(gru_type='bogus'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
                dict(image_size=32), dict(stoch_discrete=0), dict(layer_norm=False)):
         conf = config.load_config('defaults', 'atari', **kw)
         with pytest.raises(NotImplementedError):

@@ -118,6 +118,15 @@ def test_oracle_matches_reference_iwae():
         _check_step(g, conf, res)
 
 
+@pytest.mark.parametrize('gru_type', ['gru_layernorm', 'gru_layernorm_dv2'])
+def test_oracle_matches_reference_layernorm_gru_cells(gru_type):
+    """NormGRUCell / NormGRUCellLateReset (rnn.py:95-138) in place of nn.GRUCell, two training steps."""
+    g, conf, results = _replay('tiny_' + gru_type, 2)
+    assert conf.gru_type == gru_type
+    for res in results:
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_debug_literal():
     """BASELINE.json configs[0]: defaults+atari+debug, B=4, T=10, H=5, discrete(6)."""
     g, conf, results = _replay('debug_literal', 1)
