@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.dm_reduce_item) == 32
     assert ctypes.sizeof(hip.dm_mlp_params) == 8 * (9 + 9 + 8 + 8)
     assert ctypes.sizeof(hip.dm_conv_params) == 8 * 10
-    assert ctypes.sizeof(hip.dm_rssm_params) == 8 * 22
+    assert ctypes.sizeof(hip.dm_rssm_params) == 8 * 28
 
 
 def test_config_surface():
