@@ -39,6 +39,7 @@ DEFAULTS = dict(
     cnn_depth=48, reward_decoder_layers=4, terminal_decoder_layers=4,
     gamma=0.995, lambda_gae=0.95, entropy=0.003, target_interval=100, imag_horizon=15,
     actor_grad='reinforce', actor_dist='onehot',
+    aux_critic=False, aux_critic_weight=1.0, gamma_aux=0.99, lambda_gae_aux=0.95, target_interval_aux=1000,
 )
 ATARI = dict(action_dim=18, deter_dim=1024, kl_weight=0.1, gamma=0.99, entropy=0.001)
 
@@ -129,6 +130,10 @@ def param_shapes(conf):
     s[f'{c}.post_mlp_e.weight'] = (Hd, E)
     s[f'{c}.post_norm.weight'] = (Hd,); s[f'{c}.post_norm.bias'] = (Hd,)
     s[f'{c}.post_mlp.weight'] = (Z, Hd); s[f'{c}.post_mlp.bias'] = (Z,)
+    if conf.aux_critic:                                                                    # dreamer.py:267-277 (a full ActorCritic)
+        _mlp_shapes('wm.ac_aux.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s)
+        _mlp_shapes('wm.ac_aux.critic.model', Fd, 1, 4, s)
+        _mlp_shapes('wm.ac_aux.critic_target.model', Fd, 1, 4, s)
     _mlp_shapes('ac.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s)   # a2c.py:35-39
     _mlp_shapes('ac.critic.model', Fd, 1, 4, s)
     _mlp_shapes('ac.critic_target.model', Fd, 1, 4, s)
@@ -425,6 +430,13 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=Non
     loss_model_tbi = conf.kl_weight * loss_kl + loss_reconstr                 # dreamer.py:362-365
     loss_model_tb = -logavgexp(-loss_model_tbi, 2)
     loss = loss_model_tb.mean()
+    aux = None
+    if conf.aux_critic:                                                       # dreamer.py:347-358 (assumes I = 1)
+        (_, loss_critic_aux), m_aux, t_aux = ac_training_step(p, conf, feat_tbi[:, :, 0], obs['action'][1:], obs['reward'],
+                                                              obs['terminal'], prefix='wm.ac_aux', gamma=conf.gamma_aux,
+                                                              lam=conf.lambda_gae_aux)
+        loss = loss + conf.aux_critic_weight * loss_critic_aux
+        aux = (m_aux, t_aux)
 
     with torch.no_grad():
         ent_prior = dprior.entropy().mean(2)
@@ -434,10 +446,14 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=Non
                        loss_image=lae(loss_image), image_rec=decoded.mean(2).detach(),
                        loss_reward=lae(loss_reward), reward_rec=mu.mean(2).detach(),
                        loss_terminal=lae(loss_terminal), terminal_rec=tdist.mean.mean(2).detach())
+        if aux is not None:
+            tensors['policy_value_aux'] = aux[1]['value']
         metrics = dict(loss_model=loss_model_tb.mean(), loss_kl=tensors['loss_kl'].mean(),
                        entropy_prior=ent_prior.mean(), entropy_post=ent_post.mean(),
                        loss_image=tensors['loss_image'].mean(), loss_reward=tensors['loss_reward'].mean(),
                        loss_terminal=tensors['loss_terminal'].mean())
+        if aux is not None:
+            metrics.update(loss_critic_aux=aux[0]['loss_critic'], policy_value_aux=aux[0]['policy_value_im'])
     extras = dict(post_idx=torch.stack(idxs), post=posts.detach(), prior=priors.detach(), embed=embed.detach())
     if u_pred is not None:                                                    # do_image_pred, dreamer.py:381-394
         assert I == 1, 'the oracle restates do_image_pred for iwae_samples = 1'
@@ -520,11 +536,13 @@ def dream(p, conf, in_state, H, u_act, u_prior, eps_act=None):
     return feats, actions, rewards, terminals, dict(act_idx=torch.stack(act_idx), lat_idx=torch.stack(lat_idx))
 
 
-def ac_training_step(p, conf, features, actions, rewards, terminals):
-    gamma, lam = conf.gamma, conf.lambda_gae
+def ac_training_step(p, conf, features, actions, rewards, terminals, prefix='ac', gamma=None, lam=None):
+    """ActorCritic.training_step (a2c.py:61-149); prefix 'wm.ac_aux' + (gamma_aux, lambda_gae_aux) = the auxiliary critic."""
+    gamma = conf.gamma if gamma is None else gamma
+    lam = conf.lambda_gae if lam is None else lam
     reward1, terminal0, terminal1 = rewards[1:], terminals[:-1], terminals[1:]
     with torch.no_grad():
-        value_t = mlp(p, 'ac.critic_target.model', features, 4)
+        value_t = mlp(p, f'{prefix}.critic_target.model', features, 4)
     value0t, value1t = value_t[:-1], value_t[1:]
     advantage = -value0t + reward1 + gamma * (1.0 - terminal1) * value1t
     gae, agae = [], None
@@ -536,11 +554,11 @@ def ac_training_step(p, conf, features, actions, rewards, terminals):
     value_target = advantage_gae + value0t
     reality_weight = (1 - terminal0).log().cumsum(dim=0).exp()
 
-    value = mlp(p, 'ac.critic.model', features, 4)
+    value = mlp(p, f'{prefix}.critic.model', features, 4)
     value0 = value[:-1]
     loss_critic = (0.5 * torch.square(value_target.detach() - value0) * reality_weight).mean()
 
-    logits = mlp(p, 'ac.actor.model', features[:-1], 4).float()
+    logits = mlp(p, f'{prefix}.actor.model', features[:-1], 4).float()
     policy = actor_distribution(conf, logits)
     loss_policy = -policy.log_prob(actions) * advantage_gae.detach()
     policy_entropy = policy.entropy()
@@ -565,6 +583,7 @@ class OracleDreamer:
         self.conf = conf
         self.p = OrderedDict((k, v.clone().requires_grad_(group_of(k) is not None)) for k, v in params.items())
         self.train_steps = 0
+        self.aux_train_steps = 0
 
     def group(self, g):
         return [v for k, v in self.p.items() if group_of(k) == g]
@@ -585,6 +604,13 @@ class OracleDreamer:
         c, p = self.conf, self.p
         T, B = obs['action'].shape[:2]
         I = int(iwae_samples or c.iwae_samples)
+        if c.aux_critic:                                                           # a2c.py:76-79 inside wm.ac_aux
+            if self.aux_train_steps % c.target_interval_aux == 0:
+                with torch.no_grad():
+                    for k in list(p):
+                        if k.startswith('wm.ac_aux.critic_target.'):
+                            p[k].copy_(p[k.replace('critic_target', 'critic')])
+            self.aux_train_steps += 1
         loss_model, features, states, out_state, metrics, tensors, extras = \
             wm_training_step(p, c, obs, in_state, noise['u_post'], forced_idx, noise['u_pred'] if do_image_pred else None,
                              do_open_loop, iwae_samples=I)

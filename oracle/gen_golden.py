@@ -367,6 +367,14 @@ if __name__ == '__main__':
                      cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                      imag_horizon=t.imag_horizon, gru_type=gt), steps=2,
                 full_grads=('wm.core.cell.post_norm.weight', 'wm.core.cell.a_mlp.weight', 'ac.actor.model.12.weight'))
+    if 'aux' in which:
+        # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
+        t = O.tiny_conf()
+        run('tiny_aux_critic', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, aux_critic=True), steps=2,
+            full_grads=('wm.ac_aux.critic.model.12.weight', 'wm.core.cell.post_norm.weight'))
     if 'inference' in which:
         t = O.tiny_conf()
         run_inference('tiny_inference', ['defaults', 'atari'],

@@ -26,6 +26,9 @@ class GraphedTrainStep:
         dev = obs['action'].device
         if dev.type != 'cuda':
             raise H.DreamerHipError('GraphedTrainStep needs the batch on a gfx950 device (there is no CPU path)')
+        if model.wm.ac_aux is not None:
+            raise NotImplementedError('aux_critic refreshes its target network on a host-side step counter inside '
+                                      'training_step(); capture would freeze that decision - run it eagerly')
         self.model, self.optimizers = model, [o for o in optimizers]
         self.static_obs = {k: v.clone() for k, v in obs.items()}
         self.static_state = tuple(x.clone() for x in in_state)

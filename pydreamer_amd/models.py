@@ -399,8 +399,9 @@ def _multi_sum(items, device, out=None):
 # One device buffer per step for every loss / metric scalar: slot layout
 METRIC_SLOTS = dict(loss_kl=0, loss_image=1, loss_reward=2, loss_terminal=3, entropy_prior=4, entropy_post=5, loss_model=6,
                     loss_critic=8, loss_actor=9, policy_entropy=10, policy_value=11, policy_value_im=12, policy_reward=13,
-                    policy_reward_std=14, grad_norm=16, grad_norm_probe=18, grad_norm_actor=20, grad_norm_critic=22)
-METRIC_BUF_FLOATS = 24
+                    policy_reward_std=14, grad_norm=16, grad_norm_probe=18, grad_norm_actor=20, grad_norm_critic=22,
+                    loss_critic_aux=24, policy_value_aux=25)      # slot 7: loss_model + aux_critic_weight * loss_critic_aux
+METRIC_BUF_FLOATS = 28
 
 
 def _finish_backward(owner, grads, flat, direct, grad_loss):
@@ -578,7 +579,7 @@ class _WMStep(torch.autograd.Function):
             torch.cuda.current_stream().wait_stream(ov.s_wm)
         else:
             grads, flat, direct = wm._backward(pk, pk['ws'])
-        for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts'):
+        for k in ('enc_acts', 'rssm_acts', 'dec_acts', 'r_acts', 't_acts', 'aux'):
             pk.pop(k, None)                               # only now: the side stream may have been reading them
         pk['consumed'] = True
         return (None, None) + _finish_backward(wm, grads, flat, direct, grad_loss)
@@ -589,8 +590,8 @@ class WorldModel(_Params):
 
     def __init__(self, conf):
         super().__init__()
-        if conf.aux_critic:
-            raise NotImplementedError('aux_critic is not built in the HIP path')
+        if conf.aux_critic and conf.iwae_samples != 1:
+            raise NotImplementedError('aux_critic assumes iwae_samples = 1 (as the reference does, dreamer.py:349)')
         if conf.image_size != 64:
             raise NotImplementedError('conv geometry is built for 64x64 observations')
         self.conf = conf
@@ -605,7 +606,14 @@ class WorldModel(_Params):
         self.core = RSSMCore(embed_dim=self.encoder.out_dim, action_dim=conf.action_dim, deter_dim=conf.deter_dim,
                              stoch_dim=conf.stoch_dim, stoch_discrete=conf.stoch_discrete, hidden_dim=conf.hidden_dim,
                              gru_layers=conf.gru_layers, gru_type=conf.gru_type, layer_norm=conf.layer_norm)
+        # Auxiliary critic on the real trajectory (dreamer.py:267-279): a full ActorCritic lives inside the world model (its
+        # parameters belong to the world-model optimizer and get the tf2 init); only its critic is trained (dreamer.py:347-358)
         self.ac_aux = None
+        if conf.aux_critic:
+            self.ac_aux = ActorCritic(in_dim=features_dim, out_actions=conf.action_dim, layer_norm=conf.layer_norm,
+                                      gamma=conf.gamma_aux, lambda_gae=conf.lambda_gae_aux, entropy_weight=conf.entropy,
+                                      target_interval=conf.target_interval_aux, actor_grad=conf.actor_grad,
+                                      actor_dist=conf.actor_dist)
         for m in self.modules():
             init_weights_tf2(m)
         self._ws = None
@@ -831,10 +839,39 @@ class WorldModel(_Params):
         loss = mbuf[6]
         w = (ctypes.c_float * 4)(self.kl_weight, dec.image_weight, dec.reward_weight, dec.terminal_weight)
         iw = None
+        aux = None
+        if self.ac_aux is not None and T >= 2:
+            # Auxiliary critic (dreamer.py:347-358): ActorCritic.training_step on the REAL trajectory - features (T,B,F) as
+            # the "dream", the batch's own actions / rewards / terminals; only loss_critic is kept.  Its actor forward and
+            # policy loss are computed by the reference and then thrown away, so they are simply not run here.
+            ac = self.ac_aux
+            if torch.is_grad_enabled():
+                if ac.train_steps % ac.target_interval == 0:
+                    ac.update_critic_target()
+                ac.train_steps += 1
+            rows = (T - 1) * B
+            value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False)
+            value, aux_acts = ac.critic.fwd(feat, F_, N, ws)
+            adv, agae, vtgt, wgt = (torch.empty(T - 1, B, device=dev) for _ in range(4))
+            H.call('dm_gae_losses', T - 1, B, ac.gamma, ac.lambda_, H.fptr(reward_t), H.fptr(terminal_t), H.fptr(value_t),
+                   H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
+            lc = torch.empty(rows, device=dev)
+            dvalue = torch.zeros(N, device=dev)                      # value[-1] gets no gradient
+            H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), self.aux_critic_weight / rows, H.fptr(lc),
+                   H.fptr(dvalue), H.stream())
+            _multi_sum([(lc, 1.0 / rows), (value.view(T, B)[:-1], 1.0 / rows)], dev, out=mbuf[24:26])
+            aux = dict(acts=aux_acts, dvalue=dvalue, value=value, lc=lc, rows=rows)
         if I == 1:
             means = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
                                 (ent_prior, 1.0 / N), (ent_post, 1.0 / N)], dev, out=mbuf[0:6])
             H.call('dm_combine', 4, H.fptr(means), w, ctypes.c_void_p(mbuf.data_ptr() + 24), H.stream())   # dreamer.py:362-365
+            if aux is not None:       # loss = loss_model.mean() + aux_critic_weight * loss_critic_aux (dreamer.py:365) -> slot 7
+                t5 = _multi_sum([(kl, 1.0 / N), (loss_image, 1.0 / N), (loss_reward, 1.0 / N), (loss_terminal, 1.0 / N),
+                                 (aux['lc'], 1.0 / aux['rows'])], dev)
+                w5 = (ctypes.c_float * 5)(self.kl_weight, dec.image_weight, dec.reward_weight, dec.terminal_weight,
+                                          self.aux_critic_weight)
+                H.call('dm_combine', 5, H.fptr(t5), w5, ctypes.c_void_p(mbuf.data_ptr() + 28), H.stream())
+                loss = mbuf[7]
             tb = lambda x: x.view(T, B)
             t_kl, t_ep, t_eq, t_li, t_lr, t_lt, t_rr, t_tr = (tb(x) for x in (kl, ent_prior, ent_post, loss_image, loss_reward,
                                                                               loss_terminal, reward_rec, terminal_rec))
@@ -861,7 +898,7 @@ class WorldModel(_Params):
             t_kl, t_li, t_lr, t_lt, t_ep, t_eq, t_rr, t_tr = (tb(red[j]) for j in range(1, 9))
 
         pk.update(loss=loss, image=image, action=action, reset=reset, enc_acts=enc_acts, rssm_acts=rssm_acts,
-                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws, mbuf=mbuf, iw=iw)
+                  dec_acts=dec_acts, r_acts=r_acts, t_acts=t_acts, dmu=dmu, dtl=dtl, ws=ws, mbuf=mbuf, iw=iw, aux=aux)
         pk['tensors'] = LazyTensors(loss_kl=t_kl, entropy_prior=t_ep, entropy_post=t_eq,
                                     loss_image=t_li, image_rec=None,
                                     loss_reward=t_lr, reward_rec=t_rr,
@@ -875,8 +912,11 @@ class WorldModel(_Params):
                 rec = pred.transpose(1, 2).contiguous().view(T, B, I, Cc, c.image_size, c.image_size)   # -> (T,B,I,C,H,W)
                 return rec[:, :, 0] if I == 1 else rec.mean(2)       # decoded.mean(dim=2), decoders.py:171 (logging only)
         pk['tensors'].lazy('image_rec', image_rec_thunk)
-        pk['metrics'] = dict(loss_model=loss.detach(), loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
+        pk['metrics'] = dict(loss_model=mbuf[6], loss_kl=means[0], entropy_prior=means[4], entropy_post=means[5],
                              loss_image=means[1], loss_reward=means[2], loss_terminal=means[3])
+        if aux is not None:
+            pk['metrics'].update(loss_critic_aux=mbuf[24], policy_value_aux=mbuf[25])
+            pk['tensors']['policy_value_aux'] = aux['value'].view(T, B)
         return pk
 
     def _param_order(self):
@@ -900,7 +940,10 @@ class WorldModel(_Params):
             for dout in (pk['dmu'], pk['dtl']):
                 H.call('dm_scale_rows', N, 1, H.fptr(dout), 1, H.fptr(iw), 1.0, H.stream())
             pk['iw_applied'] = True
-        for head, acts, dout in ((dec.reward.model, pk['r_acts'], pk['dmu']), (dec.terminal.model, pk['t_acts'], pk['dtl'])):
+        heads = [(dec.reward.model, pk['r_acts'], pk['dmu']), (dec.terminal.model, pk['t_acts'], pk['dtl'])]
+        if pk.get('aux') is not None:          # the auxiliary critic trains on the world model's own features (not detached)
+            heads.append((self.ac_aux.critic, pk['aux']['acts'], pk['aux']['dvalue']))
+        for head, acts, dout in heads:
             st, gs = head.struct(), head.grad_struct(gof)
             H.call('dm_mlp_head_bwd', N, F_, head.hidden_dim, head.hidden_layers, 1, H.fptr(feat), F_, ctypes.byref(st),
                    H.fptr(acts), H.fptr(dout), ctypes.byref(gs), H.fptr(dfeat), F_, 1, H.ptr(ws), ws.numel(), H.stream())
@@ -1173,7 +1216,10 @@ class Dreamer(nn.Module):
 
     def init_optimizers(self, lr, lr_actor=None, lr_critic=None, eps=1e-5):
         groups = self.param_groups()
-        self._opt = dict(wm=FusedAdamW(groups['wm'], lr=lr, eps=eps), probe=FusedAdamW(groups['probe'], lr=lr, eps=eps),
+        # the auxiliary ActorCritic's actor never receives a gradient (dreamer.py:347-358 keeps only loss_critic): torch's AdamW
+        # skips such parameters entirely, so they are frozen here too (its critic_target has requires_grad=False already)
+        frozen = list(self.wm.ac_aux.actor.parameters()) if self.wm.ac_aux is not None else []
+        self._opt = dict(wm=FusedAdamW(groups['wm'], lr=lr, eps=eps, frozen=frozen), probe=FusedAdamW(groups['probe'], lr=lr, eps=eps),
                          actor=FusedAdamW(groups['actor'], lr=lr_actor or lr, eps=eps),
                          critic=FusedAdamW(groups['critic'], lr=lr_critic or lr, eps=eps))
         # the backward passes write straight into these optimizers' gradient buffers (see _flat_views)

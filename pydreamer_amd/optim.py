@@ -15,7 +15,10 @@ from . import hip as H
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.01):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=0.01, frozen=()):
+        """frozen: parameters of this group that never receive a gradient (requires_grad=False, or sub-networks whose loss
+        is not part of the group's objective - the auxiliary ActorCritic's actor, dreamer.py:267-279).  torch.optim.AdamW
+        skips parameters whose .grad is None entirely (no moment update AND no weight decay); so does step() here."""
         params = list(params)
         if not params:
             raise ValueError('FusedAdamW got an empty parameter list')
@@ -49,6 +52,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self.early_reduce = None                          # (work handle) all-reduce of `scratch` already in flight (dist.py)
         self._reduced = False                             # flat_grad already holds the all-reduced gradient of this step
         self._ids = {id(p) for p in params}
+        fz = {id(p) for p in frozen} | {id(p) for p in params if not p.requires_grad}
+        self._frozen_idx = {i for i, p in enumerate(params) if id(p) in fz}
+        self._spans, start = [], None          # maximal runs [begin, end) of the flat buffer that step() updates
+        for i, (p, off) in enumerate(zip(params, self._offsets)):
+            end = self._offsets[i + 1] if i + 1 < len(params) else n
+            if i in self._frozen_idx:
+                if start is not None:
+                    self._spans.append((start, off))
+                    start = None
+            elif start is None:
+                start = off
+            _ = end
+        if start is not None:
+            self._spans.append((start, n))
         with torch.no_grad():
             for p, off in zip(params, self._offsets):
                 k = p.numel()
@@ -196,9 +213,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ensure_zeroed()
         g = self.param_groups[0]
         self.step_count += 1
-        H.call('dm_adamw_step', H.fptr(self.flat_param), H.fptr(self.flat_grad), H.fptr(self.exp_avg),
-               H.fptr(self.exp_avg_sq), self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
-               self.step_count, None, H.stream())
+        for b, e in self._spans:
+            o = 4 * b
+            H.call('dm_adamw_step', ctypes.c_void_p(self.flat_param.data_ptr() + o), ctypes.c_void_p(self.flat_grad.data_ptr() + o),
+                   ctypes.c_void_p(self.exp_avg.data_ptr() + o), ctypes.c_void_p(self.exp_avg_sq.data_ptr() + o), e - b, g['lr'],
+                   g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count, None, H.stream())
 
     # ---- checkpoint format: EXACTLY torch.optim.AdamW's (per-parameter 'state' entries, 'params' index lists), so that
     # tools.mlflow_save_checkpoint / mlflow_load_checkpoint (tools.py:164-197) move `optimizer_{i}_state_dict` between a
@@ -211,6 +230,8 @@ class FusedAdamW(torch.optim.Optimizer):
         state = {}
         if self.step_count > 0:                      # torch creates the per-parameter state lazily at the first step
             for i, (p, off) in enumerate(zip(self._plist, self._offsets)):
+                if i in self._frozen_idx:         # torch keeps no state for parameters that never had a gradient
+                    continue
                 k = p.numel()
                 state[i] = dict(step=torch.tensor(float(self.step_count)),
                                 exp_avg=self.exp_avg[off:off + k].view(p.shape).clone(),

@@ -270,9 +270,10 @@ def test_training_step_continuous_actor_vs_oracle(hip):
 
 def test_training_step_matches_reference_goldens(hip):
     """Directly against the fixtures written by the real reference (tests/golden/tiny.npz, debug_literal.npz, tiny_dmc.npz,
-    and the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz - SURVEY 8(f) N4)."""
+    the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz, and the auxiliary critic
+    of dreamer.py:267-279,347-358: tiny_aux_critic.npz - SURVEY 8(f) N4)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
-                        ('tiny_gru_layernorm_dv2', 2)):
+                        ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)

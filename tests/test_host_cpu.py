@@ -64,7 +64,7 @@ def test_state_dict_keys_match_reference_table():
     """oracle.param_shapes was asserted key-for-key against the reference's state_dict by gen_golden.py."""
     from pydreamer_amd.models import Dreamer
     for oconf in (O.tiny_conf(), O.atari_literal_conf(), O.tiny_conf(gru_type='gru_layernorm'),
-                  O.tiny_conf(gru_type='gru_layernorm_dv2')):
+                  O.tiny_conf(gru_type='gru_layernorm_dv2'), O.tiny_conf(aux_critic=True)):
         shapes = O.param_shapes(oconf)
         conf = config.load_config('defaults', 'atari', **vars(oconf))
         with torch.device('meta'):
@@ -76,7 +76,7 @@ def test_state_dict_keys_match_reference_table():
 
 def test_unsupported_configs_fail_loudly():
     from pydreamer_amd.models import Dreamer
-    for kw in (dict(aux_critic=True), dict(gru_layers=2), dict(gru_type='bogus'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
+    for kw in (dict(aux_critic=True, iwae_samples=2), dict(gru_layers=2), dict(gru_type='bogus'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
                dict(image_size=32), dict(stoch_discrete=0), dict(layer_norm=False)):
         conf = config.load_config('defaults', 'atari', **kw)
         with pytest.raises(NotImplementedError):

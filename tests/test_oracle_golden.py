@@ -127,6 +127,14 @@ def test_oracle_matches_reference_layernorm_gru_cells(gru_type):
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_aux_critic():
+    """aux_critic (dreamer.py:267-279,347-358), two training steps."""
+    g, conf, results = _replay('tiny_aux_critic', 2)
+    assert conf.aux_critic
+    for res in results:
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_debug_literal():
     """BASELINE.json configs[0]: defaults+atari+debug, B=4, T=10, H=5, discrete(6)."""
     g, conf, results = _replay('debug_literal', 1)
