@@ -1,0 +1,278 @@
+"""Replay reader -> device ring: the caller side of the hot path.
+
+The reference feeds `train.py` from `DataSequential` (data.py:128-304: B independent episode streams cut into
+truncated-BPTT windows of `batch_length`, files chosen at random forever) through `Preprocessor.apply`
+(preprocessing.py:87-180) in DataLoader workers, and the trainer moves every batch to the device as float32.
+Here the same batches are produced as what the HIP path consumes directly:
+
+  * `LocalEpisodeRepository`  - episode `.npz` files in local directories (the reference lists mlflow artifacts,
+    data.py:53-122; the file-name grammar `ep{from}_{to}-r{reward}-{steps}.npz` is the same);
+  * `SequentialReplay`        - DataSequential's algorithm: per-column sequential iteration (`iter_single`), random start
+    in the first file (`skip_first`), partial-window carry (`allow_mid_reset`), `randomize_resets`, `buffer_size`
+    filtering, `image_t` HWCT -> THWC (data.py:237-239), `reset[0] = True` / `reward[0] = 0` per file (data.py:256-260);
+    the random stream is an explicit `numpy.random.RandomState` (the reference uses the global one);
+  * `preprocess_batch`        - the hot-path subset of Preprocessor.apply: one-hot float32 actions, float32 reward with
+    `clip_rewards`, float32 terminal, bool reset - and the image is LEFT AS uint8 (T,B,H,W,C): x/255-0.5 and HWC->CHW
+    happen inside the first conv's patch loader on the GPU (N1), so a batch crosses PCIe at 1 byte per pixel value;
+  * `DeviceRing`              - a background thread fills pinned host buffers and issues the H2D copies on its own HIP
+    stream into a ring of device-resident batches; `next()` hands out a batch whose copy the consumer's stream waits on.
+
+parity: the reference's data.py imports mlflow at module scope, which is absent here, so this reader is pinned by its
+own property tests (tests/test_replay_cpu.py), not against the reference implementation - "parity unpinned" for this file.
+"""
+import os
+import queue
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass
+class FileInfo:
+    path: str
+    episode_from: int
+    episode_to: int
+    steps: int
+
+    def load_data(self):
+        with open(self.path, 'rb') as f:
+            fdata = np.load(f)
+            return {k: fdata[k] for k in fdata}
+
+
+def parse_episode_name(fname):
+    """data.py:103-122."""
+    fname = os.path.basename(fname).split('.')[0]
+    steps = fname.split('-')[-1]
+    steps = int(steps) if steps.isnumeric() else 0
+    if fname.startswith('ep'):
+        body = fname.split('ep')[1].split('-')[0]
+        ep_from, ep_to = body.split('_')[0], body.split('_')[-1]
+        return (int(ep_from) if ep_from.isnumeric() else 0, int(ep_to) if ep_to.isnumeric() else 0, steps)
+    return (0, 0, steps)
+
+
+class LocalEpisodeRepository:
+    def __init__(self, dirs):
+        self.dirs = [dirs] if isinstance(dirs, str) else list(dirs)
+
+    def list_files(self):
+        files = []
+        for d in self.dirs:
+            for name in sorted(os.listdir(d)):
+                if name.endswith('.npz'):
+                    a, b, steps = parse_episode_name(name)
+                    files.append(FileInfo(os.path.join(d, name), a, b, steps))
+        return files
+
+    def save_data(self, data, episode_from, episode_to):
+        """data.py:62-69 naming; written with np.savez_compressed like tools.py:200-207."""
+        n_episodes = int(data['reset'].sum())
+        steps = len(data['reset']) - n_episodes
+        name = f"ep{episode_from:06}_{episode_to:06}-r{float(data['reward'].sum()):.0f}-{steps:04}.npz"
+        path = os.path.join(self.dirs[0], name)
+        np.savez_compressed(path, **data)
+        return path
+
+
+def _lenb(batch):
+    return batch['reward'].shape[0]
+
+
+class SequentialReplay:
+    """DataSequential (data.py:128-304) as a plain iterator of time-major numpy batches {key: (T, B, ...)}."""
+
+    def __init__(self, repository, batch_length, batch_size, skip_first=True, buffer_size=0, reset_interval=0,
+                 allow_mid_reset=False, seed=0, check_nonempty=True):
+        self.repository = repository
+        self.batch_length, self.batch_size = batch_length, batch_size
+        self.skip_first, self.buffer_size = skip_first, buffer_size
+        self.reset_interval, self.allow_mid_reset = reset_interval, allow_mid_reset
+        self.rs = np.random.RandomState(seed)
+        self.reload_files()
+        if check_nonempty:
+            assert len(self.files) > 0, 'No data found'
+
+    def reload_files(self):
+        files_all = self.repository.list_files()
+        files_all.sort(key=lambda e: -e.episode_to)                  # newest first (data.py:164)
+        files, total = [], 0
+        for f in files_all:
+            total += f.steps
+            if total < self.buffer_size or not self.buffer_size:
+                files.append(f)
+        self.files, self.stats_steps = files, total
+
+    def __iter__(self):
+        iters = [self.iter_single(ix) for ix in range(self.batch_size)]
+        for batches in zip(*iters):
+            yield {k: np.stack([b[k] for b in batches], axis=1) for k in batches[0]}      # (T, B, ...)
+
+    def iter_single(self, ix):
+        skip_random = self.skip_first
+        last_partial = None
+        while True:
+            file = self.files[self.rs.randint(len(self.files))]                          # iter_shuffled_files
+            first_shorter = self.batch_length - _lenb(last_partial) if last_partial else None
+            it = self.iter_file(file, skip_random, first_shorter)
+            if last_partial is not None:
+                for batch, partial in it:
+                    assert not partial, 'First batch must be full. Is episode_length < batch_size?'
+                    batch = {k: np.concatenate([last_partial[k], batch[k]]) for k in batch}
+                    assert _lenb(batch) == self.batch_length
+                    last_partial = None
+                    yield batch
+                    break
+            for batch, partial in it:
+                if partial:
+                    last_partial = batch if self.allow_mid_reset else None
+                    break
+                yield batch
+            skip_random = False
+
+    def iter_file(self, file, skip_random=False, first_shorter_length=None):
+        try:
+            data = file.load_data()
+        except Exception as e:                                       # data.py:229-233: skip unreadable files
+            print('Error reading file - skipping', file.path, e)
+            return
+        if 'image' not in data and 'image_t' in data:
+            data['image'] = data['image_t'].transpose(3, 0, 1, 2)    # HWCT => THWC
+            del data['image_t']
+        data['action_next'] = np.concatenate([data['action'][1:], np.zeros_like(data['action'][:1])])
+        n = _lenb(data)
+        if n < self.batch_length:
+            return
+        if 'reset' not in data:
+            data['reset'] = np.zeros(n, bool)
+        data['reset'] = data['reset'].copy()
+        data['reward'] = data['reward'].copy()
+        data['reset'][0] = True                                      # a file starts with a reset ...
+        data['reward'][0] = 0.0                                      # ... and no reward
+        i = 0 if not skip_random else self.rs.randint(n - self.batch_length + 1)
+        l = first_shorter_length or self.batch_length
+        random_resets = (self.randomize_resets(data['reset'], self.reset_interval, self.batch_length)
+                         if self.reset_interval else np.zeros_like(data['reset']))
+        while i < n:
+            batch = {k: data[k][i:i + l] for k in data}
+            if np.any(random_resets[i:i + l]):
+                assert not np.any(batch['reset']), 'randomize_resets should not coincide with actual resets'
+                batch['reset'] = batch['reset'].copy()
+                batch['reset'][0] = True                             # always at the start of a window: longer backprop
+            partial = _lenb(batch) < l
+            i += l
+            l = self.batch_length
+            yield batch, partial
+
+    def randomize_resets(self, resets, reset_interval, batch_length):
+        """data.py:280-300."""
+        assert resets[0]
+        bounds = np.where(resets)[0].tolist() + [len(resets)]
+        out = np.zeros_like(resets)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            steps = b - a
+            n_int = self.rs.randint(1, steps // reset_interval + 2)
+            if n_int > 1:
+                cuts = np.sort(self.rs.choice(steps - batch_length * n_int, n_int - 1))
+                out[a + cuts + np.arange(1, n_int) * batch_length] = True
+        return out
+
+
+def preprocess_batch(batch, action_dim, clip_rewards=None, image_key='image'):
+    """Hot-path subset of Preprocessor.apply (preprocessing.py:87-180), images left uint8 (T,B,H,W,C)."""
+    T, B = batch['reward'].shape[:2]
+    out = {}
+    img = batch[image_key]
+    assert img.dtype == np.uint8 and img.ndim == 5, f'expected uint8 (T,B,H,W,C) frames, got {img.dtype} {img.shape}'
+    out['image'] = np.ascontiguousarray(img)
+    for k in ('action', 'action_next'):
+        if k in batch:
+            a = batch[k]
+            if a.ndim == 2:
+                a = np.eye(action_dim, dtype=np.float32)[a]
+            assert a.ndim == 3
+            out[k] = a.astype(np.float32)
+    out['terminal'] = batch.get('terminal', np.zeros((T, B))).astype(np.float32)
+    r = batch.get('reward', np.zeros((T, B))).astype(np.float32)
+    if clip_rewards == 'tanh':
+        r = np.tanh(r)
+    elif clip_rewards == 'log1p':
+        r = np.log1p(r)
+    elif clip_rewards:
+        raise ValueError(clip_rewards)
+    out['reward'] = r
+    out['reset'] = batch.get('reset', np.zeros((T, B), bool)).astype(bool)
+    return out
+
+
+class DeviceRing:
+    """Pinned staging + asynchronous H2D into a ring of device-resident batches.
+
+    A producer thread pulls numpy batches from `source` (an iterator of preprocess_batch outputs), copies them into one of
+    `depth` pinned host slots and enqueues the H2D copies on a dedicated copy stream; `next()` returns the device batch of
+    the oldest filled slot after making the CURRENT stream wait for that slot's copy event.  A slot is recycled when the
+    consumer asks for the batch after next (so the previous batch stays valid while the current step runs)."""
+
+    def __init__(self, source, device, depth=4):
+        self.source, self.device, self.depth = iter(source), torch.device(device), max(2, depth)
+        self.stream = torch.cuda.Stream(self.device)
+        self.free = queue.Queue()
+        self.ready = queue.Queue(maxsize=self.depth)
+        self.slots = None
+        self.held = []
+        self.error = None
+        for i in range(self.depth):
+            self.free.put(i)
+        self.thread = threading.Thread(target=self._produce, daemon=True, name='dm-replay')
+        self.thread.start()
+
+    def _alloc(self, batch):
+        self.slots = []
+        for _ in range(self.depth):
+            host = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().pin_memory() for k, v in batch.items()}
+            dev = {k: torch.empty_like(h, device=self.device) for k, h in host.items()}
+            self.slots.append((host, dev, torch.cuda.Event(), [None]))        # [3]: event after the consumer's last use
+
+    def _produce(self):
+        try:
+            with torch.cuda.device(self.device):
+                for batch in self.source:
+                    if self.slots is None:
+                        self._alloc(batch)
+                    i = self.free.get()
+                    if i is None:
+                        return
+                    host, dev, ev, done = self.slots[i]
+                    for k, v in batch.items():
+                        host[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+                    if done[0] is not None:         # the steps that read this slot's previous batch must have finished on the GPU
+                        self.stream.wait_event(done[0])
+                    with torch.cuda.stream(self.stream):
+                        for k in host:
+                            dev[k].copy_(host[k], non_blocking=True)
+                        ev.record(self.stream)
+                    self.ready.put(i)
+        except Exception as e:          # surfaced by next()
+            self.error = e
+            self.ready.put(None)
+
+    def next(self):
+        i = self.ready.get()
+        if i is None:
+            raise RuntimeError('replay producer failed') from self.error
+        host, dev, ev, done = self.slots[i]
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        self.held.append(i)
+        if len(self.held) > 2:          # the batch before the previous one: everything that reads it is already enqueued
+            j = self.held.pop(0)
+            e = torch.cuda.Event()
+            e.record(cur)
+            self.slots[j][3][0] = e
+            self.free.put(j)
+        return dev
+
+    def close(self):
+        self.free.put(None)
