@@ -262,23 +262,23 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
-        out = (ctypes.c_double * 88)()
-        n = hip.lib().dm_prof_end(out, 22)
+        out = (ctypes.c_double * 92)()
+        n = hip.lib().dm_prof_end(out, 23)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
         tiles = ('128,128', '128,64', '64,64', '128,96', '96,128')
-        for k in range(22):
+        for k in range(23):
             cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
                 kname = (f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>" if k < 20 else
-                         ('panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2'))
+                         ('panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2' if k == 21 else 'mlp_chain_fwd_kernel'))
                 kinds.append(dict(kernel=kname,
-                                  layout=names[k & 3] if k < 20 else ('row panel fwd' if k == 20 else 'row panel bwd'), launches_per_step=cnt / args.prof_steps,
+                                  layout=names[k & 3] if k < 20 else ('row panel fwd' if k == 20 else 'row panel bwd' if k == 21 else 'whole-MLP forward, 16-row blocks'), launches_per_step=cnt / args.prof_steps,
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
                                   ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12,
                                   alg_bytes_per_launch=by / cnt, alg_flops_per_launch=fl / cnt))
-        tot_fl = sum(out[4 * k + 1] for k in range(22))
-        tot_ms = sum(out[4 * k + 2] for k in range(22))
+        tot_fl = sum(out[4 * k + 1] for k in range(23))
+        tot_ms = sum(out[4 * k + 2] for k in range(23))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3 if args.dtype == 'f32' else 2500.0       # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE

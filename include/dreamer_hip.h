@@ -301,6 +301,9 @@ int dm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* clip_coef, void* stream);
 int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* critic_target <- critic, a2c.py:151-152 */
+/* Row threshold from which the 400-wide MLP heads run their whole forward as ONE launch (csrc/mlp_chain.hip; default 1024,
+ * below it the per-layer launches are faster).  rows >= 1 sets it; returns the previous value (rows < 1: query only). */
+int dm_mlp_chain_min_rows(int rows);
 /* GEMM operand precision of the whole library (process-wide): 0 = fp32 (default); 1 = operands rounded to bf16 (RNE) on
  * their way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results and storage (BASELINE
  * configs[2], the reference's `amp` switch).  The <= 64-row chain products stay fp32. */
@@ -310,7 +313,7 @@ int dm_get_gemm_precision(void);
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for
  * kind = tile*4 + a_layout*2 + b_layout with tile 0..4 = 128x128 / 128x64 / 64x64 / 128x96 / 96x128, kind 20 = row-panel
- * Linear+LayerNorm+ELU forward, 21 = row-panel backward (22 kinds; nkinds >= 22; `out` holds 4*nkinds doubles) and returns the
+ * Linear+LayerNorm+ELU forward, 21 = row-panel backward, 22 = whole-MLP forward chain (23 kinds; nkinds >= 23; `out` holds 4*nkinds doubles) and returns the
  * number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);

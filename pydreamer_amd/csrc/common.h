@@ -155,6 +155,12 @@ int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int 
 int dm_panel_colsum_final_launch(int count, const float* const* part, float* const* out, int n, int npanels, int pstride,
                                  hipStream_t st);
 
+// whole-MLP forward in one launch for the 400-wide heads below the panel threshold (mlp_chain.hip)
+bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                     const dm_mlp_params* p);
+int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
+                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, hipStream_t st);
+
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
 void dm_prof_slot_end(int slot, hipStream_t st);
 

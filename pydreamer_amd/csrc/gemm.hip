@@ -440,7 +440,7 @@ static int prof_before(int kind, double flops, double bytes, hipStream_t st) {
 static void prof_after(int slot, hipStream_t st) {
   if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
 }
-// other translation units (panel.hip: kinds 20 = row-panel forward, 21 = row-panel backward)
+// other translation units (panel.hip: kinds 20 = row-panel forward, 21 = row-panel backward; mlp_chain.hip: 22)
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st) { return prof_before(kind, flops, bytes, st); }
 void dm_prof_slot_end(int slot, hipStream_t st) { prof_after(slot, st); }
 extern "C" int dm_prof_begin(int max_launches) {
@@ -463,7 +463,7 @@ extern "C" int dm_prof_begin(int max_launches) {
 // kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x96, 4: 96x128); returns the number of recorded launches
 // (negative on error).  Synchronises on the recorded events.
 extern "C" int dm_prof_end(double* out, int nkinds) {
-  DM_REQUIRE(out && nkinds >= 22, DM_E_SHAPE, "prof_end: need room for 22 kinds");
+  DM_REQUIRE(out && nkinds >= 23, DM_E_SHAPE, "prof_end: need room for 23 kinds");
   g_prof.on = false;
   for (int i = 0; i < nkinds * 4; ++i) out[i] = 0.0;
   for (size_t i = 0; i < g_prof.n; ++i) {

@@ -69,6 +69,9 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
   const float* in = x;
   int ldin = ldx, kin = in_dim;
   const bool panel = dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
+  if (!panel && dm_mlp_chain_ok(rows, in_dim, hidden, layers, out_dim, x, ldx, p))      // all layers + output in ONE launch
+    return dm_mlp_chain_fwd_launch(rows, in_dim, layers, out_dim, x, ldx, p, acts ? a.xpre : nullptr,
+                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, st);
   if (panel) {
     const bool fuse_out = out_dim <= 32;
     for (int l = 0; l < layers; ++l) {

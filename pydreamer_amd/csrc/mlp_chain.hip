@@ -1,0 +1,347 @@
+// Whole-MLP forward in ONE launch for the 400-wide heads at small and mid row counts (common.py:37-65; a2c.py:37-39;
+// decoders.py:257-319):   [Linear -> LayerNorm(eps) -> ELU] x L  ->  Linear(out_dim <= 32)
+//
+// Where it runs: the actor inside the imagination rollout (M = T*B = 2500 rows per horizon step, dreamer.py:188-216), the
+// reward / terminal heads over the T*B posterior features, and every head at a data-parallel shard's row counts.  There
+// the per-layer form costs 3 launches per layer (GEMM + split-K reduce or LayerNorm) on N = 400-wide products that the
+// tiled GEMM runs at 30-55 TF/s, 13 dependent launches for the actor - 15 times per step on the critical stream.
+//
+// Tiling: a workgroup owns 16 COMPLETE rows through all layers; the activation row block lives in LDS between layers and
+// never visits HBM unless the caller wants it saved for backward.  Inside a layer the 4 waves split the 25 column blocks
+// (7 + 6 + 6 + 6; v_mfma_f32_16x16x4_f32, <= 28 accumulator registers) and walk K together, so every weight element is
+// read exactly once per workgroup, straight from L2 into the MFMA operand layout (lane l: weight row 16*blk + (l&15),
+// k = 32*pair + 16*half + 4*(l>>4) .. +3 - one 16-byte load feeds 4 MFMAs).  The unit of the software pipeline is a PAIR
+// of 16-k groups: a lane's two loads of a pair touch adjacent 64-byte halves, so the second is an L1 hit and the L2->L1
+// port (64 B/clk/CU) carries every weight line once - a first version with K split across the waves brought each line up
+// twice and sat on that port at 250 us for the 2500-row actor.  Two pairs of loads are in flight under a pair's 56 MFMAs.
+// LayerNorm needs whole rows: the waves exchange per-row partial sums through LDS (two-pass variance), normalise their
+// own columns in registers, write the next layer's LDS block, and after the last layer reduce the output layer's dot
+// products the same way.
+//
+// Work split: ceil(rows/16) workgroups - 157 for the 2500-row rollout step; the kernel is bound by one CU's matrix pipes
+// walking 16 x 1.13 M MACs (the 7-block wave: 102 + 3*25 groups x 28 MFMAs x 32 clk = 158 k cycles = 66 us).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_NBLK = 25;                    // hidden = 400
+constexpr int CH_N = CH_NBLK * 16;
+constexpr int CH_LD = CH_N + 4;                // LDS row stride (floats): rows stay 16-byte aligned
+constexpr int CH_WB = 7;                       // column blocks per wave (wave 0: 0..6; waves 1..3: 6 real blocks + a dummy)
+
+struct ChainArgs {
+  const float* x; int ldx, in_dim;
+  int rows, layers, out_dim, ldout;
+  const float* w[DM_MAX_MLP_LAYERS + 1];
+  const float* b[DM_MAX_MLP_LAYERS + 1];
+  const float* gamma[DM_MAX_MLP_LAYERS];
+  const float* beta[DM_MAX_MLP_LAYERS];
+  float eps;
+  float* xpre[DM_MAX_MLP_LAYERS];              // all three optional (nullptr: nothing is saved for backward)
+  float* stats[DM_MAX_MLP_LAYERS];
+  float* y[DM_MAX_MLP_LAYERS];
+  float* out;
+};
+
+__device__ __forceinline__ float chain_red16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// operands of one pair of 16-k groups.  k past K: the address is clamped into the row and the ACTIVATION fragment is
+// zeroed when it is consumed (K is a multiple of 4, so a 16-byte fragment is valid or not as a whole).
+struct ChainFrag {
+  float4 a[2];
+  float4 b[CH_WB][2];
+};
+// Weight fragments are buffer loads: one descriptor per layer (wave-uniform), the block's byte offset in the scalar
+// offset, and ONE 32-bit vector offset per half shared by the 7 loads (per-load 64-bit vector addresses made the register
+// allocator recycle in-flight load destinations as address temporaries, which put an s_waitcnt vmcnt(0) at the top of
+// the loop and serialised the pipeline).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 chain_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <bool FIRST>
+__device__ __forceinline__ void chain_load(ChainFrag& f, const float* A, const float* ybuf, __amdgpu_buffer_rsrc_t W,
+                                           unsigned wblk, int K, int pair, int l15, int q, int last) {
+  unsigned off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int k = pair * 32 + h * 16 + 4 * q;
+    k = k < K ? k : K - 4;
+    off[h] = (unsigned)(l15 * K + k) * 4u;
+    f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+  }
+#pragma unroll
+  for (int i = 0; i < CH_WB; ++i) {
+    const unsigned soff = wblk + (unsigned)(i == CH_WB - 1 ? last : i) * 16u * (unsigned)K * 4u;       // wave-uniform bytes
+#pragma unroll
+    for (int h = 0; h < 2; ++h) f.b[i][h] = chain_bload(W, off[h], soff);
+  }
+}
+__device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag& f, int K, int pair, int q) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bool valid = pair * 32 + h * 16 + 4 * q < K;
+    const float aj[4] = {valid ? f.a[h].x : 0.f, valid ? f.a[h].y : 0.f, valid ? f.a[h].z : 0.f, valid ? f.a[h].w : 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < CH_WB; ++i) {
+        const float4 bb = f.b[i][h];
+        const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bv, acc[i], 0, 0, 0);
+      }
+  }
+}
+
+// A: this lane's activation row (layer 0, global); W: this lane's weight row of the wave's first block.
+template <bool FIRST>
+__device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A, const float* ybuf,
+                                            __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
+  const int np = (K + 31) >> 5;
+  ChainFrag f0, f1, f2;
+  chain_load<FIRST>(f0, A, ybuf, W, wblk, K, 0, l15, q, last);
+  chain_load<FIRST>(f1, A, ybuf, W, wblk, K, 1 < np ? 1 : 0, l15, q, last);
+  for (int p = 0; p < np; p += 3) {
+    chain_load<FIRST>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_mfma(acc, f0, K, p, q);
+    if (p + 1 >= np) break;
+    chain_load<FIRST>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_mfma(acc, f1, K, p + 1, q);
+    if (p + 2 >= np) break;
+    chain_load<FIRST>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_mfma(acc, f2, K, p + 2, q);
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g) {
+  __shared__ __attribute__((aligned(16))) float ybuf[16 * CH_LD];      // the next layer's input block
+  __shared__ float red[4][16];                                         // per-wave row partials
+  __shared__ float outp[4][16][32];                                    // per-wave output-layer partials
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // tell the compiler it is wave-uniform
+  const int l15 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int nb0 = wave == 0 ? 0 : 1 + 6 * wave;          // first block of this wave: 0, 7, 13, 19
+  const int cnt = wave == 0 ? 7 : 6;                     // real blocks; block index cnt.. are dummies (clamped, ignored)
+  // layer 0 reads its activation rows from global memory; rows past the end re-read the last row (never written back)
+  const int arow = m0 + l15 < g.rows ? m0 + l15 : g.rows - 1;
+  const float* A0 = g.x + (size_t)arow * g.ldx;
+  // C/D map of the 16x16 MFMA: col = lane & 15 (+16*block), row = 4*(lane>>4) + r
+  const int rbase = m0 + 4 * q;
+  bool rok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rok[r] = rbase + r < g.rows;
+  const float inv_n = 1.0f / (float)CH_N;
+
+  for (int l = 0; l < g.layers; ++l) {
+    f32x4 acc[CH_WB];
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int K = l == 0 ? g.in_dim : CH_N;
+    // all waves walk 7 blocks (wave 0 sets the pace anyway); the 7th of waves 1..3 is a dummy that re-reads the wave's
+    // first block and is ignored below
+    const __amdgpu_buffer_rsrc_t Wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w[l]), 0, CH_N * K * 4, 0x00020000);
+    const unsigned wblk = (unsigned)(nb0 * 16) * (unsigned)K * 4u;
+    const int last = cnt == CH_WB ? CH_WB - 1 : 0;
+    // the epilogue's per-column parameters, fetched BEFORE the k-loop (dependent global round trips after it cost ~2 us
+    // each on a workgroup that has nothing else to run)
+    float pbi[CH_WB], pga[CH_WB], pbe[CH_WB];
+    {
+      const float* bias = g.b[l];
+      const float* gam = g.gamma[l];
+      const float* bet = g.beta[l];
+#pragma unroll
+      for (int i = 0; i < CH_WB; ++i) {
+        const int c = (nb0 + (i < cnt ? i : 0)) * 16 + l15;
+        pbi[i] = bias ? bias[c] : 0.f;
+        pga[i] = gam[c];
+        pbe[i] = bet[c];
+      }
+    }
+    if (l == 0) chain_layer<true>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+    else chain_layer<false>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i)
+      if (i < cnt) {
+        const float bi = pbi[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[i][r] += bi;
+          s[r] += acc[i][r];
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = chain_red16(s[r]);
+      if (l15 == 0) red[wave][4 * q + r] = t;
+    }
+    __syncthreads();                                     // also: every wave is done reading ybuf
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      mean[r] = ((red[0][4 * q + r] + red[1][4 * q + r]) + (red[2][4 * q + r] + red[3][4 * q + r])) * inv_n;
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i)
+      if (i < cnt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][r] - mean[r];
+          ss[r] += d * d;
+        }
+      }
+    __syncthreads();                                     // red is re-used
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = chain_red16(ss[r]);
+      if (l15 == 0) red[wave][4 * q + r] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      rstd[r] = 1.0f / sqrtf(((red[0][4 * q + r] + red[1][4 * q + r]) + (red[2][4 * q + r] + red[3][4 * q + r])) * inv_n + g.eps);
+    if (g.stats[l] && wave == 0 && l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (rok[r]) { g.stats[l][2 * (size_t)(rbase + r)] = mean[r]; g.stats[l][2 * (size_t)(rbase + r) + 1] = rstd[r]; }
+    }
+    if (g.xpre[l]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (rok[r]) {
+          float* xr = g.xpre[l] + (size_t)(rbase + r) * CH_N + nb0 * 16 + l15;
+#pragma unroll
+          for (int i = 0; i < CH_WB; ++i)
+            if (i < cnt) xr[i * 16] = acc[i][r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i)
+      if (i < cnt) {
+        const float ga = pga[i], be = pbe[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = dm_elu((acc[i][r] - mean[r]) * rstd[r] * ga + be);
+      }
+    if (g.y[l]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (rok[r]) {
+          float* yr = g.y[l] + (size_t)(rbase + r) * CH_N + nb0 * 16 + l15;
+#pragma unroll
+          for (int i = 0; i < CH_WB; ++i)
+            if (i < cnt) yr[i * 16] = acc[i][r];
+        }
+    }
+    // the post-activation block goes to LDS: the next layer's (or the output layer's) A operand
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i)
+      if (i < cnt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ybuf[(4 * q + r) * CH_LD + (nb0 + i) * 16 + l15] = acc[i][r];
+      }
+    __syncthreads();
+  }
+
+  // The MLP's output layer out = y Wout^T + bout (out_dim <= 32) as one more product: two 16-column blocks (output rows past
+  // out_dim re-read the last one and are dropped), the 25 k-groups split over the 4 waves (7 + 6 + 6 + 6), ALL loads issued up
+  // front (one global round trip), partial blocks summed through LDS in a fixed order.
+  {
+    const float* wout = g.w[g.layers];
+    const float* bout = g.b[g.layers];
+    const int g0 = wave == 0 ? 0 : 1 + 6 * wave, gn = wave == 0 ? 7 : 6;
+    const int o0 = l15 < g.out_dim ? l15 : g.out_dim - 1, o1 = 16 + l15 < g.out_dim ? 16 + l15 : g.out_dim - 1;
+    float4 wa[7], w0[7], w1[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int k = (g0 + (i < gn ? i : 0)) * 16 + 4 * q;
+      w0[i] = *reinterpret_cast<const float4*>(wout + (size_t)o0 * CH_N + k);
+      w1[i] = *reinterpret_cast<const float4*>(wout + (size_t)o1 * CH_N + k);
+      wa[i] = *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+    }
+    f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < gn) {
+        const float aj[4] = {wa[i].x, wa[i].y, wa[i].z, wa[i].w};
+        const float b0[4] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w};
+        const float b1[4] = {w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], b0[j], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], b1[j], c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      outp[wave][4 * q + r][l15] = c0[r];
+      outp[wave][4 * q + r][16 + l15] = c1[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * g.out_dim; e += 256) {
+      const int r = e / g.out_dim, o = e % g.out_dim;
+      if (m0 + r < g.rows)
+        g.out[(size_t)(m0 + r) * g.ldout + o] = ((outp[0][r][o] + outp[1][r][o]) + (outp[2][r][o] + outp[3][r][o])) +
+                                                (bout ? bout[o] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side ---------------------
+static const int g_chain_off = getenv("DM_MLP_NO_CHAIN") ? 1 : 0;       // A/B switch: keep the per-layer launches
+// A row block takes ~135 us however many there are (one CU walks all 1.13 M MACs per row: 66 us of MFMA issue plus the
+// weight stream's latency), so the launch pays once the per-layer form's ~13 launches on the same rows cost more: from
+// ~1000 rows up (2500-row rollout step: 137 vs 167 us); at a 350-row shard the per-layer products, which spread over all
+// CUs by split-K, take 95 us.  DM_CHAIN_MIN_ROWS overrides.
+static int g_chain_min_rows = getenv("DM_CHAIN_MIN_ROWS") ? atoi(getenv("DM_CHAIN_MIN_ROWS")) : 1024;
+extern "C" int dm_mlp_chain_min_rows(int rows) {       // rows >= 1: set; returns the previous value
+  const int prev = g_chain_min_rows;
+  if (rows >= 1) g_chain_min_rows = rows;
+  return prev;
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
+                     const dm_mlp_params* p) {
+  if (g_chain_off || hidden != CH_N || rows < 1 || rows < g_chain_min_rows || layers < 1 || layers > DM_MAX_MLP_LAYERS || out_dim < 1 || out_dim > 32)
+    return false;
+  if ((in_dim & 3) != 0 || in_dim < 4 || (ldx & 3) != 0 || !al16(x)) return false;
+  for (int l = 0; l < layers; ++l)
+    if (!al16(p->w[l]) || !p->ln_g[l] || !p->ln_b[l]) return false;
+  return true;
+}
+
+// acts pointers per layer may be null (nothing saved); all row pointers already include the caller's row offset.
+int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
+                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, hipStream_t st) {
+  ChainArgs a = {};
+  a.x = x; a.ldx = ldx; a.in_dim = in_dim;
+  a.rows = rows; a.layers = layers; a.out_dim = out_dim; a.ldout = ldout;
+  for (int l = 0; l <= layers; ++l) { a.w[l] = p->w[l]; a.b[l] = p->b[l]; }
+  for (int l = 0; l < layers; ++l) {
+    a.gamma[l] = p->ln_g[l]; a.beta[l] = p->ln_b[l];
+    a.xpre[l] = xpre ? xpre[l] : nullptr; a.stats[l] = stats ? stats[l] : nullptr; a.y[l] = y ? y[l] : nullptr;
+  }
+  a.eps = 1e-3f;
+  a.out = out;
+  double macs = (double)in_dim * CH_N + (double)(layers - 1) * CH_N * CH_N + (double)out_dim * CH_N;
+  const int slot = dm_prof_slot_begin(22, 2.0 * rows * macs,
+                                      4.0 * ((double)rows * in_dim + macs + (double)rows * out_dim +
+                                             (xpre ? 2.0 * rows * CH_N * layers : 0.0)), st);
+  hipLaunchKernelGGL(mlp_chain_fwd_kernel, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
+  dm_prof_slot_end(slot, st);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

@@ -161,6 +161,7 @@ _SIGNATURES = {
     'dm_get_gemm_precision': (c_int, []),
     'dm_prof_begin': (c_int, [c_int]),
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
+    'dm_mlp_chain_min_rows': (c_int, [c_int]),
 }
 
 _lib = None

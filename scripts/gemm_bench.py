@@ -46,7 +46,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')       # comma-separated indices into SHAPES
     ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--bf16', action='store_true')       # bf16 operands / fp32 accumulate (conf.amp)
     args = ap.parse_args()
+    hip.call('dm_set_gemm_precision', int(args.bf16))
     shapes = [SHAPES[int(i)] for i in args.only.split(',')] if args.only else SHAPES
     ws = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
     for al, bl, M, N, K, what in shapes:

@@ -107,6 +107,50 @@ def test_mlp_head_panel_fwd_bwd(hip, rows, in_dim, out_dim):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
+@pytest.mark.parametrize('rows,in_dim,out_dim,layers', [(2500, 1624, 18, 4), (350, 1624, 1, 4), (17, 136, 6, 2), (1, 400, 32, 1)])
+def test_mlp_head_chain_fwd_bwd(hip, rows, in_dim, out_dim, layers):
+    """rows below the panel threshold: the WHOLE forward ([Linear -> LayerNorm -> ELU] x L -> Linear) is one launch
+    (csrc/mlp_chain.hip: 16-row blocks, activations in LDS between layers, K split over the 4 waves).  Ragged last block,
+    a K that is not a multiple of 16 (1624 = 101.5 groups), 1..4 layers, a single row.  The saved activations must be
+    what the per-layer backward expects (gradients checked through dm_mlp_head_bwd); the acts-free call gives identical
+    outputs; DM_MLP_NO_CHAIN=1 is the A/B switch back to GEMM + LayerNorm launches."""
+    from pydreamer_amd.models import MLP
+    prev = hip.lib().dm_mlp_chain_min_rows(1)            # the production threshold is 1024 rows
+    try:
+        _chain_case(rows, in_dim, out_dim, layers)
+    finally:
+        hip.lib().dm_mlp_chain_min_rows(prev)
+
+
+def _chain_case(rows, in_dim, out_dim, layers):
+    from pydreamer_amd.models import MLP
+    torch.manual_seed(3)
+    m = MLP(in_dim, out_dim, 400, layers).to(DEV)
+    with torch.no_grad():
+        for i in range(layers):
+            m.model[3 * i + 1].weight.uniform_(0.5, 1.5)
+            m.model[3 * i + 1].bias.uniform_(-0.5, 0.5)
+    ld = in_dim + 8                                    # a strided input (feature-matrix rows)
+    xs = torch.randn(rows, ld, device=DEV)
+    x = xs[:, :in_dim]
+    dout = torch.randn(rows, out_dim, device=DEV) / rows
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    out, acts = m.fwd(xs, ld, rows, ws)
+    out2, none = m.fwd(xs, ld, rows, ws, save_acts=False)
+    assert none is None and torch.equal(out, out2)
+    dx = torch.zeros(rows, in_dim, device=DEV)
+    grads, _, _ = m.bwd(xs, ld, rows, acts, dout, ws, dx=dx, lddx=in_dim, dx_accum=False)
+    p = {f'h.{k}': v.detach().double().cpu().requires_grad_(True) for k, v in m.model.state_dict().items()}
+    xr = x.double().cpu().requires_grad_(True)
+    ref = O.mlp(p, 'h', xr, layers)
+    _close(out, ref.reshape(out.shape), 1e-4, 1e-5, 'chain mlp fwd')
+    ref.backward(dout.double().cpu().reshape(ref.shape))
+    assert _rel_l2(dx, xr.grad) < 1e-4, 'chain mlp dx'
+    for (name, _), g in zip(m.named_parameters(), grads):
+        key = 'h.' + name.replace('model.', '', 1)
+        assert _rel_l2(g, p[key].grad) < 1e-4, name
+
+
 def test_conv_encoder_fwd_bwd(hip):
     import ctypes
     from pydreamer_amd import hip as H
