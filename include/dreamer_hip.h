@@ -58,6 +58,11 @@ typedef struct dm_shape {
 /* bits 5-6: recurrent cell (rnn.py:40-67 `gru_type`): 0 = gru (nn.GRUCell), 1 = gru_layernorm (NormGRUCell, rnn.py:95-114),
  * 2 = gru_layernorm_dv2 (NormGRUCellLateReset, rnn.py:117-138) */
 #define DM_FLAG_GRU_SHIFT 5
+/* bit 7: mixed precision (the reference's `amp` switch, train.py:166; BASELINE configs[2]/[4]) for THIS call: every
+ * contraction the call runs takes its operands rounded to bf16 (RNE) into bf16 MFMA with fp32 accumulation; results,
+ * LayerNorm, losses and storage stay fp32.  Precision is a per-call argument (here, dm_mlp_params.precision, DM_GEMM_BF16);
+ * there is no process-wide switch. */
+#define DM_FLAG_BF16 128
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
@@ -74,6 +79,7 @@ size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call 
  * Replaces torch.nn.functional.linear and its backward (common.py:37-65, rssm.py:138-146, rnn.py:48-49). */
 #define DM_GEMM_ACCUM 1
 #define DM_GEMM_ELU 2
+#define DM_GEMM_BF16 256      /* this product only: operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulation */
 int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, const float* add, int ldadd, int flags,
@@ -146,6 +152,8 @@ typedef struct dm_mlp_params {
   const float* b[DM_MAX_MLP_LAYERS + 1];
   const float* ln_g[DM_MAX_MLP_LAYERS];
   const float* ln_b[DM_MAX_MLP_LAYERS];
+  int32_t precision;                       /* 0 = fp32; 1 = bf16 operands / fp32 accumulate for the calls given this struct */
+  int32_t reserved_;
 } dm_mlp_params;
 typedef struct dm_mlp_grads {
   float* w[DM_MAX_MLP_LAYERS + 1];
@@ -304,11 +312,6 @@ int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* 
 /* Row threshold from which the 400-wide MLP heads run their whole forward as ONE launch (csrc/mlp_chain.hip; default 1024,
  * below it the per-layer launches are faster).  rows >= 1 sets it; returns the previous value (rows < 1: query only). */
 int dm_mlp_chain_min_rows(int rows);
-/* GEMM operand precision of the whole library (process-wide): 0 = fp32 (default); 1 = operands rounded to bf16 (RNE) on
- * their way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results and storage (BASELINE
- * configs[2], the reference's `amp` switch).  The <= 64-row chain products stay fp32. */
-int dm_set_gemm_precision(int mode);
-int dm_get_gemm_precision(void);
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for

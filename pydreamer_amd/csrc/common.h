@@ -43,9 +43,23 @@ struct DmArena {
   }
 };
 
+// ---- operand precision of the call in progress ---------------------------------------------------
+// Every C-ABI entry point that runs contractions takes its precision from ITS OWN arguments (dm_shape.flags bit
+// DM_FLAG_BF16, dm_mlp_params.precision, the DM_GEMM_BF16 flag of dm_gemm_f32) and holds it in a thread-local for the
+// duration of the call, so the products it builds internally (DmGemm's default) inherit it; concurrent calls from
+// different host threads / streams with different precisions do not interact.  0 = fp32, 1 = bf16 operands (RNE) with
+// fp32 accumulation.
+int dm_cur_precision();
+struct DmPrecisionScope {
+  int prev;
+  explicit DmPrecisionScope(int p);
+  ~DmPrecisionScope();
+};
+
 // ---- internal (C++) entry points shared between translation units -------------------------------
 struct DmGatesBwd;
 struct DmGemm {
+  int bf16 = dm_cur_precision();                  // operand precision (see DmPrecisionScope)
   int a_layout = 0, b_layout = 0;
   int M = 0, N = 0, K = 0;
   const float* A = nullptr; int lda = 0;

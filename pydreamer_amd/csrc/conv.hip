@@ -459,6 +459,7 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
                                         const dm_conv_params* p, float* acts, float* embed, void* ws, size_t ws_bytes,
                                         void* stream) {
   DM_REQUIRE(shp && image && p && acts && embed && ws, DM_E_NULL, "conv_encoder_fwd: null pointer");
+  DmPrecisionScope prec(shp->flags & DM_FLAG_BF16);
   EncGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry (img=%d, E=%d, depth=%d)", shp->img, shp->E,
              shp->cnn_depth);
@@ -516,6 +517,7 @@ extern "C" int dm_conv_encoder_fwd(const dm_shape* shp, const float* image, cons
 extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, const dm_conv_params* p, const float* acts,
                                    const float* dembed, const dm_conv_grads* gr, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && p && acts && dembed && gr && ws, DM_E_NULL, "conv_encoder_bwd: null pointer");
+  DmPrecisionScope prec(shp->flags & DM_FLAG_BF16);
   (void)image;
   EncGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry");
@@ -678,6 +680,7 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
                                             const float* target, const dm_conv_params* p, float* acts, float* loss_image,
                                             float* image_rec, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && feat && target && p && acts && ws, DM_E_NULL, "conv_decoder_fwd: null pointer");
+  DmPrecisionScope prec(shp->flags & DM_FLAG_BF16);
   DecGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry (img=%d)", shp->img);
   DM_REQUIRE(n0 >= 0 && n >= 0 && n0 + n <= g.N, DM_E_SHAPE, "conv_decoder_fwd: frame range [%d,%d) outside 0..%d", n0,
@@ -808,6 +811,7 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
                                      const dm_conv_params* p, const float* acts, float scale, const float* row_scale,
                                      const dm_conv_grads* gr, float* dfeat, int lddf, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && feat && target && p && acts && gr && ws, DM_E_NULL, "conv_decoder_bwd: null pointer");
+  DmPrecisionScope prec(shp->flags & DM_FLAG_BF16);
   DecGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_decoder: unsupported geometry");
   hipStream_t st = (hipStream_t)stream;

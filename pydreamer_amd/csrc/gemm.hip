@@ -499,14 +499,12 @@ static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 gr
   return DM_OK;
 }
 
-// process-wide GEMM operand precision: 0 = fp32 (default), 1 = bf16 operands / fp32 accumulate (see gemm_store_tile_bf16)
-static int g_gemm_bf16 = 0;
-extern "C" int dm_set_gemm_precision(int mode) {
-  DM_REQUIRE(mode == 0 || mode == 1, DM_E_SHAPE, "set_gemm_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
-  g_gemm_bf16 = mode;
-  return DM_OK;
-}
-extern "C" int dm_get_gemm_precision(void) { return g_gemm_bf16; }
+// operand precision of the call in progress on this host thread (common.h: DmPrecisionScope)
+static thread_local int tl_precision = 0;
+int dm_cur_precision() { return tl_precision; }
+DmPrecisionScope::DmPrecisionScope(int p) : prev(tl_precision) { tl_precision = p ? 1 : 0; }
+DmPrecisionScope::~DmPrecisionScope() { tl_precision = prev; }
+
 
 int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
   DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1, DM_E_SHAPE, "gemm: bad dims M=%d N=%d K=%d (K must be >= 1)", q.M, q.N, q.K);
@@ -631,7 +629,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
                                4.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N), stream);
   int rc;
   const bool vec = a.a_vec && a.b_vec;
-  if (vec && g_gemm_bf16) {
+  if (vec && q.bf16) {
     if (tc == 0) rc = gemm_dispatch<128, 128, true, 2, 2, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 1) rc = gemm_dispatch<128, 64, true, 2, 2, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
@@ -662,10 +660,11 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
 extern "C" int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda,
                            const float* B, int ldb, float* C, int ldc, const float* bias, const float* add,
                            int ldadd, int flags, void* ws, size_t ws_bytes, void* stream) {
+  DmPrecisionScope prec(flags & DM_GEMM_BF16);
   DmGemm g;
   g.a_layout = a_layout; g.b_layout = b_layout;
   g.M = M; g.N = N; g.K = K;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-  g.bias = bias; g.add = add; g.ldadd = ldadd; g.flags = flags;
+  g.bias = bias; g.add = add; g.ldadd = ldadd; g.flags = flags & ~DM_GEMM_BF16;
   return dm_gemm_launch(g, ws, ws_bytes, (hipStream_t)stream);
 }

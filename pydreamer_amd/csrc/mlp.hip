@@ -110,6 +110,7 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
 extern "C" int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                                const dm_mlp_params* p, float* acts, float* out, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(x && p && out && ws, DM_E_NULL, "mlp_head_fwd: null pointer");      // acts may be NULL (no backward)
+  DmPrecisionScope prec(p->precision);
   return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, rows, 0, out, out_dim, ws, ws_bytes,
                            (hipStream_t)stream);
 }
@@ -118,6 +119,7 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
                                const dm_mlp_params* p, const float* acts, const float* dout, const dm_mlp_grads* g,
                                float* dx, int lddx, int dx_accum, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(x && p && acts && dout && g && ws, DM_E_NULL, "mlp_head_bwd: null pointer");
+  DmPrecisionScope prec(p->precision);
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   hipStream_t st = (hipStream_t)stream;
   MlpActs a;

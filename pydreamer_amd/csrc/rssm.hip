@@ -110,6 +110,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DM_REQUIRE(s && embed && action && reset && h0 && z0 && P && acts && feat && post && prior && ws, DM_E_NULL,
              "rssm_sequence_fwd: null pointer");
   DM_REQUIRE(u || forced_idx, DM_E_NULL, "rssm_sequence_fwd: need uniforms or forced indices");
+  DmPrecisionScope prec(s->flags & DM_FLAG_BF16);
   DM_TRY(rssm_check(s));
   DM_REQUIRE(t0 >= 0 && t0 <= t1 && t1 <= s->T, DM_E_SHAPE, "rssm_sequence_fwd: step range [%d,%d) outside 0..%d", t0, t1, s->T);
   if (t0 == t1) return DM_OK;
@@ -235,6 +236,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
                                     void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(s && embed && action && reset && P && acts && feat && post && dfeat && dpost && dprior && G && ws, DM_E_NULL,
              "rssm_sequence_bwd: null pointer");
+  DmPrecisionScope prec(s->flags & DM_FLAG_BF16);
   DM_TRY(rssm_check(s));
   hipStream_t st = (hipStream_t)stream;
   const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
@@ -395,6 +397,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
                                 size_t ws_bytes, void* stream) {
   DM_REQUIRE(s && start && P && actor && u_act && u_prior && feats && actions && ws, DM_E_NULL,
              "dream_rollout: null pointer");
+  DmPrecisionScope prec(s->flags & DM_FLAG_BF16);
   DM_TRY(rssm_check(s));
   DM_REQUIRE(M >= 1 && s->H >= 1, DM_E_SHAPE, "dream_rollout: M=%d H=%d", M, s->H);
   hipStream_t st = (hipStream_t)stream;

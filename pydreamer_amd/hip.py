@@ -19,6 +19,8 @@ DM_GEMM_ACCUM = 1
 DM_GEMM_ELU = 2
 DM_C2I_ELU = 1
 DM_FLAG_IMAGE_U8 = 16
+DM_FLAG_BF16 = 128            # dm_shape.flags: this call runs its contractions on bf16 operands (conf.amp)
+DM_GEMM_BF16 = 256            # dm_gemm_f32 flags: the same for a single product
 DM_SPLITK_FLOATS = 16 * 1024 * 1024    # split-K partial region carved at the front of every operator workspace
 
 RSSM_PARAM_ORDER = [
@@ -63,10 +65,13 @@ class dm_shape(Structure):
 
 class dm_mlp_params(Structure):
     _fields_ = [('w', c_void_p * (DM_MAX_MLP_LAYERS + 1)), ('b', c_void_p * (DM_MAX_MLP_LAYERS + 1)),
+                ('ln_g', c_void_p * DM_MAX_MLP_LAYERS), ('ln_b', c_void_p * DM_MAX_MLP_LAYERS),
+                ('precision', c_int32), ('reserved_', c_int32)]      # precision: 0 fp32, 1 bf16 operands (conf.amp)
+
+
+class dm_mlp_grads(Structure):
+    _fields_ = [('w', c_void_p * (DM_MAX_MLP_LAYERS + 1)), ('b', c_void_p * (DM_MAX_MLP_LAYERS + 1)),
                 ('ln_g', c_void_p * DM_MAX_MLP_LAYERS), ('ln_b', c_void_p * DM_MAX_MLP_LAYERS)]
-
-
-dm_mlp_grads = dm_mlp_params   # identical layout (float* instead of const float*)
 
 
 class dm_conv_params(Structure):
@@ -157,8 +162,6 @@ _SIGNATURES = {
     'dm_adamw_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     'dm_copy_params': (c_int, [_P, _P, c_int64, _P]),
     'dm_axpby': (c_int, [c_int64, c_float, _P, c_float, _P, _P]),
-    'dm_set_gemm_precision': (c_int, [c_int]),
-    'dm_get_gemm_precision': (c_int, []),
     'dm_prof_begin': (c_int, [c_int]),
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
@@ -229,9 +232,11 @@ def workspace_bytes(shape):
     return int(lib().dm_workspace_bytes(ctypes.byref(shape)))
 
 
-def mlp_struct(tensors_w, tensors_b, tensors_g, tensors_be, cls=dm_mlp_params):
+def mlp_struct(tensors_w, tensors_b, tensors_g, tensors_be, cls=dm_mlp_params, precision=0):
     """Pack per-layer tensors into a dm_mlp_params / dm_mlp_grads struct (keeps no references)."""
     s = cls()
+    if cls is dm_mlp_params:
+        s.precision = int(precision)
     for i, t in enumerate(tensors_w):
         s.w[i] = t.data_ptr()
     for i, t in enumerate(tensors_b):

@@ -119,7 +119,8 @@ class MLP(_Params):
         return list(self.parameters())
 
     def struct(self):
-        return H.mlp_struct(*self.tensors())
+        # precision: 1 = this head's contractions take bf16 operands (set by Dreamer from conf.amp; per call, no global)
+        return H.mlp_struct(*self.tensors(), precision=getattr(self, 'precision', 0))
 
     def grad_struct(self, grads_by_param):
         w, b, g, be = self.tensors()
@@ -633,7 +634,8 @@ class WorldModel(_Params):
         return H.make_shape(T=T, B=B, I=1, H=H_, D=c.deter_dim, Hd=c.hidden_dim, S=c.stoch_dim, C=c.stoch_discrete,
                             E=self.encoder.out_dim, A=c.action_dim, mlp_hidden=MLP_HIDDEN, mlp_layers=4,
                             cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels,
-                            flags=ACTOR_KINDS.get(c.actor_dist, 0) | (H.GRU_KINDS[c.gru_type] << H.DM_FLAG_GRU_SHIFT))
+                            flags=ACTOR_KINDS.get(c.actor_dist, 0) | (H.GRU_KINDS[c.gru_type] << H.DM_FLAG_GRU_SHIFT) |
+                            (H.DM_FLAG_BF16 if getattr(c, 'amp', False) else 0))
 
     def workspace(self, shp, device):
         need = H.workspace_bytes(shp)
@@ -1204,8 +1206,12 @@ class Dreamer(nn.Module):
         self.probe_gradients = conf.probe_gradients
         self._groups = None
         # conf.amp (defaults.yaml:55; train.py:166 runs the step under autocast): GEMM operands in bf16, fp32 accumulation,
-        # fp32 storage.  The switch is process-wide inside the library and is (re)asserted at the start of every step.
+        # fp32 storage.  Precision is an argument of every library call (dm_shape.flags bit DM_FLAG_BF16 via
+        # WorldModel.shape(), dm_mlp_params.precision via MLP.struct()); there is no process-wide switch.
         self.amp = bool(getattr(conf, 'amp', False))
+        for m in self.modules():
+            if isinstance(m, MLP):
+                m.precision = int(self.amp)
         self._overlap = None
         self.overlap_backward = True      # pre-launch the three backward passes on side streams (see _Overlap)
 
@@ -1323,8 +1329,6 @@ class Dreamer(nn.Module):
         iwae_samples = int(iwae_samples or self.iwae_samples)
         imag_horizon = int(imag_horizon or self.imag_horizon)
         T, B = obs['action'].shape[:2]
-        if H.lib().dm_get_gemm_precision() != int(self.amp):
-            H.call('dm_set_gemm_precision', int(self.amp))
         noise = noise or {}
         I = iwae_samples
         if I > 1 and do_dream_tensors:

@@ -48,7 +48,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--bf16', action='store_true')       # bf16 operands / fp32 accumulate (conf.amp)
     args = ap.parse_args()
-    hip.call('dm_set_gemm_precision', int(args.bf16))
+    gflags = hip.DM_GEMM_BF16 if args.bf16 else 0
     shapes = [SHAPES[int(i)] for i in args.only.split(',')] if args.only else SHAPES
     ws = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
     for al, bl, M, N, K, what in shapes:
@@ -57,7 +57,7 @@ def main():
         C = torch.empty(M, N, device='cuda')
         def run():
             hip.call('dm_gemm_f32', al, bl, M, N, K, hip.fptr(A), A.shape[1], hip.fptr(B), B.shape[1], hip.fptr(C), N,
-                     None, None, 0, 0, hip.ptr(ws), ws.numel(), hip.stream())
+                     None, None, 0, gflags, hip.ptr(ws), ws.numel(), hip.stream())
         for _ in range(3):
             run()
         torch.cuda.synchronize()

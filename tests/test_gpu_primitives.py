@@ -64,7 +64,7 @@ def test_gemm_layouts(hip, al, bl, M, N, K):
 @pytest.mark.parametrize('al,bl,M,N,K', [(0, 0, 300, 200, 160), (0, 1, 257, 96, 100), (1, 0, 132, 131, 64),
                                           (1, 1, 96, 260, 4000), (0, 0, 2500, 400, 1624), (1, 1, 400, 400, 40000)])
 def test_gemm_bf16_operands(hip, al, bl, M, N, K):
-    """dm_set_gemm_precision(1): operands rounded to bf16 (RNE), fp32 accumulation.  Reference = the same product of the
+    """DM_GEMM_BF16 (a per-call flag): operands rounded to bf16 (RNE), fp32 accumulation.  Reference = the same product of the
     bf16-ROUNDED operands in fp64, so the only difference left is fp32 summation order: same tolerance as the fp32 test.
     Every operand layout (the row-contiguous ones are transposed into the [row][k] LDS image), ragged edges, split-K."""
     A = _rand(M, K, seed=21)
@@ -73,14 +73,13 @@ def test_gemm_bf16_operands(hip, al, bl, M, N, K):
     Bd = B if bl == 0 else B.t().contiguous()
     C = torch.full((M, N), float('nan'), device=DEV)
     ws = _ws()
-    hip.call('dm_set_gemm_precision', 1)
-    try:
-        assert hip.lib().dm_get_gemm_precision() == 1
-        hip.call('dm_gemm_f32', al, bl, M, N, K, hip.fptr(Ad), Ad.shape[1], hip.fptr(Bd), Bd.shape[1], hip.fptr(C), N,
-                 None, None, 0, 0, hip.ptr(ws), ws.numel(), hip.stream())
-        torch.cuda.synchronize()
-    finally:
-        hip.call('dm_set_gemm_precision', 0)
+    hip.call('dm_gemm_f32', al, bl, M, N, K, hip.fptr(Ad), Ad.shape[1], hip.fptr(Bd), Bd.shape[1], hip.fptr(C), N,
+             None, None, 0, hip.DM_GEMM_BF16, hip.ptr(ws), ws.numel(), hip.stream())
+    C32 = torch.empty_like(C)      # the next call, without the flag, is an fp32 product again: nothing sticks
+    hip.call('dm_gemm_f32', al, bl, M, N, K, hip.fptr(Ad), Ad.shape[1], hip.fptr(Bd), Bd.shape[1], hip.fptr(C32), N,
+             None, None, 0, 0, hip.ptr(ws), ws.numel(), hip.stream())
+    torch.cuda.synchronize()
+    _close(C32, A.double() @ B.double().t(), 0, 3e-6 * np.sqrt(K) * 4, f'fp32 gemm after a bf16 one {al}{bl} {M}x{N}x{K}')
     ref = A.bfloat16().double() @ B.bfloat16().double().t()
     _close(C, ref, 0, 3e-6 * np.sqrt(K) * 4, f'bf16 gemm {al}{bl} {M}x{N}x{K}')
     # and it really is a different (coarser) product than fp32

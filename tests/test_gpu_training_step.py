@@ -912,7 +912,7 @@ def test_amp_bf16_step_tracks_fp32(hip):
                 loss.backward()
             runs.append(([float(x) for x in losses], opts[0].flat_grad.clone(), model))
     finally:
-        hip.call('dm_set_gemm_precision', 0)
+        pass        # precision is a per-call argument: nothing to restore
     (l1, g1, m1), (l2, g2, _), (l3, g3, _) = runs
     assert l1 == l2 and torch.equal(g1, g2), 'bf16 path is not deterministic'
     assert l1 != l3, 'amp=True did not change the arithmetic'
@@ -1086,7 +1086,7 @@ def test_amp_against_reference_autocast_golden(hip, fixture):
             losses, _, metrics, _, _ = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise,
                                                            forced_idx=fidx)
     finally:
-        hip.call('dm_set_gemm_precision', 0)
+        pass        # precision is a per-call argument: nothing to restore
     ref_bf16, ref_fp32 = float(g['bf16_losses'][0]), float(g['fp32_losses'][0])
     print('loss_model: build amp', float(losses[0]), 'reference autocast', ref_bf16, 'reference fp32', ref_fp32)
     assert abs(float(losses[0]) - ref_bf16) < 1e-3 * ref_bf16

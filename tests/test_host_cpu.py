@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
     lib = hip.lib()
-    assert lib.dm_version() == 2
+    assert lib.dm_version() == 3
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
@@ -40,7 +40,9 @@ def test_error_reporting_without_gpu():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.dm_shape) == 16 * 4
     assert ctypes.sizeof(hip.dm_reduce_item) == 32
-    assert ctypes.sizeof(hip.dm_mlp_params) == 8 * (9 + 9 + 8 + 8)
+    assert ctypes.sizeof(hip.dm_mlp_params) == 8 * (9 + 9 + 8 + 8) + 8          # + precision, reserved_ (ABI v3)
+    assert ctypes.sizeof(hip.dm_mlp_grads) == 8 * (9 + 9 + 8 + 8)
+    assert hip.dm_mlp_params.precision.offset == 8 * 34
     assert ctypes.sizeof(hip.dm_conv_params) == 8 * 10
     assert ctypes.sizeof(hip.dm_rssm_params) == 8 * 28
 
