@@ -164,7 +164,7 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
                            const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
                            const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st);
 int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,
-                           const float* stats, const float* gamma, const float* beta, float* dx, float* colpart,
+                           const float* stats, const float* gamma, const float* beta, float* dx, float* colpart, float* wt,
                            hipStream_t st);
 int dm_panel_colsum_final_launch(int count, const float* const* part, float* const* out, int n, int npanels, int pstride,
                                  hipStream_t st);
@@ -180,6 +180,17 @@ void dm_prof_slot_end(int slot, hipStream_t st);
 
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;
+
+// bf16 operand path: round-to-nearest-even fp32 -> bf16 (bit pattern in the low 16 bits), 8-element MFMA fragments
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned dm_f2bf(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint2 dm_pack_bf16x4(float4 v) {
+  return make_uint2(dm_f2bf(v.x) | (dm_f2bf(v.y) << 16), dm_f2bf(v.z) | (dm_f2bf(v.w) << 16));
+}
 
 __device__ __forceinline__ float dm_elu(float v) { return v > 0.f ? v : expm1f(v); }
 // ELU'(x) expressed through y = ELU(x):  1 for x>0, exp(x) = y+1 otherwise.

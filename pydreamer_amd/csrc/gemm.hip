@@ -146,13 +146,7 @@ __device__ __forceinline__ void gemm_store_tile(const float4 (&rr)[NF4], unsigne
 // accumulation; results, activations and everything outside the GEMMs stay fp32.  The LDS image is [row][k] bf16
 // (row stride 40 elements = 80 bytes, 16-byte aligned) for BOTH source layouts - a row-contiguous source is transposed
 // by 2-byte stores - because the MFMA wants 8 consecutive k per lane: lane l feeds row l&31, k = 8*(l>>5) .. +7.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDKB = 40;
-__device__ __forceinline__ unsigned dm_f2bf(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
 template <int ROWS, int LAYOUT, int NF4, bool KSEQ = false>
 __device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], unsigned mask, unsigned short* S, int tid) {
   if (LAYOUT == 1 && KSEQ) {      // rr[i] = rows r4..r4+3 at k = kq*NF4 + i: one packed write of NF4 bf16 per row

@@ -27,7 +27,8 @@ extern "C" size_t dm_mlp_acts_floats(int rows, int hidden, int layers) {
 // buffer (3 x rows x hidden), backward ping-pong (2 x rows x hidden) and the panel kernels' column partials.
 static size_t mlp_ws_floats(int rows, int hidden, int layers) {
   const size_t rh = dm_align_up((size_t)rows * hidden, 64);
-  return DM_SPLITK_FLOATS + 3 * rh + dm_align_up((size_t)layers * dm_panel_count(rows) * 3 * hidden, 64) + 256;
+  return DM_SPLITK_FLOATS + 3 * rh + dm_align_up((size_t)layers * dm_panel_count(rows) * 3 * hidden, 64) +
+         dm_align_up((size_t)hidden * hidden, 64) + 256;      // + the bf16 panel backward's transposed weights
 }
 extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
   if (rows < 0 || hidden < 0 || layers < 0 || layers > DM_MAX_MLP_LAYERS) return 0;
@@ -131,6 +132,7 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
   const bool panel = dm_panel_ok(rows, hidden) && ((uintptr_t)p->w[layers] & 15) == 0;
   const int npanels = dm_panel_count(rows);
   float* colpart = ar.take(panel ? (size_t)layers * npanels * 3 * hidden : 0);
+  float* wt = (panel && dm_cur_precision()) ? ar.take((size_t)hidden * hidden) : nullptr;
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "mlp_head_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
@@ -151,7 +153,7 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
     float* other = dy;
     DM_TRY(dm_panel_ln_bwd_launch(rows, hidden, out_dim, dout, out_dim, p->w[layers], a.xpre[layers - 1],
                                   a.stats[layers - 1], p->ln_g[layers - 1], p->ln_b[layers - 1], cur,
-                                  colpart + (size_t)(layers - 1) * npanels * 3 * hidden, st));
+                                  colpart + (size_t)(layers - 1) * npanels * 3 * hidden, nullptr, st));
     for (int l = layers - 1; l >= 0; --l) {
       const float* in = l == 0 ? x : a.y[l - 1];
       const int ldin = l == 0 ? ldx : hidden;
@@ -166,7 +168,7 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
       if (l > 0) {
         DM_TRY(dm_panel_ln_bwd_launch(rows, hidden, hidden, cur, hidden, p->w[l], a.xpre[l - 1], a.stats[l - 1],
                                       p->ln_g[l - 1], p->ln_b[l - 1], other, colpart + (size_t)(l - 1) * npanels * 3 * hidden,
-                                      st));
+                                      wt, st));
         float* t = cur; cur = other; other = t;
       } else if (dx) {
         DmGemm d;   // d(in)[r][i] = sum_h dxp_0[r][h] W_0[h][i]

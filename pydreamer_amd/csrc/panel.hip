@@ -126,73 +126,12 @@ struct PanelB {
   }
 };
 
-template <int NBLK, int BL, int EPI, bool AVEC>
-__global__ void __launch_bounds__(256, 2) panel_linear_kernel(const PanelArgs g) {
-  typedef PanelB<NBLK, BL> PB;
-  constexpr int GRP = (NBLK % 5 == 0) ? 5 : (NBLK % 4 == 0) ? 4 : (NBLK % 3 == 0) ? 3 : (NBLK % 2 == 0) ? 2 : 1;
-  constexpr int A_FLOATS = PANEL_BM * PANEL_LDA;
-  constexpr int RED_FLOATS = (EPI == PANEL_EPI_LN_BWD) ? 4 * 3 * NBLK * 16 : 0;
-  constexpr int MAIN_FLOATS = A_FLOATS + PB::FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS > RED_FLOATS ? MAIN_FLOATS : RED_FLOATS];
-  float* As = smem;
-  float* Bs = smem + A_FLOATS;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Epilogue shared by the fp32 and the bf16-operand main loops: the workgroup's 64 complete rows are in `acc` in the MFMA
+// C/D layout.  `smem` is the kernel's LDS (free after the main loop's trailing barrier; the backward epilogue reduces through it).
+template <int NBLK, int EPI>
+__device__ __forceinline__ void panel_epilogue(f32x4 (&acc)[NBLK], const PanelArgs& g, float* smem, int m0, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * PANEL_BM;
-
-  f32x4 acc[NBLK];
-#pragma unroll
-  for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float4 ra[2], rb[PB::NF4];
-  unsigned ma = 0u, mb = 0u;
-  const int nkt = (g.K + 31) / 32;
-  panel_load_a<AVEC>(ra, ma, g, m0, 0, tid);
-  PB::load(rb, mb, g, 0, tid);
-  for (int kt = 0; kt < nkt; ++kt) {
-    panel_store_a(ra, ma, As, tid);
-    PB::store(rb, mb, Bs, tid);
-    __syncthreads();
-    if (kt + 1 < nkt) {                               // register prefetch of the next tile under the MFMAs below
-      panel_load_a<AVEC>(ra, ma, g, m0, (kt + 1) * 32, tid);
-      PB::load(rb, mb, g, (kt + 1) * 32, tid);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      const float4 a4 = *reinterpret_cast<const float4*>(&As[(wave * 16 + l15) * PANEL_LDA + kg * 16 + 4 * q]);
-      const float aj[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-      for (int gb = 0; gb < NBLK / GRP; ++gb) {
-        if (BL == 0) {
-          float bj[GRP][4];
-#pragma unroll
-          for (int u = 0; u < GRP; ++u) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[((gb * GRP + u) * 16 + l15) * PANEL_LDA + kg * 16 + 4 * q]);
-            bj[u][0] = b4.x; bj[u][1] = b4.y; bj[u][2] = b4.z; bj[u][3] = b4.w;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < GRP; ++u)
-              acc[gb * GRP + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bj[u][j], acc[gb * GRP + u], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float bv[GRP];
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) bv[u] = Bs[(kg * 16 + 4 * q + j) * PB::LDM + (gb * GRP + u) * 16 + l15];
-#pragma unroll
-            for (int u = 0; u < GRP; ++u)
-              acc[gb * GRP + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bv[u], acc[gb * GRP + u], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
   // C/D map of the 16x16 MFMA: col = lane & 15 (+16*block), row = 4*(lane>>4) + r.  This lane's 4 rows start at rbase.
   // N == 16*NBLK exactly (host-checked), so every column of every block is a real column.
   const int rbase = m0 + wave * 16 + 4 * q;
@@ -346,6 +285,156 @@ __global__ void __launch_bounds__(256, 2) panel_linear_kernel(const PanelArgs g)
   }
 }
 
+template <int NBLK, int BL, int EPI, bool AVEC>
+__global__ void __launch_bounds__(256, 2) panel_linear_kernel(const PanelArgs g) {
+  typedef PanelB<NBLK, BL> PB;
+  constexpr int GRP = (NBLK % 5 == 0) ? 5 : (NBLK % 4 == 0) ? 4 : (NBLK % 3 == 0) ? 3 : (NBLK % 2 == 0) ? 2 : 1;
+  constexpr int A_FLOATS = PANEL_BM * PANEL_LDA;
+  constexpr int RED_FLOATS = (EPI == PANEL_EPI_LN_BWD) ? 4 * 3 * NBLK * 16 : 0;
+  constexpr int MAIN_FLOATS = A_FLOATS + PB::FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS > RED_FLOATS ? MAIN_FLOATS : RED_FLOATS];
+  float* As = smem;
+  float* Bs = smem + A_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * PANEL_BM;
+
+  f32x4 acc[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2], rb[PB::NF4];
+  unsigned ma = 0u, mb = 0u;
+  const int nkt = (g.K + 31) / 32;
+  panel_load_a<AVEC>(ra, ma, g, m0, 0, tid);
+  PB::load(rb, mb, g, 0, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    panel_store_a(ra, ma, As, tid);
+    PB::store(rb, mb, Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {                               // register prefetch of the next tile under the MFMAs below
+      panel_load_a<AVEC>(ra, ma, g, m0, (kt + 1) * 32, tid);
+      PB::load(rb, mb, g, (kt + 1) * 32, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&As[(wave * 16 + l15) * PANEL_LDA + kg * 16 + 4 * q]);
+      const float aj[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int gb = 0; gb < NBLK / GRP; ++gb) {
+        if (BL == 0) {
+          float bj[GRP][4];
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[((gb * GRP + u) * 16 + l15) * PANEL_LDA + kg * 16 + 4 * q]);
+            bj[u][0] = b4.x; bj[u][1] = b4.y; bj[u][2] = b4.z; bj[u][3] = b4.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < GRP; ++u)
+              acc[gb * GRP + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bj[u][j], acc[gb * GRP + u], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float bv[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) bv[u] = Bs[(kg * 16 + 4 * q + j) * PB::LDM + (gb * GRP + u) * 16 + l15];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u)
+              acc[gb * GRP + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bv[u], acc[gb * GRP + u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  panel_epilogue<NBLK, EPI>(acc, g, smem, m0, tid);
+}
+
+// ---- bf16-operand main loop (conf.amp; dm_mlp_params.precision = 1).  Same panels, same epilogues; A and B (weights
+// [n][k], the forward layout - the backward caller hands a transposed copy) are loaded as fp32 with the register prefetch
+// above, rounded to bf16 (RNE) on their way into LDS and multiplied on v_mfma_f32_16x16x32_bf16 (lane l: row l&15,
+// k = 8*(l>>4) .. +7; one ds_read_b128 per fragment) with fp32 accumulation.  25 MFMAs of ~20 cycles replace the 200 fp32
+// MFMAs of 32 cycles per 32-k tile, so the loop is no longer matrix-pipe bound: LDS is double-buffered (one barrier per
+// tile; 2 x 37 KB, two workgroups per CU) and the kernel runs at the rate its fp32 operands stream in.
+constexpr int PANEL_LDH = 40;         // bf16 row stride of the [row][k] images (80 bytes: 16-byte aligned fragments)
+template <int NBLK, int EPI, bool AVEC>
+__global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelArgs g) {
+  typedef PanelB<NBLK, 0> PB;
+  constexpr int A_H = PANEL_BM * PANEL_LDH, B_H = NBLK * 16 * PANEL_LDH;            // bf16 elements per buffer
+  constexpr int MAIN_BYTES = 2 * (A_H + B_H) * 2;
+  constexpr int RED_BYTES = (EPI == PANEL_EPI_LN_BWD) ? 4 * 3 * NBLK * 16 * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[MAIN_BYTES > RED_BYTES ? MAIN_BYTES : RED_BYTES];
+  unsigned short* const hbase = reinterpret_cast<unsigned short*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * PANEL_BM;
+
+  f32x4 acc[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2], rb[PB::NF4];
+  unsigned ma = 0u, mb = 0u;
+  const int nkt = (g.K + 31) / 32;
+  auto stash = [&](int buf) {         // registers -> bf16 LDS images of buffer `buf`
+    unsigned short* Ah = hbase + buf * (A_H + B_H);
+    unsigned short* Bh = Ah + A_H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 256;
+      float4 v;
+      v.x = (ma >> (4 * i + 0)) & 1u ? ra[i].x : 0.f;
+      v.y = (ma >> (4 * i + 1)) & 1u ? ra[i].y : 0.f;
+      v.z = (ma >> (4 * i + 2)) & 1u ? ra[i].z : 0.f;
+      v.w = (ma >> (4 * i + 3)) & 1u ? ra[i].w : 0.f;
+      *reinterpret_cast<uint2*>(&Ah[(f >> 3) * PANEL_LDH + ((f & 7) << 2)]) = dm_pack_bf16x4(v);
+    }
+#pragma unroll
+    for (int i = 0; i < PB::NF4; ++i) {
+      const int f = tid + i * 256;
+      if (f < PB::TOTAL) {
+        const float4 v = (mb >> i) & 1u ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<uint2*>(&Bh[(f >> 3) * PANEL_LDH + ((f & 7) << 2)]) = dm_pack_bf16x4(v);
+      }
+    }
+  };
+  panel_load_a<AVEC>(ra, ma, g, m0, 0, tid);
+  PB::load(rb, mb, g, 0, tid);
+  stash(0);
+  if (nkt > 1) {
+    panel_load_a<AVEC>(ra, ma, g, m0, 32, tid);
+    PB::load(rb, mb, g, 32, tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) {
+      stash(cur ^ 1);                                   // tile kt+1 (its loads had the whole previous iteration to land)
+      if (kt + 2 < nkt) {
+        panel_load_a<AVEC>(ra, ma, g, m0, (kt + 2) * 32, tid);
+        PB::load(rb, mb, g, (kt + 2) * 32, tid);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned short* Ah = hbase + cur * (A_H + B_H);
+    const unsigned short* Bh = Ah + A_H;
+    const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(&Ah[(wave * 16 + l15) * PANEL_LDH + 8 * q]);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(&Bh[(b * 16 + l15) * PANEL_LDH + 8 * q]);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  panel_epilogue<NBLK, EPI>(acc, g, reinterpret_cast<float*>(smem_raw), m0, tid);
+}
+
 // out_t[col] = sum_p colpart_t[p][col] for up to 3*DM_MAX_MLP_LAYERS column vectors in ONE launch (fixed order).
 struct PanelFinalArgs {
   const float* part[3 * DM_MAX_MLP_LAYERS];   // first panel's vector; panels are `pstride` floats apart
@@ -403,7 +492,11 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
   const dim3 grid((unsigned)dm_panel_count(rows)), blk(256);
   const int slot = dm_prof_slot_begin(20, 2.0 * rows * hidden * ((double)kin + (wout ? out_dim : 0)),
                                       4.0 * ((double)rows * kin + (double)hidden * kin + (double)rows * hidden * (xpre ? 2 : 1)), st);
-  if ((ldx & 3) == 0 && al16(x)) hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
+  const bool avec = (ldx & 3) == 0 && al16(x);
+  if (dm_cur_precision()) {
+    if (avec) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, false>), grid, blk, 0, st, a);
+  } else if (avec) hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, false>), grid, blk, 0, st, a);
   dm_prof_slot_end(slot, st);
   DM_LAUNCH_CHECK();
@@ -412,8 +505,10 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
 
 // dx = LN/ELU backward of dy = dup W (dup: rows x kup, W: kup x hidden row-major), column partials into colpart
 // (dm_panel_count(rows) x 3 x hidden floats: [dbias | dgamma | dbeta] per panel).
+// wt (optional, hidden x kup floats of scratch): with bf16 operands (dm_cur_precision()) and kup a multiple of 32 the
+// weights are transposed into it once and the product runs on the bf16 main loop, which wants them [n][k].
 int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,
-                           const float* stats, const float* gamma, const float* beta, float* dx, float* colpart,
+                           const float* stats, const float* gamma, const float* beta, float* dx, float* colpart, float* wt,
                            hipStream_t st) {
   DM_REQUIRE(hidden == 400, DM_E_SHAPE, "panel_ln_bwd: hidden %d (built for 400)", hidden);
   DM_REQUIRE(al16(W), DM_E_SHAPE, "panel_ln_bwd: weight must be 16-byte aligned");
@@ -426,7 +521,12 @@ int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int 
   const dim3 grid((unsigned)dm_panel_count(rows)), blk(256);
   const int slot = dm_prof_slot_begin(21, 2.0 * rows * hidden * (double)kup,
                                       4.0 * ((double)rows * kup + (double)hidden * kup + 2.0 * rows * hidden), st);
-  if ((kup & 3) == 0 && (lddup & 3) == 0 && al16(dup))
+  const bool avec = (kup & 3) == 0 && (lddup & 3) == 0 && al16(dup);
+  if (dm_cur_precision() && wt && avec && kup >= 32 && al16(wt)) {
+    DM_TRY(dm_permute4_launch(W, wt, 1, 1, kup, hidden, 0, 1, 3, 2, st));       // W (kup x hidden) -> wt (hidden x kup)
+    a.B = wt; a.ldb = kup;
+    hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_BWD, true>), grid, blk, 0, st, a);
+  } else if (avec)
     hipLaunchKernelGGL((panel_linear_kernel<25, 1, PANEL_EPI_LN_BWD, true>), grid, blk, 0, st, a);
   else
     hipLaunchKernelGGL((panel_linear_kernel<25, 1, PANEL_EPI_LN_BWD, false>), grid, blk, 0, st, a);

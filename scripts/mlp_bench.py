@@ -36,6 +36,7 @@ def main():
     for rows, in_dim, out_dim, acts, what in CASES:
         torch.manual_seed(0)
         m = MLP(in_dim, out_dim, 400, 4).to('cuda')
+        m.precision = 1 if '--bf16' in sys.argv else 0
         x = torch.randn(rows, in_dim, device='cuda')
         dout = torch.randn(rows, out_dim, device='cuda')
         a = torch.empty(m.acts_floats(rows), device='cuda') if acts else None

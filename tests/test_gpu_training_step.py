@@ -107,6 +107,49 @@ def test_mlp_head_panel_fwd_bwd(hip, rows, in_dim, out_dim):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
+@pytest.mark.parametrize('rows,in_dim,out_dim', [(16400, 136, 6), (20000, 1624, 1)])
+def test_mlp_head_panel_bf16_operands(hip, rows, in_dim, out_dim):
+    """dm_mlp_params.precision = 1 (conf.amp) on the row-panel path: operands of every hidden-layer product rounded to bf16
+    (RNE), fp32 accumulation, fp32 LayerNorm / ELU / output layer.  Forward against exactly that arithmetic in fp64
+    (only the summation order differs: fp32-class tolerance); gradients against the fp32 path's at a bf16-class bound
+    (2^-8 operand rounding), and deterministic."""
+    from pydreamer_amd.models import MLP
+    torch.manual_seed(5)
+    m = MLP(in_dim, out_dim, 400, 4).to(DEV)
+    with torch.no_grad():
+        for i in range(4):
+            m.model[3 * i + 1].weight.uniform_(0.5, 1.5)
+            m.model[3 * i + 1].bias.uniform_(-0.5, 0.5)
+    x = torch.randn(rows, in_dim, device=DEV)
+    dout = torch.randn(rows, out_dim, device=DEV) / rows
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    dx32 = torch.zeros(rows, in_dim, device=DEV)
+    out32, acts32 = m.fwd(x, in_dim, rows, ws)
+    g32 = [g.clone() for g in m.bwd(x, in_dim, rows, acts32, dout, ws, dx=dx32, lddx=in_dim)[0]]
+    m.precision = 1
+    out, acts = m.fwd(x, in_dim, rows, ws)
+    dx = torch.zeros(rows, in_dim, device=DEV)
+    g16 = [g.clone() for g in m.bwd(x, in_dim, rows, acts, dout, ws, dx=dx, lddx=in_dim)[0]]
+    out_b, acts_b = m.fwd(x, in_dim, rows, ws)
+    assert torch.equal(out, out_b)
+    # forward emulation: bf16-rounded operands, fp64 accumulation, everything else fp64
+    h = x.double().cpu()
+    sd = {k: v.detach().double().cpu() for k, v in m.model.state_dict().items()}
+    for i in range(4):
+        pre = h.float().bfloat16().double() @ sd[f'{3 * i}.weight'].float().bfloat16().double().t() + sd[f'{3 * i}.bias']
+        pre = F.layer_norm(pre, (400,), sd[f'{3 * i + 1}.weight'], sd[f'{3 * i + 1}.bias'], 1e-3)
+        h = F.elu(pre)
+    ref = h @ sd['12.weight'].t() + sd['12.bias']                 # the fused output layer stays fp32 (a row reduction)
+    # an fp32-vs-fp64 difference in a hidden activation can flip its bf16 rounding (2^-8 relative on that element), so the
+    # bound is bf16-class per element - but the result must sit much closer to the bf16 arithmetic than to the fp32 one
+    err = (out.double().cpu() - ref.reshape(out.shape)).abs()
+    gap = (out32.double().cpu() - ref.reshape(out.shape)).abs()
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 0.2 * float(gap.mean()), (float(err.max()), float(err.mean()), float(gap.mean()))
+    assert _rel_l2(dx, dx32) < 2e-2
+    for a, b in zip(g16, g32):
+        assert _rel_l2(a, b) < 2e-2
+
+
 @pytest.mark.parametrize('rows,in_dim,out_dim,layers', [(2500, 1624, 18, 4), (350, 1624, 1, 4), (17, 136, 6, 2), (1, 400, 32, 1)])
 def test_mlp_head_chain_fwd_bwd(hip, rows, in_dim, out_dim, layers):
     """rows below the panel threshold: the WHOLE forward ([Linear -> LayerNorm -> ELU] x L -> Linear) is one launch
