@@ -182,14 +182,18 @@ void dm_prof_slot_end(int slot, hipStream_t st);
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;
 
 // bf16 operand path: round-to-nearest-even fp32 -> bf16 (bit pattern in the low 16 bits), 8-element MFMA fragments
+// (v_cvt_pk_bf16_f32: two conversions per instruction - the integer form cost ~5 VALU operations per element and made
+// the conversion, not the MFMAs or the loads, the bound of every bf16-operand main loop)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned dm_f2bf(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dm_pack_bf16x2(float lo, float hi) {       // lo in bits 0-15, hi in bits 16-31
+  const dm_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ unsigned dm_f2bf(float x) { return dm_pack_bf16x2(x, 0.f) & 0xFFFFu; }
 __device__ __forceinline__ uint2 dm_pack_bf16x4(float4 v) {
-  return make_uint2(dm_f2bf(v.x) | (dm_f2bf(v.y) << 16), dm_f2bf(v.z) | (dm_f2bf(v.w) << 16));
+  return make_uint2(dm_pack_bf16x2(v.x, v.y), dm_pack_bf16x2(v.z, v.w));
 }
 
 __device__ __forceinline__ float dm_elu(float v) { return v > 0.f ? v : expm1f(v); }

@@ -153,22 +153,22 @@ __device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], un
     constexpr int F4_PER_K = ROWS / 4;
     const int kq = (tid / F4_PER_K) * NF4;
     const int r4 = (tid % F4_PER_K) << 2;
-    unsigned h[4][NF4];
+    float h[4][NF4];
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
-      h[0][i] = dm_f2bf((mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f);
-      h[1][i] = dm_f2bf((mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f);
-      h[2][i] = dm_f2bf((mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f);
-      h[3][i] = dm_f2bf((mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f);
+      h[0][i] = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
+      h[1][i] = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
+      h[2][i] = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
+      h[3][i] = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned short* d = &S[(r4 + j) * LDKB + kq];
-      if (NF4 == 4) *reinterpret_cast<uint2*>(d) = make_uint2(h[j][0] | (h[j][1] << 16), h[j][2] | (h[j][3] << 16));
-      else if (NF4 == 2) *reinterpret_cast<unsigned*>(d) = h[j][0] | (h[j][1] << 16);
+      if (NF4 == 4) *reinterpret_cast<uint2*>(d) = make_uint2(dm_pack_bf16x2(h[j][0], h[j][1]), dm_pack_bf16x2(h[j][2], h[j][3]));
+      else if (NF4 == 2) *reinterpret_cast<unsigned*>(d) = dm_pack_bf16x2(h[j][0], h[j][1]);
       else
 #pragma unroll
-        for (int i = 0; i < NF4; ++i) d[i] = (unsigned short)h[j][i];
+        for (int i = 0; i < NF4; ++i) d[i] = (unsigned short)dm_f2bf(h[j][i]);
     }
     return;
   }
@@ -178,12 +178,13 @@ __device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], un
     const float y = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
     const float z = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
     const float w = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
-    const unsigned b0 = dm_f2bf(x), b1 = dm_f2bf(y), b2 = dm_f2bf(z), b3 = dm_f2bf(w);
+    const unsigned p01 = dm_pack_bf16x2(x, y), p23 = dm_pack_bf16x2(z, w);
+    const unsigned b0 = p01 & 0xFFFFu, b1 = p01 >> 16, b2 = p23 & 0xFFFFu, b3 = p23 >> 16;
     const int f = tid + i * 256;
     if (LAYOUT == 0) {
       const int row = f >> 3;
       const int kq = (f & 7) << 2;
-      *reinterpret_cast<uint2*>(&S[row * LDKB + kq]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+      *reinterpret_cast<uint2*>(&S[row * LDKB + kq]) = make_uint2(p01, p23);
     } else {
       constexpr int F4_PER_K = ROWS / 4;
       const int kr = f / F4_PER_K;
