@@ -85,7 +85,25 @@ __device__ __forceinline__ void chain_load(ChainFrag& f, const float* A, const f
     for (int h = 0; h < 2; ++h) f.b[i][h] = chain_bload(W, off[h], soff);
   }
 }
+// BF (dm_mlp_params.precision = 1, conf.amp): the pair's 32 k are ONE v_mfma_f32_16x16x32_bf16 per block - a lane's two
+// fragments (k = 32p + 4q.. and 32p + 16 + 4q..) are its 8 operand values, rounded to bf16 (RNE) in registers; A and B use
+// the same k order, which is all the product needs.
+__device__ __forceinline__ bf16x8 chain_bf8(float4 lo, float4 hi) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {dm_pack_bf16x2(lo.x, lo.y), dm_pack_bf16x2(lo.z, lo.w), dm_pack_bf16x2(hi.x, hi.y), dm_pack_bf16x2(hi.z, hi.w)};
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <bool BF>
 __device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag& f, int K, int pair, int q) {
+  if (BF) {
+    const bool v0 = pair * 32 + 4 * q < K, v1 = pair * 32 + 16 + 4 * q < K;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bf16x8 a8 = chain_bf8(v0 ? f.a[0] : z, v1 ? f.a[1] : z);
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, chain_bf8(f.b[i][0], f.b[i][1]), acc[i], 0, 0, 0);
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const bool valid = pair * 32 + h * 16 + 4 * q < K;
@@ -102,7 +120,7 @@ __device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag&
 }
 
 // A: this lane's activation row (layer 0, global); W: this lane's weight row of the wave's first block.
-template <bool FIRST>
+template <bool FIRST, bool BF>
 __device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A, const float* ybuf,
                                             __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
   const int np = (K + 31) >> 5;
@@ -112,18 +130,19 @@ __device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A,
   for (int p = 0; p < np; p += 3) {
     chain_load<FIRST>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma(acc, f0, K, p, q);
+    chain_mfma<BF>(acc, f0, K, p, q);
     if (p + 1 >= np) break;
     chain_load<FIRST>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma(acc, f1, K, p + 1, q);
+    chain_mfma<BF>(acc, f1, K, p + 1, q);
     if (p + 2 >= np) break;
     chain_load<FIRST>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma(acc, f2, K, p + 2, q);
+    chain_mfma<BF>(acc, f2, K, p + 2, q);
   }
 }
 
+template <bool BF>
 __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g) {
   __shared__ __attribute__((aligned(16))) float ybuf[16 * CH_LD];      // the next layer's input block
   __shared__ float red[4][16];                                         // per-wave row partials
@@ -169,8 +188,8 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
         pbe[i] = bet[c];
       }
     }
-    if (l == 0) chain_layer<true>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-    else chain_layer<false>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    if (l == 0) chain_layer<true, BF>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+    else chain_layer<false, BF>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i)
@@ -340,7 +359,8 @@ int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const
   const int slot = dm_prof_slot_begin(22, 2.0 * rows * macs,
                                       4.0 * ((double)rows * in_dim + macs + (double)rows * out_dim +
                                              (xpre ? 2.0 * rows * CH_N * layers : 0.0)), st);
-  hipLaunchKernelGGL(mlp_chain_fwd_kernel, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
+  if (dm_cur_precision()) hipLaunchKernelGGL(mlp_chain_fwd_kernel<true>, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mlp_chain_fwd_kernel<false>, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
   dm_prof_slot_end(slot, st);
   DM_LAUNCH_CHECK();
   return DM_OK;

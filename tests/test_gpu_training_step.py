@@ -194,6 +194,31 @@ def _chain_case(rows, in_dim, out_dim, layers):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
+def test_mlp_head_chain_bf16_operands(hip):
+    """precision = 1 on the whole-MLP forward kernel: the hidden-layer products run on bf16 MFMA with fp32 accumulation.
+    Same bars as the row-panel bf16 test (bf16-class per element, far closer to the bf16 arithmetic than to fp32)."""
+    from pydreamer_amd.models import MLP
+    rows, in_dim, out_dim = 2500, 1624, 18
+    torch.manual_seed(6)
+    m = MLP(in_dim, out_dim, 400, 4).to(DEV)
+    x = torch.randn(rows, in_dim, device=DEV)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    out32, _ = m.fwd(x, in_dim, rows, ws)
+    m.precision = 1
+    out, acts = m.fwd(x, in_dim, rows, ws)
+    out_b, _ = m.fwd(x, in_dim, rows, ws, save_acts=False)
+    assert torch.equal(out, out_b)
+    h = x.double().cpu()
+    sd = {k: v.detach().double().cpu() for k, v in m.model.state_dict().items()}
+    for i in range(4):
+        pre = h.float().bfloat16().double() @ sd[f'{3 * i}.weight'].float().bfloat16().double().t() + sd[f'{3 * i}.bias']
+        h = F.elu(F.layer_norm(pre, (400,), sd[f'{3 * i + 1}.weight'], sd[f'{3 * i + 1}.bias'], 1e-3))
+    ref = h @ sd['12.weight'].t() + sd['12.bias']
+    err = (out.double().cpu() - ref).abs()
+    gap = (out32.double().cpu() - ref).abs()
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 0.2 * float(gap.mean()), (float(err.max()), float(err.mean()), float(gap.mean()))
+
+
 def test_conv_encoder_fwd_bwd(hip):
     import ctypes
     from pydreamer_amd import hip as H
