@@ -23,6 +23,10 @@ python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_
 cd $REPO
 python bench.py --pmc-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
+python bench.py --dtype bf16 --no-cpu-baseline --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16.json 2>/dev/null
+# per-CU operand load ceilings (coalesced vs MFMA-fragment gather), see scripts/microbench/l2_stream.hip
+(cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 l2_stream.hip -o /tmp/l2_stream 2>/dev/null && \
+ for kib in 2048 8192 65536; do /tmp/l2_stream $kib 8 256 4 0; /tmp/l2_stream $kib 8 1024 1 0; /tmp/l2_stream $kib 8 256 4 1; /tmp/l2_stream $kib 8 1024 1 1; done) > $OUT/${TAG}_l2_stream.txt 2>&1
 python - << PY
 import json
 d = json.load(open('$OUT/${TAG}_bench.json'))
@@ -32,5 +36,7 @@ p = json.load(open('$OUT/${TAG}_pmc_traffic.json'))
 print('HBM GB/step', p['total_gb_per_step'])
 s = json.load(open('$OUT/${TAG}_bench_shard7of50.json'))
 print('shard 7 of 50:', s['ms_per_step'])
+b = json.load(open('$OUT/${TAG}_bench_bf16.json'))
+print('bf16:', b['ms_per_step'], b['value'])
 PY
 head -3 $OUT/${TAG}_timeline.txt

@@ -12,15 +12,26 @@ import re
 import sys
 
 
+STEADY = {}      # counter -> (KB inside the steady-state steps, number of such steps)
+
+
 def load(path, counter):
+    """Per-kernel sums over ALL dispatches, and - for the per-step total - the bytes of the dispatches between the end of
+    the first gradient step and the end of the last one (4 adamw_kernel launches close a step): the benchmark's own
+    set-up kernels (synthetic replay ring, parameter initialisation) and the first step's lazy allocations stay out."""
     acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    for r in rows:
         name = re.sub(r'\(.*$', '', r['Kernel_Name']).replace('void ', '')
         a = acc[name]
         a[0] += float(r['Counter_Value'])
         a[1] += 1
+    if rows and 'Dispatch_Id' in rows[0]:
+        rows.sort(key=lambda r: int(r['Dispatch_Id']))
+        ad = [int(r['Dispatch_Id']) for r in rows if r['Kernel_Name'].startswith('adamw_kernel')]
+        if len(ad) >= 8 and len(ad) % 4 == 0:
+            lo, hi = ad[3], ad[-1]
+            STEADY[counter] = (sum(float(r['Counter_Value']) for r in rows if lo < int(r['Dispatch_Id']) <= hi), len(ad) // 4 - 1)
     return acc
 
 
@@ -37,7 +48,12 @@ for name in sorted(set(fetch) | set(write)):
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3        # bench.py --steps S --warmup W --prof-steps 0: S + W steps in total
 sha = sys.argv[4] if len(sys.argv) > 4 else None            # `python bench.py --csrc-sha`: fingerprint of the kernel sources
 total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values()) / steps / 1e9
+total_all = total
+scope = 'all dispatches of the process / steps (includes the benchmark set-up kernels)'
+if 'FETCH_SIZE' in STEADY and 'WRITE_SIZE' in STEADY and STEADY['FETCH_SIZE'][1] == STEADY['WRITE_SIZE'][1] >= 1:
+    total = 1024.0 * (2.0 * STEADY['FETCH_SIZE'][0] + STEADY['WRITE_SIZE'][0]) / STEADY['FETCH_SIZE'][1] / 1e9
+    scope = f"dispatches after the first gradient step only ({STEADY['FETCH_SIZE'][1]} step(s)); with set-up kernels: {total_all:.2f}"
 json.dump(dict(note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 2 '
                     '--warmup 1 --no-overlap --prof-steps 0; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes',
-               csrc_sha=sha, steps_profiled=steps, total_gb_per_step=round(total, 2), kernels=out),
+               csrc_sha=sha, steps_profiled=steps, total_gb_per_step=round(total, 2), total_scope=scope, kernels=out),
           sys.stdout, indent=1)
