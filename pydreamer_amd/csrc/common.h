@@ -83,10 +83,26 @@ struct DmGemm {
   // LayerNorm+ELU BACKWARD prologue on A (A holds dy; the product uses dx): lnb_x = pre-activations, lnb_stats = (mean, rstd)
   const float* lnb_x = nullptr; int lnb_ldx = 0; const float* lnb_stats = nullptr;
   const struct DmGatesBwd* gates = nullptr;       // GRU gates backward in the epilogue (C = dh', N = D), skinny products only
+  // Fragment-major copies of <= 64-row chain operands (dm_frag_off): A_frag mirrors A (the skinny kernel then loads its
+  // MFMA fragments as contiguous KiB instead of 16 rows x 64 B per instruction); C_frag receives such a copy of C for
+  // the NEXT product of the chain.  Both optional; a product that does not take the skinny path ignores A_frag and
+  // fills C_frag with a pack launch, so callers may set them unconditionally.
+  const float* A_frag = nullptr;
+  float* C_frag = nullptr;
 };
+// Fragment-major layout of a <= 64-row block X[row][k]: the 16 B a lane of v_mfma_f32_16x16x4_f32 loads for a 16-k chunk
+// (lane l: row 16*mb + (l&15), k = 16*c + 4*(l>>4) .. +3) sit at ((c*4 + mb)*4 + (l>>4))*16 + (l&15) in units of 16 B, so
+// one load instruction of a wave reads ONE contiguous KiB.  Measured (scripts/microbench/l2_stream.hip): the row-major
+// gather of the same fragments runs at 16.6 B/clk/CU whatever the cache level, contiguous loads at ~50.
+__host__ __device__ __forceinline__ size_t dm_frag_off(int row, int k) {
+  return ((((size_t)(k >> 4) * 4 + (row >> 4)) * 4 + ((k >> 2) & 3)) * 16 + (row & 15)) * 4 + (k & 3);
+}
+static inline size_t dm_frag_floats(int K) { return (size_t)dm_cdiv(K, 16) * 1024; }      // 64 rows x K rounded up to 16
+int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hipStream_t st);
 struct DmGatesBwd {
   const float* gi; const float* gh; const float* h_in; int ldh, D;
   float* dgi; float* dgh; float* dprev; int ldp; const uint8_t* row_zero;   // dprev (nullable) += mask * dh' * u
+  float* dgi_frag = nullptr; float* dgh_frag = nullptr;                     // optional fragment-major copies (dm_frag_off, K = 3D)
 };
 // categorical sampler riding in the epilogue of a <= 64-row logits product (gemm_skinny.hip)
 struct DmSample {
@@ -94,6 +110,7 @@ struct DmSample {
   float* onehot = nullptr; int ldo = 0;                        // one-hot sample rows (leading dim ldo)
   int32_t* idx = nullptr;                                      // optional (rows, groups)
   float* z_next = nullptr; const uint8_t* next_reset = nullptr;   // optional: next step's reset-masked sample input (dense rows)
+  float* z_next_frag = nullptr;                                // optional: fragment-major copy of z_next (dm_frag_off)
 };
 bool dm_skinny_ln_ok(int M, int N, int K);
 int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t stream);
@@ -122,8 +139,10 @@ int dm_gru_norm_bwd_launch(int kind, int rows, int D, const float* gh, const flo
 int dm_gru_norm_param_grads_launch(int kind, int rows, int D, const float* gs, const float* gst, const float* dg, float* dgam,
                                    float* dbet, hipStream_t st);
 // h_next (optional, rows x D): the NEXT step's masked state input, next_reset[r] ? 0 : h_out   (rssm.py:134)
+// h_frag / h_next_frag (optional, rows <= 64): fragment-major copies (dm_frag_off) of h_out and of h_next
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
-                            int ldo, float* h_next, const uint8_t* next_reset, hipStream_t st);
+                            int ldo, float* h_next, const uint8_t* next_reset, float* h_frag, float* h_next_frag,
+                            hipStream_t st);
 // dh_in (+)= row_mask * dh_out*u  (accum: add into dh_in; row_zero: rows whose flag is set contribute 0)
 int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                             const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,

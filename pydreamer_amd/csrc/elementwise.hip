@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
                                                             const float* __restrict__ gh, const float* __restrict__ h_in,
                                                             int ldh, float* __restrict__ h_out, int ldo,
                                                             float* __restrict__ h_next,
-                                                            const uint8_t* __restrict__ next_reset) {
+                                                            const uint8_t* __restrict__ next_reset,
+                                                            float* __restrict__ h_frag, float* __restrict__ h_next_frag) {
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / D), d = (int)(i % D);
@@ -341,7 +342,19 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
     const float h = h_in[(size_t)r * ldh + d];
     const float ho = (h - ng) * ug + ng;
     h_out[(size_t)r * ldo + d] = ho;
-    if (h_next) h_next[(size_t)r * D + d] = (next_reset && next_reset[r]) ? 0.f : ho;
+    const float hn = (next_reset && next_reset[r]) ? 0.f : ho;
+    if (h_next) h_next[(size_t)r * D + d] = hn;
+    if (h_frag) h_frag[dm_frag_off(r, d)] = ho;
+    if (h_next_frag) h_next_frag[dm_frag_off(r, d)] = hn;
+  }
+}
+// Xf = fragment-major copy (dm_frag_off) of the <= 64-row block X
+__global__ void __launch_bounds__(256) frag_pack_kernel(int rows, int K, const float* __restrict__ X, int ldx,
+                                                        float* __restrict__ Xf) {
+  const int total = rows * K;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / K, k = i % K;
+    Xf[dm_frag_off(r, k)] = X[(size_t)r * ldx + k];
   }
 }
 
@@ -626,11 +639,20 @@ static inline int ew_blocks(size_t total) {
   return (int)b;
 }
 
+int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hipStream_t st) {
+  DM_REQUIRE(rows >= 0 && rows <= 64 && K >= 1 && X && Xf, DM_E_SHAPE, "frag_pack: rows %d (<= 64), K %d", rows, K);
+  if (rows == 0) return DM_OK;
+  hipLaunchKernelGGL(frag_pack_kernel, dim3(ew_blocks((size_t)rows * K)), dim3(256), 0, st, rows, K, X, ldx, Xf);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
-                            int ldo, float* h_next, const uint8_t* next_reset, hipStream_t st) {
+                            int ldo, float* h_next, const uint8_t* next_reset, float* h_frag, float* h_next_frag,
+                            hipStream_t st) {
   if (rows <= 0) return DM_OK;
+  DM_REQUIRE((!h_frag && !h_next_frag) || rows <= 64, DM_E_SHAPE, "gru_gates_fwd: fragment-major copies need rows <= 64");
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
-                     ldh, h_out, ldo, h_next, next_reset);
+                     ldh, h_out, ldo, h_next, next_reset, h_frag, h_next_frag);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -646,7 +668,8 @@ int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, c
 extern "C" int dm_gru_gates_fwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                                 float* h_out, int ldo, void* stream) {
   DM_REQUIRE(gi && gh && h_in && h_out, DM_E_NULL, "gru_gates_fwd: null pointer");
-  return dm_gru_gates_fwd_launch(rows, D, gi, gh, h_in, ldh, h_out, ldo, nullptr, nullptr, (hipStream_t)stream);
+  return dm_gru_gates_fwd_launch(rows, D, gi, gh, h_in, ldh, h_out, ldo, nullptr, nullptr, nullptr, nullptr,
+                                 (hipStream_t)stream);
 }
 extern "C" int dm_gru_gates_bwd(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                                 const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi,

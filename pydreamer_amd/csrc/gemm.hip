@@ -649,6 +649,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
   }
+  if (q.C_frag) {      // the skinny kernel writes this copy in its epilogue; the tiled path owes it to the chain's next product
+    DM_REQUIRE(q.M <= 64 && !q.c_tab, DM_E_SHAPE, "gemm: a fragment-major copy of C needs M <= 64 (M=%d)", q.M);
+    DM_TRY(dm_frag_pack_launch(q.M, q.N, q.C, q.ldc, q.C_frag, stream));
+  }
   return DM_OK;
 }
 

@@ -36,6 +36,9 @@ struct SkinnyArgs {
   // EPI 2 (GRU gates backward in the epilogue; the strip holds 16 hidden units of dh' = C): see skinny_gates_bwd
   const float* gb_gi; const float* gb_gh; const float* gb_hin; int gb_ldh, gb_D;
   float* gb_dgi; float* gb_dgh; float* gb_dprev; int gb_ldp; const uint8_t* gb_rz;
+  float* gb_dgif; float* gb_dghf;
+  // fragment-major operand copies (common.h dm_frag_off; single 64-row chunk only): Af mirrors A, Cf receives C, znf z_next
+  const float* Af; float* Cf; float* znf;
 };
 
 // Raw loads from clamped (always valid) addresses + a validity mask (bits 0-3: A row blocks, bit 4: B).  The zero-fill
@@ -51,7 +54,10 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0,
   for (int mb = 0; mb < NRB; ++mb) {
     const int m = m0 + mb * 16 + l15;
     const bool ok = kin && m < g.M;
-    a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
+    if (g.Af)       // one contiguous KiB per instruction (rows past M hold stale data: masked like the clamped loads)
+      a[mb] = *reinterpret_cast<const float4*>(g.Af + ((((size_t)(c >> 4) * 4 + mb) * 4 + q) * 16 + l15) * 4);
+    else
+      a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
     mask |= ok ? (1u << mb) : 0u;
   }
 #pragma unroll
@@ -254,6 +260,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       if (g.flags & DM_GEMM_ACCUM) v += *cp;
       if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
       *cp = v;
+      if (g.Cf) g.Cf[dm_frag_off(row, col)] = v;
       if (GATESB) {
         // v = dh'[row][d] (complete): GRU gates backward for hidden unit d = col (rnn.py:48-49 / nn.GRUCell, gates recomputed
         // from the saved products), the same arithmetic as gru_gates_bwd_kernel (elementwise.hip)
@@ -271,6 +278,12 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
         const float dpu = du * ug * (1.f - ug);
         g.gb_dgi[g0 + col] = dpr; g.gb_dgi[g0 + D + col] = dpu; g.gb_dgi[g0 + 2 * D + col] = dpn;
         g.gb_dgh[g0 + col] = dpr; g.gb_dgh[g0 + D + col] = dpu; g.gb_dgh[g0 + 2 * D + col] = dpn * rg;
+        if (g.gb_dgif) {
+          g.gb_dgif[dm_frag_off(row, col)] = dpr; g.gb_dgif[dm_frag_off(row, D + col)] = dpu;
+          g.gb_dgif[dm_frag_off(row, 2 * D + col)] = dpn;
+          g.gb_dghf[dm_frag_off(row, col)] = dpr; g.gb_dghf[dm_frag_off(row, D + col)] = dpu;
+          g.gb_dghf[dm_frag_off(row, 2 * D + col)] = dpn * rg;
+        }
         if (g.gb_dprev) {
           const float dv = (g.gb_rz && g.gb_rz[row]) ? 0.f : v * ug;
           g.gb_dprev[(size_t)row * g.gb_ldp + col] += dv;
@@ -326,6 +339,13 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
         for (int q4 = 0; q4 < C / 4; ++q4)
           dn[q4] = make_float4(keep == 4 * q4 ? 1.f : 0.f, keep == 4 * q4 + 1 ? 1.f : 0.f, keep == 4 * q4 + 2 ? 1.f : 0.f,
                                keep == 4 * q4 + 3 ? 1.f : 0.f);
+        if (g.znf) {
+#pragma unroll
+          for (int q4 = 0; q4 < C / 4; ++q4)
+            *reinterpret_cast<float4*>(g.znf + dm_frag_off(row, strip * C + 4 * q4)) =
+                make_float4(keep == 4 * q4 ? 1.f : 0.f, keep == 4 * q4 + 1 ? 1.f : 0.f, keep == 4 * q4 + 2 ? 1.f : 0.f,
+                            keep == 4 * q4 + 3 ? 1.f : 0.f);
+        }
       }
       if (g.idx) g.idx[i] = idx;
     }
@@ -380,12 +400,15 @@ static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.ln_g = q.ln_g; a.ln_b = q.ln_b; a.ln_eps = q.ln_eps;
   a.lnb_x = q.lnb_x; a.lnb_ldx = q.lnb_ldx; a.lnb_stats = q.lnb_stats;
   a.gb_gi = nullptr; a.gb_gh = nullptr; a.gb_hin = nullptr; a.gb_ldh = 0; a.gb_D = 0; a.gb_dgi = nullptr; a.gb_dgh = nullptr;
-  a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr;
+  a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr; a.gb_dgif = nullptr; a.gb_dghf = nullptr;
   if (q.gates) {
     a.gb_gi = q.gates->gi; a.gb_gh = q.gates->gh; a.gb_hin = q.gates->h_in; a.gb_ldh = q.gates->ldh; a.gb_D = q.gates->D;
     a.gb_dgi = q.gates->dgi; a.gb_dgh = q.gates->dgh; a.gb_dprev = q.gates->dprev; a.gb_ldp = q.gates->ldp; a.gb_rz = q.gates->row_zero;
+    if (q.M <= 64 && q.gates->dgi_frag && q.gates->dgh_frag) { a.gb_dgif = q.gates->dgi_frag; a.gb_dghf = q.gates->dgh_frag; }
   }
   a.u = nullptr; a.forced = nullptr; a.onehot = nullptr; a.ldo = 0; a.idx = nullptr; a.z_next = nullptr; a.next_reset = nullptr;
+  const bool one_chunk = q.M <= 64;       // the fragment-major layout holds ONE 64-row chunk
+  a.Af = one_chunk ? q.A_frag : nullptr; a.Cf = one_chunk ? q.C_frag : nullptr; a.znf = nullptr;
 }
 static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
 static const int g_skinny_nofuse = getenv("DM_SKINNY_NO_FUSE") ? 1 : 0;        // A/B switch: keep LayerNorm / sampler launches
@@ -400,6 +423,7 @@ bool dm_skinny_ln_ok(int M, int N, int K) {
 // Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
 int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   if (g_skinny_disabled || !skinny_ok(q, g_skinny_max_m)) return 0;
+  if (q.C_frag && q.M > 64) return 0;      // the tiled path reports the misuse
   // beyond one chunk it pays only for short reductions over small weight matrices (measured at M = 350: 1000x1024
   // 31.9 -> 24.8 us, 400x400 15.1 -> 8.7 us; 1800x1000 equal; 400x1624 18.2 -> 19.9 us)
   if (q.M > 64 && (q.K > 1024 || (int64_t)q.N * q.K > (int64_t)1100 * 1024)) return 0;
@@ -475,6 +499,7 @@ int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t strea
   skinny_fill(q, a);
   a.u = sm.u; a.forced = sm.forced; a.onehot = sm.onehot; a.ldo = sm.ldo; a.idx = sm.idx; a.z_next = sm.z_next;
   a.next_reset = sm.next_reset;
+  a.znf = sm.z_next ? sm.z_next_frag : nullptr;
   const dim3 grid((unsigned)(q.N / 32)), blk(SK_WAVES * 64);
   if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_sample_kernel<1>), grid, blk, 0, stream, a);
   else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_sample_kernel<2>), grid, blk, 0, stream, a);

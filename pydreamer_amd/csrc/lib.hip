@@ -69,7 +69,8 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) + 1024;
   const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024;   // + gather tables, padded image-layer weights
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
-                          pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D);    // + the transposed BPTT weights, LN-GRU dg
+                          pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg
+                          2 * pad64((3 * D + 15) / 16 * 1024) + 2 * pad64((Hd + 15) / 16 * 1024);   // + fragment-major dgi / dgh / dpin / dza
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +

@@ -11,6 +11,7 @@
 //  * reset masks (rssm.py:41,134-135) are applied forward by a tiny row-scale kernel (the masked states are saved
 //    for backward) and backward through the GEMM / GRU epilogues' row_zero option.
 #include "common.h"
+#include <stdlib.h>
 
 struct RssmActs {
   float *ea, *ee, *hin, *zin, *x1, *st1, *za, *gi, *gh, *x2, *st2, *pin, *x3, *st3, *prin;
@@ -141,6 +142,18 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   const bool fuse_ln = dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
   const bool fuse_sample = fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
+  // Fragment-major copies of the chain's <= 64-row operands (common.h dm_frag_off), written by the kernel that produces
+  // each operand next to its ordinary copy and read by the product that consumes it: z_in -> x1 -> (gi | gh from h_in)
+  // -> h -> x2 -> z.  One buffer per operand is enough (producer and consumer alternate in stream order).
+  static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;          // A/B switch
+  float *zinf = nullptr, *x1f = nullptr, *hinf = nullptr, *hf = nullptr, *x2f = nullptr;
+  if (!no_frag && fuse_sample && kind == 0 && B <= 64) {
+    DmArena ar(ws, ws_bytes);
+    ar.take(DM_SPLITK_FLOATS);
+    float* f0 = ar.take(dm_frag_floats(Z)); float* f1 = ar.take(dm_frag_floats(Hd)); float* f2 = ar.take(dm_frag_floats(D));
+    float* f3 = ar.take(dm_frag_floats(D)); float* f4 = ar.take(dm_frag_floats(Hd));
+    if (ar.ok) { zinf = f0; x1f = f1; hinf = f2; hf = f3; x2f = f4; }
+  }
   // 8 launches per step otherwise: the reset masks of step t+1 are applied by the kernels that produce h_t and z_t (only
   // the first step of a range needs the stand-alone mask kernel), and the GRU's two gate products share one launch.
   for (int t = t0; t < t1; ++t) {
@@ -152,13 +165,23 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       const float* pz = t == 0 ? z0 : feat + (r0 - B) * F + D;
       const int ldp_h = t == 0 ? D : F, ldp_z = t == 0 ? Z : F;
       DM_TRY(dm_mask_rows2_launch(B, D, ph, ldp_h, hin, D, Z, pz, ldp_z, zin, Z, reset + r0, st));
+      if (zinf) {
+        DM_TRY(dm_frag_pack_launch(B, D, hin, D, hinf, st));
+        DM_TRY(dm_frag_pack_launch(B, Z, zin, Z, zinf, st));
+      }
     }
     const bool more = t + 1 < t1;
     float* hin_next = more ? a.hin + (r0 + B) * D : nullptr;
     float* zin_next = more ? a.zin + (r0 + B) * Z : nullptr;
     const uint8_t* reset_next = more ? reset + r0 + B : nullptr;
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
-    DM_TRY(linear(st, ws, skb, B, Hd, Z, zin, Z, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd, a.x1 + r0 * Hd, Hd));
+    {
+      DmGemm q;
+      q.M = B; q.N = Hd; q.K = Z; q.A = zin; q.lda = Z; q.B = p[DM_RSSM_Z_W]; q.ldb = Z; q.C = a.x1 + r0 * Hd; q.ldc = Hd;
+      q.bias = p[DM_RSSM_Z_B]; q.add = a.ea + r0 * Hd; q.ldadd = Hd;
+      q.A_frag = zinf; q.C_frag = x1f;
+      DM_TRY(dm_gemm_launch(q, ws, skb, st));
+    }
     if (!fuse_ln)
       DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
                                   a.st1 + r0 * 2, st));
@@ -166,7 +189,11 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     {
       DmGemm gi_q, gh_q;
       gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
-      if (fuse_ln) { gi_q.A = a.x1 + r0 * Hd; gi_q.ln_g = p[DM_RSSM_IN_G]; gi_q.ln_b = p[DM_RSSM_IN_B]; gi_q.ln_eps = 1e-3f; }
+      if (fuse_ln) {
+        gi_q.A = a.x1 + r0 * Hd; gi_q.ln_g = p[DM_RSSM_IN_G]; gi_q.ln_b = p[DM_RSSM_IN_B]; gi_q.ln_eps = 1e-3f;
+        gi_q.A_frag = x1f;
+      }
+      gh_q.A_frag = hinf;
       gi_q.C = a.gi + r0 * 3 * D; gi_q.ldc = 3 * D; gi_q.bias = p[DM_RSSM_GRU_BIH];
       gh_q.M = B; gh_q.N = 3 * D; gh_q.K = D; gh_q.A = hin; gh_q.lda = D; gh_q.B = p[DM_RSSM_GRU_WHH]; gh_q.ldb = D;
       gh_q.C = a.gh + r0 * 3 * D; gh_q.ldc = 3 * D; gh_q.bias = p[DM_RSSM_GRU_BHH];
@@ -174,23 +201,29 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     }
     if (kind == 0)
       DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, hin_next,
-                                     reset_next, st));
+                                     reset_next, hf, more ? hinf : nullptr, st));
     else
       DM_TRY(dm_gru_norm_fwd_launch(kind, B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, lng, lnb, feat + r0 * F, F,
                                     a.gs + r0 * 3 * D, a.gst + r0 * 6, hin_next, reset_next, st));
     // post = post_mlp(ELU(post_norm(post_mlp_h(h) + post_mlp_e(embed))))               rssm.py:143-146
-    DM_TRY(linear(st, ws, skb, B, Hd, D, feat + r0 * F, F, p[DM_RSSM_POST_H_W], p[DM_RSSM_POST_H_B], a.ee + r0 * Hd, Hd,
-                  a.x2 + r0 * Hd, Hd));
+    {
+      DmGemm q;
+      q.M = B; q.N = Hd; q.K = D; q.A = feat + r0 * F; q.lda = F; q.B = p[DM_RSSM_POST_H_W]; q.ldb = D;
+      q.C = a.x2 + r0 * Hd; q.ldc = Hd; q.bias = p[DM_RSSM_POST_H_B]; q.add = a.ee + r0 * Hd; q.ldadd = Hd;
+      q.A_frag = hf; q.C_frag = x2f;
+      DM_TRY(dm_gemm_launch(q, ws, skb, st));
+    }
     if (fuse_ln) {
       DmGemm pq;      // post = post_mlp(ELU(post_norm(x2))), LayerNorm in the prologue
       pq.M = B; pq.N = Z; pq.K = Hd; pq.A = a.x2 + r0 * Hd; pq.lda = Hd; pq.B = p[DM_RSSM_POST_W]; pq.ldb = Hd;
       pq.C = post + r0 * Z; pq.ldc = Z; pq.bias = p[DM_RSSM_POST_OB];
       pq.ln_g = p[DM_RSSM_POST_G]; pq.ln_b = p[DM_RSSM_POST_B]; pq.ln_eps = 1e-3f;
+      pq.A_frag = x2f;
       if (fuse_sample) {   // ... and z ~ OneHotCategoricalStraightThrough(post) in the epilogue        rssm.py:147-148
         DmSample sm;
         sm.u = u ? u + r0 * S : nullptr; sm.forced = forced_idx ? forced_idx + r0 * S : nullptr;
         sm.onehot = feat + r0 * F + D; sm.ldo = F; sm.idx = idx ? idx + r0 * S : nullptr;
-        sm.z_next = zin_next; sm.next_reset = reset_next;
+        sm.z_next = zin_next; sm.next_reset = reset_next; sm.z_next_frag = zinf;
         DM_TRY(dm_gemm_sample_launch(pq, sm, st));
         continue;
       }
@@ -293,6 +326,14 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
   const bool fuse_b = kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
+  // backward epilogue, read by the two products that follow it
+  static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;
+  float* dgif = (fuse_b && !no_frag && B <= 64) ? ar.take(dm_frag_floats(3 * D)) : nullptr;
+  float* dghf = dgif ? ar.take(dm_frag_floats(3 * D)) : nullptr;
+  float* dpinf = dgif ? ar.take(dm_frag_floats(Hd)) : nullptr;      // ... and of dpin, dza (written by the epilogue of the
+  float* dzaf = dgif ? ar.take(dm_frag_floats(Hd)) : nullptr;       // product that makes them)
+  if (!ar.ok) { dgif = nullptr; dghf = nullptr; dpinf = nullptr; dzaf = nullptr; }
   for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
@@ -300,28 +341,42 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     // straight-through sample: dpost += softmax'(post)^T dz'
     DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * Z, Z, dft + D, F, dpt, Z, 1, st));
     // post_mlp, post_norm+ELU, post_mlp_h
-    DM_TRY(dgrad_t(st, sk, skb, B, Z, Hd, dpt, Z, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
+    if (fuse_b) {
+      DmGemm q3;   // dpin = dpost Wpost
+      q3.M = B; q3.N = Hd; q3.K = Z; q3.A = dpt; q3.lda = Z; q3.B = wt_post; q3.ldb = Z; q3.C = dpin + r0 * Hd; q3.ldc = Hd;
+      q3.C_frag = dpinf;
+      DM_TRY(dm_gemm_launch(q3, sk, skb, st));
+    } else {
+      DM_TRY(dgrad_t(st, sk, skb, B, Z, Hd, dpt, Z, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
+    }
     if (fuse_b) {
       const uint8_t* rz = reset + r0;
       float* dprev = t > 0 ? dfeat + (r0 - B) * F : nullptr;
       DmGatesBwd gb;
       gb.gi = a.gi + r0 * 3 * D; gb.gh = a.gh + r0 * 3 * D; gb.h_in = a.hin + r0 * D; gb.ldh = D; gb.D = D;
       gb.dgi = dgi + r0 * 3 * D; gb.dgh = dgh + r0 * 3 * D; gb.dprev = dprev; gb.ldp = F; gb.row_zero = rz;
+      gb.dgi_frag = dgif; gb.dgh_frag = dghf;
       DmGemm q4;     // dh' += LNbwd(dpin) Wph ; then the GRU gates backward on the completed dh'
       q4.M = B; q4.N = D; q4.K = Hd; q4.A = dpin + r0 * Hd; q4.lda = Hd; q4.B = wt_post_h; q4.ldb = Hd;
       q4.C = dft; q4.ldc = F; q4.flags = DM_GEMM_ACCUM;
       q4.ln_g = p[DM_RSSM_POST_G]; q4.ln_b = p[DM_RSSM_POST_B]; q4.lnb_x = a.x2 + r0 * Hd; q4.lnb_ldx = Hd;
-      q4.lnb_stats = a.st2 + r0 * 2; q4.gates = &gb;
+      q4.lnb_stats = a.st2 + r0 * 2; q4.gates = &gb; q4.A_frag = dpinf;
       DM_TRY(dm_gemm_launch(q4, sk, skb, st));
-      DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, wt_ih, dza + r0 * Hd, Hd, 0, nullptr));
+      {
+        DmGemm q5;   // dza = dgi Wih
+        q5.M = B; q5.N = Hd; q5.K = 3 * D; q5.A = dgi + r0 * 3 * D; q5.lda = 3 * D; q5.B = wt_ih; q5.ldb = 3 * D;
+        q5.C = dza + r0 * Hd; q5.ldc = Hd; q5.A_frag = dgif; q5.C_frag = dzaf;
+        DM_TRY(dm_gemm_launch(q5, sk, skb, st));
+      }
       if (t > 0) {   // both products into step t-1's [dh' | dz']; the second one consumes LNbwd(dza)
         DmGemm qh, qz;
         qh.M = B; qh.N = D; qh.K = 3 * D; qh.A = dgh + r0 * 3 * D; qh.lda = 3 * D; qh.B = wt_hh; qh.ldb = 3 * D;
+        qh.A_frag = dghf;
         qh.C = dprev; qh.ldc = F; qh.flags = DM_GEMM_ACCUM; qh.row_zero = rz;
         qz.M = B; qz.N = Z; qz.K = Hd; qz.A = dza + r0 * Hd; qz.lda = Hd; qz.B = wt_z; qz.ldb = Hd;
         qz.C = dprev + D; qz.ldc = F; qz.flags = DM_GEMM_ACCUM; qz.row_zero = rz;
         qz.ln_g = p[DM_RSSM_IN_G]; qz.ln_b = p[DM_RSSM_IN_B]; qz.lnb_x = a.x1 + r0 * Hd; qz.lnb_ldx = Hd;
-        qz.lnb_stats = a.st1 + r0 * 2;
+        qz.lnb_stats = a.st1 + r0 * 2; qz.A_frag = dzaf;
         DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));
       }
       continue;
@@ -452,7 +507,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
     DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
-    if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, st));
+    if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, nullptr, nullptr, st));
     else DM_TRY(dm_gru_norm_fwd_launch(kind, M, D, gi, gh, cur, F, lng, lnb, nxt, F, gsw, gstw, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));

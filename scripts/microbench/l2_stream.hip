@@ -2,6 +2,8 @@
 //   l2_stream <buffer KiB> <loads in flight per thread U: 4|8|16|32> <threads per WG> <WGs per CU> <pattern 0|1>
 // pattern 0: fully coalesced 16-byte loads (thread t of a wave reads 16 B at t*16: 8 full 128-byte lines per instruction)
 // pattern 1: MFMA-fragment gather (lane l reads 16 B of row l&15 at column 4*(l>>4): 16 rows x 64 B per instruction)
+// pattern 2: GEMM-tile rows (8 lanes per row: 8 rows x 128 B per instruction, rows `row4` float4 apart)
+// pattern 3: 16 lanes per row: 4 rows x 256 B per instruction
 // Every WG streams the same buffer `reps` times, so after the first pass it is L2 / MALL resident as its size allows.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,6 +21,19 @@ __global__ void __launch_bounds__(1024) stream_kernel(const float4* __restrict__
         for (int u = 0; u < U; ++u) v[u] = buf[i + (size_t)u * blockDim.x];
 #pragma unroll
         for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+    } else if (PAT == 2 || PAT == 3) {
+      constexpr int LPR = PAT == 2 ? 8 : 16;           // lanes per row
+      constexpr int RPI = 64 / LPR;                    // rows per instruction
+      const size_t rows = n4 / row4;
+      for (size_t band = wave; band * (RPI * U) + RPI * U - 1 < rows; band += nw) {
+        for (int c = 0; c + LPR <= row4; c += LPR) {
+          float4 v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) v[u] = buf[(band * (RPI * U) + u * RPI + lane / LPR) * row4 + c + (lane % LPR)];
+#pragma unroll
+          for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
       }
     } else {
       // rows of row4 float4; a wave walks 16-row bands: lane -> (row = band*16 + (l&15), col4 = c*4 + (l>>4))
@@ -54,6 +69,8 @@ int main(int argc, char** argv) {
     hipEventRecord(e0);
 #define L(UU) \
     if (pat == 0) hipLaunchKernelGGL((stream_kernel<UU, 0>), dim3(ncu * wgs_per_cu), dim3(threads), 0, 0, buf, n4, reps, row4, out); \
+    else if (pat == 2) hipLaunchKernelGGL((stream_kernel<UU, 2>), dim3(ncu * wgs_per_cu), dim3(threads), 0, 0, buf, n4, reps, row4, out); \
+    else if (pat == 3) hipLaunchKernelGGL((stream_kernel<UU, 3>), dim3(ncu * wgs_per_cu), dim3(threads), 0, 0, buf, n4, reps, row4, out); \
     else hipLaunchKernelGGL((stream_kernel<UU, 1>), dim3(ncu * wgs_per_cu), dim3(threads), 0, 0, buf, n4, reps, row4, out);
     if (U == 4) { L(4) } else if (U == 8) { L(8) } else if (U == 16) { L(16) } else { L(32) }
     hipEventRecord(e1); hipEventSynchronize(e1);
