@@ -50,12 +50,14 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0,
   const int l15 = lane & 15, q = lane >> 4;
   const int k = c + 4 * q;
   const bool kin = k < kend;                      // kend % 4 == 0 (host-checked K % 4): a group of 4 is all in or all out
+  const int nch = (g.K + 15) >> 4;                // fragment-major copy: a chunk past the range re-reads the last one (masked)
+  const int cc = (c >> 4) < nch ? (c >> 4) : nch - 1;
 #pragma unroll
   for (int mb = 0; mb < NRB; ++mb) {
     const int m = m0 + mb * 16 + l15;
     const bool ok = kin && m < g.M;
     if (g.Af)       // one contiguous KiB per instruction (rows past M hold stale data: masked like the clamped loads)
-      a[mb] = *reinterpret_cast<const float4*>(g.Af + ((((size_t)(c >> 4) * 4 + mb) * 4 + q) * 16 + l15) * 4);
+      a[mb] = *reinterpret_cast<const float4*>(g.Af + ((((size_t)cc * 4 + mb) * 4 + q) * 16 + l15) * 4);
     else
       a[mb] = *reinterpret_cast<const float4*>(g.A + (ok ? (size_t)m * g.lda + k : 0));
     mask |= ok ? (1u << mb) : 0u;
