@@ -184,9 +184,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1')
     import torch.distributed as dist
+    # DM_BENCH_ONE_DEVICE=1 (smoke test of the N > 1 code path on a 1-GPU box, tests/test_gpu_dist.py): every rank uses
+    # cuda:0 and the ranks talk over gloo; the line is marked invalid as a metric
+    one_device = bool(os.environ.get('DM_BENCH_ONE_DEVICE')) and world > 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -327,6 +332,7 @@ def main():
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=2.76),
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
+                    **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
                     **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),

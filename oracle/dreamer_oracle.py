@@ -370,6 +370,16 @@ def nanmean(x):
     return torch.nansum(x) / (~torch.isnan(x)).sum()
 
 
+def grad_probe(g, pidx):
+    """Two closed-form directions per parameter (no RNG involved): slim full-size fixtures store the projections of every
+    gradient onto them next to its norm, which pins the gradient's DIRECTION in 16 bytes (a norm alone does not)."""
+    v = g.detach().double().reshape(-1).cpu()
+    i = torch.arange(v.numel(), dtype=torch.float64)
+    w1 = torch.cos(i * 0.7548776662466927 + float(pidx))
+    w2 = torch.cos(i * 0.5698402909980532 + 2.0 * float(pidx) + 0.5)
+    return float((v * w1).sum()), float((v * w2).sum())
+
+
 def logavgexp(x, dim):
     """functions.py:97-102."""
     if x.size(dim) > 1:

@@ -165,6 +165,7 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
             out[pre + 'idx_lat'] = lat_idx.numpy().astype(np.uint8)
         out[pre + 'grad_norms'] = np.array([float(g.double().norm()) for g in grads.values()])
         out[pre + 'grad_names'] = np.array(list(grads.keys()))
+        out[pre + 'grad_proj'] = np.array([O.grad_probe(g, i) for i, g in enumerate(grads.values())])     # (P, 2): directions
         for k in full_grads:
             out[pre + 'grad_' + k] = grads[k].numpy()
         post = dict(model.state_dict())

@@ -7,6 +7,7 @@ columns of the 1-rank run (uniforms are sliced from the global layout); paramete
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 
@@ -116,3 +117,28 @@ def test_two_rank_step_equals_one_rank(hip, overlap):
     # both ranks hold identical replicas
     for a, b in zip(res[0]['params'], res[1]['params']):
         assert torch.equal(a, b)
+
+
+def test_bench_multi_rank_code_path_smoke(hip):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on whatever this box has:
+    with one GPU both ranks share cuda:0 over gloo (DM_BENCH_ONE_DEVICE=1, the line carries an INVALID marker).  Checks the
+    contract of the N > 1 line: one JSON line from rank 0, n_gpus, steps, the uneven 25/25 sharding, finite loss."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env['DM_BENCH_ONE_DEVICE'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--prof-steps', '1']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['cpu_baseline'] is None
+    assert d['value'] > 0 and abs(d['ms_per_step'] * d['value'] - 1e3) < 1e-6 * 1e3
+    assert '[25, 25]' in d['config']['parallelism']
+    assert np.isfinite(d['loss_model_last']) and d['roofline'] is not None and d['roofline']['frac'] > 0

@@ -757,6 +757,13 @@ def test_training_step_matches_reference_at_atari_literal(hip):
     worst = max(abs(float(named[n].grad.double().norm()) - r) / max(r, 1e-7) for n, r in zip(names, g['s0_grad_norms']))
     print('worst per-parameter grad-norm rel err', worst)
     assert worst < 2e-2
+    if 's0_grad_proj' in g.files:      # gradient DIRECTIONS: projections onto two closed-form directions per parameter
+        wp = 0.0
+        for i, (n, r, pr) in enumerate(zip(names, g['s0_grad_norms'], g['s0_grad_proj'])):
+            got = O.grad_probe(named[n].grad, i)
+            wp = max(wp, max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) / max(r, 1e-7))
+        print('worst per-parameter gradient-projection error / norm', wp)
+        assert wp < 1e-2
 
 
 def test_training_step_matches_reference_at_dmc_native(hip):
@@ -801,6 +808,13 @@ def test_training_step_matches_reference_at_dmc_native(hip):
     worst = max(abs(float(named[n].grad.double().norm()) - r) / max(r, 1e-7) for n, r in zip(names, g['s0_grad_norms']))
     print('worst per-parameter grad-norm rel err', worst)
     assert worst < 2e-2
+    if 's0_grad_proj' in g.files:      # gradient DIRECTIONS: projections onto two closed-form directions per parameter
+        wp = 0.0
+        for i, (n, r, pr) in enumerate(zip(names, g['s0_grad_norms'], g['s0_grad_proj'])):
+            got = O.grad_probe(named[n].grad, i)
+            wp = max(wp, max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) / max(r, 1e-7))
+        print('worst per-parameter gradient-projection error / norm', wp)
+        assert wp < 1e-2
 
 
 def test_forward_time_chunk_pipeline_is_exact(hip):

@@ -188,6 +188,15 @@ def test_oracle_matches_reference_at_atari_literal():
         ref = float(g['s0_metric_' + k])
         tol = 2e-6 if k in wm_keys else 1e-2
         assert _rel(v, ref) < tol or abs(float(v) - ref) < 1e-3 * (k not in wm_keys) + 1e-7, (k, float(v), ref)
+    # world-model gradient DIRECTIONS (two closed-form projections per parameter, O.grad_probe); the actor / critic
+    # gradients inherit the one diverged imagination row and are left to the norm-level metrics above
+    if 's0_grad_proj' in g.files:
+        names = [str(n) for n in g['s0_grad_names']]
+        for i, (n, r, pr) in enumerate(zip(names, g['s0_grad_norms'], g['s0_grad_proj'])):
+            if not n.startswith('wm.') or n not in grads:
+                continue
+            got = O.grad_probe(grads[n], i)
+            assert max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) <= 1e-4 * r + 1e-9, (n, got, pr, r)
 
 
 def test_oracle_matches_reference_at_dmc_native():
