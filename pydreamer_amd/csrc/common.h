@@ -172,9 +172,11 @@ int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int
                        hipStream_t st);
 
 // fused MLP (mlp.hip)
+// chain_wpack (optional): fragment-major weights already packed by the caller (dm_mlp_chain_pack_launch) for the whole-MLP
+// kernel; null: packed here, per call, into the workspace
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr);
 
 // row-panel Linear + LayerNorm/ELU kernels for the 400-wide MLP heads (panel.hip)
 bool dm_panel_ok(int rows, int hidden);
@@ -191,8 +193,11 @@ int dm_panel_colsum_final_launch(int count, const float* const* part, float* con
 // whole-MLP forward in one launch for the 400-wide heads below the panel threshold (mlp_chain.hip)
 bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                      const dm_mlp_params* p);
+size_t dm_mlp_chain_pack_floats(int in_dim, int layers);
+int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st);
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
-                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, hipStream_t st);
+                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
+                            hipStream_t st);
 
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
 void dm_prof_slot_end(int slot, hipStream_t st);

@@ -44,7 +44,7 @@ extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
 // leave most CUs idle there).
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
   MlpActs a;
@@ -70,9 +70,18 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
   const float* in = x;
   int ldin = ldx, kin = in_dim;
   const bool panel = dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
-  if (!panel && dm_mlp_chain_ok(rows, in_dim, hidden, layers, out_dim, x, ldx, p))      // all layers + output in ONE launch
+  if (!panel && dm_mlp_chain_ok(rows, in_dim, hidden, layers, out_dim, x, ldx, p)) {    // all layers + output in ONE launch
+    const float* wpack = chain_wpack;
+    if (!wpack) {      // pack the weights fragment-major into the (otherwise unused) split-K region of the workspace
+      const size_t need = dm_mlp_chain_pack_floats(in_dim, layers);
+      if (need <= DM_SPLITK_FLOATS && ws_bytes >= need * sizeof(float) && ((uintptr_t)ws & 15) == 0) {
+        DM_TRY(dm_mlp_chain_pack_launch(in_dim, layers, p, (float*)ws, st));
+        wpack = (const float*)ws;
+      }
+    }
     return dm_mlp_chain_fwd_launch(rows, in_dim, layers, out_dim, x, ldx, p, acts ? a.xpre : nullptr,
-                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, st);
+                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, wpack, st);
+  }
   if (panel) {
     const bool fuse_out = out_dim <= 32;
     for (int l = 0; l < layers; ++l) {

@@ -42,6 +42,11 @@ struct ChainArgs {
   float* stats[DM_MAX_MLP_LAYERS];
   float* y[DM_MAX_MLP_LAYERS];
   float* out;
+  // fragment-major copies of the hidden-layer weights (dm_mlp_chain_pack_launch; null: gather from the row-major weights).
+  // Layout per layer: [block nb][pair p][half h][lane group q][lane l&15][4 floats]: the 64 lanes of one weight-fragment load
+  // read ONE contiguous KiB.  The row-major gather (16 rows x 64 B per instruction) is limited to 16.6 B/clk/CU by the
+  // texture path whatever the cache level (scripts/microbench/l2_stream.hip), contiguous loads reach ~50.
+  const float* wp[DM_MAX_MLP_LAYERS];
 };
 
 __device__ __forceinline__ float chain_red16(float v) {
@@ -67,9 +72,26 @@ __device__ __forceinline__ float4 chain_bload(__amdgpu_buffer_rsrc_t r, unsigned
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-template <bool FIRST>
+template <bool FIRST, bool PACKED>
 __device__ __forceinline__ void chain_load(ChainFrag& f, const float* A, const float* ybuf, __amdgpu_buffer_rsrc_t W,
                                            unsigned wblk, int K, int pair, int l15, int q, int last) {
+  if (PACKED) {      // wblk = first block of the wave; K-edge zeros are in the packed copy
+    const int np = (K + 31) >> 5;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int k = pair * 32 + h * 16 + 4 * q;
+      k = k < K ? k : K - 4;
+      f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+    }
+    const unsigned voff = (unsigned)(q * 16 + l15) * 16u;
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i) {
+      const unsigned blk = wblk + (unsigned)(i == CH_WB - 1 ? last : i);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) f.b[i][h] = chain_bload(W, voff, ((blk * (unsigned)np + (unsigned)pair) * 2u + (unsigned)h) * 1024u);
+    }
+    return;
+  }
   unsigned off[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -120,23 +142,23 @@ __device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag&
 }
 
 // A: this lane's activation row (layer 0, global); W: this lane's weight row of the wave's first block.
-template <bool FIRST, bool BF>
+template <bool FIRST, bool BF, bool PACKED>
 __device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A, const float* ybuf,
                                             __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
   const int np = (K + 31) >> 5;
   ChainFrag f0, f1, f2;
-  chain_load<FIRST>(f0, A, ybuf, W, wblk, K, 0, l15, q, last);
-  chain_load<FIRST>(f1, A, ybuf, W, wblk, K, 1 < np ? 1 : 0, l15, q, last);
+  chain_load<FIRST, PACKED>(f0, A, ybuf, W, wblk, K, 0, l15, q, last);
+  chain_load<FIRST, PACKED>(f1, A, ybuf, W, wblk, K, 1 < np ? 1 : 0, l15, q, last);
   for (int p = 0; p < np; p += 3) {
-    chain_load<FIRST>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
+    chain_load<FIRST, PACKED>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
     chain_mfma<BF>(acc, f0, K, p, q);
     if (p + 1 >= np) break;
-    chain_load<FIRST>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
+    chain_load<FIRST, PACKED>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
     chain_mfma<BF>(acc, f1, K, p + 1, q);
     if (p + 2 >= np) break;
-    chain_load<FIRST>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
+    chain_load<FIRST, PACKED>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
     chain_mfma<BF>(acc, f2, K, p + 2, q);
   }
@@ -170,8 +192,12 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
     const int K = l == 0 ? g.in_dim : CH_N;
     // all waves walk 7 blocks (wave 0 sets the pace anyway); the 7th of waves 1..3 is a dummy that re-reads the wave's
     // first block and is ignored below
-    const __amdgpu_buffer_rsrc_t Wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w[l]), 0, CH_N * K * 4, 0x00020000);
-    const unsigned wblk = (unsigned)(nb0 * 16) * (unsigned)K * 4u;
+    const bool packed = g.wp[l] != nullptr;
+    const int npr = (K + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t Wl = packed
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp[l]), 0, CH_NBLK * npr * 2048, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w[l]), 0, CH_N * K * 4, 0x00020000);
+    const unsigned wblk = packed ? (unsigned)nb0 : (unsigned)(nb0 * 16) * (unsigned)K * 4u;
     const int last = cnt == CH_WB ? CH_WB - 1 : 0;
     // the epilogue's per-column parameters, fetched BEFORE the k-loop (dependent global round trips after it cost ~2 us
     // each on a workgroup that has nothing else to run)
@@ -188,8 +214,13 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
         pbe[i] = bet[c];
       }
     }
-    if (l == 0) chain_layer<true, BF>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-    else chain_layer<false, BF>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    if (packed) {
+      if (l == 0) chain_layer<true, BF, true>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+      else chain_layer<false, BF, true>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    } else {
+      if (l == 0) chain_layer<true, BF, false>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+      else chain_layer<false, BF, false>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i)
@@ -317,6 +348,32 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
   }
 }
 
+// fragment-major copy of the hidden-layer weights, all layers in one launch: one thread per destination 16-byte group
+struct ChainPackArgs {
+  const float* w[DM_MAX_MLP_LAYERS];
+  float* dst[DM_MAX_MLP_LAYERS];
+  int K[DM_MAX_MLP_LAYERS];
+  unsigned first[DM_MAX_MLP_LAYERS + 1];      // first group of each layer (prefix sums of 25 * npairs * 128)
+  int layers;
+};
+__global__ void __launch_bounds__(256) mlp_chain_pack_kernel(const ChainPackArgs a) {
+  const unsigned total = a.first[a.layers];
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < a.layers && e >= a.first[l + 1]) ++l;
+    const unsigned r = e - a.first[l];
+    const int K = a.K[l], np = (K + 31) >> 5;
+    const int l15 = r & 15, q = (r >> 4) & 3, h = (r >> 6) & 1;
+    const unsigned bp = r >> 7;
+    const int p = bp % np, nb = bp / np;
+    const int k = p * 32 + h * 16 + 4 * q;
+    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * K + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k + 3 < K) v = make_float4(src[0], src[1], src[2], src[3]);        // K % 4 == 0 (host-checked)
+    reinterpret_cast<float4*>(a.dst[l])[r] = v;
+  }
+}
+
 // ---------------------------------------------------------------- host side ---------------------
 static const int g_chain_off = getenv("DM_MLP_NO_CHAIN") ? 1 : 0;       // A/B switch: keep the per-layer launches
 // A row block takes ~135 us however many there are (one CU walks all 1.13 M MACs per row: 66 us of MFMA issue plus the
@@ -342,10 +399,48 @@ bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, 
   return true;
 }
 
+static size_t chain_pack_layer_floats(int K) { return (size_t)CH_NBLK * ((K + 31) / 32) * 512; }
+size_t dm_mlp_chain_pack_floats(int in_dim, int layers) {
+  size_t n = chain_pack_layer_floats(in_dim);
+  for (int l = 1; l < layers; ++l) n += chain_pack_layer_floats(CH_N);
+  return n;
+}
+static const int g_chain_nopack = getenv("DM_CHAIN_NO_PACK") ? 1 : 0;      // A/B switch
+// wpack: dm_mlp_chain_pack_floats(in_dim, layers) floats, 16-byte aligned.  A caller that runs the same weights several times
+// (the H steps of a rollout) packs once.
+int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st) {
+  DM_REQUIRE(wpack && al16(wpack) && (in_dim & 3) == 0 && layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp_chain_pack");
+  ChainPackArgs a = {};
+  a.layers = layers;
+  size_t off = 0;
+  unsigned first = 0;
+  for (int l = 0; l < layers; ++l) {
+    const int K = l == 0 ? in_dim : CH_N;
+    a.w[l] = p->w[l]; a.dst[l] = wpack + off; a.K[l] = K; a.first[l] = first;
+    off += chain_pack_layer_floats(K);
+    first += (unsigned)(chain_pack_layer_floats(K) / 4);
+  }
+  a.first[layers] = first;
+  int blocks = dm_cdiv(first, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(blocks), dim3(256), 0, st, a);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // acts pointers per layer may be null (nothing saved); all row pointers already include the caller's row offset.
+// wpack: fragment-major weights from dm_mlp_chain_pack_launch (null: the kernel gathers from the row-major weights).
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
-                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, hipStream_t st) {
+                            float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
+                            hipStream_t st) {
   ChainArgs a = {};
+  if (wpack && !g_chain_nopack) {
+    size_t off = 0;
+    for (int l = 0; l < layers; ++l) {
+      a.wp[l] = wpack + off;
+      off += chain_pack_layer_floats(l == 0 ? in_dim : CH_N);
+    }
+  }
   a.x = x; a.ldx = ldx; a.in_dim = in_dim;
   a.rows = rows; a.layers = layers; a.out_dim = out_dim; a.ldout = ldout;
   for (int l = 0; l <= layers; ++l) { a.w[l] = p->w[l]; a.b[l] = p->b[l]; }

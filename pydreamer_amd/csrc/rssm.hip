@@ -483,6 +483,15 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
+  const float* actor_wpack = nullptr;
+  if (dm_mlp_chain_ok(M, F, Hm, L, AO, feats, F, actor) && !dm_panel_ok(M, Hm)) {
+    float* wpk = ar.take(dm_mlp_chain_pack_floats(F, L));
+    if (ar.ok) {
+      DM_TRY(dm_mlp_chain_pack_launch(F, L, actor, wpk, st));
+      actor_wpack = wpk;
+    }
+  }
 
   hipError_t e = hipMemcpyAsync(feats, start, (size_t)M * F * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "dream_rollout: %s", hipGetErrorString(e));
@@ -494,8 +503,9 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     // with actor_acts the activations of all H steps are kept (rows i*M..) so ActorCritic's policy-gradient backward
     // reuses them instead of recomputing forward_actor(features[:-1]) (the reference's own TODO, a2c.py:119)
     float* logits = actor_acts ? actor_logits + (size_t)i * M * AO : logits_ws;
-    if (actor_acts) DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st));
-    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st));
+    if (actor_acts)
+      DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st, actor_wpack));
+    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack));
     if (adist == 0)
       DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
                                      act_idx ? act_idx + (size_t)i * M : nullptr, nullptr, nullptr, st));
