@@ -360,10 +360,10 @@ def _flat_views(plist, device, fused=None, scratch=False):
     backward without zero_grad = gradient accumulation) a scratch buffer is returned and autograd accumulates as usual.
     scratch=True (backward passes pre-launched inside training_step, i.e. BEFORE the trainer's zero_grad): the optimizer's
     persistent scratch buffer in the same padded layout; _finish_backward() moves it into `.grad` with one kernel."""
-    if fused is not None and scratch:
-        views = fused.scratch_views(plist)
+    if fused is not None and scratch:      # scratch: True, or the generation training_step() claimed on the caller's thread
+        views = fused.scratch_views(plist, bump=scratch is True)
         if views is not None:
-            return fused.scratch, views, ('scratch', fused.scratch_gen)
+            return fused.scratch, views, ('scratch', fused.scratch_gen if scratch is True else int(scratch))
     if fused is not None and not scratch:
         views = fused.claim_fresh_grads(plist)
         if views is not None:
@@ -1352,16 +1352,17 @@ class Dreamer(nn.Module):
                 self._overlap = _Overlap(dev)
             ov = self._overlap
             pk['overlap'] = ov
-            for owner in (self.wm, self.ac.actor, self.ac.critic):      # main thread: zero_grad() may come before the
-                if getattr(owner, '_fused', None) is not None:          # launcher thread has claimed the buffers
-                    owner._fused._pending = True
+            gens = {}
+            for owner in (self.wm, self.ac.actor, self.ac.critic):      # main thread: zero_grad() - or a backward() on
+                if getattr(owner, '_fused', None) is not None:          # an OLDER step's losses - may come before the
+                    gens[id(owner)] = owner._fused.claim_scratch()      # launcher thread has touched the buffers
             # world-model backward: on its own stream and workspace, concurrent with everything below
             need = pk['ws'].numel()
             if ov.ws_wm is None or ov.ws_wm.numel() < need:
                 ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
             ov.ev_wm_fwd.record(torch.cuda.current_stream())
             pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: _prelaunched(self.wm, lambda: self.wm._backward(
-                pk, ov.ws_wm, scratch=True)))
+                pk, ov.ws_wm, scratch=gens.get(id(self.wm), True))))
         metrics, tensors = dict(metrics), tensors.copy()          # LazyTensors.copy(): image_rec stays a thunk
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)
@@ -1384,7 +1385,7 @@ class Dreamer(nn.Module):
             ov.ev_fwd.record(torch.cuda.current_stream())
             for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
                 hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: _prelaunched(mlp, lambda: mlp.bwd(
-                    hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=True)))
+                    hp['x'], hp['ldx'], hp['rows'], hp['acts'], hp['dout'], ov.ws_ac, scratch=gens.get(id(mlp), True))))
         metrics.update(**metrics_ac)
         if I == 1:
             tensors.update(policy_value=tensors_ac['value'][0].view(T, B))

@@ -136,14 +136,23 @@ class FusedAdamW(torch.optim.Optimizer):
         self.fresh = True
         self._reduced = False
 
-    def scratch_views(self, plist):
+    def claim_scratch(self):
+        """Called by training_step() on the CALLER's thread before the backward pass is handed to the launcher thread:
+        the generation is bumped here, synchronously, so a backward() on the losses of an older training_step() is refused
+        deterministically (the launcher thread may not have touched the buffer yet).  Returns the generation claimed."""
+        self.scratch_gen += 1
+        self._pending = True
+        return self.scratch_gen
+
+    def scratch_views(self, plist, bump=True):
         """Per-parameter views of the other gradient buffer (pad slots stay zero forever), or None if `plist` is not
-        exactly this group's parameter set."""
+        exactly this group's parameter set.  bump=False: the generation was claimed by claim_scratch()."""
         if len(plist) != len(self._plist) or any(id(p) not in self._ids for p in plist):
             return None
         if self.scratch is None:
             self.scratch = torch.zeros_like(self.flat_grad)
-        self.scratch_gen += 1
+        if bump:
+            self.scratch_gen += 1
         self._pending = True
         self.early_reduce = None
         by_id = {id(p): v for p, v in zip(self._plist, self._views_of(self.scratch))}
