@@ -140,7 +140,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DM_REQUIRE(kind == 0 || (lng[0] && lnb[0] && (kind == 2 || (lng[1] && lnb[1] && lng[2] && lnb[2]))), DM_E_NULL,
              "rssm_sequence_fwd: LayerNorm GRU cell without its LayerNorm parameters");
   const bool fuse_ln = dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
-  const bool fuse_sample = fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
+  static const int no_fuse_sample = getenv("DM_RSSM_NO_FUSE_SAMPLE") ? 1 : 0;      // A/B switch
+  const bool fuse_sample = !no_fuse_sample && fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
   // Fragment-major copies of the chain's <= 64-row operands (common.h dm_frag_off), written by the kernel that produces
   // each operand next to its ordinary copy and read by the product that consumes it: z_in -> x1 -> (gi | gh from h_in)
