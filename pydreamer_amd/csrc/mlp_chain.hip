@@ -72,10 +72,28 @@ __device__ __forceinline__ float4 chain_bload(__amdgpu_buffer_rsrc_t r, unsigned
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-template <bool FIRST, bool PACKED>
+// PACKED: 0 = row-major weights, 1 = fragment-major fp32, 2 = fragment-major bf16 (a lane's 8 operand values of a pair in
+// ONE 16-byte load, already rounded: half the stream and no conversion in the loop)
+template <bool FIRST, int PACKED>
 __device__ __forceinline__ void chain_load(ChainFrag& f, const float* A, const float* ybuf, __amdgpu_buffer_rsrc_t W,
                                            unsigned wblk, int K, int pair, int l15, int q, int last) {
-  if (PACKED) {      // wblk = first block of the wave; K-edge zeros are in the packed copy
+  if (PACKED == 2) {
+    const int np = (K + 31) >> 5;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int k = pair * 32 + h * 16 + 4 * q;
+      k = k < K ? k : K - 4;
+      f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+    }
+    const unsigned voff = (unsigned)(q * 16 + l15) * 16u;
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i) {
+      const unsigned blk = wblk + (unsigned)(i == CH_WB - 1 ? last : i);
+      f.b[i][0] = chain_bload(W, voff, (blk * (unsigned)np + (unsigned)pair) * 1024u);
+    }
+    return;
+  }
+  if (PACKED == 1) {      // wblk = first block of the wave; K-edge zeros are in the packed copy
     const int np = (K + 31) >> 5;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -115,15 +133,17 @@ __device__ __forceinline__ bf16x8 chain_bf8(float4 lo, float4 hi) {
   const u4 v = {dm_pack_bf16x2(lo.x, lo.y), dm_pack_bf16x2(lo.z, lo.w), dm_pack_bf16x2(hi.x, hi.y), dm_pack_bf16x2(hi.z, hi.w)};
   return __builtin_bit_cast(bf16x8, v);
 }
-template <bool BF>
+template <bool BF, int PACKED>
 __device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag& f, int K, int pair, int q) {
   if (BF) {
     const bool v0 = pair * 32 + 4 * q < K, v1 = pair * 32 + 16 + 4 * q < K;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const bf16x8 a8 = chain_bf8(v0 ? f.a[0] : z, v1 ? f.a[1] : z);
 #pragma unroll
-    for (int i = 0; i < CH_WB; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, chain_bf8(f.b[i][0], f.b[i][1]), acc[i], 0, 0, 0);
+    for (int i = 0; i < CH_WB; ++i) {
+      const bf16x8 b8 = PACKED == 2 ? __builtin_bit_cast(bf16x8, f.b[i][0]) : chain_bf8(f.b[i][0], f.b[i][1]);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
+    }
     return;
   }
 #pragma unroll
@@ -142,7 +162,7 @@ __device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag&
 }
 
 // A: this lane's activation row (layer 0, global); W: this lane's weight row of the wave's first block.
-template <bool FIRST, bool BF, bool PACKED>
+template <bool FIRST, bool BF, int PACKED>
 __device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A, const float* ybuf,
                                             __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
   const int np = (K + 31) >> 5;
@@ -152,15 +172,15 @@ __device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A,
   for (int p = 0; p < np; p += 3) {
     chain_load<FIRST, PACKED>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF>(acc, f0, K, p, q);
+    chain_mfma<BF, PACKED>(acc, f0, K, p, q);
     if (p + 1 >= np) break;
     chain_load<FIRST, PACKED>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF>(acc, f1, K, p + 1, q);
+    chain_mfma<BF, PACKED>(acc, f1, K, p + 1, q);
     if (p + 2 >= np) break;
     chain_load<FIRST, PACKED>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
     __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF>(acc, f2, K, p + 2, q);
+    chain_mfma<BF, PACKED>(acc, f2, K, p + 2, q);
   }
 }
 
@@ -195,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
     const bool packed = g.wp[l] != nullptr;
     const int npr = (K + 31) >> 5;
     const __amdgpu_buffer_rsrc_t Wl = packed
-        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp[l]), 0, CH_NBLK * npr * 2048, 0x00020000)
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp[l]), 0, CH_NBLK * npr * (BF ? 1024 : 2048), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w[l]), 0, CH_N * K * 4, 0x00020000);
     const unsigned wblk = packed ? (unsigned)nb0 : (unsigned)(nb0 * 16) * (unsigned)K * 4u;
     const int last = cnt == CH_WB ? CH_WB - 1 : 0;
@@ -214,12 +234,12 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
         pbe[i] = bet[c];
       }
     }
-    if (packed) {
-      if (l == 0) chain_layer<true, BF, true>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-      else chain_layer<false, BF, true>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    if (packed) {      // packed copies are bf16 when the kernel multiplies in bf16 (host: dm_mlp_chain_pack_launch)
+      if (l == 0) chain_layer<true, BF, BF ? 2 : 1>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+      else chain_layer<false, BF, BF ? 2 : 1>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
     } else {
-      if (l == 0) chain_layer<true, BF, false>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-      else chain_layer<false, BF, false>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+      if (l == 0) chain_layer<true, BF, 0>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
+      else chain_layer<false, BF, 0>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -356,6 +376,33 @@ struct ChainPackArgs {
   unsigned first[DM_MAX_MLP_LAYERS + 1];      // first group of each layer (prefix sums of 25 * npairs * 128)
   int layers;
 };
+// bf16 form: one 16-byte group = the 8 values (k = 32p + 4q .. +3 and 32p + 16 + 4q .. +3) a lane feeds to ONE
+// v_mfma_f32_16x16x32_bf16; group index inside a layer = (nb * npairs + p) * 64 + q * 16 + l15
+__global__ void __launch_bounds__(256) mlp_chain_pack_bf16_kernel(const ChainPackArgs a) {
+  const unsigned total = a.first[a.layers];
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < a.layers && e >= a.first[l + 1]) ++l;
+    const unsigned r = e - a.first[l];
+    const int K = a.K[l], np = (K + 31) >> 5;
+    const int l15 = r & 15, q = (r >> 4) & 3;
+    const unsigned bp = r >> 6;
+    const int p = bp % np, nb = bp / np;
+    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * K;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = p * 32 + h * 16 + 4 * q + j;
+        v[4 * h + j] = k < K ? src[k] : 0.f;
+      }
+    uint4 o;
+    o.x = dm_pack_bf16x2(v[0], v[1]); o.y = dm_pack_bf16x2(v[2], v[3]);
+    o.z = dm_pack_bf16x2(v[4], v[5]); o.w = dm_pack_bf16x2(v[6], v[7]);
+    reinterpret_cast<uint4*>(a.dst[l])[r] = o;
+  }
+}
 __global__ void __launch_bounds__(256) mlp_chain_pack_kernel(const ChainPackArgs a) {
   const unsigned total = a.first[a.layers];
   for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -412,18 +459,20 @@ int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, flo
   DM_REQUIRE(wpack && al16(wpack) && (in_dim & 3) == 0 && layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp_chain_pack");
   ChainPackArgs a = {};
   a.layers = layers;
+  const bool bf = dm_cur_precision() != 0;      // the copy's element type follows the precision of the call that will use it
   size_t off = 0;
   unsigned first = 0;
   for (int l = 0; l < layers; ++l) {
     const int K = l == 0 ? in_dim : CH_N;
     a.w[l] = p->w[l]; a.dst[l] = wpack + off; a.K[l] = K; a.first[l] = first;
-    off += chain_pack_layer_floats(K);
-    first += (unsigned)(chain_pack_layer_floats(K) / 4);
+    off += chain_pack_layer_floats(K);                                         // the layer offsets are the fp32 ones in both forms
+    first += (unsigned)(chain_pack_layer_floats(K) / (bf ? 8 : 4));           // 16-byte groups: half as many in bf16
   }
   a.first[layers] = first;
   int blocks = dm_cdiv(first, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (bf) hipLaunchKernelGGL(mlp_chain_pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(blocks), dim3(256), 0, st, a);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
