@@ -183,10 +183,13 @@ bool dm_panel_ok(int rows, int hidden);
 int dm_panel_count(int rows);
 int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ldx, const float* W, const float* b,
                            const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
-                           const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st);
+                           const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st,
+                           const unsigned short* Wh = nullptr);
+int dm_panel_bf16_weights_launch(int count, const float* const* w, unsigned short* const* dst, const int* rows, const int* cols,
+                                 int transpose, hipStream_t st);
 int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,
                            const float* stats, const float* gamma, const float* beta, float* dx, float* colpart, float* wt,
-                           hipStream_t st);
+                           hipStream_t st, const unsigned short* Wth = nullptr);
 int dm_panel_colsum_final_launch(int count, const float* const* part, float* const* out, int n, int npanels, int pstride,
                                  hipStream_t st);
 

@@ -28,7 +28,8 @@ extern "C" size_t dm_mlp_acts_floats(int rows, int hidden, int layers) {
 static size_t mlp_ws_floats(int rows, int hidden, int layers) {
   const size_t rh = dm_align_up((size_t)rows * hidden, 64);
   return DM_SPLITK_FLOATS + 3 * rh + dm_align_up((size_t)layers * dm_panel_count(rows) * 3 * hidden, 64) +
-         dm_align_up((size_t)hidden * hidden, 64) + 256;      // + the bf16 panel backward's transposed weights
+         dm_align_up((size_t)hidden * hidden, 64) + 256 +     // + the bf16 panel backward's transposed weights
+         dm_align_up((size_t)hidden * 2048 + (size_t)layers * hidden * hidden / 2 + 64, 64);      // + bf16 weight copies (in_dim <= 4096)
 }
 extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
   if (rows < 0 || hidden < 0 || layers < 0 || layers > DM_MAX_MLP_LAYERS) return 0;
@@ -84,13 +85,32 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
   }
   if (panel) {
     const bool fuse_out = out_dim <= 32;
+    // bf16 operands: one bf16 copy of the hidden-layer weights per call (the panels then stream half the bytes, unconverted)
+    const unsigned short* wh[DM_MAX_MLP_LAYERS] = {};
+    if (dm_cur_precision() && in_dim <= 4096 && (in_dim & 7) == 0) {
+      DmArena ar(ws, ws_bytes);
+      ar.take(DM_SPLITK_FLOATS);
+      ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * 2);
+      const float* src[DM_MAX_MLP_LAYERS];
+      unsigned short* dst[DM_MAX_MLP_LAYERS];
+      int rws[DM_MAX_MLP_LAYERS], cls[DM_MAX_MLP_LAYERS];
+      for (int l = 0; l < layers; ++l) {
+        const int k = l == 0 ? in_dim : hidden;
+        src[l] = p->w[l]; rws[l] = hidden; cls[l] = k;
+        dst[l] = (unsigned short*)ar.take(((size_t)hidden * k + 1) / 2);
+      }
+      if (ar.ok) {
+        DM_TRY(dm_panel_bf16_weights_launch(layers, src, dst, rws, cls, 0, st));
+        for (int l = 0; l < layers; ++l) wh[l] = dst[l];
+      }
+    }
     for (int l = 0; l < layers; ++l) {
       const bool last = l == layers - 1;
       const bool fo = last && fuse_out;
       DM_TRY(dm_panel_ln_fwd_launch(rows, hidden, kin, in, ldin, p->w[l], p->b[l], p->ln_g[l], p->ln_b[l], 1e-3f,
                                     acts ? a.xpre[l] : nullptr, acts ? a.stats[l] : nullptr,
                                     (fo && !acts) ? nullptr : a.y[l], fo ? p->w[layers] : nullptr,
-                                    fo ? p->b[layers] : nullptr, out, out_dim, ldout, st));
+                                    fo ? p->b[layers] : nullptr, out, out_dim, ldout, st, wh[l]));
       in = a.y[l]; ldin = hidden; kin = hidden;
     }
     if (fuse_out) return DM_OK;
@@ -143,6 +163,21 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
   float* colpart = ar.take(panel ? (size_t)layers * npanels * 3 * hidden : 0);
   float* wt = (panel && dm_cur_precision()) ? ar.take((size_t)hidden * hidden) : nullptr;
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "mlp_head_bwd: workspace too small (need %zu floats)", ar.off);
+  // bf16 operands: bf16 copies of W_l^T (hidden x hidden, l >= 1) for the data-gradient panels, one launch for all layers
+  const unsigned short* wth[DM_MAX_MLP_LAYERS] = {};
+  if (panel && dm_cur_precision() && (hidden & 7) == 0 && layers > 1) {
+    const float* src[DM_MAX_MLP_LAYERS];
+    unsigned short* dst[DM_MAX_MLP_LAYERS];
+    int rws[DM_MAX_MLP_LAYERS], cls[DM_MAX_MLP_LAYERS];
+    for (int l = 1; l < layers; ++l) {
+      src[l - 1] = p->w[l]; rws[l - 1] = hidden; cls[l - 1] = hidden;          // destination (in x out) = W_l^T, W_l is (out x in)
+      dst[l - 1] = (unsigned short*)ar.take(((size_t)hidden * hidden + 1) / 2);
+    }
+    if (ar.ok) {
+      DM_TRY(dm_panel_bf16_weights_launch(layers - 1, src, dst, rws, cls, 1, st));
+      for (int l = 1; l < layers; ++l) wth[l] = dst[l - 1];
+    }
+  }
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
   if (panel) {
@@ -177,7 +212,7 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
       if (l > 0) {
         DM_TRY(dm_panel_ln_bwd_launch(rows, hidden, hidden, cur, hidden, p->w[l], a.xpre[l - 1], a.stats[l - 1],
                                       p->ln_g[l - 1], p->ln_b[l - 1], other, colpart + (size_t)(l - 1) * npanels * 3 * hidden,
-                                      wt, st));
+                                      wt, st, wth[l]));
         float* t = cur; cur = other; other = t;
       } else if (dx) {
         DmGemm d;   // d(in)[r][i] = sum_h dxp_0[r][h] W_0[h][i]

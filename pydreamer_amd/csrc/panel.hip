@@ -35,6 +35,7 @@ struct PanelArgs {
   const float* wout; const float* bout; float* out; int out_dim, ldout;
   // EPI_LN_BWD inputs / outputs
   const float* xin; const float* stin; float* dx; int lddx; float* colpart;
+  const unsigned short* Bh;      // bf16 copy of B ([n][k], row stride ldb elements; K % 8 == 0), bf16-operand kernel only
 };
 
 __device__ __forceinline__ float panel_red16(float v) {      // sum over the 16 lanes that share lane>>4
@@ -362,9 +363,13 @@ __global__ void __launch_bounds__(256, 2) panel_linear_kernel(const PanelArgs g)
 // MFMAs of 32 cycles per 32-k tile, so the loop is no longer matrix-pipe bound: LDS is double-buffered (one barrier per
 // tile; 2 x 37 KB, two workgroups per CU) and the kernel runs at the rate its fp32 operands stream in.
 constexpr int PANEL_LDH = 40;         // bf16 row stride of the [row][k] images (80 bytes: 16-byte aligned fragments)
-template <int NBLK, int EPI, bool AVEC>
+// BH: the weights come as a bf16 copy (dm_panel_bf16_weights_launch: one conversion per call instead of one per panel):
+// a B tile is 6.25 16-byte loads per thread that go to LDS as they are, instead of 12.5 float4 loads + conversions.
+template <int NBLK, int EPI, bool AVEC, bool BH>
 __global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelArgs g) {
   typedef PanelB<NBLK, 0> PB;
+  constexpr int BH_TOTAL = NBLK * 16 * 4;                   // 16-byte groups per tile: 400 rows x 4
+  constexpr int BH_N = (BH_TOTAL + 255) / 256;
   constexpr int A_H = PANEL_BM * PANEL_LDH, B_H = NBLK * 16 * PANEL_LDH;            // bf16 elements per buffer
   constexpr int MAIN_BYTES = 2 * (A_H + B_H) * 2;
   constexpr int RED_BYTES = (EPI == PANEL_EPI_LN_BWD) ? 4 * 3 * NBLK * 16 * 4 : 0;
@@ -379,9 +384,25 @@ __global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelAr
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[2], rb[PB::NF4];
+  float4 ra[2], rb[BH ? 1 : PB::NF4];
+  uint4 rh[BH ? BH_N : 1];
   unsigned ma = 0u, mb = 0u;
   const int nkt = (g.K + 31) / 32;
+  auto load_b = [&](int k0) {
+    if constexpr (BH) {
+      mb = 0u;
+#pragma unroll
+      for (int i = 0; i < BH_N; ++i) {
+        const int f = tid + i * 256;
+        const int n = f >> 2, k = k0 + ((f & 3) << 3);
+        const bool ok = f < BH_TOTAL && k < g.K;            // K % 8 == 0 (host-checked): a group is all in or all out
+        rh[i] = *reinterpret_cast<const uint4*>(g.Bh + (ok ? (size_t)n * g.ldb + k : 0));
+        mb |= ok ? (1u << i) : 0u;
+      }
+    } else {
+      PB::load(rb, mb, g, k0, tid);
+    }
+  };
   auto stash = [&](int buf) {         // registers -> bf16 LDS images of buffer `buf`
     unsigned short* Ah = hbase + buf * (A_H + B_H);
     unsigned short* Bh = Ah + A_H;
@@ -395,21 +416,30 @@ __global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelAr
       v.w = (ma >> (4 * i + 3)) & 1u ? ra[i].w : 0.f;
       *reinterpret_cast<uint2*>(&Ah[(f >> 3) * PANEL_LDH + ((f & 7) << 2)]) = dm_pack_bf16x4(v);
     }
+    if constexpr (BH) {
 #pragma unroll
-    for (int i = 0; i < PB::NF4; ++i) {
-      const int f = tid + i * 256;
-      if (f < PB::TOTAL) {
-        const float4 v = (mb >> i) & 1u ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<uint2*>(&Bh[(f >> 3) * PANEL_LDH + ((f & 7) << 2)]) = dm_pack_bf16x4(v);
+      for (int i = 0; i < BH_N; ++i) {
+        const int f = tid + i * 256;
+        if (f < BH_TOTAL)
+          *reinterpret_cast<uint4*>(&Bh[(f >> 2) * PANEL_LDH + ((f & 3) << 3)]) = (mb >> i) & 1u ? rh[i] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PB::NF4; ++i) {
+        const int f = tid + i * 256;
+        if (f < PB::TOTAL) {
+          const float4 v = (mb >> i) & 1u ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<uint2*>(&Bh[(f >> 3) * PANEL_LDH + ((f & 7) << 2)]) = dm_pack_bf16x4(v);
+        }
       }
     }
   };
   panel_load_a<AVEC>(ra, ma, g, m0, 0, tid);
-  PB::load(rb, mb, g, 0, tid);
+  load_b(0);
   stash(0);
   if (nkt > 1) {
     panel_load_a<AVEC>(ra, ma, g, m0, 32, tid);
-    PB::load(rb, mb, g, 32, tid);
+    load_b(32);
   }
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
@@ -418,7 +448,7 @@ __global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelAr
       stash(cur ^ 1);                                   // tile kt+1 (its loads had the whole previous iteration to land)
       if (kt + 2 < nkt) {
         panel_load_a<AVEC>(ra, ma, g, m0, (kt + 2) * 32, tid);
-        PB::load(rb, mb, g, (kt + 2) * 32, tid);
+        load_b((kt + 2) * 32);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -433,6 +463,44 @@ __global__ void __launch_bounds__(256, 2) panel_linear_bf16_kernel(const PanelAr
     __syncthreads();
   }
   panel_epilogue<NBLK, EPI>(acc, g, reinterpret_cast<float*>(smem_raw), m0, tid);
+}
+
+// bf16 copies of weight matrices for the bf16-operand panels: dst[n][k] = bf16(W[n][k]) (TR = 0) or bf16(W[k][n]) (TR = 1: the
+// backward's transposed weights in the same pass).  One launch per MLP call, all layers.
+struct PanelCvtArgs {
+  const float* w[DM_MAX_MLP_LAYERS + 1];
+  unsigned short* dst[DM_MAX_MLP_LAYERS + 1];
+  int rows[DM_MAX_MLP_LAYERS + 1], cols[DM_MAX_MLP_LAYERS + 1];      // destination shape (rows x cols, cols contiguous)
+  unsigned first[DM_MAX_MLP_LAYERS + 2];
+  int count, transpose;
+};
+__global__ void __launch_bounds__(256) panel_cvt_bf16_kernel(const PanelCvtArgs a) {
+  const unsigned total = a.first[a.count];
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < a.count && e >= a.first[l + 1]) ++l;
+    const unsigned r = e - a.first[l];
+    const int cols = a.cols[l], rows = a.rows[l];
+    const int n = r / cols, k = r % cols;
+    const float v = a.transpose ? a.w[l][(size_t)k * rows + n] : a.w[l][(size_t)n * cols + k];
+    a.dst[l][r] = (unsigned short)dm_f2bf(v);
+  }
+}
+int dm_panel_bf16_weights_launch(int count, const float* const* w, unsigned short* const* dst, const int* rows, const int* cols,
+                                 int transpose, hipStream_t st) {
+  DM_REQUIRE(count >= 1 && count <= DM_MAX_MLP_LAYERS + 1, DM_E_SHAPE, "panel_bf16_weights: count %d", count);
+  PanelCvtArgs a = {};
+  unsigned first = 0;
+  for (int i = 0; i < count; ++i) {
+    a.w[i] = w[i]; a.dst[i] = dst[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.first[i] = first;
+    first += (unsigned)rows[i] * (unsigned)cols[i];
+  }
+  a.first[count] = first; a.count = count; a.transpose = transpose;
+  int blocks = dm_cdiv(first, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(panel_cvt_bf16_kernel, dim3(blocks), dim3(256), 0, st, a);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
 }
 
 // out_t[col] = sum_p colpart_t[p][col] for up to 3*DM_MAX_MLP_LAYERS column vectors in ONE launch (fixed order).
@@ -477,9 +545,11 @@ int dm_panel_count(int rows) { return dm_cdiv(rows, PANEL_BM); }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // y = ELU(LN(x W^T + b)) for rows x hidden; xpre / stats / y / fused output layer optional.
+// Wh (optional): bf16 copy of W (dm_panel_bf16_weights_launch) for the bf16-operand kernel
 int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ldx, const float* W, const float* b,
                            const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
-                           const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st) {
+                           const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st,
+                           const unsigned short* Wh) {
   DM_REQUIRE(hidden == 400, DM_E_SHAPE, "panel_ln_fwd: hidden %d (built for 400)", hidden);
   DM_REQUIRE((kin & 3) == 0 && al16(W), DM_E_SHAPE, "panel_ln_fwd: weight rows must be 16-byte aligned (kin %d)", kin);
   if (rows <= 0) return DM_OK;
@@ -494,8 +564,10 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
                                       4.0 * ((double)rows * kin + (double)hidden * kin + (double)rows * hidden * (xpre ? 2 : 1)), st);
   const bool avec = (ldx & 3) == 0 && al16(x);
   if (dm_cur_precision()) {
-    if (avec) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, false>), grid, blk, 0, st, a);
+    a.Bh = Wh;
+    if (Wh && avec && (kin & 7) == 0 && al16(Wh)) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true, true>), grid, blk, 0, st, a);
+    else if (avec) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, false, false>), grid, blk, 0, st, a);
   } else if (avec) hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, false>), grid, blk, 0, st, a);
   dm_prof_slot_end(slot, st);
@@ -509,7 +581,7 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
 // weights are transposed into it once and the product runs on the bf16 main loop, which wants them [n][k].
 int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,
                            const float* stats, const float* gamma, const float* beta, float* dx, float* colpart, float* wt,
-                           hipStream_t st) {
+                           hipStream_t st, const unsigned short* Wth) {
   DM_REQUIRE(hidden == 400, DM_E_SHAPE, "panel_ln_bwd: hidden %d (built for 400)", hidden);
   DM_REQUIRE(al16(W), DM_E_SHAPE, "panel_ln_bwd: weight must be 16-byte aligned");
   if (rows <= 0) return DM_OK;
@@ -522,10 +594,13 @@ int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int 
   const int slot = dm_prof_slot_begin(21, 2.0 * rows * hidden * (double)kup,
                                       4.0 * ((double)rows * kup + (double)hidden * kup + 2.0 * rows * hidden), st);
   const bool avec = (kup & 3) == 0 && (lddup & 3) == 0 && al16(dup);
-  if (dm_cur_precision() && wt && avec && kup >= 32 && al16(wt)) {
+  if (dm_cur_precision() && Wth && avec && kup >= 32 && (kup & 7) == 0 && al16(Wth)) {
+    a.Bh = Wth; a.ldb = kup;          // bf16 copy of W^T (hidden x kup), made once per call by the caller
+    hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_BWD, true, true>), grid, blk, 0, st, a);
+  } else if (dm_cur_precision() && wt && avec && kup >= 32 && al16(wt)) {
     DM_TRY(dm_permute4_launch(W, wt, 1, 1, kup, hidden, 0, 1, 3, 2, st));       // W (kup x hidden) -> wt (hidden x kup)
     a.B = wt; a.ldb = kup;
-    hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_BWD, true>), grid, blk, 0, st, a);
+    hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_BWD, true, false>), grid, blk, 0, st, a);
   } else if (avec)
     hipLaunchKernelGGL((panel_linear_kernel<25, 1, PANEL_EPI_LN_BWD, true>), grid, blk, 0, st, a);
   else
