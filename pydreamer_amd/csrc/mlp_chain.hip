@@ -1,25 +1,28 @@
 // Whole-MLP forward in ONE launch for the 400-wide heads at small and mid row counts (common.py:37-65; a2c.py:37-39;
 // decoders.py:257-319):   [Linear -> LayerNorm(eps) -> ELU] x L  ->  Linear(out_dim <= 32)
 //
-// Where it runs: the actor inside the imagination rollout (M = T*B = 2500 rows per horizon step, dreamer.py:188-216), the
-// reward / terminal heads over the T*B posterior features, and every head at a data-parallel shard's row counts.  There
-// the per-layer form costs 3 launches per layer (GEMM + split-K reduce or LayerNorm) on N = 400-wide products that the
-// tiled GEMM runs at 30-55 TF/s, 13 dependent launches for the actor - 15 times per step on the critical stream.
+// Where it runs (rows >= dm_mlp_chain_min_rows, default 1024, below the row-panel threshold): the actor inside the
+// imagination rollout (M = T*B = 2500 rows per horizon step, dreamer.py:188-216) and the reward / terminal heads over the
+// T*B posterior features.  There the per-layer form costs 3 launches per layer (GEMM + split-K reduce or LayerNorm) on
+// N = 400-wide products that the tiled GEMM runs at 30-55 TF/s: 13 dependent launches for the actor, 15 times per step.
 //
 // Tiling: a workgroup owns 16 COMPLETE rows through all layers; the activation row block lives in LDS between layers and
 // never visits HBM unless the caller wants it saved for backward.  Inside a layer the 4 waves split the 25 column blocks
-// (7 + 6 + 6 + 6; v_mfma_f32_16x16x4_f32, <= 28 accumulator registers) and walk K together, so every weight element is
-// read exactly once per workgroup, straight from L2 into the MFMA operand layout (lane l: weight row 16*blk + (l&15),
-// k = 32*pair + 16*half + 4*(l>>4) .. +3 - one 16-byte load feeds 4 MFMAs).  The unit of the software pipeline is a PAIR
-// of 16-k groups: a lane's two loads of a pair touch adjacent 64-byte halves, so the second is an L1 hit and the L2->L1
-// port (64 B/clk/CU) carries every weight line once - a first version with K split across the waves brought each line up
-// twice and sat on that port at 250 us for the 2500-row actor.  Two pairs of loads are in flight under a pair's 56 MFMAs.
-// LayerNorm needs whole rows: the waves exchange per-row partial sums through LDS (two-pass variance), normalise their
-// own columns in registers, write the next layer's LDS block, and after the last layer reduce the output layer's dot
-// products the same way.
+// (7 + 6 + 6 + 6; v_mfma_f32_16x16x4_f32, <= 28 accumulator registers) and walk K together in PAIRS of 16-k groups, so
+// every weight element is read exactly once per workgroup.  The weights come from a FRAGMENT-MAJOR copy
+// (dm_mlp_chain_pack_launch, once per rollout): the 64 lanes of one load read one contiguous KiB in the MFMA operand
+// order (lane l: weight row 16*blk + (l&15), k = 32*pair + 16*half + 4*(l>>4) .. +3; with bf16 operands a lane's 8 values
+// are ONE 16-byte load, already rounded).  Gathering the same fragments from the row-major weights (16 rows x 64 B per
+// instruction) runs at 16.6 B/clk/CU whatever the cache level - the kernel then streams its 4.5 MB at 40 GB/s per CU,
+// 140 us in fp32 and no faster in bf16; a still earlier version with K split across the waves brought every line up from
+// L2 twice (250 us).  Two pairs of loads are in flight under a pair's 56 MFMAs (buffer loads: scalar base + one vector
+// offset).  LayerNorm needs whole rows: the waves exchange per-row partial sums through LDS (two-pass variance),
+// normalise their own columns in registers, write the next layer's LDS block; the output layer is one more small MFMA
+// product with all loads issued up front.
 //
-// Work split: ceil(rows/16) workgroups - 157 for the 2500-row rollout step; the kernel is bound by one CU's matrix pipes
-// walking 16 x 1.13 M MACs (the 7-block wave: 102 + 3*25 groups x 28 MFMAs x 32 clk = 158 k cycles = 66 us).
+// Work split: ceil(rows/16) workgroups - 157 for the 2500-row rollout step; a row block costs 16 x 1.13 M MACs whatever
+// the tiling (the 7-block wave: 102 + 3*25 groups x 28 MFMAs x 32 clk = 158 k cycles = 66 us in fp32).  Measured per
+// 2500-row call: 130 us fp32, 65 us bf16 (per-layer launches: 167 / 136).
 #include "common.h"
 #include <stdlib.h>
 
