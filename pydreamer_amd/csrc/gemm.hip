@@ -583,8 +583,14 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     }
     if (sp_fill > kt1) sp_fill = kt1;
     if (sp_fill < 1) sp_fill = 1;
-    const int sps[4] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill};
-    for (int pass = 0; pass < 4; ++pass) {
+    // grids of a few tiles also try 1.5x and 2x the fill split: a long reduction on few tiles is latency /
+    // bandwidth bound per workgroup (per_kt = lat_macs below), so more, shorter workgroups per CU finish sooner
+    // (decoder layer-4 weight gradient 48 x 144 x 2.25 M: 1096 -> 700 us); DM_GEMM_NO_WIDE_SPLIT=1 restores {1, fill}
+    static const int no_wide = getenv("DM_GEMM_NO_WIDE_SPLIT") ? 1 : 0;
+    const bool wide = t < 16 && !no_wide;          // (at 16+ tiles the extra partial traffic loses: 400 x 400 x 40 000 196 -> 225 us)
+    const int sp15 = wide ? sp_fill + sp_fill / 2 : sp_fill, sp20 = wide ? 2 * sp_fill : sp_fill;
+    const int sps[6] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill, sp15, sp20};
+    for (int pass = 0; pass < 6; ++pass) {
       int sp = force_split > 0 ? force_split : sps[pass];
       if (force_split <= 0 && sp > max_split) sp = max_split;
       if (sp > kt1) sp = kt1;

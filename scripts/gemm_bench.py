@@ -34,6 +34,7 @@ SHAPES = [
     (0, 1, 2250000, 108, 48, 'dec L4 Ycol'),
     (0, 0, 422500, 96, 1728, 'dec L3 dX'),
     (1, 1, 96, 1728, 422500, 'dec L3 dW'),
+    (1, 1, 48, 144, 2250000, 'dec L4 dW (cout padded to 4)'),
     # data-parallel shard (B = 7 of 50 columns): imagination products at M = T*B/8 = 350 rows
     (0, 0, 350, 1000, 1024, 'shard dream z_mlp'),
     (0, 0, 350, 1800, 1000, 'shard dream gru ih'),
