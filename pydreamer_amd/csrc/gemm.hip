@@ -589,8 +589,16 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     static const int no_wide = getenv("DM_GEMM_NO_WIDE_SPLIT") ? 1 : 0;
     const bool wide = t < 16 && !no_wide;          // (at 16+ tiles the extra partial traffic loses: 400 x 400 x 40 000 196 -> 225 us)
     const int sp15 = wide ? sp_fill + sp_fill / 2 : sp_fill, sp20 = wide ? 2 * sp_fill : sp_fill;
-    const int sps[6] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill, sp15, sp20};
-    for (int pass = 0; pass < 6; ++pass) {
+    // ... and the BALANCED splits floor(256 k / tiles), k = 2..5: just under k workgroups on EVERY CU.  When all workgroups
+    // of a launch are resident at once it ends with its fullest CU, so the load model below takes ceil(workgroups per CU)
+    // there: 52 tiles x 10 splits = 520 workgroups leave 8 CUs with 3 and run 1.5x longer than 52 x 19 = 988 (3.86 per CU).
+    // Measured: 400 x 1624 x 40 000 820 -> 602 us, 96 x 1728 x 422 500 1889 -> 1301 us, 96 x 768 x 490 000 928 -> 702 us,
+    // no shape slower, step -0.46 ms.  DM_GEMM_NO_BALANCED_SPLIT=1 restores the previous candidate set and fractional load.
+    static const int balanced = getenv("DM_GEMM_NO_BALANCED_SPLIT") ? 0 : 1;
+    int sps[10] = {1, sp_fill, t >= 256 ? 2 : sp_fill, t >= 256 ? 4 : sp_fill, sp15, sp20, sp_fill, sp_fill, sp_fill, sp_fill};
+    if (balanced && t < 256)
+      for (int k = 2; k <= 5; ++k) sps[4 + k] = (int)((256 * k) / t) > 0 ? (int)((256 * k) / t) : 1;
+    for (int pass = 0; pass < 10; ++pass) {
       int sp = force_split > 0 ? force_split : sps[pass];
       if (force_split <= 0 && sp > max_split) sp = max_split;
       if (sp > kt1) sp = kt1;
@@ -598,7 +606,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
       const double avg = (double)(t * sp) / 256.0;
       const double R = resid[c];
       const double waves = avg > R ? ceil(avg / R) : 1.0;
-      const double conc = avg > R ? avg / waves : (avg > 1.0 ? avg : 1.0);
+      const double conc = avg > R ? avg / waves : (avg > 1.0 ? (balanced ? ceil(avg - 1e-9) : avg) : 1.0);
       const double nkt = (double)dm_cdiv(kt1, sp);
       const double tm = (double)bm * bn * 32.0 / rate[c];
       const double per_kt = conc * tm > lat_macs ? conc * tm : lat_macs;
