@@ -175,6 +175,7 @@ def main():
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
+    ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -267,6 +268,21 @@ def main():
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
+        if args.shape_table:        # per-shape table of the profiled pass (diagnostic, stderr / file)
+            cap = 8192 * args.prof_steps
+            rows = (ctypes.c_double * (8 * cap))()
+            nr = hip.lib().dm_prof_rows(rows, cap)
+            agg = {}
+            for i in range(nr):
+                r = rows[8 * i:8 * i + 8]
+                key = tuple(int(x) for x in r[:6])
+                a = agg.setdefault(key, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += r[6]; a[2] += r[7]
+            with open(args.shape_table, 'w') as f:
+                f.write('kind M N K split flags launches/step ms/step us/launch TF/s\n')
+                for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                    f.write(' '.join(str(x) for x in key) + f' {a[0] / args.prof_steps:.1f} {a[2] / args.prof_steps:.3f} '
+                            f'{1e3 * a[2] / a[0]:.1f} {a[1] / (a[2] * 1e-3) / 1e12 if a[2] > 0 else 0:.1f}\n')
         out = (ctypes.c_double * 92)()
         n = hip.lib().dm_prof_end(out, 23)
         kinds = []

@@ -320,6 +320,9 @@ int dm_mlp_chain_min_rows(int rows);
  * number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
+/* Per-launch rows of the armed region (call before dm_prof_end): rows[i*8 + {0..7}] = {kind, M, N, K, split count, flags
+ * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands), flops, milliseconds}; returns the row count. */
+int dm_prof_rows(double* rows, int max_rows);
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
 

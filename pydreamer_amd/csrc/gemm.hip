@@ -419,6 +419,7 @@ struct GemmProf {
   bool on = false;
   size_t cap = 0, n = 0;
   std::vector<hipEvent_t> ev;      // 2 per slot
+  std::vector<long long> shape;    // 5 per slot: M, N, K, split count, gather/scatter flags (bench.py --shape-table)
   std::vector<double> flops, bytes;
   std::vector<int> kind;
 };
@@ -449,10 +450,29 @@ extern "C" int dm_prof_begin(int max_launches) {
   g_prof.flops.assign(max_launches, 0.0);
   g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
+  g_prof.shape.assign(5 * (size_t)max_launches, 0);
   g_prof.cap = max_launches;
   g_prof.n = 0;
   g_prof.on = true;
   return DM_OK;
+}
+// Per-launch rows of the profiled region, BEFORE dm_prof_end: rows[i*8 + {0..7}] = {kind, M, N, K, split count, flags
+// (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands), flops, milliseconds}; M = 0 for the non-GEMM kinds
+// (row panels, whole-MLP kernel).  Returns the number of rows written (<= max_rows).  Synchronises on the events.
+extern "C" int dm_prof_rows(double* rows, int max_rows) {
+  DM_REQUIRE(rows && max_rows > 0, DM_E_NULL, "prof_rows: null output");
+  int n = 0;
+  for (size_t i = 0; i < g_prof.n && n < max_rows; ++i, ++n) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return dm_fail(DM_E_HIP, "prof_rows: event sync failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      return dm_fail(DM_E_HIP, "prof_rows: hipEventElapsedTime failed");
+    double* r = rows + 8 * (size_t)n;
+    r[0] = g_prof.kind[i];
+    for (int j = 0; j < 5; ++j) r[1 + j] = (double)g_prof.shape[5 * i + j];
+    r[6] = g_prof.flops[i]; r[7] = ms;
+  }
+  return n;
 }
 // out[kind*4 + {0,1,2,3}] = {launches, flops, milliseconds, algorithmic bytes (4*(M*K + N*K + M*N))} for
 // kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x96, 4: 96x128); returns the number of recorded launches
@@ -636,6 +656,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   const int kind = tc * 4 + q.a_layout * 2 + q.b_layout;
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K,
                                4.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N), stream);
+  if (slot >= 0) {
+    long long* sh = &g_prof.shape[5 * (size_t)slot];
+    sh[0] = q.M; sh[1] = q.N; sh[2] = q.K; sh[3] = nsplit; sh[4] = (q.a_maj ? 1 : 0) | (q.b_maj ? 2 : 0) | (q.c_tab ? 4 : 0) | (q.bf16 ? 8 : 0);
+  }
   int rc;
   const bool vec = a.a_vec && a.b_vec;
   if (vec && q.bf16) {

@@ -142,28 +142,47 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
   if (LNB) {
     // row terms of the LayerNorm backward: mean / rstd from the forward's statistics, mean(g) and mean(g xhat) over the row
     for (int e = tid; e < g.K; e += SK_WAVES * 64) { sh->lng[e] = g.ln_g[e]; sh->lnb[e] = g.ln_b[e]; }
-    for (int rr = wave; rr < 16 * NRB; rr += SK_WAVES) {
-      const int row = m0 + rr;
-      const bool rok = row < g.M;
-      const float* dr = g.A + (size_t)(rok ? row : 0) * g.lda;
-      const float* xr = g.lnb_x + (size_t)(rok ? row : 0) * g.lnb_ldx;
-      const float mean = g.lnb_stats[2 * (size_t)(rok ? row : 0)], rstd = g.lnb_stats[2 * (size_t)(rok ? row : 0) + 1];
-      float sg = 0.f, sgx = 0.f;
+    // A wave's rows (wave, wave + 16, ...; NRB of them) are reduced TOGETHER: the loads of all of them for a column batch
+    // are in flight at once and gamma / beta are fetched once per column (one row at a time this prologue was a chain of
+    // ~16 dependent load rounds per workgroup: 49 -> 3x us on the BPTT products)
+    {
+      const float* dr[NRB]; const float* xr[NRB];
+      float mean[NRB], rstd[NRB], sg[NRB], sgx[NRB];
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) {
+        const int row = m0 + wave + SK_WAVES * i;
+        const size_t rc = row < g.M ? (size_t)row : 0;
+        dr[i] = g.A + rc * g.lda;
+        xr[i] = g.lnb_x + rc * g.lnb_ldx;
+        mean[i] = g.lnb_stats[2 * rc]; rstd[i] = g.lnb_stats[2 * rc + 1];
+        sg[i] = 0.f; sgx[i] = 0.f;
+      }
 #pragma unroll 4
       for (int j = 0; j < SK_LN_MAXK / 64; ++j) {
         const int cidx = lane + 64 * j;
-        if (cidx < g.K) {
-          const float ga = g.ln_g[cidx];
-          const float xh = (xr[cidx] - mean) * rstd;
-          const float pre = xh * ga + g.ln_b[cidx];
-          const float gg = dr[cidx] * (pre > 0.f ? 1.f : __expf(pre)) * ga;
-          sg += gg;
-          sgx += gg * xh;
+        const bool cin = cidx < g.K;
+        const int cc = cin ? cidx : 0;
+        const float ga = g.ln_g[cc], be = g.ln_b[cc];
+        float dv[NRB], xv[NRB];
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) { dv[i] = dr[i][cc]; xv[i] = xr[i][cc]; }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+          const float xh = (xv[i] - mean[i]) * rstd[i];
+          const float pre = xh * ga + be;
+          const float gg = cin ? dv[i] * (pre > 0.f ? 1.f : __expf(pre)) * ga : 0.f;
+          sg[i] += gg;
+          sgx[i] += gg * xh;
         }
       }
-      sg = dm_wave_sum(sg) / (float)g.K;
-      sgx = dm_wave_sum(sgx) / (float)g.K;
-      if (lane == 0) { sh->lnstat[rr][0] = mean; sh->lnstat[rr][1] = rstd; sh->lnstat[rr][2] = sg; sh->lnstat[rr][3] = sgx; }
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) {
+        const float a0 = dm_wave_sum(sg[i]) / (float)g.K, a1 = dm_wave_sum(sgx[i]) / (float)g.K;
+        if (lane == 0) {
+          const int rr = wave + SK_WAVES * i;
+          sh->lnstat[rr][0] = mean[i]; sh->lnstat[rr][1] = rstd[i]; sh->lnstat[rr][2] = a0; sh->lnstat[rr][3] = a1;
+        }
+      }
     }
     __syncthreads();
   }

@@ -164,6 +164,7 @@ _SIGNATURES = {
     'dm_axpby': (c_int, [c_int64, c_float, _P, c_float, _P, _P]),
     'dm_prof_begin': (c_int, [c_int]),
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
+    'dm_prof_rows': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
 }
 

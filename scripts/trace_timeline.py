@@ -23,11 +23,14 @@ busy += ce - cs
 print(f'step {1e-6 * (e - s):.2f} ms, {len(st)} kernels, busy union {1e-6 * busy:.2f} ms, sum {1e-6 * sum(b - a for a, b, _, _ in st):.2f} ms')
 tot = collections.Counter()
 cnt = collections.Counter()
+durs = collections.defaultdict(list)
 for a, b, n, q in st:
     tot[n[:70]] += b - a
     cnt[n[:70]] += 1
+    durs[n[:70]].append(b - a)
 for n, d in tot.most_common(22):
-    print(f'  {n:70s} {cnt[n]:5d} {d / 1e6:7.2f} ms {d / cnt[n] / 1e3:8.1f} us')
+    ds = sorted(durs[n])
+    print(f'  {n:70s} {cnt[n]:5d} {d / 1e6:7.2f} ms {d / cnt[n] / 1e3:8.1f} us  (median {ds[len(ds) // 2] / 1e3:.1f}, min {ds[0] / 1e3:.1f})')
 bins = collections.defaultdict(collections.Counter)
 for a, b, n, q in st:
     bins[int((a - s) / 1e6)][(n[:34], q)] += b - a
