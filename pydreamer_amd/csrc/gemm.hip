@@ -592,7 +592,9 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   double best_cost = -1.0;
   const int kt1 = ktiles > 0 ? ktiles : 1;
   for (int c = 0; c < 5; ++c) {
+    static const int sc_tile = getenv("DM_SC_TILE") ? atoi(getenv("DM_SC_TILE")) : 0;      // tuning override: scatter-epilogue products only
     if (force_tile && c != force_tile - 1) continue;
+    if (sc_tile && q.c_tab && c != sc_tile - 1) continue;
     if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
     const int bm = cand[c][0], bn = cand[c][1];
     const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
@@ -632,6 +634,14 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
       const double per_kt = conc * tm > lat_macs ? conc * tm : lat_macs;
       double cost = waves * (nkt * per_kt + conc * bm * bn * keq[c] / rate[c]);
       if (sp > 1) cost += 0.4 * sp * out_elems + 1.2e6;
+      // scatter-epilogue products (gather-form transposed convolution): the epilogue (table look-ups, 4 parity classes) is
+      // dearer per tile than the model's, which was fitted to plain stores.  Measured on the step's three such products
+      // (DM_SC_TILE sweep): 562500x192x384 1176 -> 1051 us and 122500x384x768 981 -> 837 us on 64x64, 562500x192x864
+      // 2214 -> 2087 us on 128x96
+      if (q.c_tab) {
+        if (c == 2 && q.K <= 800) cost *= 0.8;
+        if (c == 3 && q.N % 96 == 0 && q.K > 800) cost *= 0.8;
+      }
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
     }
   }
