@@ -595,6 +595,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     static const int sc_tile = getenv("DM_SC_TILE") ? atoi(getenv("DM_SC_TILE")) : 0;      // tuning override: scatter-epilogue products only
     if (force_tile && c != force_tile - 1) continue;
     if (sc_tile && q.c_tab && c != sc_tile - 1) continue;
+    static const int ga_tile = getenv("DM_GA_TILE") ? atoi(getenv("DM_GA_TILE")) : 0;      // tuning override: gathered-operand products
+    if (ga_tile && !q.c_tab && (q.a_maj || q.b_maj) && c != ga_tile - 1) continue;
     if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
     const int bm = cand[c][0], bn = cand[c][1];
     const int64_t t = (int64_t)dm_cdiv(q.M, bm) * dm_cdiv(q.N, bn);
@@ -638,6 +640,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
       // dearer per tile than the model's, which was fitted to plain stores.  Measured on the step's three such products
       // (DM_SC_TILE sweep): 562500x192x384 1176 -> 1051 us and 122500x384x768 981 -> 837 us on 64x64, 562500x192x864
       // 2214 -> 2087 us on 128x96
+      if (q.a_maj && !q.c_tab && q.N <= 64 && c == 2) cost *= 0.8;      // gathered patches x <= 64 channels (DM_GA_TILE sweep): 2250000x48x144 742 -> 597 us
       if (q.c_tab) {
         if (c == 2 && q.K <= 800) cost *= 0.8;
         if (c == 3 && q.N % 96 == 0 && q.K > 800) cost *= 0.8;
