@@ -595,6 +595,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
     static const int sc_tile = getenv("DM_SC_TILE") ? atoi(getenv("DM_SC_TILE")) : 0;      // tuning override: scatter-epilogue products only
     if (force_tile && c != force_tile - 1) continue;
     if (sc_tile && q.c_tab && c != sc_tile - 1) continue;
+    static const int plain_tile = getenv("DM_PLAIN_TILE") ? atoi(getenv("DM_PLAIN_TILE")) : 0;   // tuning override: products without gather / scatter
+    if (plain_tile && !q.c_tab && !q.a_maj && !q.b_maj && c != plain_tile - 1) continue;
     static const int ga_tile = getenv("DM_GA_TILE") ? atoi(getenv("DM_GA_TILE")) : 0;      // tuning override: gathered-operand products
     if (ga_tile && !q.c_tab && (q.a_maj || q.b_maj) && c != ga_tile - 1) continue;
     if (!(a.a_vec && a.b_vec) && c != 2) continue;        // the scalar-load variant exists for the 64x64 tile only
