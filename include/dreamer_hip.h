@@ -63,10 +63,13 @@ typedef struct dm_shape {
  * LayerNorm, losses and storage stay fp32.  Precision is a per-call argument (here, dm_mlp_params.precision, DM_GEMM_BF16);
  * there is no process-wide switch. */
 #define DM_FLAG_BF16 128
+/* bits 8-9: gru_layers - 1 (GRUCellStack depth, rnn.py:40-67; up to 4 layers, plain GRU cells only) */
+#define DM_FLAG_GRU_LAYERS_SHIFT 8
+#define DM_FLAG_GRU_LAYERS_MASK (3 << DM_FLAG_GRU_LAYERS_SHIFT)
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 2 (round 2: dm_rssm_params grew by the LayerNorm-GRU slots) */
+int dm_version(void);                 /* ABI version, currently 4 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -231,6 +234,12 @@ enum {
    * gru_layernorm: (G0,B0) = ln_reset, (G1,B1) = ln_update, (G2,B2) = ln_newval, D floats each;
    * gru_layernorm_dv2: (G0,B0) = lnorm, 3D floats */
   DM_RSSM_GRU_LN_G0, DM_RSSM_GRU_LN_B0, DM_RSSM_GRU_LN_G1, DM_RSSM_GRU_LN_B1, DM_RSSM_GRU_LN_G2, DM_RSSM_GRU_LN_B2,
+  /* GRUCellStack layers 1..3 (rnn.py:40-67, gru_layers > 1, gru_type = gru): weight_ih, weight_hh, bias_ih, bias_hh each;
+   * layer 0 is the DM_RSSM_GRU_* group above.  Layer i maps (i == 0 ? hidden : D/L) -> D/L and owns state columns
+   * [i*D/L, (i+1)*D/L). */
+  DM_RSSM_GRU_L1_WIH, DM_RSSM_GRU_L1_WHH, DM_RSSM_GRU_L1_BIH, DM_RSSM_GRU_L1_BHH,
+  DM_RSSM_GRU_L2_WIH, DM_RSSM_GRU_L2_WHH, DM_RSSM_GRU_L2_BIH, DM_RSSM_GRU_L2_BHH,
+  DM_RSSM_GRU_L3_WIH, DM_RSSM_GRU_L3_WHH, DM_RSSM_GRU_L3_BIH, DM_RSSM_GRU_L3_BHH,
   DM_RSSM_NPARAMS
 };
 typedef struct dm_rssm_params { const float* p[DM_RSSM_NPARAMS]; } dm_rssm_params;

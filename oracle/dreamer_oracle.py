@@ -110,19 +110,23 @@ def param_shapes(conf):
     s[f'{c}.z_mlp.weight'] = (Hd, Z); s[f'{c}.z_mlp.bias'] = (Hd,)
     s[f'{c}.a_mlp.weight'] = (Hd, A)
     s[f'{c}.in_norm.weight'] = (Hd,); s[f'{c}.in_norm.bias'] = (Hd,)
-    gl = f'{c}.gru.layers.0'
-    if conf.gru_type == 'gru':                                                             # nn.GRUCell, rnn.py:47-48
-        s[f'{gl}.weight_ih'] = (3 * D_, Hd); s[f'{gl}.weight_hh'] = (3 * D_, D_)
-        s[f'{gl}.bias_ih'] = (3 * D_,); s[f'{gl}.bias_hh'] = (3 * D_,)
-    elif conf.gru_type == 'gru_layernorm':                                                 # NormGRUCell, rnn.py:95-104
-        s[f'{gl}.weight_ih.weight'] = (3 * D_, Hd); s[f'{gl}.weight_hh.weight'] = (3 * D_, D_)
-        for n in ('ln_reset', 'ln_update', 'ln_newval'):
-            s[f'{gl}.{n}.weight'] = (D_,); s[f'{gl}.{n}.bias'] = (D_,)
-    elif conf.gru_type == 'gru_layernorm_dv2':                                             # NormGRUCellLateReset, rnn.py:117-125
-        s[f'{gl}.weight_ih.weight'] = (3 * D_, Hd); s[f'{gl}.weight_hh.weight'] = (3 * D_, D_)
-        s[f'{gl}.lnorm.weight'] = (3 * D_,); s[f'{gl}.lnorm.bias'] = (3 * D_,)
-    else:
-        raise ValueError(conf.gru_type)
+    GL = int(getattr(conf, 'gru_layers', 1))                                               # GRUCellStack, rnn.py:43-57
+    ls = D_ // GL
+    assert ls * GL == D_, 'Must be divisible'
+    for li in range(GL):
+        gl, kin = f'{c}.gru.layers.{li}', (Hd if li == 0 else ls)
+        if conf.gru_type == 'gru':                                                         # nn.GRUCell, rnn.py:47-48
+            s[f'{gl}.weight_ih'] = (3 * ls, kin); s[f'{gl}.weight_hh'] = (3 * ls, ls)
+            s[f'{gl}.bias_ih'] = (3 * ls,); s[f'{gl}.bias_hh'] = (3 * ls,)
+        elif conf.gru_type == 'gru_layernorm':                                             # NormGRUCell, rnn.py:95-104
+            s[f'{gl}.weight_ih.weight'] = (3 * ls, kin); s[f'{gl}.weight_hh.weight'] = (3 * ls, ls)
+            for n in ('ln_reset', 'ln_update', 'ln_newval'):
+                s[f'{gl}.{n}.weight'] = (ls,); s[f'{gl}.{n}.bias'] = (ls,)
+        elif conf.gru_type == 'gru_layernorm_dv2':                                         # NormGRUCellLateReset, rnn.py:117-125
+            s[f'{gl}.weight_ih.weight'] = (3 * ls, kin); s[f'{gl}.weight_hh.weight'] = (3 * ls, ls)
+            s[f'{gl}.lnorm.weight'] = (3 * ls,); s[f'{gl}.lnorm.bias'] = (3 * ls,)
+        else:
+            raise ValueError(conf.gru_type)
     s[f'{c}.prior_mlp_h.weight'] = (Hd, D_); s[f'{c}.prior_mlp_h.bias'] = (Hd,)
     s[f'{c}.prior_norm.weight'] = (Hd,); s[f'{c}.prior_norm.bias'] = (Hd,)
     s[f'{c}.prior_mlp.weight'] = (Z, Hd); s[f'{c}.prior_mlp.bias'] = (Z,)
@@ -277,9 +281,22 @@ def conv_decoder(p, features):
 
 
 def gru_cell(p, x, h):
-    """GRUCellStack with one layer (rnn.py:40-67): nn.GRUCell (gate order r,z,n), NormGRUCell (rnn.py:95-114) or
-    NormGRUCellLateReset (rnn.py:117-138), told apart by the parameter names of the cell."""
-    c = 'wm.core.cell.gru.layers.0'
+    """GRUCellStack (rnn.py:40-67): layer i takes the new state of layer i-1 as input and the i-th chunk of the incoming
+    state as its own state; the new states are concatenated (rnn.py:59-67)."""
+    n = 1
+    while any(k.startswith(f'wm.core.cell.gru.layers.{n}.') for k in p):
+        n += 1
+    outs = []
+    for i, hi in enumerate(h.chunk(n, -1)):
+        x = gru_layer(p, x, hi, i)
+        outs.append(x)
+    return torch.cat(outs, -1) if n > 1 else outs[0]
+
+
+def gru_layer(p, x, h, layer=0):
+    """One cell of the stack: nn.GRUCell (gate order r,z,n), NormGRUCell (rnn.py:95-114) or NormGRUCellLateReset
+    (rnn.py:117-138), told apart by the parameter names of the cell."""
+    c = f'wm.core.cell.gru.layers.{layer}'
     ln = lambda v, n: F.layer_norm(v, (v.shape[-1],), p[f'{c}.{n}.weight'], p[f'{c}.{n}.bias'], 1e-3)
     if f'{c}.lnorm.weight' in p:                               # gru_layernorm_dv2
         gates = ln(F.linear(x, p[f'{c}.weight_ih.weight']) + F.linear(h, p[f'{c}.weight_hh.weight']), 'lnorm')

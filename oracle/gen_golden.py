@@ -368,6 +368,16 @@ if __name__ == '__main__':
                      cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                      imag_horizon=t.imag_horizon, gru_type=gt), steps=2,
                 full_grads=('wm.core.cell.post_norm.weight', 'wm.core.cell.a_mlp.weight', 'ac.actor.model.12.weight'))
+    if 'gru_layers' in which:
+        # GRUCellStack with several layers (rnn.py:40-67): 3 plain GRU cells of width deter_dim/3 = 32
+        t = O.tiny_conf()
+        run('tiny_gru_layers3', ['defaults', 'atari'],
+            dict(deter_dim=96, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, gru_layers=3), steps=2,
+            full_grads=('wm.core.cell.gru.layers.0.weight_ih', 'wm.core.cell.gru.layers.1.weight_ih',
+                        'wm.core.cell.gru.layers.2.weight_hh', 'wm.core.cell.gru.layers.1.bias_hh',
+                        'wm.core.cell.z_mlp.weight', 'ac.actor.model.12.weight'))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

@@ -142,11 +142,11 @@ int dm_gru_norm_param_grads_launch(int kind, int rows, int D, const float* gs, c
 // h_frag / h_next_frag (optional, rows <= 64): fragment-major copies (dm_frag_off) of h_out and of h_next
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
                             int ldo, float* h_next, const uint8_t* next_reset, float* h_frag, float* h_next_frag,
-                            hipStream_t st);
+                            hipStream_t st, int ldg = 0, int ldn = 0);      // ldg / ldn: row strides of gi, gh / h_next (0: 3*D / D)
 // dh_in (+)= row_mask * dh_out*u  (accum: add into dh_in; row_zero: rows whose flag is set contribute 0)
 int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                             const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,
-                            const uint8_t* row_zero, hipStream_t st);
+                            const uint8_t* row_zero, hipStream_t st, int ldg = 0);
 // z_next (optional, rows x groups*C): the NEXT step's masked sample input, next_reset[r] ? 0 : onehot
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                             const int32_t* forced, float* onehot, int ldo, int32_t* idx, float* z_next,

@@ -330,12 +330,13 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
                                                             int ldh, float* __restrict__ h_out, int ldo,
                                                             float* __restrict__ h_next,
                                                             const uint8_t* __restrict__ next_reset,
-                                                            float* __restrict__ h_frag, float* __restrict__ h_next_frag) {
+                                                            float* __restrict__ h_frag, float* __restrict__ h_next_frag,
+                                                            int ldg, int ldn) {
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / D), d = (int)(i % D);
-    const float* gir = gi + (size_t)r * 3 * D;
-    const float* ghr = gh + (size_t)r * 3 * D;
+    const float* gir = gi + (size_t)r * ldg;        // ldg: row stride of the gate products (3*D, or 3*deter_dim for one layer
+    const float* ghr = gh + (size_t)r * ldg;        //      of a GRUCellStack, rnn.py:40-67)
     const float rg = dm_sigmoid(gir[d] + ghr[d]);
     const float ug = dm_sigmoid(gir[D + d] + ghr[D + d]);
     const float ng = tanhf(gir[2 * D + d] + rg * ghr[2 * D + d]);
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
     const float ho = (h - ng) * ug + ng;
     h_out[(size_t)r * ldo + d] = ho;
     const float hn = (next_reset && next_reset[r]) ? 0.f : ho;
-    if (h_next) h_next[(size_t)r * D + d] = hn;
+    if (h_next) h_next[(size_t)r * ldn + d] = hn;
     if (h_frag) h_frag[dm_frag_off(r, d)] = ho;
     if (h_next_frag) h_next_frag[dm_frag_off(r, d)] = hn;
   }
@@ -363,11 +364,11 @@ __global__ void __launch_bounds__(256) gru_gates_bwd_kernel(int rows, int D, con
                                                             int ldh, const float* __restrict__ dh_out, int lddh,
                                                             float* __restrict__ dgi, float* __restrict__ dgh,
                                                             float* __restrict__ dh_in, int lddi, int accum,
-                                                            const uint8_t* __restrict__ row_zero) {
+                                                            const uint8_t* __restrict__ row_zero, int ldg) {
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / D), d = (int)(i % D);
-    const size_t g0 = (size_t)r * 3 * D;
+    const size_t g0 = (size_t)r * ldg;
     const float ghn = gh[g0 + 2 * D + d];
     const float rg = dm_sigmoid(gi[g0 + d] + gh[g0 + d]);
     const float ug = dm_sigmoid(gi[g0 + D + d] + gh[g0 + D + d]);
@@ -648,20 +649,20 @@ int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hip
 }
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,
                             int ldo, float* h_next, const uint8_t* next_reset, float* h_frag, float* h_next_frag,
-                            hipStream_t st) {
+                            hipStream_t st, int ldg, int ldn) {
   if (rows <= 0) return DM_OK;
   DM_REQUIRE((!h_frag && !h_next_frag) || rows <= 64, DM_E_SHAPE, "gru_gates_fwd: fragment-major copies need rows <= 64");
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
-                     ldh, h_out, ldo, h_next, next_reset, h_frag, h_next_frag);
+                     ldh, h_out, ldo, h_next, next_reset, h_frag, h_next_frag, ldg > 0 ? ldg : 3 * D, ldn > 0 ? ldn : D);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
 int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                             const float* dh_out, int lddh, float* dgi, float* dgh, float* dh_in, int lddi, int accum,
-                            const uint8_t* row_zero, hipStream_t st) {
+                            const uint8_t* row_zero, hipStream_t st, int ldg) {
   if (rows <= 0) return DM_OK;
   hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
-                     ldh, dh_out, lddh, dgi, dgh, dh_in, lddi, accum, row_zero);
+                     ldh, dh_out, lddh, dgi, dgh, dh_in, lddi, accum, row_zero, ldg > 0 ? ldg : 3 * D);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -18,6 +18,9 @@ struct RssmActs {
   float *gs, *gst;      // LayerNorm GRU cells: pre-LayerNorm gate sums (N,3D) and their statistics (N,6)
 };
 static inline int rssm_gru_kind(const dm_shape* s) { return (s->flags & DM_FLAG_GRU_MASK) >> DM_FLAG_GRU_SHIFT; }
+static inline int rssm_gru_layers(const dm_shape* s) {
+  return 1 + ((s->flags & DM_FLAG_GRU_LAYERS_MASK) >> DM_FLAG_GRU_LAYERS_SHIFT);
+}
 static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
   const size_t N = (size_t)s->T * s->B, Hd = s->Hd, D = s->D, Z = (size_t)s->S * s->C;
   DmArena ar(base, (size_t)1 << 62);
@@ -44,6 +47,35 @@ static int rssm_check(const dm_shape* s) {
              DM_E_SHAPE, "rssm: bad shape");
   DM_REQUIRE((s->D & 3) == 0, DM_E_SHAPE, "rssm: deter_dim must be a multiple of 4 (got %d)", s->D);
   DM_REQUIRE(rssm_gru_kind(s) <= 2, DM_E_SHAPE, "rssm: unknown recurrent cell kind %d", rssm_gru_kind(s));
+  const int GL = rssm_gru_layers(s);
+  DM_REQUIRE(GL == 1 || rssm_gru_kind(s) == 0, DM_E_SHAPE, "rssm: gru_layers=%d needs gru_type=gru", GL);
+  DM_REQUIRE(s->D % (4 * GL) == 0, DM_E_SHAPE, "rssm: deter_dim=%d must be a multiple of 4*gru_layers (%d)", s->D, 4 * GL);
+  return DM_OK;
+}
+
+// GRUCellStack (rnn.py:40-67): L plain GRU cells of width ls = D/L.  Layer i reads x_i (x_0 = the cell input, x_i = the NEW
+// state of layer i-1) and its own slice [i*ls, (i+1)*ls) of the incoming state, and writes the same slice of the new
+// state.  The gate products of layer i live at columns [3*ls*i, 3*ls*(i+1)) of the (rows, 3D) gi / gh matrices.
+struct GruStack {
+  int L, ls;
+  const float *wih[4], *whh[4], *bih[4], *bhh[4];
+  float *g_wih[4], *g_whh[4], *g_bih[4], *g_bhh[4];
+};
+static int gru_stack(const dm_shape* s, const float* const* p, float* const* g, GruStack* k) {
+  k->L = rssm_gru_layers(s);
+  k->ls = s->D / k->L;
+  for (int i = 0; i < k->L; ++i) {
+    const int b = i == 0 ? DM_RSSM_GRU_WIH : DM_RSSM_GRU_L1_WIH + 4 * (i - 1);
+    k->wih[i] = p[b]; k->whh[i] = p[b + 1]; k->bih[i] = p[b + 2]; k->bhh[i] = p[b + 3];
+    const bool biased = rssm_gru_kind(s) == 0;      // the LayerNorm cells have no gate biases (rnn.py:99-100)
+    DM_REQUIRE(k->wih[i] && k->whh[i] && (!biased || (k->bih[i] && k->bhh[i])), DM_E_NULL,
+               "rssm: GRU layer %d has a null parameter", i);
+    if (g) {
+      k->g_wih[i] = g[b]; k->g_whh[i] = g[b + 1]; k->g_bih[i] = g[b + 2]; k->g_bhh[i] = g[b + 3];
+      DM_REQUIRE(k->g_wih[i] && k->g_whh[i] && (!biased || (k->g_bih[i] && k->g_bhh[i])), DM_E_NULL,
+                 "rssm: GRU layer %d has a null gradient slot", i);
+    }
+  }
   return DM_OK;
 }
 
@@ -100,6 +132,22 @@ static int transpose(hipStream_t st, const float* W, float* Wt, int rows, int co
   return dm_permute4_launch(W, Wt, 1, 1, rows, cols, 0, 1, 3, 2, st);
 }
 
+// One step of the stack, forward: 3 launches per layer.  `hout` may alias nothing of `hin`.
+static int gru_stack_fwd(hipStream_t st, void* sk, size_t skb, const GruStack& k, int rows, int Hd, int D, const float* x0,
+                         const float* hin, int ldh, float* gi, float* gh, float* hout, int ldo, float* h_next,
+                         const uint8_t* next_reset) {
+  const int ls = k.ls;
+  for (int i = 0; i < k.L; ++i) {
+    const float* x = i == 0 ? x0 : hout + (size_t)(i - 1) * ls;
+    const int ldx = i == 0 ? Hd : ldo, kin = i == 0 ? Hd : ls;
+    DM_TRY(linear(st, sk, skb, rows, 3 * ls, kin, x, ldx, k.wih[i], k.bih[i], nullptr, 0, gi + 3 * ls * i, 3 * D));
+    DM_TRY(linear(st, sk, skb, rows, 3 * ls, ls, hin + i * ls, ldh, k.whh[i], k.bhh[i], nullptr, 0, gh + 3 * ls * i, 3 * D));
+    DM_TRY(dm_gru_gates_fwd_launch(rows, ls, gi + 3 * ls * i, gh + 3 * ls * i, hin + i * ls, ldh, hout + i * ls, ldo,
+                                   h_next ? h_next + i * ls : nullptr, next_reset, nullptr, nullptr, st, 3 * D, D));
+  }
+  return DM_OK;
+}
+
 // Time steps [t0, t1) of the sequence; all buffers are the full (T*B)-row ones.  Step t0 > 0 continues from the state
 // that step t0-1 left in `feat`, so consecutive ranges issued in order on one stream equal one full call; the encoder
 // range that feeds them and the decoder range that consumes them can then run on other streams (see WorldModel._forward).
@@ -139,7 +187,10 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(kind == 0 || (lng[0] && lnb[0] && (kind == 2 || (lng[1] && lnb[1] && lng[2] && lnb[2]))), DM_E_NULL,
              "rssm_sequence_fwd: LayerNorm GRU cell without its LayerNorm parameters");
-  const bool fuse_ln = dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
+  GruStack gk;
+  DM_TRY(gru_stack(s, p, nullptr, &gk));
+  const bool stacked = gk.L > 1;      // GRUCellStack with several layers: the unfused schedule, 3 launches per layer
+  const bool fuse_ln = !stacked && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
   static const int no_fuse_sample = getenv("DM_RSSM_NO_FUSE_SAMPLE") ? 1 : 0;      // A/B switch
   const bool fuse_sample = !no_fuse_sample && fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
@@ -187,7 +238,10 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
                                   a.st1 + r0 * 2, st));
     // h = GRUCell(za, h_in)                                                             rssm.py:141
-    {
+    if (stacked) {
+      DM_TRY(gru_stack_fwd(st, ws, skb, gk, B, Hd, D, a.za + r0 * Hd, hin, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D,
+                           feat + r0 * F, F, hin_next, reset_next));
+    } else {
       DmGemm gi_q, gh_q;
       gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
       if (fuse_ln) {
@@ -200,7 +254,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       gh_q.C = a.gh + r0 * 3 * D; gh_q.ldc = 3 * D; gh_q.bias = p[DM_RSSM_GRU_BHH];
       DM_TRY(dm_gemm_pair_launch(gi_q, gh_q, ws, skb, st));
     }
-    if (kind == 0)
+    if (stacked) {
+    } else if (kind == 0)
       DM_TRY(dm_gru_gates_fwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, hin, D, feat + r0 * F, F, hin_next,
                                      reset_next, hf, more ? hinf : nullptr, st));
     else
@@ -319,14 +374,19 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
   DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, Z, Hd));
   DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
-  DM_TRY(transpose(st, p[DM_RSSM_GRU_WIH], wt_ih, 3 * D, Hd));
-  DM_TRY(transpose(st, p[DM_RSSM_GRU_WHH], wt_hh, 3 * D, D));
+  GruStack gk;
+  DM_TRY(gru_stack(s, p, g, &gk));
+  const bool stacked = gk.L > 1;
+  if (!stacked) {
+    DM_TRY(transpose(st, p[DM_RSSM_GRU_WIH], wt_ih, 3 * D, Hd));
+    DM_TRY(transpose(st, p[DM_RSSM_GRU_WHH], wt_hh, 3 * D, D));
+  }
   DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
   // Fused schedule (5 launches per step instead of 8), mirror of the forward T loop: both LayerNorm+ELU BACKWARD stages
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  const bool fuse_b = !stacked && kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
   // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
   // backward epilogue, read by the two products that follow it
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;
@@ -388,6 +448,25 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     // GRU gates; the direct path dh'*u goes (masked) straight into step t-1's dh'
     const uint8_t* rz = reset + r0;
     float* dprev = t > 0 ? dfeat + (r0 - B) * F : nullptr;
+    if (stacked) {
+      // layers in reverse: layer i's input gradient lands in the new-state gradient of layer i-1 before that layer's own
+      // gates run; its recurrent-input gradient goes (masked) into step t-1's dh' slice
+      const int ls = gk.ls;
+      for (int i = gk.L - 1; i >= 0; --i) {
+        float* dgi_i = dgi + r0 * 3 * D + 3 * ls * i;
+        float* dgh_i = dgh + r0 * 3 * D + 3 * ls * i;
+        DM_TRY(dm_gru_gates_bwd_launch(B, ls, a.gi + r0 * 3 * D + 3 * ls * i, a.gh + r0 * 3 * D + 3 * ls * i,
+                                       a.hin + r0 * D + i * ls, D, dft + i * ls, F, dgi_i, dgh_i,
+                                       dprev ? dprev + i * ls : nullptr, F, 1, rz, st, 3 * D));
+        if (i > 0) DM_TRY(dgrad(st, sk, skb, B, 3 * ls, ls, dgi_i, 3 * D, gk.wih[i], dft + (i - 1) * ls, F, 1, nullptr));
+        else DM_TRY(dgrad(st, sk, skb, B, 3 * ls, Hd, dgi_i, 3 * D, gk.wih[0], dza + r0 * Hd, Hd, 0, nullptr));
+        if (dprev) DM_TRY(dgrad(st, sk, skb, B, 3 * ls, ls, dgh_i, 3 * D, gk.whh[i], dprev + i * ls, F, 1, rz));
+      }
+      DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
+                                     dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
+      if (t > 0) DM_TRY(dgrad_t(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, wt_z, dprev + D, F, 1, rz));
+      continue;
+    }
     if (kind == 0)
       DM_TRY(dm_gru_gates_bwd_launch(B, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, dft, F,
                                      dgi + r0 * 3 * D, dgh + r0 * 3 * D, dprev, F, 1, rz, st));
@@ -420,9 +499,22 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(dm_colsum_launch(N, Hd, dx2, Hd, g[DM_RSSM_POST_H_B], sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, E, dx2, Hd, embed, E, g[DM_RSSM_POST_E_W]));
   if (dembed) DM_TRY(dgrad(st, sk, skb, N, Hd, E, dx2, Hd, p[DM_RSSM_POST_E_W], dembed, E, 0, nullptr));
-  DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
-  DM_TRY(wgrad(st, sk, skb, N, 3 * D, D, dgh, 3 * D, a.hin, D, g[DM_RSSM_GRU_WHH]));
-  if (kind == 0) {
+  if (stacked) {
+    const int ls = gk.ls;
+    for (int i = 0; i < gk.L; ++i) {
+      const float* x = i == 0 ? a.za : feat + (size_t)(i - 1) * ls;
+      const int ldx = i == 0 ? Hd : F, kin = i == 0 ? Hd : ls;
+      DM_TRY(wgrad(st, sk, skb, N, 3 * ls, kin, dgi + 3 * ls * i, 3 * D, x, ldx, gk.g_wih[i]));
+      DM_TRY(wgrad(st, sk, skb, N, 3 * ls, ls, dgh + 3 * ls * i, 3 * D, a.hin + i * ls, D, gk.g_whh[i]));
+      DM_TRY(dm_colsum_launch(N, 3 * ls, dgi + 3 * ls * i, 3 * D, gk.g_bih[i], sk, skb, st));
+      DM_TRY(dm_colsum_launch(N, 3 * ls, dgh + 3 * ls * i, 3 * D, gk.g_bhh[i], sk, skb, st));
+    }
+  } else {
+    DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
+    DM_TRY(wgrad(st, sk, skb, N, 3 * D, D, dgh, 3 * D, a.hin, D, g[DM_RSSM_GRU_WHH]));
+  }
+  if (stacked) {
+  } else if (kind == 0) {
     DM_TRY(dm_colsum_launch(N, 3 * D, dgi, 3 * D, g[DM_RSSM_GRU_BIH], sk, skb, st));
     DM_TRY(dm_colsum_launch(N, 3 * D, dgh, 3 * D, g[DM_RSSM_GRU_BHH], sk, skb, st));
   } else {      // LayerNorm parameters of the cell: one batched column pass over all rows, then split into the thirds
@@ -485,6 +577,8 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
+  GruStack gk;
+  DM_TRY(gru_stack(s, p, nullptr, &gk));
   const float* actor_wpack = nullptr;
   if (dm_mlp_chain_ok(M, F, Hm, L, AO, feats, F, actor) && !dm_panel_ok(M, Hm)) {
     float* wpk = ar.take(dm_mlp_chain_pack_floats(F, L));
@@ -516,9 +610,14 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(linear(st, sk, skb, M, Hd, A, act, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, ea, Hd));
     DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
-    DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
-    DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
-    if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, nullptr, nullptr, st));
+    if (gk.L > 1) {
+      DM_TRY(gru_stack_fwd(st, sk, skb, gk, M, Hd, D, za, cur, F, gi, gh, nxt, F, nullptr, nullptr));
+    } else {
+      DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
+      DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));
+    }
+    if (gk.L > 1) {
+    } else if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, nullptr, nullptr, st));
     else DM_TRY(dm_gru_norm_fwd_launch(kind, M, D, gi, gh, cur, F, lng, lnb, nxt, F, gsw, gstw, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));

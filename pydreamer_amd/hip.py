@@ -41,17 +41,24 @@ _LN_SLOTS = {
 }
 
 
-def rssm_param_names(gru_type='gru'):
+DM_FLAG_GRU_LAYERS_SHIFT = 8
+DM_MAX_GRU_LAYERS = 4
+
+
+def rssm_param_names(gru_type='gru', gru_layers=1):
     """Parameter name (relative to wm.core.cell) of every dm_rssm_params slot, None for slots the cell does not have."""
     names = list(RSSM_PARAM_ORDER)
     if gru_type != 'gru':
         ren = {'gru.layers.0.weight_ih': 'gru.layers.0.weight_ih.weight', 'gru.layers.0.weight_hh': 'gru.layers.0.weight_hh.weight',
                'gru.layers.0.bias_ih': None, 'gru.layers.0.bias_hh': None}
         names = [ren.get(n, n) for n in names]
-    return names + _LN_SLOTS[gru_type]
+    names = names + _LN_SLOTS[gru_type]
+    for i in range(1, DM_MAX_GRU_LAYERS):       # GRUCellStack layers 1..3 (rnn.py:56): DM_RSSM_GRU_L{i}_{WIH,WHH,BIH,BHH}
+        names += [f'gru.layers.{i}.{n}' if i < gru_layers else None for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    return names
 
 
-DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER) + 6
+DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER) + 6 + 4 * (DM_MAX_GRU_LAYERS - 1)
 
 
 class DreamerHipError(RuntimeError):
@@ -259,7 +266,8 @@ def conv_struct(ws, bs, cls=dm_conv_params):
 
 
 def rssm_struct(tensors, cls=dm_rssm_params):
-    """tensors: one per slot (rssm_param_names order); the 6 LayerNorm-GRU slots may be omitted, absent slots are None."""
+    """tensors: one per slot (rssm_param_names order); trailing slots (the 6 LayerNorm-GRU ones, the 12 of the stack's
+    layers 1..3) may be omitted, absent slots are None."""
     tensors = list(tensors) + [None] * (DM_RSSM_NPARAMS - len(tensors))
     assert len(tensors) == DM_RSSM_NPARAMS
     s = cls()

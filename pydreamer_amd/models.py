@@ -261,15 +261,21 @@ class NormGRUCellLateResetP(_Params):
 
 
 class GRUCellStack(_Params):
-    """rnn.py:40-67 with num_layers=1; cell_type in {gru, gru_layernorm, gru_layernorm_dv2}."""
+    """rnn.py:40-67; cell_type in {gru, gru_layernorm, gru_layernorm_dv2}.  Up to 4 layers of plain GRU cells (the
+    LayerNorm cells are built for num_layers=1 only): layer i owns columns [i*layer_size, (i+1)*layer_size) of the state."""
 
     def __init__(self, input_size, hidden_size, num_layers, cell_type):
         super().__init__()
         cells = dict(gru=GRUCellP, gru_layernorm=NormGRUCellP, gru_layernorm_dv2=NormGRUCellLateResetP)
-        if cell_type not in cells or num_layers != 1:
+        if cell_type not in cells or not 1 <= num_layers <= H.DM_MAX_GRU_LAYERS or (num_layers > 1 and cell_type != 'gru'):
             raise NotImplementedError(f'gru_type={cell_type!r}, gru_layers={num_layers} not built in the HIP path')
-        self.cell_type = cell_type
-        self.layers = nn.ModuleList([cells[cell_type](input_size, hidden_size)])
+        layer_size = hidden_size // num_layers
+        assert layer_size * num_layers == hidden_size, 'Must be divisible'
+        if layer_size % 4:
+            raise NotImplementedError(f'deter_dim / gru_layers = {layer_size} must be a multiple of 4 in the HIP path')
+        self.cell_type, self.num_layers = cell_type, num_layers
+        self.layers = nn.ModuleList([cells[cell_type](input_size, layer_size)] +
+                                    [cells[cell_type](layer_size, layer_size) for _ in range(num_layers - 1)])
 
 
 class RSSMCell(_Params):
@@ -296,7 +302,7 @@ class RSSMCell(_Params):
     def ordered(self):
         """Tensors in the DM_RSSM_* order of include/dreamer_hip.h (None for slots this cell type does not have)."""
         named = dict(self.named_parameters())
-        return [None if n is None else named[n] for n in H.rssm_param_names(self.gru.cell_type)]
+        return [None if n is None else named[n] for n in H.rssm_param_names(self.gru.cell_type, self.gru.num_layers)]
 
     def init_state(self, batch_size):
         dev = self.z_mlp.weight.device
@@ -635,6 +641,7 @@ class WorldModel(_Params):
                             E=self.encoder.out_dim, A=c.action_dim, mlp_hidden=MLP_HIDDEN, mlp_layers=4,
                             cnn_depth=c.cnn_depth, img=c.image_size, img_ch=c.image_channels,
                             flags=ACTOR_KINDS.get(c.actor_dist, 0) | (H.GRU_KINDS[c.gru_type] << H.DM_FLAG_GRU_SHIFT) |
+                            ((c.gru_layers - 1) << H.DM_FLAG_GRU_LAYERS_SHIFT) |
                             (H.DM_FLAG_BF16 if getattr(c, 'amp', False) else 0))
 
     def workspace(self, shp, device):

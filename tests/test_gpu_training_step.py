@@ -380,12 +380,22 @@ def test_training_step_continuous_actor_vs_oracle(hip):
             _check_pair(r, oconf)
 
 
+@pytest.mark.parametrize('layers,deter', [(2, 64), (4, 96)])
+def test_training_step_gru_cell_stack_vs_oracle(hip, layers, deter):
+    """GRUCellStack with several layers (rnn.py:40-67) against the oracle: every loss, metric and per-parameter gradient
+    of two consecutive steps (resets included)."""
+    oconf = O.tiny_conf(gru_layers=layers, deter_dim=deter)
+    for r in _run_pair(oconf, 2):
+        _check_pair(r, oconf)
+
+
 def test_training_step_matches_reference_goldens(hip):
     """Directly against the fixtures written by the real reference (tests/golden/tiny.npz, debug_literal.npz, tiny_dmc.npz,
     the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz, and the auxiliary critic
-    of dreamer.py:267-279,347-358: tiny_aux_critic.npz - SURVEY 8(f) N4)."""
+    of dreamer.py:267-279,347-358: tiny_aux_critic.npz, and the 3-layer GRUCellStack of rnn.py:40-67: tiny_gru_layers3.npz -
+    SURVEY 8(f) N4)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
-                        ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2)):
+                        ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)

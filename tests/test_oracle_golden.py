@@ -84,7 +84,11 @@ def _check_step(g, conf, res):
         got = float(grads[n].double().norm())
         assert abs(got - ref) <= 1e-4 * ref + 1e-7, (n, got, ref)
     for key in g.files:
-        if key.startswith(pre + 'grad_') and key not in (pre + 'grad_norms', pre + 'grad_names'):
+        if key == pre + 'grad_proj':      # gradient DIRECTION of every parameter: two closed-form projections (O.grad_probe)
+            for i, (n, r, pr) in enumerate(zip(names, g[pre + 'grad_norms'], g[key])):
+                got = O.grad_probe(grads[n], i)
+                assert max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) <= 1e-4 * r + 1e-9, (n, got, pr, r)
+        elif key.startswith(pre + 'grad_') and key not in (pre + 'grad_norms', pre + 'grad_names'):
             n = key[len(pre + 'grad_'):]
             ref = g[key]
             np.testing.assert_allclose(grads[n].numpy(), ref, rtol=0, atol=1e-4 * max(np.abs(ref).max(), 1e-8))
@@ -123,6 +127,15 @@ def test_oracle_matches_reference_layernorm_gru_cells(gru_type):
     """NormGRUCell / NormGRUCellLateReset (rnn.py:95-138) in place of nn.GRUCell, two training steps."""
     g, conf, results = _replay('tiny_' + gru_type, 2)
     assert conf.gru_type == gru_type
+    for res in results:
+        _check_step(g, conf, res)
+
+
+def test_oracle_matches_reference_gru_cell_stack():
+    """GRUCellStack with gru_layers = 3 (rnn.py:40-67; each cell deter_dim/3 wide, layer i fed by layer
+    i-1's new state), two training steps."""
+    g, conf, results = _replay('tiny_gru_layers3', 2)
+    assert (conf.gru_layers, conf.deter_dim) == (3, 96)
     for res in results:
         _check_step(g, conf, res)
 
