@@ -73,6 +73,10 @@ int dm_version(void);                 /* ABI version, currently 4 (v2: LayerNorm
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
+/* A stream confined to the CUs whose bit is set in mask[0..words) (32 CUs per word): the host mirror reserves CUs for the
+ * posterior loop's latency chain with it (no reference counterpart: torch exposes no CU masks). */
+int dm_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
+int dm_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------- primitives ------------------- */
 /* C[m,n] (ldc) = epi( sum_k A(m,k) * B(n,k) ), fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -27,6 +27,24 @@ extern "C" int dm_device_check(void) {
   return DM_OK;
 }
 
+// A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): `mask` has one bit per CU, 32
+// per word.  Used by WorldModel's time-chunk pipeline to RESERVE a few CUs of every XCD for the posterior loop's latency
+// chain, so its small kernels never queue behind the convolution GEMMs of the neighbouring streams.
+extern "C" int dm_stream_create_cu_mask(const uint32_t* mask, int words, void** stream) {
+  DM_REQUIRE(mask && stream && words >= 1, DM_E_NULL, "stream_create_cu_mask: null argument");
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *stream = (void*)s;
+  return DM_OK;
+}
+extern "C" int dm_stream_destroy(void* stream) {
+  if (!stream) return DM_OK;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 // Scratch sizing: the largest transient of any fused operator at this shape, mirroring the arena carves in
 // conv.hip / rssm.hip / mlp.hip (every carve is rounded up to 64 floats).  See DESIGN.md "HBM layout".
 static size_t pad64(size_t n) { return (n + 63) / 64 * 64; }

@@ -105,6 +105,8 @@ _SIGNATURES = {
     'dm_last_error': (c_char_p, []),
     'dm_device_check': (c_int, []),
     'dm_workspace_bytes': (c_size_t, [POINTER(dm_shape)]),
+    'dm_stream_create_cu_mask': (c_int, [_P, c_int, POINTER(c_void_p)]),
+    'dm_stream_destroy': (c_int, [_P]),
     'dm_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int,
                             _P, c_size_t, _P]),
     'dm_ln_elu_fwd': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_float, _P, c_int, _P, _P]),
@@ -263,6 +265,16 @@ def conv_struct(ws, bs, cls=dm_conv_params):
     for i, t in enumerate(bs):
         s.b[i] = t.data_ptr()
     return s
+
+
+def cu_masked_stream(words, device):
+    """A torch stream confined to the CUs set in `words` (list of uint32, 32 CUs each); lives for the process."""
+    import torch
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    out = c_void_p()
+    with torch.cuda.device(device):
+        call('dm_stream_create_cu_mask', arr, len(words), ctypes.byref(out))
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 def rssm_struct(tensors, cls=dm_rssm_params):

@@ -659,8 +659,17 @@ class WorldModel(_Params):
             ranges = [(t, min(t + step, T)) for t in range(0, T, step)]
             sub = H.dm_shape.from_buffer_copy(shp)
             sub.T = step                                   # per-range decoder workspace: patch matrices scale with rows
-            pp = dict(key=key, ranges=ranges,
-                      s_chain=torch.cuda.Stream(device, priority=-1), s_dec=torch.cuda.Stream(device),
+            # DM_PIPE_RESERVE_CUS=r (0..31): the chain stream owns r CUs of every 32 and the convolution streams the other
+            # 32-r (hipExtStreamCreateWithCUMask), so the chain's small kernels never wait for a CU to drain
+            r = int(os.environ.get('DM_PIPE_RESERVE_CUS', '0'))
+            if 0 < r < 32:
+                lo, n_words = (1 << r) - 1, 8
+                s_chain = H.cu_masked_stream([lo] * n_words, device)
+                s_dec = H.cu_masked_stream([0xFFFFFFFF ^ lo] * n_words, device)
+                s_enc = H.cu_masked_stream([0xFFFFFFFF ^ lo] * n_words, device)
+            else:
+                s_chain, s_dec, s_enc = torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device), None
+            pp = dict(key=key, ranges=ranges, s_chain=s_chain, s_dec=s_dec, s_enc=s_enc,
                       ev_prep=torch.cuda.Event(), ev_enc=[torch.cuda.Event() for _ in ranges],
                       ev_chain=[torch.cuda.Event() for _ in ranges],
                       ws_chain=torch.empty((int(H.DM_SPLITK_FLOATS) + 4096) * 4, dtype=torch.uint8, device=device),
@@ -796,10 +805,13 @@ class WorldModel(_Params):
             pp['ev_prep'].record(main)
             pp['s_chain'].wait_event(pp['ev_prep'])
             pp['s_dec'].wait_event(pp['ev_prep'])
+            s_enc = pp['s_enc'] or main
+            s_enc.wait_event(pp['ev_prep'])
             for i, (t0, t1) in enumerate(pp['ranges']):
-                H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.ptr(image),
-                       ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
-                pp['ev_enc'][i].record(main)
+                with torch.cuda.stream(s_enc):
+                    H.call('dm_conv_encoder_fwd_rows', ctypes.byref(shp), t0 * B, (t1 - t0) * B, 0, H.ptr(image),
+                           ctypes.byref(enc_p), H.fptr(enc_acts), H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
+                    pp['ev_enc'][i].record(s_enc)
                 pp['s_chain'].wait_event(pp['ev_enc'][i])
                 with torch.cuda.stream(pp['s_chain']):
                     H.call('dm_rssm_sequence_fwd_steps', ctypes.byref(shp), t0, t1, H.fptr(embed), H.fptr(action),
@@ -814,6 +826,8 @@ class WorldModel(_Params):
                            H.ptr(pp['ws_dec']), pp['ws_dec'].numel(), H.stream())
             main.wait_stream(pp['s_chain'])
             main.wait_stream(pp['s_dec'])
+            if pp['s_enc'] is not None:
+                main.wait_stream(pp['s_enc'])
 
         last = feat[(T - 1) * BI:]
         out_state = (last[:, :D_].clone(), last[:, D_:].clone())                  # detached by construction (rssm.py:77)
