@@ -99,6 +99,13 @@ __host__ __device__ __forceinline__ size_t dm_frag_off(int row, int k) {
 }
 static inline size_t dm_frag_floats(int K) { return (size_t)dm_cdiv(K, 16) * 1024; }      // 64 rows x K rounded up to 16
 int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hipStream_t st);
+// x = bias + add + sum_s Wt[s*C + idx[r][s]] (+ Wt2[idx2[r]])  (z_mlp of a one-hot latent as a gather-sum; Wt = W^T, (S*C, n)
+// row-major; idx2 / Wt2 optional: one more gathered row per output row, a_mlp of a one-hot action);
+// y (optional) = ELU(LayerNorm(x)); x (optional when y is given); x_frag (optional, rows <= 64): fragment-major copy of x
+bool dm_z_embed_ok(int n);
+int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
+                      const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
+                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st);
 struct DmGatesBwd {
   const float* gi; const float* gh; const float* h_in; int ldh, D;
   float* dgi; float* dgh; float* dprev; int ldp; const uint8_t* row_zero;   // dprev (nullable) += mask * dh' * u

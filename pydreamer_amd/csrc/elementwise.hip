@@ -640,6 +640,135 @@ static inline int ew_blocks(size_t total) {
   return (int)b;
 }
 
+// z_mlp of a ONE-HOT latent as an embedding gather-sum (rssm.py:138,162: x = z_mlp(z) + a_mlp(a)).  The forward value of a
+// straight-through sample is exactly its one-hot (onehot + (p - p)), so z W^T is the sum of one row of W^T per group:
+//   x[r][:] = bias + add[r][:] + sum_s Wt[s*C + idx[r][s]][:]            (row_zero[r]: the reset-masked z is 0, no rows)
+//             (+ Wt2[idx2[r]][:]: a_mlp of a one-hot action the same way, for the rollout)
+// S rows of n floats per output row instead of an n x S*C product (32 KB instead of a 2.05 MFLOP dot for the 32x32 latent).
+// One wave per row, 4 x float4 per lane (n <= 1024, n % 4 == 0), the S gathers independent and in flight together; optional
+// LayerNorm + ELU of the row in the same pass (the rollout has no use for the pre-activation), optional fragment-major copy.
+__global__ void __launch_bounds__(256) z_embed_kernel(int rows, int n, int S, int C, const int32_t* __restrict__ idx,
+                                                      const uint8_t* __restrict__ row_zero, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, const float* __restrict__ add,
+                                                      int ldadd, const int32_t* __restrict__ idx2,
+                                                      const float* __restrict__ Wt2, float* __restrict__ x, int ldx,
+                                                      float* __restrict__ x_frag,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, float* __restrict__ y, int ldy) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  // branch-free loads: a lane whose columns fall outside n reads column 0 instead and its sums are never stored (a branch
+  // around a load makes hipcc drain vmcnt after every one of them)
+  float4 acc[4];
+  bool in[4];
+  int off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    in[j] = c < n;
+    off[j] = in[j] ? c : 0;
+    acc[j] = bias ? *reinterpret_cast<const float4*>(bias + off[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (add) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(add + (size_t)row * ldadd + off[j]);
+      acc[j].x += a.x; acc[j].y += a.y; acc[j].z += a.z; acc[j].w += a.w;
+    }
+  }
+  if (idx2) {       // + a_mlp of a one-hot action: row idx2[r] of a_mlp^T
+    const float* wr = Wt2 + (size_t)idx2[row] * n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(wr + off[j]);
+      acc[j].x += a.x; acc[j].y += a.y; acc[j].z += a.z; acc[j].w += a.w;
+    }
+  }
+  if (!(row_zero && row_zero[row])) {
+    // the row's indices are fetched 64 at a time (one per lane) and broadcast, so the S gathers do not wait on S
+    // dependent index loads; 8 groups per trip keep 32 loads of a lane in flight
+    const int32_t* ir = idx + (size_t)row * S;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int mine = ir[min(s0 + lane, S - 1)];
+      const int cnt = min(64, S - s0);
+      int t = 0;
+      for (; t + 8 <= cnt; t += 8) {
+        float4 w[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float* wr = Wt + ((size_t)(s0 + t + u) * C + __shfl(mine, t + u, 64)) * n;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[u][j] = *reinterpret_cast<const float4*>(wr + off[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // all 32 loads issued before the first add waits on one
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[j].x += w[u][j].x; acc[j].y += w[u][j].y; acc[j].z += w[u][j].z; acc[j].w += w[u][j].w;
+          }
+      }
+      for (; t < cnt; ++t) {
+        const float* wr = Wt + ((size_t)(s0 + t) * C + __shfl(mine, t, 64)) * n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(wr + off[j]);
+          acc[j].x += w.x; acc[j].y += w.y; acc[j].z += w.z; acc[j].w += w.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (in[j]) {
+      const int c = (lane + 64 * j) * 4;
+      if (x) *reinterpret_cast<float4*>(x + (size_t)row * ldx + c) = acc[j];
+      if (x_frag) *reinterpret_cast<float4*>(x_frag + dm_frag_off(row, c)) = acc[j];
+    }
+  if (!y) return;
+  float s1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (in[j]) s1 += (acc[j].x + acc[j].y) + (acc[j].z + acc[j].w);
+  const float mean = dm_wave_sum(s1) / (float)n;
+  float s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (in[j]) {
+      const float dx = acc[j].x - mean, dy = acc[j].y - mean, dz = acc[j].z - mean, dw = acc[j].w - mean;
+      s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = 1.0f / sqrtf(dm_wave_sum(s2) / (float)n + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (in[j]) {
+      const int c = (lane + 64 * j) * 4;
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = dm_elu((acc[j].x - mean) * rstd * g.x + b.x);
+      o.y = dm_elu((acc[j].y - mean) * rstd * g.y + b.y);
+      o.z = dm_elu((acc[j].z - mean) * rstd * g.z + b.z);
+      o.w = dm_elu((acc[j].w - mean) * rstd * g.w + b.w);
+      *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+    }
+}
+bool dm_z_embed_ok(int n) { return n <= 1024 && (n & 3) == 0; }
+int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
+                      const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
+                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  DM_REQUIRE(!idx2 || Wt2, DM_E_NULL, "z_embed: second index list without its table");
+  DM_REQUIRE(dm_z_embed_ok(n) && idx && Wt && (x || y), DM_E_SHAPE, "z_embed: n=%d needs n <= 1024, n %% 4 == 0", n);
+  DM_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0, DM_E_SHAPE, "z_embed: leading dims must be multiples of 4");
+  DM_REQUIRE(!x_frag || rows <= 64, DM_E_SHAPE, "z_embed: the fragment-major copy needs rows <= 64");
+  DM_REQUIRE(!y || (gamma && beta), DM_E_NULL, "z_embed: LayerNorm output without its parameters");
+  hipLaunchKernelGGL(z_embed_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, S, C, idx, row_zero, Wt, bias, add,
+                     ldadd, idx2, Wt2, x, ldx, x_frag, gamma, beta, eps, y, ldy);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hipStream_t st) {
   DM_REQUIRE(rows >= 0 && rows <= 64 && K >= 1 && X && Xf, DM_E_SHAPE, "frag_pack: rows %d (<= 64), K %d", rows, K);
   if (rows == 0) return DM_OK;

@@ -93,7 +93,8 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
                        3 * pad64(N * 3 * D) + pad64(N * 6) + pad64(N * Z) +
-                       pad64(25 * 512 * (((D + Z + 31) / 32) + (L > 0 ? L - 1 : 0) * ((Hm + 31) / 32)));   // + fragment-major actor weights
+                       pad64(25 * 512 * (((D + Z + 31) / 32) + (L > 0 ? L - 1 : 0) * ((Hm + 31) / 32))) +   // + fragment-major actor weights
+                       pad64(Z * Hd) + pad64(A * Hd) + pad64(N * (size_t)s->S) + pad64(N);   // + z_mlp^T, a_mlp^T and the sampled indices (z_embed)
   size_t m = enc_bwd;
   if (dec_fwd > m) m = dec_fwd;
   if (dec_bwd > m) m = dec_bwd;

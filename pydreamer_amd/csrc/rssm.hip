@@ -199,9 +199,24 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   // -> h -> x2 -> z.  One buffer per operand is enough (producer and consumer alternate in stream order).
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;          // A/B switch
   float *zinf = nullptr, *x1f = nullptr, *hinf = nullptr, *hf = nullptr, *x2f = nullptr;
+  DmArena ar(ws, ws_bytes);
+  ar.take(DM_SPLITK_FLOATS);
+  // z_mlp of the sampled (one-hot) latent as a gather-sum over rows of z_mlp^T (dm_z_embed_launch): every step after the
+  // first of a range takes its z from the sampler, whose indices are at hand; the first step's z comes from the caller as
+  // a dense vector and keeps the product.
+  static const int no_embed = getenv("DM_RSSM_NO_Z_EMBED") ? 1 : 0;        // A/B switch
+  float* wzt = nullptr;
+  if (!no_embed && idx && t1 - t0 > 1 && dm_z_embed_ok(Hd)) {
+    const size_t mark = ar.off;
+    float* w = ar.take((size_t)Z * Hd);
+    if (ar.ok) {
+      wzt = w;
+      DM_TRY(transpose(st, p[DM_RSSM_Z_W], wzt, Hd, Z));
+    } else {      // optional: a small workspace keeps the product
+      ar.off = mark; ar.ok = true;
+    }
+  }
   if (!no_frag && fuse_sample && kind == 0 && B <= 64) {
-    DmArena ar(ws, ws_bytes);
-    ar.take(DM_SPLITK_FLOATS);
     float* f0 = ar.take(dm_frag_floats(Z)); float* f1 = ar.take(dm_frag_floats(Hd)); float* f2 = ar.take(dm_frag_floats(D));
     float* f3 = ar.take(dm_frag_floats(D)); float* f4 = ar.take(dm_frag_floats(Hd));
     if (ar.ok) { zinf = f0; x1f = f1; hinf = f2; hf = f3; x2f = f4; }
@@ -227,7 +242,10 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     float* zin_next = more ? a.zin + (r0 + B) * Z : nullptr;
     const uint8_t* reset_next = more ? reset + r0 + B : nullptr;
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
-    {
+    if (wzt && t > t0) {
+      DM_TRY(dm_z_embed_launch(B, Hd, S, C, idx + (r0 - B) * S, reset + r0, wzt, p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd,
+                               nullptr, nullptr, a.x1 + r0 * Hd, Hd, x1f, nullptr, nullptr, 0.f, nullptr, 0, st));
+    } else {
       DmGemm q;
       q.M = B; q.N = Hd; q.K = Z; q.A = zin; q.lda = Z; q.B = p[DM_RSSM_Z_W]; q.ldb = Z; q.C = a.x1 + r0 * Hd; q.ldc = Hd;
       q.bias = p[DM_RSSM_Z_B]; q.add = a.ea + r0 * Hd; q.ldadd = Hd;
@@ -579,6 +597,28 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
   GruStack gk;
   DM_TRY(gru_stack(s, p, nullptr, &gk));
+  // steps 1.. of the rollout read the z the prior sampler of the step before drew: z_mlp + in_norm + ELU become one
+  // gather-sum launch over z_mlp^T (dm_z_embed_launch) instead of a (M x Hd x Z) product and a LayerNorm launch
+  static const int no_embed = getenv("DM_RSSM_NO_Z_EMBED") ? 1 : 0;        // A/B switch
+  float *wzt = nullptr, *wat = nullptr;
+  int32_t *pidx = nullptr, *aidx = nullptr;
+  if (!no_embed && H > 1 && dm_z_embed_ok(Hd)) {
+    const size_t mark = ar.off;
+    float* w = ar.take((size_t)Z * Hd);
+    float* w2 = ar.take((size_t)A * Hd);
+    int32_t* ix = reinterpret_cast<int32_t*>(ar.take((size_t)M * S));
+    int32_t* ax = reinterpret_cast<int32_t*>(ar.take((size_t)M));
+    if (ar.ok) {
+      wzt = w; pidx = ix;
+      DM_TRY(transpose(st, p[DM_RSSM_Z_W], wzt, Hd, Z));
+      if (adist == 0) {       // one-hot actions: a_mlp(action) is a row of a_mlp^T too
+        wat = w2; aidx = ax;
+        DM_TRY(transpose(st, p[DM_RSSM_A_W], wat, Hd, A));
+      }
+    } else {      // optional buffers: the product path below needs none of them
+      ar.off = mark; ar.ok = true;
+    }
+  }
   const float* actor_wpack = nullptr;
   if (dm_mlp_chain_ok(M, F, Hm, L, AO, feats, F, actor) && !dm_panel_ok(M, Hm)) {
     float* wpk = ar.take(dm_mlp_chain_pack_floats(F, L));
@@ -601,15 +641,22 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     if (actor_acts)
       DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st, actor_wpack));
     else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack));
+    int32_t* ai = act_idx ? act_idx + (size_t)i * M : aidx;       // the sampled action's index (scratch if the caller wants none)
     if (adist == 0)
-      DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A,
-                                     act_idx ? act_idx + (size_t)i * M : nullptr, nullptr, nullptr, st));
+      DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A, ai, nullptr, nullptr, st));
     else
       DM_TRY(dm_sample_continuous_launch(adist, M, A, logits, u_act + (size_t)i * M * A, act, st));
     // cell.forward_prior(action, None, (h, z))                                          rssm.py:155-184
-    DM_TRY(linear(st, sk, skb, M, Hd, A, act, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, ea, Hd));
-    DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));
-    DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
+    const bool embed = wzt && i > 0, embed_a = embed && wat && ai;
+    if (!embed_a) DM_TRY(linear(st, sk, skb, M, Hd, A, act, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, ea, Hd));
+    if (embed) {
+      DM_TRY(dm_z_embed_launch(M, Hd, S, C, pidx, nullptr, wzt, p[DM_RSSM_Z_B], embed_a ? nullptr : ea, Hd,
+                               embed_a ? ai : nullptr, wat, nullptr, Hd, nullptr, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f,
+                               za, Hd, st));
+    } else {
+      DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));
+      DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
+    }
     if (gk.L > 1) {
       DM_TRY(gru_stack_fwd(st, sk, skb, gk, M, Hd, D, za, cur, F, gi, gh, nxt, F, nullptr, nullptr));
     } else {
@@ -622,7 +669,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
-    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, nullptr, nullptr,
+    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
                                    nullptr, st));
   }
   return DM_OK;
