@@ -178,6 +178,14 @@ size_t dm_mlp_ws_floats(int rows, int hidden, int layers);
 int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim,
                     const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
                     void* ws, size_t ws_bytes, void* stream);
+/* The same head when the LAST sparse_cols columns of x are known to be mostly zero - the one-hot latent part of a feature
+ * row (rssm.py:83-84: feature = cat(h, z), z = 32 one-hot groups of 32).  Same result (x W^T = x_dense W_d^T + sum over the
+ * non-zero e of x_e W^T[e], exact for ANY x); on the row-panel path layer 0 then multiplies only the dense columns and
+ * adds the sparse ones as a sum of weight rows (63 % of that layer's flops for the 600 + 1024 feature).  acts / out as above,
+ * dm_mlp_head_bwd unchanged. */
+int dm_mlp_head_fwd_sparse(int rows, int in_dim, int sparse_cols, int hidden, int layers, int out_dim,
+                           const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
+                           void* ws, size_t ws_bytes, void* stream);
 /* dout (rows,out_dim); grads overwritten; dx (rows,in_dim; ld lddx) written if non-null (accumulated if dx_accum). */
 int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim,
                     const float* x, int ldx, const dm_mlp_params* p, const float* acts, const float* dout,

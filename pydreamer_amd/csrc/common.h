@@ -103,6 +103,10 @@ int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hip
 // row-major; idx2 / Wt2 optional: one more gathered row per output row, a_mlp of a one-hot action);
 // y (optional) = ELU(LayerNorm(x)); x (optional when y is given); x_frag (optional, rows <= 64): fragment-major copy of x
 bool dm_z_embed_ok(int n);
+// x[r][:] = sum over the non-zero e of z[r][e] * Wt[e][:]   (Wt: (Zc, n) row-major, n <= 1024, n % 4 == 0): exact for any z,
+// cheap for rows of concatenated one-hot groups
+int dm_sparse_rows_launch(int rows, int n, int Zc, const float* z, int ldz, const float* Wt, float* x, int ldx,
+                          hipStream_t st);
 int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
                       const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
                       float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st);
@@ -183,7 +187,9 @@ int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int
 // kernel; null: packed here, per call, into the workspace
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr);
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr, int sparse_cols = 0);
+// sparse_cols > 0: the LAST sparse_cols columns of x are mostly zero (one-hot latent groups); the row-panel path then
+// multiplies only the dense columns and adds the sparse ones' contribution as a sum of weight rows (dm_sparse_rows_launch)
 
 // row-panel Linear + LayerNorm/ELU kernels for the 400-wide MLP heads (panel.hip)
 bool dm_panel_ok(int rows, int hidden);
@@ -191,7 +197,9 @@ int dm_panel_count(int rows);
 int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ldx, const float* W, const float* b,
                            const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
                            const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st,
-                           const unsigned short* Wh = nullptr);
+                           const unsigned short* Wh = nullptr, int ldw = 0, const float* addm = nullptr);
+// ldw: row stride of W / Wh when the product covers only the first kin of its columns (0: kin); addm (rows x hidden):
+// added to the product before the LayerNorm (the other columns' contribution, computed elsewhere)
 int dm_panel_bf16_weights_launch(int count, const float* const* w, unsigned short* const* dst, const int* rows, const int* cols,
                                  int transpose, hipStream_t st);
 int dm_panel_ln_bwd_launch(int rows, int hidden, int kup, const float* dup, int lddup, const float* W, const float* xpre,

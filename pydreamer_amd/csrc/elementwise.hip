@@ -753,6 +753,65 @@ __global__ void __launch_bounds__(256) z_embed_kernel(int rows, int n, int S, in
       *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
     }
 }
+// x[r][:] = sum_e z[r][e] * Wt[e][:] over the NON-ZERO e of row r: a sparse-row product, exact for any z and cheap when z is
+// a concatenation of one-hot groups (the latent part of a DreamerV2 feature row: 32 non-zeros of 1024).  One wave per
+// row; the row is scanned 64 elements at a time and the rows of Wt named by the ballot of non-zeros are summed.
+template <int NJ>
+__global__ void __launch_bounds__(256) sparse_rows_kernel(int rows, int n, int Zc, const float* __restrict__ z, int ldz,
+                                                          const float* __restrict__ Wt, float* __restrict__ x, int ldx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float4 acc[NJ];
+  int off[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    off[j] = c < n ? c : 0;
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float* zr = z + (size_t)row * ldz;
+  for (int e0 = 0; e0 < Zc; e0 += 256) {          // 4 scans in flight, then their gathers
+    float v[4];
+    unsigned long long m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = zr[min(e0 + 64 * u + lane, Zc - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = __ballot(e0 + 64 * u + lane < Zc && v[u] != 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      unsigned long long mm = m[u];
+      while (mm) {
+        const int b = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const float ze = __shfl(v[u], b, 64);
+        const float* wr = Wt + (size_t)(e0 + 64 * u + b) * n;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(wr + off[j]);
+          acc[j].x += ze * w.x; acc[j].y += ze * w.y; acc[j].z += ze * w.z; acc[j].w += ze * w.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (c < n) *reinterpret_cast<float4*>(x + (size_t)row * ldx + c) = acc[j];
+  }
+}
+int dm_sparse_rows_launch(int rows, int n, int Zc, const float* z, int ldz, const float* Wt, float* x, int ldx,
+                          hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  DM_REQUIRE(n >= 4 && n <= 1024 && (n & 3) == 0 && (ldx & 3) == 0 && Zc >= 1, DM_E_SHAPE, "sparse_rows: n=%d Zc=%d", n, Zc);
+  const dim3 grid(dm_cdiv(rows, 4)), blk(256);
+  if (n <= 256) hipLaunchKernelGGL((sparse_rows_kernel<1>), grid, blk, 0, st, rows, n, Zc, z, ldz, Wt, x, ldx);
+  else if (n <= 512) hipLaunchKernelGGL((sparse_rows_kernel<2>), grid, blk, 0, st, rows, n, Zc, z, ldz, Wt, x, ldx);
+  else hipLaunchKernelGGL((sparse_rows_kernel<4>), grid, blk, 0, st, rows, n, Zc, z, ldz, Wt, x, ldx);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 bool dm_z_embed_ok(int n) { return n <= 1024 && (n & 3) == 0; }
 int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
                       const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,

@@ -2,6 +2,7 @@
 // Used by the reward / terminal decoders (decoders.py:257-319) and actor / critic / critic_target (a2c.py:37-39).
 // Contractions run on gemm.hip (MFMA); LayerNorm+ELU and the bias / gamma / beta column sums are row kernels.
 #include "common.h"
+#include <stdlib.h>
 
 struct MlpActs {
   float* xpre[DM_MAX_MLP_LAYERS];
@@ -29,7 +30,8 @@ static size_t mlp_ws_floats(int rows, int hidden, int layers) {
   const size_t rh = dm_align_up((size_t)rows * hidden, 64);
   return DM_SPLITK_FLOATS + 3 * rh + dm_align_up((size_t)layers * dm_panel_count(rows) * 3 * hidden, 64) +
          dm_align_up((size_t)hidden * hidden, 64) + 256 +     // + the bf16 panel backward's transposed weights
-         dm_align_up((size_t)hidden * 2048 + (size_t)layers * hidden * hidden / 2 + 64, 64);      // + bf16 weight copies (in_dim <= 4096)
+         dm_align_up((size_t)hidden * 2048 + (size_t)layers * hidden * hidden / 2 + 64, 64) +     // + bf16 weight copies (in_dim <= 4096)
+         rh + dm_align_up((size_t)hidden * 4096, 64);       // + sparse-column contribution and W0^T (sparse_cols, in_dim <= 4096)
 }
 extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
   if (rows < 0 || hidden < 0 || layers < 0 || layers > DM_MAX_MLP_LAYERS) return 0;
@@ -45,8 +47,9 @@ extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
 // leave most CUs idle there).
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack) {
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack, int sparse_cols) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
+  DM_REQUIRE(sparse_cols >= 0 && sparse_cols < in_dim, DM_E_SHAPE, "mlp: sparse_cols=%d of in_dim=%d", sparse_cols, in_dim);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
   MlpActs a;
   if (acts) {
@@ -87,10 +90,11 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
     const bool fuse_out = out_dim <= 32;
     // bf16 operands: one bf16 copy of the hidden-layer weights per call (the panels then stream half the bytes, unconverted)
     const unsigned short* wh[DM_MAX_MLP_LAYERS] = {};
-    if (dm_cur_precision() && in_dim <= 4096 && (in_dim & 7) == 0) {
-      DmArena ar(ws, ws_bytes);
-      ar.take(DM_SPLITK_FLOATS);
-      ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * 2);
+    DmArena ar(ws, ws_bytes);       // optional scratch of this path, past the split-K region and the activation ping-pong
+    ar.take(DM_SPLITK_FLOATS);
+    ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * 2);
+    if (ar.ok && dm_cur_precision() && in_dim <= 4096 && (in_dim & 7) == 0) {
+      const size_t mark = ar.off;
       const float* src[DM_MAX_MLP_LAYERS];
       unsigned short* dst[DM_MAX_MLP_LAYERS];
       int rws[DM_MAX_MLP_LAYERS], cls[DM_MAX_MLP_LAYERS];
@@ -102,15 +106,37 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
       if (ar.ok) {
         DM_TRY(dm_panel_bf16_weights_launch(layers, src, dst, rws, cls, 0, st));
         for (int l = 0; l < layers; ++l) wh[l] = dst[l];
+      } else {
+        ar.off = mark; ar.ok = true;
+      }
+    }
+    // Sparse trailing columns (the one-hot latent of a feature row): layer 0 multiplies only the dense columns, the
+    // others contribute the sum of the weight rows their non-zeros name (x W^T = x_dense W_d^T + sum_e x_e W^T[e]);
+    // for the DreamerV2 feature (600 dense + 32 of 1024) that is 63 % of the layer's flops replaced by a 32-row gather
+    // (40 000 rows: 764 us -> 290 us + 135 us).  fp32 only: with bf16 operands the product is cheaper than the gather
+    // (measured: step +0.4 ms), DM_MLP_SPARSE_BF16=1 forces it there for tests.
+    static const int no_sparse = getenv("DM_MLP_NO_SPARSE") ? 1 : 0;         // A/B switch
+    static const int sparse_bf16 = getenv("DM_MLP_SPARSE_BF16") ? 1 : 0;
+    const float* addm = nullptr;
+    int k0 = in_dim;
+    const int dense = in_dim - sparse_cols;
+    if (ar.ok && sparse_cols > 0 && !no_sparse && (!dm_cur_precision() || sparse_bf16) && in_dim <= 4096 && (dense & 7) == 0 && dense >= 32 && (ldx & 3) == 0) {
+      float* g = ar.take((size_t)rows * hidden);
+      float* w0t = ar.take((size_t)in_dim * hidden);
+      if (ar.ok) {
+        DM_TRY(dm_permute4_launch(p->w[0], w0t, 1, 1, hidden, in_dim, 0, 1, 3, 2, st));       // W0 (hidden, in) -> W0^T (in, hidden)
+        DM_TRY(dm_sparse_rows_launch(rows, hidden, sparse_cols, x + dense, ldx, w0t + (size_t)dense * hidden, g, hidden, st));
+        addm = g; k0 = dense;
       }
     }
     for (int l = 0; l < layers; ++l) {
       const bool last = l == layers - 1;
       const bool fo = last && fuse_out;
-      DM_TRY(dm_panel_ln_fwd_launch(rows, hidden, kin, in, ldin, p->w[l], p->b[l], p->ln_g[l], p->ln_b[l], 1e-3f,
+      DM_TRY(dm_panel_ln_fwd_launch(rows, hidden, l == 0 ? k0 : kin, in, ldin, p->w[l], p->b[l], p->ln_g[l], p->ln_b[l], 1e-3f,
                                     acts ? a.xpre[l] : nullptr, acts ? a.stats[l] : nullptr,
                                     (fo && !acts) ? nullptr : a.y[l], fo ? p->w[layers] : nullptr,
-                                    fo ? p->b[layers] : nullptr, out, out_dim, ldout, st, wh[l]));
+                                    fo ? p->b[layers] : nullptr, out, out_dim, ldout, st, wh[l], l == 0 ? in_dim : 0,
+                                    l == 0 ? addm : nullptr));
       in = a.y[l]; ldin = hidden; kin = hidden;
     }
     if (fuse_out) return DM_OK;
@@ -143,6 +169,15 @@ extern "C" int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int
   DmPrecisionScope prec(p->precision);
   return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, rows, 0, out, out_dim, ws, ws_bytes,
                            (hipStream_t)stream);
+}
+
+extern "C" int dm_mlp_head_fwd_sparse(int rows, int in_dim, int sparse_cols, int hidden, int layers, int out_dim,
+                                      const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && p && out && ws, DM_E_NULL, "mlp_head_fwd_sparse: null pointer");
+  DmPrecisionScope prec(p->precision);
+  return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x, ldx, p, acts, rows, 0, out, out_dim, ws, ws_bytes,
+                           (hipStream_t)stream, nullptr, sparse_cols);
 }
 
 extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,

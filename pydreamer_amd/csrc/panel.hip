@@ -36,6 +36,7 @@ struct PanelArgs {
   // EPI_LN_BWD inputs / outputs
   const float* xin; const float* stin; float* dx; int lddx; float* colpart;
   const unsigned short* Bh;      // bf16 copy of B ([n][k], row stride ldb elements; K % 8 == 0), bf16-operand kernel only
+  const float* addm;             // EPI_LN_FWD, optional (M x N, dense): added to the product before the LayerNorm
 };
 
 __device__ __forceinline__ float panel_red16(float v) {      // sum over the 16 lanes that share lane>>4
@@ -149,6 +150,7 @@ __device__ __forceinline__ void panel_epilogue(f32x4 (&acc)[NBLK], const PanelAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         acc[b][r] += bi;
+        if (g.addm && rok[r]) acc[b][r] += g.addm[(size_t)(rbase + r) * (NBLK * 16) + b * 16 + l15];
         s[r] += acc[b][r];
       }
     }
@@ -549,12 +551,14 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ldx, const float* W, const float* b,
                            const float* gamma, const float* beta, float eps, float* xpre, float* stats, float* y,
                            const float* wout, const float* bout, float* out, int out_dim, int ldout, hipStream_t st,
-                           const unsigned short* Wh) {
+                           const unsigned short* Wh, int ldw, const float* addm) {
   DM_REQUIRE(hidden == 400, DM_E_SHAPE, "panel_ln_fwd: hidden %d (built for 400)", hidden);
-  DM_REQUIRE((kin & 3) == 0 && al16(W), DM_E_SHAPE, "panel_ln_fwd: weight rows must be 16-byte aligned (kin %d)", kin);
+  if (ldw <= 0) ldw = kin;
+  DM_REQUIRE((kin & 3) == 0 && (ldw & 3) == 0 && ldw >= kin && al16(W), DM_E_SHAPE,
+             "panel_ln_fwd: weight rows must be 16-byte aligned (kin %d, ldw %d)", kin, ldw);
   if (rows <= 0) return DM_OK;
   PanelArgs a = {};
-  a.A = x; a.lda = ldx; a.B = W; a.ldb = kin; a.bias = b;
+  a.A = x; a.lda = ldx; a.B = W; a.ldb = ldw; a.bias = b; a.addm = addm;
   a.M = rows; a.N = hidden; a.K = kin;
   a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.xpre = xpre; a.stats = stats; a.y = y; a.ldy = hidden;
@@ -565,7 +569,7 @@ int dm_panel_ln_fwd_launch(int rows, int hidden, int kin, const float* x, int ld
   const bool avec = (ldx & 3) == 0 && al16(x);
   if (dm_cur_precision()) {
     a.Bh = Wh;
-    if (Wh && avec && (kin & 7) == 0 && al16(Wh)) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true, true>), grid, blk, 0, st, a);
+    if (Wh && avec && (kin & 7) == 0 && (ldw & 7) == 0 && al16(Wh)) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true, true>), grid, blk, 0, st, a);
     else if (avec) hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, true, false>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((panel_linear_bf16_kernel<25, PANEL_EPI_LN_FWD, false, false>), grid, blk, 0, st, a);
   } else if (avec) hipLaunchKernelGGL((panel_linear_kernel<25, 0, PANEL_EPI_LN_FWD, true>), grid, blk, 0, st, a);

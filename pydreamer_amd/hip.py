@@ -130,6 +130,7 @@ _SIGNATURES = {
     'dm_mlp_ws_floats': (c_size_t, [c_int, c_int, c_int]),
     'dm_mlp_head_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P,
                                 c_size_t, _P]),
+    'dm_mlp_head_fwd_sparse': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P, c_size_t, _P]),
     'dm_mlp_head_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P,
                                 POINTER(dm_mlp_grads), _P, c_int, c_int, _P, c_size_t, _P]),
     'dm_head_loss': (c_int, [c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),

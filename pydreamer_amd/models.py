@@ -130,10 +130,12 @@ class MLP(_Params):
     def acts_floats(self, rows):
         return int(H.lib().dm_mlp_acts_floats(rows, self.hidden_dim, self.hidden_layers))
 
-    def fwd(self, x2d, ldx, rows, ws, acts=None, save_acts=True):
+    def fwd(self, x2d, ldx, rows, ws, acts=None, save_acts=True, sparse_cols=0):
         """x2d: device tensor whose rows (leading dim ldx floats) hold in_dim features. Returns (out, acts).
         save_acts=False (heads nobody differentiates: critic_target, the dream's reward / terminal heads, inference):
-        no activation buffer is allocated or written; the library ping-pongs through the workspace."""
+        no activation buffer is allocated or written; the library ping-pongs through the workspace.
+        sparse_cols: the last sparse_cols input columns are mostly zero (the one-hot latent part of a feature row); same
+        result for any input, cheaper first layer on large batches (dm_mlp_head_fwd_sparse)."""
         if acts is None and save_acts:
             acts = torch.empty(self.acts_floats(rows), device=x2d.device)
         need = 4 * int(H.lib().dm_mlp_ws_floats(rows, self.hidden_dim, self.hidden_layers))
@@ -141,8 +143,12 @@ class MLP(_Params):
             raise H.DreamerHipError(f'MLP.fwd: workspace of {ws.numel()} bytes, need {need} for {rows} rows')
         out = torch.empty(rows, self.out_dim, device=x2d.device)
         st = self.struct()
-        H.call('dm_mlp_head_fwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
-               ctypes.byref(st), H.fptr(acts), H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
+        if 0 < sparse_cols < self.in_dim:
+            H.call('dm_mlp_head_fwd_sparse', rows, self.in_dim, sparse_cols, self.hidden_dim, self.hidden_layers, self.out_dim,
+                   H.fptr(x2d), ldx, ctypes.byref(st), H.fptr(acts), H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
+        else:
+            H.call('dm_mlp_head_fwd', rows, self.in_dim, self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx,
+                   ctypes.byref(st), H.fptr(acts), H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
         return out, acts
 
     def bwd(self, x2d, ldx, rows, acts, dout, ws, dx=None, lddx=0, dx_accum=False, scratch=False):
@@ -873,8 +879,8 @@ class WorldModel(_Params):
                     ac.update_critic_target()
                 ac.train_steps += 1
             rows = (T - 1) * B
-            value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False)
-            value, aux_acts = ac.critic.fwd(feat, F_, N, ws)
+            value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False, sparse_cols=Z)
+            value, aux_acts = ac.critic.fwd(feat, F_, N, ws, sparse_cols=Z)
             adv, agae, vtgt, wgt = (torch.empty(T - 1, B, device=dev) for _ in range(4))
             H.call('dm_gae_losses', T - 1, B, ac.gamma, ac.lambda_, H.fptr(reward_t), H.fptr(terminal_t), H.fptr(value_t),
                    H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
@@ -1130,6 +1136,7 @@ class ActorCritic(_Params):
         self.critic_target = MLP(in_dim, 1, hidden_dim, hidden_layers, layer_norm)
         self.critic_target.requires_grad_(False)
         self.train_steps = 0
+        self.sparse_cols = 0                  # trailing feature columns known to be one-hot samples (set by the owner)
         self.defer_target_update = False      # set by pydreamer_amd.graph while capturing (refresh + counter done there)
 
     def update_critic_target(self):
@@ -1159,12 +1166,13 @@ class ActorCritic(_Params):
         if ws is None:
             raise H.DreamerHipError('ActorCritic.training_step needs the model workspace (called through Dreamer.training_step)')
 
-        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws, save_acts=False)
-        value, c_acts = self.critic.fwd(feats, F_, J * M, ws)
+        sp = self.sparse_cols        # the one-hot latent columns at the end of a feature row (0: unknown)
+        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws, save_acts=False, sparse_cols=sp)
+        value, c_acts = self.critic.fwd(feats, F_, J * M, ws, sparse_cols=sp)
         if actor_acts is not None:
             logits, a_acts = actor_logits, actor_acts
         else:
-            logits, a_acts = self.actor.fwd(feats, F_, Hh * M, ws)   # features[:-1] = first H*M rows
+            logits, a_acts = self.actor.fwd(feats, F_, Hh * M, ws, sparse_cols=sp)   # features[:-1] = first H*M rows
         adv, agae, vtgt, wgt = (torch.empty(Hh, M, device=dev) for _ in range(4))
         H.call('dm_gae_losses', Hh, M, self.gamma, self.lambda_, H.fptr(rewards), H.fptr(terminals), H.fptr(value_t),
                H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
@@ -1223,6 +1231,7 @@ class Dreamer(nn.Module):
         self.ac = ActorCritic(in_dim=features_dim, out_actions=conf.action_dim, layer_norm=conf.layer_norm, gamma=conf.gamma,
                               lambda_gae=conf.lambda_gae, entropy_weight=conf.entropy, target_interval=conf.target_interval,
                               actor_grad=conf.actor_grad, actor_dist=conf.actor_dist)
+        self.ac.sparse_cols = conf.stoch_dim * conf.stoch_discrete       # feature = [h | one-hot z] (rssm.py:83-84)
         self.probe_model = NoProbeHead()
         self.probe_gradients = conf.probe_gradients
         self._groups = None
@@ -1332,8 +1341,9 @@ class Dreamer(nn.Module):
                H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
         rows = (Hh + 1) * M
         f2 = feats.view(rows, F_)
-        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws, save_acts=False)
-        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws, save_acts=False)
+        Zc = c.stoch_dim * c.stoch_discrete            # the sampled one-hot latent columns of a feature row
+        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws, save_acts=False, sparse_cols=Zc)
+        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws, save_acts=False, sparse_cols=Zc)
         term = torch.empty(rows, device=dev)
         H.call('dm_head_loss', 1, rows, H.fptr(tl), None, 0.0, 0.0, None, None, H.fptr(term), H.stream())
         if _pack is not None:

@@ -107,6 +107,52 @@ def test_mlp_head_panel_fwd_bwd(hip, rows, in_dim, out_dim):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
+@pytest.mark.parametrize('rows,dense,S,C,out_dim', [(16400, 72, 8, 8, 6), (20000, 600, 32, 32, 1)])
+def test_mlp_head_sparse_trailing_columns(hip, rows, dense, S, C, out_dim):
+    """dm_mlp_head_fwd_sparse (layer 0 = dense columns on the matrix pipe + the one-hot latent columns as a sum of weight
+    rows) equals dm_mlp_head_fwd on feature rows [h | one-hot z] - output, saved pre-activations and statistics, so the
+    unchanged dm_mlp_head_bwd gives the same gradients - and stays EXACT for arbitrary (dense, scaled, all-zero) trailing
+    columns; fp64 reference; bf16 operands too."""
+    from pydreamer_amd.models import MLP
+    torch.manual_seed(11)
+    Z = S * C
+    in_dim = dense + Z
+    m = MLP(in_dim, out_dim, 400, 4).to(DEV)
+    ws = torch.empty(768 << 20, dtype=torch.uint8, device=DEV)
+    idx = torch.randint(0, C, (rows, S), device=DEV)
+    z = F.one_hot(idx, C).float().reshape(rows, Z)
+    x = torch.cat((torch.randn(rows, dense, device=DEV), z), -1).contiguous()
+    out_d, acts_d = m.fwd(x, in_dim, rows, ws, acts=torch.zeros(m.acts_floats(rows), device=DEV))
+    out_s, acts_s = m.fwd(x, in_dim, rows, ws, acts=torch.zeros(m.acts_floats(rows), device=DEV), sparse_cols=Z)
+    sd = {k: v.detach().double().cpu() for k, v in m.model.state_dict().items()}
+    h = x.double().cpu()
+    for i in range(4):
+        h = F.elu(F.layer_norm(h @ sd[f'{3 * i}.weight'].t() + sd[f'{3 * i}.bias'], (400,), sd[f'{3 * i + 1}.weight'],
+                               sd[f'{3 * i + 1}.bias'], 1e-3))
+    ref = (h @ sd['12.weight'].t() + sd['12.bias']).reshape(out_s.shape)
+    e_s, e_d = float((out_s.double().cpu() - ref).abs().max()), float((out_d.double().cpu() - ref).abs().max())
+    assert e_s < 2e-5 * max(1.0, float(ref.abs().max())) and e_s < 4 * e_d + 1e-6, (e_s, e_d)
+    assert _rel_l2(acts_s, acts_d) < 2e-6
+    dout = torch.randn(rows, out_dim, device=DEV) / rows
+    g_s = [g.clone() for g in m.bwd(x, in_dim, rows, acts_s, dout, ws)[0]]
+    g_d = [g.clone() for g in m.bwd(x, in_dim, rows, acts_d, dout, ws)[0]]
+    for a_, b_ in zip(g_s, g_d):
+        assert _rel_l2(a_, b_) < 1e-5
+    # not one-hot at all: scaled, dense and empty trailing columns - the sparse-row product is exact for any input
+    x2 = x.clone()
+    x2[: rows // 3, dense:] = torch.randn(rows // 3, Z, device=DEV)
+    x2[rows // 3: rows // 2, dense:] *= 2.5
+    x2[rows // 2: rows // 2 + 7, dense:] = 0
+    o_d, _ = m.fwd(x2, in_dim, rows, ws, save_acts=False)
+    o_s, _ = m.fwd(x2, in_dim, rows, ws, save_acts=False, sparse_cols=Z)
+    assert _rel_l2(o_s, o_d) < 2e-6 and float((o_s - o_d).abs().max()) < 2e-5 * max(1.0, float(o_d.abs().max()))
+    # bf16 operands (conf.amp) keep the full product (the gather does not pay there): identical results
+    m.precision = 1
+    o16_d, _ = m.fwd(x, in_dim, rows, ws, save_acts=False)
+    o16_s, _ = m.fwd(x, in_dim, rows, ws, save_acts=False, sparse_cols=Z)
+    assert torch.equal(o16_s, o16_d)
+
+
 @pytest.mark.parametrize('rows,in_dim,out_dim', [(16400, 136, 6), (20000, 1624, 1)])
 def test_mlp_head_panel_bf16_operands(hip, rows, in_dim, out_dim):
     """dm_mlp_params.precision = 1 (conf.amp) on the row-panel path: operands of every hidden-layer product rounded to bf16
