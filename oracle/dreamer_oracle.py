@@ -77,13 +77,14 @@ def feature_dim(conf):
 MLP_HIDDEN = 400   # a2c.py:16, decoders.py:259,289
 
 
-def _mlp_shapes(prefix, in_dim, out_dim, layers, out):
+def _mlp_shapes(prefix, in_dim, out_dim, layers, out, layer_norm=True):
     dim = in_dim
     for i in range(layers):                                 # common.py:43-50
         out[f'{prefix}.{3 * i}.weight'] = (MLP_HIDDEN, dim)
         out[f'{prefix}.{3 * i}.bias'] = (MLP_HIDDEN,)
-        out[f'{prefix}.{3 * i + 1}.weight'] = (MLP_HIDDEN,)
-        out[f'{prefix}.{3 * i + 1}.bias'] = (MLP_HIDDEN,)
+        if layer_norm:                                      # NoNorm (common.py:68-74) has no parameters
+            out[f'{prefix}.{3 * i + 1}.weight'] = (MLP_HIDDEN,)
+            out[f'{prefix}.{3 * i + 1}.bias'] = (MLP_HIDDEN,)
         dim = MLP_HIDDEN
     out[f'{prefix}.{3 * layers}.weight'] = (out_dim, dim)   # common.py:51-53
     out[f'{prefix}.{3 * layers}.bias'] = (out_dim,)
@@ -104,12 +105,13 @@ def param_shapes(conf):
     for i, (ci, co, k) in enumerate([(32 * d, 4 * d, 5), (4 * d, 2 * d, 5), (2 * d, d, 6), (d, ch, 6)]):   # decoders.py:149-155
         s[f'{dec}.{2 + 2 * i}.weight'] = (ci, co, k, k)
         s[f'{dec}.{2 + 2 * i}.bias'] = (co,)
-    _mlp_shapes('wm.decoder.reward.model.model', Fd, 1, conf.reward_decoder_layers, s)
-    _mlp_shapes('wm.decoder.terminal.model.model', Fd, 1, conf.terminal_decoder_layers, s)
+    _mlp_shapes('wm.decoder.reward.model.model', Fd, 1, conf.reward_decoder_layers, s, conf.layer_norm)
+    _mlp_shapes('wm.decoder.terminal.model.model', Fd, 1, conf.terminal_decoder_layers, s, conf.layer_norm)
     c = 'wm.core.cell'                                                                     # rssm.py:103-116
     s[f'{c}.z_mlp.weight'] = (Hd, Z); s[f'{c}.z_mlp.bias'] = (Hd,)
     s[f'{c}.a_mlp.weight'] = (Hd, A)
-    s[f'{c}.in_norm.weight'] = (Hd,); s[f'{c}.in_norm.bias'] = (Hd,)
+    if conf.layer_norm:
+        s[f'{c}.in_norm.weight'] = (Hd,); s[f'{c}.in_norm.bias'] = (Hd,)
     GL = int(getattr(conf, 'gru_layers', 1))                                               # GRUCellStack, rnn.py:43-57
     ls = D_ // GL
     assert ls * GL == D_, 'Must be divisible'
@@ -128,19 +130,21 @@ def param_shapes(conf):
         else:
             raise ValueError(conf.gru_type)
     s[f'{c}.prior_mlp_h.weight'] = (Hd, D_); s[f'{c}.prior_mlp_h.bias'] = (Hd,)
-    s[f'{c}.prior_norm.weight'] = (Hd,); s[f'{c}.prior_norm.bias'] = (Hd,)
+    if conf.layer_norm:
+        s[f'{c}.prior_norm.weight'] = (Hd,); s[f'{c}.prior_norm.bias'] = (Hd,)
     s[f'{c}.prior_mlp.weight'] = (Z, Hd); s[f'{c}.prior_mlp.bias'] = (Z,)
     s[f'{c}.post_mlp_h.weight'] = (Hd, D_); s[f'{c}.post_mlp_h.bias'] = (Hd,)
     s[f'{c}.post_mlp_e.weight'] = (Hd, E)
-    s[f'{c}.post_norm.weight'] = (Hd,); s[f'{c}.post_norm.bias'] = (Hd,)
+    if conf.layer_norm:
+        s[f'{c}.post_norm.weight'] = (Hd,); s[f'{c}.post_norm.bias'] = (Hd,)
     s[f'{c}.post_mlp.weight'] = (Z, Hd); s[f'{c}.post_mlp.bias'] = (Z,)
     if conf.aux_critic:                                                                    # dreamer.py:267-277 (a full ActorCritic)
-        _mlp_shapes('wm.ac_aux.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s)
-        _mlp_shapes('wm.ac_aux.critic.model', Fd, 1, 4, s)
-        _mlp_shapes('wm.ac_aux.critic_target.model', Fd, 1, 4, s)
-    _mlp_shapes('ac.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s)   # a2c.py:35-39
-    _mlp_shapes('ac.critic.model', Fd, 1, 4, s)
-    _mlp_shapes('ac.critic_target.model', Fd, 1, 4, s)
+        _mlp_shapes('wm.ac_aux.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s, conf.layer_norm)
+        _mlp_shapes('wm.ac_aux.critic.model', Fd, 1, 4, s, conf.layer_norm)
+        _mlp_shapes('wm.ac_aux.critic_target.model', Fd, 1, 4, s, conf.layer_norm)
+    _mlp_shapes('ac.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s, conf.layer_norm)   # a2c.py:35-39
+    _mlp_shapes('ac.critic.model', Fd, 1, 4, s, conf.layer_norm)
+    _mlp_shapes('ac.critic_target.model', Fd, 1, 4, s, conf.layer_norm)
     s['probe_model.dummy'] = (1,)                                                          # probes.py:144
     return s
 
@@ -242,14 +246,21 @@ def sample_inverse_cdf(probs, u):
     return (cdf <= target).sum(-1).clamp(max=probs.shape[-1] - 1)
 
 
+def _norm(p, name, x):
+    """nn.LayerNorm(eps=1e-3), or NoNorm (common.py:68-74: identity, no parameters) when the model was built with
+    layer_norm=False - told apart by the presence of the parameters."""
+    if f'{name}.weight' not in p:
+        return x
+    return F.layer_norm(x, (x.shape[-1],), p[f'{name}.weight'], p[f'{name}.bias'], 1e-3)
+
+
 def mlp(p, prefix, x, layers):
     """common.py:37-65."""
     lead = x.shape[:-1]
     y = x.reshape(-1, x.shape[-1])
     for i in range(layers):
         y = F.linear(y, p[f'{prefix}.{3 * i}.weight'], p[f'{prefix}.{3 * i}.bias'])
-        y = F.layer_norm(y, (y.shape[-1],), p[f'{prefix}.{3 * i + 1}.weight'], p[f'{prefix}.{3 * i + 1}.bias'], 1e-3)
-        y = F.elu(y)
+        y = F.elu(_norm(p, f'{prefix}.{3 * i + 1}', y))
     y = F.linear(y, p[f'{prefix}.{3 * layers}.weight'], p[f'{prefix}.{3 * layers}.bias'])
     if y.shape[-1] == 1:
         return y.reshape(lead)            # nn.Flatten(0) + unflatten_batch, common.py:54-57,61-65
@@ -343,15 +354,14 @@ def st_sample(conf, logits, u, forced_idx=None):
 def cell_trunk(p, action, h, z):
     c = 'wm.core.cell'
     x = F.linear(z, p[f'{c}.z_mlp.weight'], p[f'{c}.z_mlp.bias']) + F.linear(action, p[f'{c}.a_mlp.weight'])
-    x = F.layer_norm(x, (x.shape[-1],), p[f'{c}.in_norm.weight'], p[f'{c}.in_norm.bias'], 1e-3)
-    return gru_cell(p, F.elu(x), h)
+    return gru_cell(p, F.elu(_norm(p, f'{c}.in_norm', x)), h)
 
 
 def prior_head(p, h):
     """rssm.py:174-177 / 186-193."""
     c = 'wm.core.cell'
     x = F.linear(h, p[f'{c}.prior_mlp_h.weight'], p[f'{c}.prior_mlp_h.bias'])
-    x = F.elu(F.layer_norm(x, (x.shape[-1],), p[f'{c}.prior_norm.weight'], p[f'{c}.prior_norm.bias'], 1e-3))
+    x = F.elu(_norm(p, f'{c}.prior_norm', x))
     return F.linear(x, p[f'{c}.prior_mlp.weight'], p[f'{c}.prior_mlp.bias'])
 
 
@@ -362,7 +372,7 @@ def cell_forward(p, conf, embed, action, reset_mask, h, z, u, forced_idx=None):
     z = z * reset_mask
     h = cell_trunk(p, action, h, z)
     x = F.linear(h, p[f'{c}.post_mlp_h.weight'], p[f'{c}.post_mlp_h.bias']) + F.linear(embed, p[f'{c}.post_mlp_e.weight'])
-    x = F.elu(F.layer_norm(x, (x.shape[-1],), p[f'{c}.post_norm.weight'], p[f'{c}.post_norm.bias'], 1e-3))
+    x = F.elu(_norm(p, f'{c}.post_norm', x))
     post = F.linear(x, p[f'{c}.post_mlp.weight'], p[f'{c}.post_mlp.bias'])
     sample, idx = st_sample(conf, post, u, forced_idx)
     return post, h, sample, idx

@@ -378,6 +378,15 @@ if __name__ == '__main__':
             full_grads=('wm.core.cell.gru.layers.0.weight_ih', 'wm.core.cell.gru.layers.1.weight_ih',
                         'wm.core.cell.gru.layers.2.weight_hh', 'wm.core.cell.gru.layers.1.bias_hh',
                         'wm.core.cell.z_mlp.weight', 'ac.actor.model.12.weight'))
+    if 'no_layernorm' in which:
+        # SURVEY 8(a) variant: layer_norm=False (common.py:68-74 NoNorm in every MLP head and in the RSSM cell's three norms)
+        t = O.tiny_conf()
+        run('tiny_no_layernorm', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, layer_norm=False), steps=2,
+            full_grads=('wm.core.cell.z_mlp.weight', 'wm.core.cell.post_mlp_h.weight', 'wm.core.cell.prior_mlp.bias',
+                        'wm.decoder.reward.model.model.12.weight', 'ac.actor.model.12.weight', 'ac.critic.model.12.weight'))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

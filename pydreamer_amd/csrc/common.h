@@ -132,6 +132,10 @@ int dm_gemm_pair_launch(const DmGemm& g0, const DmGemm& g1, void* ws, size_t ws_
 
 // element-wise / row-wise launchers (elementwise.hip)
 int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+// layer_norm=False (common.py:68-74): y = ELU(x); dx = dy * ELU'(y)
+int dm_elu_fwd_launch(int rows, int n, const float* x, int ldx, float* y, int ldy, hipStream_t st);
+int dm_elu_bwd_launch(int rows, int n, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                      hipStream_t st);
 int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
                          float* y, int ldy, float* stats, hipStream_t st);
 int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,

@@ -270,6 +270,42 @@ int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* 
   return DM_OK;
 }
 
+// layer_norm=False (common.py:68-74 NoNorm): the activation alone.  y = ELU(x); dx = dy * ELU'(y) (ELU' from the output).
+__global__ void __launch_bounds__(256) elu_fwd_kernel(int rows, int n, const float* __restrict__ x, int ldx,
+                                                      float* __restrict__ y, int ldy) {
+  const size_t total = (size_t)rows * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / n, c = i % n;
+    y[r * ldy + c] = dm_elu(x[r * ldx + c]);
+  }
+}
+__global__ void __launch_bounds__(256) elu_bwd_kernel(int rows, int n, const float* __restrict__ y, int ldy,
+                                                      const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                      int lddx) {
+  const size_t total = (size_t)rows * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / n, c = i % n;
+    dx[r * lddx + c] = dy[r * lddy + c] * dm_elu_grad_from_y(y[r * ldy + c]);
+  }
+}
+int dm_elu_fwd_launch(int rows, int n, const float* x, int ldx, float* y, int ldy, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  const size_t total = (size_t)rows * n;
+  hipLaunchKernelGGL(elu_fwd_kernel, dim3((unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536)), dim3(256), 0,
+                     st, rows, n, x, ldx, y, ldy);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+int dm_elu_bwd_launch(int rows, int n, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                      hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  const size_t total = (size_t)rows * n;
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536)), dim3(256), 0,
+                     st, rows, n, y, ldy, dy, lddy, dx, lddx);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // dx only (row kernel)
 int dm_ln_elu_bwd_dx_launch(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
                             const float* gamma, const float* dy, int lddy, float* dx, int lddx, hipStream_t st) {
@@ -727,6 +763,16 @@ __global__ void __launch_bounds__(256) z_embed_kernel(int rows, int n, int S, in
       if (x_frag) *reinterpret_cast<float4*>(x_frag + dm_frag_off(row, c)) = acc[j];
     }
   if (!y) return;
+  if (!gamma) {       // layer_norm=False: the activation alone
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (in[j]) {
+        float4 o;
+        o.x = dm_elu(acc[j].x); o.y = dm_elu(acc[j].y); o.z = dm_elu(acc[j].z); o.w = dm_elu(acc[j].w);
+        *reinterpret_cast<float4*>(y + (size_t)row * ldy + (lane + 64 * j) * 4) = o;
+      }
+    return;
+  }
   float s1 = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -821,7 +867,7 @@ int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const u
   DM_REQUIRE(dm_z_embed_ok(n) && idx && Wt && (x || y), DM_E_SHAPE, "z_embed: n=%d needs n <= 1024, n %% 4 == 0", n);
   DM_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0, DM_E_SHAPE, "z_embed: leading dims must be multiples of 4");
   DM_REQUIRE(!x_frag || rows <= 64, DM_E_SHAPE, "z_embed: the fragment-major copy needs rows <= 64");
-  DM_REQUIRE(!y || (gamma && beta), DM_E_NULL, "z_embed: LayerNorm output without its parameters");
+  DM_REQUIRE(!y || (gamma != nullptr) == (beta != nullptr), DM_E_NULL, "z_embed: LayerNorm gain without its bias");
   hipLaunchKernelGGL(z_embed_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, S, C, idx, row_zero, Wt, bias, add,
                      ldadd, idx2, Wt2, x, ldx, x_frag, gamma, beta, eps, y, ldy);
   DM_LAUNCH_CHECK();

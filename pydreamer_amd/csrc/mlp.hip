@@ -73,7 +73,12 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   const float* in = x;
   int ldin = ldx, kin = in_dim;
-  const bool panel = dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
+  // layer_norm=False (common.py:68-74 NoNorm): null LayerNorm parameters, Linear -> ELU per layer on the plain product path
+  const bool normed = p->ln_g[0] != nullptr;
+  for (int l = 0; l < layers; ++l)
+    DM_REQUIRE((p->ln_g[l] != nullptr) == normed && (p->ln_b[l] != nullptr) == normed, DM_E_NULL,
+               "mlp: layer %d mixes LayerNorm and NoNorm parameters", l);
+  const bool panel = normed && dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
   if (!panel && dm_mlp_chain_ok(rows, in_dim, hidden, layers, out_dim, x, ldx, p)) {    // all layers + output in ONE launch
     const float* wpack = chain_wpack;
     if (!wpack) {      // pack the weights fragment-major into the (otherwise unused) split-K region of the workspace
@@ -149,8 +154,10 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
       q.C = a.xpre[l]; q.ldc = hidden;
       q.bias = p->b[l];
       DM_TRY(dm_gemm_launch(q, ws, skb, st));
-      DM_TRY(dm_ln_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, p->ln_g[l], p->ln_b[l], 1e-3f, a.y[l], hidden,
-                                  a.stats[l], st));
+      if (normed)
+        DM_TRY(dm_ln_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, p->ln_g[l], p->ln_b[l], 1e-3f, a.y[l], hidden,
+                                    a.stats[l], st));
+      else DM_TRY(dm_elu_fwd_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, st));
       in = a.y[l]; ldin = hidden; kin = hidden;
     }
   }
@@ -193,7 +200,8 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
   float* splitk = ar.take(DM_SPLITK_FLOATS);
   float* dy = ar.take((size_t)rows * hidden);
   float* dxp = ar.take((size_t)rows * hidden);
-  const bool panel = dm_panel_ok(rows, hidden) && ((uintptr_t)p->w[layers] & 15) == 0;
+  const bool normed = p->ln_g[0] != nullptr;      // layer_norm=False: no LayerNorm parameters, no gradients for them
+  const bool panel = normed && dm_panel_ok(rows, hidden) && ((uintptr_t)p->w[layers] & 15) == 0;
   const int npanels = dm_panel_count(rows);
   float* colpart = ar.take(panel ? (size_t)layers * npanels * 3 * hidden : 0);
   float* wt = (panel && dm_cur_precision()) ? ar.take((size_t)hidden * hidden) : nullptr;
@@ -292,10 +300,14 @@ extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int
     const float* in = l == 0 ? x : a.y[l - 1];
     const int ldin = l == 0 ? ldx : hidden;
     const int kin = l == 0 ? in_dim : hidden;
-    DM_TRY(dm_ln_elu_bwd_dx_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], p->ln_g[l], dy, hidden,
-                                   dxp, hidden, st));
-    DM_TRY(dm_ln_elu_bwd_params_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], dy, hidden,
-                                       g->ln_g[l], g->ln_b[l], splitk, skb, st));
+    if (normed) {
+      DM_TRY(dm_ln_elu_bwd_dx_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], p->ln_g[l], dy, hidden,
+                                     dxp, hidden, st));
+      DM_TRY(dm_ln_elu_bwd_params_launch(rows, hidden, a.xpre[l], hidden, a.y[l], hidden, a.stats[l], dy, hidden,
+                                         g->ln_g[l], g->ln_b[l], splitk, skb, st));
+    } else {
+      DM_TRY(dm_elu_bwd_launch(rows, hidden, a.y[l], hidden, dy, hidden, dxp, hidden, st));
+    }
     DmGemm q;   // dW_l[h][i] = sum_r dxp[r][h] in[r][i]
     q.a_layout = 1; q.b_layout = 1;
     q.M = hidden; q.N = kin; q.K = rows;

@@ -79,6 +79,25 @@ static int gru_stack(const dm_shape* s, const float* const* p, float* const* g, 
   return DM_OK;
 }
 
+// The cell's three norms (rssm.py:103-116) are nn.LayerNorm(eps 1e-3) or, with layer_norm=False, NoNorm (common.py:68-74:
+// identity, no parameters): a null gain selects the activation alone, and no statistics / parameter gradients exist.
+static int norm_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y,
+                        int ldy, float* stats, hipStream_t st) {
+  if (gamma) return dm_ln_elu_fwd_launch(rows, n, x, ldx, gamma, beta, eps, y, ldy, stats, st);
+  return dm_elu_fwd_launch(rows, n, x, ldx, y, ldy, st);
+}
+static int norm_elu_bwd_dx(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                           const float* gamma, const float* dy, int lddy, float* dx, int lddx, hipStream_t st) {
+  if (gamma) return dm_ln_elu_bwd_dx_launch(rows, n, x, ldx, y, ldy, stats, gamma, dy, lddy, dx, lddx, st);
+  return dm_elu_bwd_launch(rows, n, y, ldy, dy, lddy, dx, lddx, st);
+}
+static int norm_elu_bwd_params(int rows, int n, const float* x, int ldx, const float* y, int ldy, const float* stats,
+                               const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
+  if (!dgamma && !dbeta) return DM_OK;
+  return dm_ln_elu_bwd_params_launch(rows, n, x, ldx, y, ldy, stats, dy, lddy, dgamma, dbeta, ws, ws_bytes, st);
+}
+
 // y = x @ W^T (+ bias) (+ add)
 static int linear(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* x, int ldx,
                   const float* W, const float* bias, const float* add, int ldadd, float* y, int ldy) {
@@ -190,7 +209,10 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   GruStack gk;
   DM_TRY(gru_stack(s, p, nullptr, &gk));
   const bool stacked = gk.L > 1;      // GRUCellStack with several layers: the unfused schedule, 3 launches per layer
-  const bool fuse_ln = !stacked && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
+  const bool normed = p[DM_RSSM_IN_G] != nullptr;      // layer_norm=False: all three norms are NoNorm (null parameters)
+  DM_REQUIRE((p[DM_RSSM_POST_G] != nullptr) == normed && (p[DM_RSSM_PRIOR_G] != nullptr) == normed, DM_E_NULL,
+             "rssm: the cell's three norms must be all LayerNorm or all NoNorm");
+  const bool fuse_ln = normed && !stacked && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
   static const int no_fuse_sample = getenv("DM_RSSM_NO_FUSE_SAMPLE") ? 1 : 0;      // A/B switch
   const bool fuse_sample = !no_fuse_sample && fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
@@ -253,7 +275,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       DM_TRY(dm_gemm_launch(q, ws, skb, st));
     }
     if (!fuse_ln)
-      DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
+      DM_TRY(norm_elu_fwd(B, Hd, a.x1 + r0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + r0 * Hd, Hd,
                                   a.st1 + r0 * 2, st));
     // h = GRUCell(za, h_in)                                                             rssm.py:141
     if (stacked) {
@@ -303,7 +325,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
       }
       DM_TRY(dm_gemm_launch(pq, ws, skb, st));
     } else {
-      DM_TRY(dm_ln_elu_fwd_launch(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
+      DM_TRY(norm_elu_fwd(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
                                   Hd, a.st2 + r0 * 2, st));
       DM_TRY(linear(st, ws, skb, B, Z, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
                     post + r0 * Z, Z));
@@ -314,15 +336,15 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
                                    idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
   }
   if (fuse_ln) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
-    DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,
+    DM_TRY(norm_elu_fwd(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,
                                 a.st1 + q0 * 2, st));
-    DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x2 + q0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + q0 * Hd, Hd,
+    DM_TRY(norm_elu_fwd(N, Hd, a.x2 + q0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + q0 * Hd, Hd,
                                 a.st2 + q0 * 2, st));
   }
   // batch_prior over all (T*B) rows                                                    rssm.py:61,186-193
   DM_TRY(linear(st, ws, skb, N, Hd, D, feat + q0 * F, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0,
                 a.x3 + q0 * Hd, Hd));
-  DM_TRY(dm_ln_elu_fwd_launch(N, Hd, a.x3 + q0 * Hd, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin + q0 * Hd,
+  DM_TRY(norm_elu_fwd(N, Hd, a.x3 + q0 * Hd, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin + q0 * Hd,
                               Hd, a.st3 + q0 * 2, st));
   DM_TRY(linear(st, ws, skb, N, Z, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
                 prior + q0 * Z, Z));
@@ -381,8 +403,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dprior, Z, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
   DM_TRY(dm_colsum_launch(N, Z, dprior, Z, g[DM_RSSM_PRIOR_OB], sk, skb, st));
   DM_TRY(dgrad(st, sk, skb, N, Z, Hd, dprior, Z, p[DM_RSSM_PRIOR_W], dprin, Hd, 0, nullptr));
-  DM_TRY(dm_ln_elu_bwd_dx_launch(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, p[DM_RSSM_PRIOR_G], dprin, Hd, dx3, Hd, st));
-  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
+  DM_TRY(norm_elu_bwd_dx(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, p[DM_RSSM_PRIOR_G], dprin, Hd, dx3, Hd, st));
+  DM_TRY(norm_elu_bwd_params(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
                                      g[DM_RSSM_PRIOR_B], sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk, skb, st));
@@ -404,7 +426,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = !stacked && kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  const bool fuse_b = p[DM_RSSM_IN_G] != nullptr && !stacked && kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
   // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
   // backward epilogue, read by the two products that follow it
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;
@@ -460,7 +482,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       }
       continue;
     }
-    DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x2 + r0 * Hd, Hd, a.pin + r0 * Hd, Hd, a.st2 + r0 * 2, p[DM_RSSM_POST_G],
+    DM_TRY(norm_elu_bwd_dx(B, Hd, a.x2 + r0 * Hd, Hd, a.pin + r0 * Hd, Hd, a.st2 + r0 * 2, p[DM_RSSM_POST_G],
                                    dpin + r0 * Hd, Hd, dx2 + r0 * Hd, Hd, st));
     DM_TRY(dgrad_t(st, sk, skb, B, Hd, D, dx2 + r0 * Hd, Hd, wt_post_h, dft, F, 1, nullptr));
     // GRU gates; the direct path dh'*u goes (masked) straight into step t-1's dh'
@@ -480,7 +502,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
         else DM_TRY(dgrad(st, sk, skb, B, 3 * ls, Hd, dgi_i, 3 * D, gk.wih[0], dza + r0 * Hd, Hd, 0, nullptr));
         if (dprev) DM_TRY(dgrad(st, sk, skb, B, 3 * ls, ls, dgh_i, 3 * D, gk.whh[i], dprev + i * ls, F, 1, rz));
       }
-      DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
+      DM_TRY(norm_elu_bwd_dx(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
                                      dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
       if (t > 0) DM_TRY(dgrad_t(st, sk, skb, B, Hd, Z, dx1 + r0 * Hd, Hd, wt_z, dprev + D, F, 1, rz));
       continue;
@@ -492,7 +514,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       DM_TRY(dm_gru_norm_bwd_launch(kind, B, D, a.gh + r0 * 3 * D, a.hin + r0 * D, D, a.gs + r0 * 3 * D, a.gst + r0 * 6, lng,
                                     lnb, dft, F, dgi + r0 * 3 * D, dgh + r0 * 3 * D, dgl + r0 * 3 * D, dprev, F, rz, st));
     DM_TRY(dgrad_t(st, sk, skb, B, 3 * D, Hd, dgi + r0 * 3 * D, 3 * D, wt_ih, dza + r0 * Hd, Hd, 0, nullptr));
-    DM_TRY(dm_ln_elu_bwd_dx_launch(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
+    DM_TRY(norm_elu_bwd_dx(B, Hd, a.x1 + r0 * Hd, Hd, a.za + r0 * Hd, Hd, a.st1 + r0 * 2, p[DM_RSSM_IN_G],
                                    dza + r0 * Hd, Hd, dx1 + r0 * Hd, Hd, st));
     if (t > 0) {     // both products into step t-1's [dh' | dz'], one launch
       DmGemm qh, qz;
@@ -505,13 +527,13 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   }
 
   if (fuse_b) {    // dx2 / dx1 of every row for the batched weight gradients below
-    DM_TRY(dm_ln_elu_bwd_dx_launch(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, p[DM_RSSM_POST_G], dpin, Hd, dx2, Hd, st));
-    DM_TRY(dm_ln_elu_bwd_dx_launch(N, Hd, a.x1, Hd, a.za, Hd, a.st1, p[DM_RSSM_IN_G], dza, Hd, dx1, Hd, st));
+    DM_TRY(norm_elu_bwd_dx(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, p[DM_RSSM_POST_G], dpin, Hd, dx2, Hd, st));
+    DM_TRY(norm_elu_bwd_dx(N, Hd, a.x1, Hd, a.za, Hd, a.st1, p[DM_RSSM_IN_G], dza, Hd, dx1, Hd, st));
   }
   // ---- weight / bias / LayerNorm gradients, batched over all rows
   DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dpost, Z, a.pin, Hd, g[DM_RSSM_POST_W]));
   DM_TRY(dm_colsum_launch(N, Z, dpost, Z, g[DM_RSSM_POST_OB], sk, skb, st));
-  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, dpin, Hd, g[DM_RSSM_POST_G], g[DM_RSSM_POST_B],
+  DM_TRY(norm_elu_bwd_params(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, dpin, Hd, g[DM_RSSM_POST_G], g[DM_RSSM_POST_B],
                                      sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx2, Hd, feat, F, g[DM_RSSM_POST_H_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx2, Hd, g[DM_RSSM_POST_H_B], sk, skb, st));
@@ -548,7 +570,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
         return dm_fail(DM_E_HIP, "rssm_sequence_bwd: gradient copy failed");
     }
   }
-  DM_TRY(dm_ln_elu_bwd_params_launch(N, Hd, a.x1, Hd, a.za, Hd, a.st1, dza, Hd, g[DM_RSSM_IN_G], g[DM_RSSM_IN_B], sk, skb,
+  DM_TRY(norm_elu_bwd_params(N, Hd, a.x1, Hd, a.za, Hd, a.st1, dza, Hd, g[DM_RSSM_IN_G], g[DM_RSSM_IN_B], sk, skb,
                                      st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx1, Hd, g[DM_RSSM_Z_B], sk, skb, st));
@@ -655,7 +677,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
                                za, Hd, st));
     } else {
       DM_TRY(linear(st, sk, skb, M, Hd, Z, cur + D, F, p[DM_RSSM_Z_W], p[DM_RSSM_Z_B], ea, Hd, x1, Hd));
-      DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
+      DM_TRY(norm_elu_fwd(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
     }
     if (gk.L > 1) {
       DM_TRY(gru_stack_fwd(st, sk, skb, gk, M, Hd, D, za, cur, F, gi, gh, nxt, F, nullptr, nullptr));
@@ -667,7 +689,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     } else if (kind == 0) DM_TRY(dm_gru_gates_fwd_launch(M, D, gi, gh, cur, F, nxt, F, nullptr, nullptr, nullptr, nullptr, st));
     else DM_TRY(dm_gru_norm_fwd_launch(kind, M, D, gi, gh, cur, F, lng, lnb, nxt, F, gsw, gstw, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
-    DM_TRY(dm_ln_elu_fwd_launch(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
+    DM_TRY(norm_elu_fwd(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
     DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
     DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
                                    nullptr, st));

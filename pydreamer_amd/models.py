@@ -8,10 +8,9 @@ model, actor, critic — so each of the 4 returned losses supports an independen
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
 Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type in {gru, gru_layernorm,
-gru_layernorm_dv2}, gru_layers=1,
-stoch_discrete>0, layer_norm=True, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh},
-actor_grad='reinforce',
-probe_model='none', no aux critic / vecobs / reward_input.
+gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0, layer_norm True or False,
+aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
+probe_model='none', no vecobs / reward_input.
 """
 import ctypes
 import os
@@ -89,16 +88,16 @@ def init_weights_tf2(m):
 
 
 class MLP(_Params):
-    """common.py:37-65: model = Sequential[Linear, LayerNorm, ELU]*L + [Linear] (+Flatten if out_dim==1)."""
+    """common.py:37-65: model = Sequential[Linear, LayerNorm | NoNorm, ELU]*L + [Linear] (+Flatten if out_dim==1).
+    layer_norm=False: the norm slots are parameter-free (common.py:68-74) and the library gets null LayerNorm pointers."""
 
     def __init__(self, in_dim, out_dim, hidden_dim, hidden_layers, layer_norm=True):
         super().__init__()
-        if not layer_norm:
-            raise NotImplementedError('layer_norm=False is not built in the HIP path')
         self.in_dim, self.out_dim, self.hidden_dim, self.hidden_layers = in_dim, out_dim, hidden_dim, hidden_layers
+        self.layer_norm = bool(layer_norm)
         layers, dim = [], in_dim
         for _ in range(hidden_layers):
-            layers += [LinearP(dim, hidden_dim), LayerNormP(hidden_dim), _Slot()]
+            layers += [LinearP(dim, hidden_dim), LayerNormP(hidden_dim) if layer_norm else _Slot(), _Slot()]
             dim = hidden_dim
         layers += [LinearP(dim, out_dim)]
         if out_dim == 1:
@@ -110,8 +109,8 @@ class MLP(_Params):
         L = self.hidden_layers
         w = [self.model[3 * i].weight for i in range(L)] + [self.model[3 * L].weight]
         b = [self.model[3 * i].bias for i in range(L)] + [self.model[3 * L].bias]
-        g = [self.model[3 * i + 1].weight for i in range(L)]
-        be = [self.model[3 * i + 1].bias for i in range(L)]
+        g = [self.model[3 * i + 1].weight for i in range(L)] if self.layer_norm else []
+        be = [self.model[3 * i + 1].bias for i in range(L)] if self.layer_norm else []
         return w, b, g, be
 
     def param_list(self):
@@ -289,26 +288,27 @@ class RSSMCell(_Params):
 
     def __init__(self, embed_dim, action_dim, deter_dim, stoch_dim, stoch_discrete, hidden_dim, gru_layers, gru_type, layer_norm):
         super().__init__()
-        if not stoch_discrete or not layer_norm:
-            raise NotImplementedError('continuous latents / layer_norm=False not built in the HIP path')
+        if not stoch_discrete:
+            raise NotImplementedError('continuous latents (stoch_discrete=0) are not built in the HIP path')
+        norm = LayerNormP if layer_norm else (lambda n: _Slot())       # NoNorm (common.py:68-74): no parameters
         self.stoch_dim, self.stoch_discrete, self.deter_dim = stoch_dim, stoch_discrete, deter_dim
         Z = stoch_dim * stoch_discrete
         self.z_mlp = LinearP(Z, hidden_dim)
         self.a_mlp = LinearP(action_dim, hidden_dim, bias=False)
-        self.in_norm = LayerNormP(hidden_dim)
+        self.in_norm = norm(hidden_dim)
         self.gru = GRUCellStack(hidden_dim, deter_dim, gru_layers, gru_type)
         self.prior_mlp_h = LinearP(deter_dim, hidden_dim)
-        self.prior_norm = LayerNormP(hidden_dim)
+        self.prior_norm = norm(hidden_dim)
         self.prior_mlp = LinearP(hidden_dim, Z)
         self.post_mlp_h = LinearP(deter_dim, hidden_dim)
         self.post_mlp_e = LinearP(embed_dim, hidden_dim, bias=False)
-        self.post_norm = LayerNormP(hidden_dim)
+        self.post_norm = norm(hidden_dim)
         self.post_mlp = LinearP(hidden_dim, Z)
 
     def ordered(self):
         """Tensors in the DM_RSSM_* order of include/dreamer_hip.h (None for slots this cell type does not have)."""
         named = dict(self.named_parameters())
-        return [None if n is None else named[n] for n in H.rssm_param_names(self.gru.cell_type, self.gru.num_layers)]
+        return [named.get(n) for n in H.rssm_param_names(self.gru.cell_type, self.gru.num_layers)]      # None: slot not present
 
     def init_state(self, batch_size):
         dev = self.z_mlp.weight.device

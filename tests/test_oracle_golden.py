@@ -140,6 +140,16 @@ def test_oracle_matches_reference_gru_cell_stack():
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_no_layernorm():
+    """SURVEY 8(a) variant: layer_norm=False - NoNorm (common.py:68-74) in every MLP head and in the RSSM cell's in / post /
+    prior norms, two training steps; the state_dict has no norm parameters at all."""
+    g, conf, results = _replay('tiny_no_layernorm', 2)
+    assert conf.layer_norm is False and not any('norm' in k or k.endswith('.1.weight') for k in O.param_shapes(conf)
+                                                  if k.startswith(('wm.core', 'ac.')))
+    for res in results:
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_aux_critic():
     """aux_critic (dreamer.py:267-279,347-358), two training steps."""
     g, conf, results = _replay('tiny_aux_critic', 2)
