@@ -68,7 +68,7 @@ def atari_literal_conf(**overrides):
 
 
 def feature_dim(conf):
-    return conf.deter_dim + conf.stoch_dim * conf.stoch_discrete
+    return conf.deter_dim + conf.stoch_dim * (conf.stoch_discrete or 1)       # rssm.py:103: Gaussian latents are stoch_dim wide
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -92,7 +92,8 @@ def _mlp_shapes(prefix, in_dim, out_dim, layers, out, layer_norm=True):
 
 def param_shapes(conf):
     d, ch = conf.cnn_depth, conf.image_channels
-    D_, Hd, Z, A = conf.deter_dim, conf.hidden_dim, conf.stoch_dim * conf.stoch_discrete, conf.action_dim
+    D_, Hd, Z, A = conf.deter_dim, conf.hidden_dim, conf.stoch_dim * (conf.stoch_discrete or 1), conf.action_dim
+    ZP = conf.stoch_dim * (conf.stoch_discrete or 2)       # width of the prior / posterior parameters (rssm.py:112,117)
     Fd, E = feature_dim(conf), conf.cnn_depth * 32
     s = OrderedDict()
     enc = 'wm.encoder.encoder_image.model'
@@ -132,12 +133,12 @@ def param_shapes(conf):
     s[f'{c}.prior_mlp_h.weight'] = (Hd, D_); s[f'{c}.prior_mlp_h.bias'] = (Hd,)
     if conf.layer_norm:
         s[f'{c}.prior_norm.weight'] = (Hd,); s[f'{c}.prior_norm.bias'] = (Hd,)
-    s[f'{c}.prior_mlp.weight'] = (Z, Hd); s[f'{c}.prior_mlp.bias'] = (Z,)
+    s[f'{c}.prior_mlp.weight'] = (ZP, Hd); s[f'{c}.prior_mlp.bias'] = (ZP,)
     s[f'{c}.post_mlp_h.weight'] = (Hd, D_); s[f'{c}.post_mlp_h.bias'] = (Hd,)
     s[f'{c}.post_mlp_e.weight'] = (Hd, E)
     if conf.layer_norm:
         s[f'{c}.post_norm.weight'] = (Hd,); s[f'{c}.post_norm.bias'] = (Hd,)
-    s[f'{c}.post_mlp.weight'] = (Z, Hd); s[f'{c}.post_mlp.bias'] = (Z,)
+    s[f'{c}.post_mlp.weight'] = (ZP, Hd); s[f'{c}.post_mlp.bias'] = (ZP,)
     if conf.aux_critic:                                                                    # dreamer.py:267-277 (a full ActorCritic)
         _mlp_shapes('wm.ac_aux.actor.model', Fd, A if conf.actor_dist == 'onehot' else 2 * A, 4, s, conf.layer_norm)
         _mlp_shapes('wm.ac_aux.critic.model', Fd, 1, 4, s, conf.layer_norm)
@@ -214,13 +215,16 @@ def preprocess(raw, conf, device='cpu'):
 
 
 def make_noise(conf, seed=777):
-    """Uniforms in reference call order: T posterior draws (B*I*S), then H x [actor (M), prior (M*S)]."""
+    """Uniforms in reference call order: T posterior draws (B*I*S), then H x [actor (M), prior (M*S)].
+    Gaussian latents (stoch_discrete = 0): the latent arrays (u_post, u_prior, u_pred, u_prior_log) hold STANDARD-NORMAL
+    draws instead - the eps of Normal.rsample (z = mean + std * eps)."""
     T, B, S, H = conf.batch_length, conf.batch_size, conf.stoch_dim, conf.imag_horizon
     M = T * B * conf.iwae_samples
     rs = np.random.RandomState(seed)
-    out = dict(u_post=torch.tensor(rs.rand(T, B * conf.iwae_samples, S), dtype=torch.float32),
+    lat = (lambda *shape: rs.rand(*shape)) if conf.stoch_discrete else (lambda *shape: rs.randn(*shape))
+    out = dict(u_post=torch.tensor(lat(T, B * conf.iwae_samples, S), dtype=torch.float32),
                u_act=torch.tensor(rs.rand(H, M), dtype=torch.float32),
-               u_prior=torch.tensor(rs.rand(H, M, S), dtype=torch.float32))
+               u_prior=torch.tensor(lat(H, M, S), dtype=torch.float32))
     # continuous actors draw normal noise instead (torch.normal in Normal.sample): x = mean + std * eps.  The noise is
     # scaled by 0.25 so that tanh(x) stays away from +-1: the reference's TanhTransform inverse is an un-clamped atanh,
     # which returns inf (and a NaN loss_actor) once a sampled action saturates in fp32 — a property of the reference
@@ -229,9 +233,9 @@ def make_noise(conf, seed=777):
     # logging variants (drawn AFTER everything above, so the streams of the plain step are unchanged):
     #   do_image_pred: one prior sample per (t,b) (dreamer.py:383); do_dream_tensors: a (T-1)-step dream from the B first states
     Bi = B * conf.iwae_samples
-    out['u_pred'] = torch.tensor(rs.rand(T, Bi, S), dtype=torch.float32)
+    out['u_pred'] = torch.tensor(lat(T, Bi, S), dtype=torch.float32)
     out['u_act_log'] = torch.tensor(rs.rand(T - 1, Bi), dtype=torch.float32)
-    out['u_prior_log'] = torch.tensor(rs.rand(T - 1, Bi, S), dtype=torch.float32)
+    out['u_prior_log'] = torch.tensor(lat(T - 1, Bi, S), dtype=torch.float32)
     out['eps_act_log'] = torch.tensor(0.25 * rs.randn(T - 1, Bi, conf.action_dim), dtype=torch.float32)
     return out
 
@@ -333,15 +337,28 @@ def gru_layer(p, x, h, layer=0):
     return (h - n) * z + n
 
 
+def gaussian_params(pp, min_std=0.1, max_std=2.0):
+    """functions.py:46-56 diag_normal: mean, std = chunk(2); std = max_std * sigmoid(std) + min_std."""
+    mean, std = pp.chunk(2, -1)
+    return mean, max_std * torch.sigmoid(std) + min_std
+
+
 def zdistr(conf, logits):
-    """rssm.py:195-201."""
+    """rssm.py:195-203."""
+    if not conf.stoch_discrete:
+        mean, std = gaussian_params(logits)
+        return D.Independent(D.Normal(mean, std), 1)
     lg = logits.reshape(logits.shape[:-1] + (conf.stoch_dim, conf.stoch_discrete)).float()
     return D.Independent(D.OneHotCategoricalStraightThrough(logits=lg), 1)
 
 
 def st_sample(conf, logits, u, forced_idx=None):
-    """OneHotCategoricalStraightThrough.rsample with explicit noise: onehot + (probs - probs.detach())."""
+    """OneHotCategoricalStraightThrough.rsample with explicit noise: onehot + (probs - probs.detach()).
+    Gaussian latents: Normal.rsample = mean + std * eps with `u` holding eps; the index slot carries zeros."""
     S, C = conf.stoch_dim, conf.stoch_discrete
+    if not C:
+        mean, std = gaussian_params(logits)
+        return mean + std * u, torch.zeros(logits.shape[:-1] + (S,), dtype=torch.long)
     lg = logits.reshape(logits.shape[:-1] + (S, C)).float()
     lg = lg - lg.logsumexp(-1, keepdim=True)            # Categorical normalises logits, then probs = softmax
     probs = torch.softmax(lg, -1)
@@ -634,7 +651,7 @@ class OracleDreamer:
 
     def init_state(self, batch):
         c = self.conf
-        return (torch.zeros(batch, c.deter_dim), torch.zeros(batch, c.stoch_dim * c.stoch_discrete))
+        return (torch.zeros(batch, c.deter_dim), torch.zeros(batch, c.stoch_dim * (c.stoch_discrete or 1)))
 
     def training_step(self, obs, in_state, noise, forced_idx=None, do_image_pred=False, do_dream_tensors=False,
                       do_open_loop=False, iwae_samples=None):

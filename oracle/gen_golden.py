@@ -43,9 +43,14 @@ def reference_conf(sections, overrides):
 
 class MultinomialPatch:
     """Replaces torch.multinomial(probs_2d, 1, True) by the shared inverse-CDF rule on queued uniforms, and
-    torch.normal(mean, std) (continuous actors: Normal.sample) by mean + std * eps on queued standard-normal noise."""
+    torch.normal(mean, std) (continuous actors: Normal.sample) by mean + std * eps on queued standard-normal noise, and
+    torch.distributions' _standard_normal (Normal.rsample: Gaussian latents, stoch_discrete = 0) by queued draws."""
 
     def __init__(self):
+        import torch.distributions.normal as tdn
+        self.tdn = tdn
+        self.orig_std = tdn._standard_normal
+        self.std_queue = []
         self.queue = []
         self.eps_queue = []
         self.calls = []
@@ -56,11 +61,18 @@ class MultinomialPatch:
     def __enter__(self):
         torch.multinomial = self
         torch.normal = self.normal
+        self.tdn._standard_normal = self.standard_normal
         return self
 
     def __exit__(self, *a):
         torch.multinomial = self.orig
         torch.normal = self.orig_normal
+        self.tdn._standard_normal = self.orig_std
+
+    def standard_normal(self, shape, dtype, device):
+        eps = self.std_queue.pop(0)
+        assert tuple(eps.shape) == tuple(shape), (eps.shape, shape)
+        return eps.to(dtype)
 
     def normal(self, mean, std, *a, **kw):
         eps = self.eps_queue.pop(0)
@@ -106,22 +118,32 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
         obs = O.preprocess(raw, oconf)
         noise = O.make_noise(oconf, seed=777 + step)
         with MultinomialPatch() as mp:
-            mp.queue = [noise['u_post'][t] for t in range(T)]
             onehot = rconf.actor_dist == 'onehot'
+            gaussian = not rconf.stoch_discrete          # Gaussian latents draw through Normal.rsample, not multinomial
+            lat_queue = mp.std_queue if gaussian else mp.queue
+            lat_queue += [noise['u_post'][t] for t in range(T)]
             for i in range(H):
-                mp.queue += ([noise['u_act'][i]] if onehot else []) + [noise['u_prior'][i]]
-                if not onehot:
+                if onehot:
+                    mp.queue.append(noise['u_act'][i])
+                else:
                     mp.eps_queue.append(noise['eps_act'][i])
+                lat_queue.append(noise['u_prior'][i])
             losses, new_state, metrics, tensors, _ = model.training_step(obs, state)
-            assert not mp.queue and not mp.eps_queue, f'{len(mp.queue)} uniforms / {len(mp.eps_queue)} normals unused'
+            assert not mp.queue and not mp.eps_queue and not mp.std_queue, \
+                f'{len(mp.queue)} uniforms / {len(mp.eps_queue)} + {len(mp.std_queue)} normals unused'
             M = T * B * rconf.iwae_samples
-            post_idx = torch.stack(mp.idx[:T]).reshape(T, B * rconf.iwae_samples, S)
-            if onehot:
-                act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
-                lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
+            if gaussian:
+                post_idx = torch.zeros(T, B * rconf.iwae_samples, S, dtype=torch.long)
+                lat_idx = torch.zeros(H, M, S, dtype=torch.long)
+                act_idx = torch.stack(mp.idx).reshape(H, M) if onehot else torch.zeros(H, M, dtype=torch.long)
             else:
-                act_idx = torch.zeros(H, M, dtype=torch.long)
-                lat_idx = torch.stack(mp.idx[T:]).reshape(H, M, S)
+                post_idx = torch.stack(mp.idx[:T]).reshape(T, B * rconf.iwae_samples, S)
+                if onehot:
+                    act_idx = torch.stack(mp.idx[T::2]).reshape(H, M)
+                    lat_idx = torch.stack(mp.idx[T + 1::2]).reshape(H, M, S)
+                else:
+                    act_idx = torch.zeros(H, M, dtype=torch.long)
+                    lat_idx = torch.stack(mp.idx[T:]).reshape(H, M, S)
         for opt in optimizers:
             opt.zero_grad()
         for loss in losses:
@@ -387,6 +409,16 @@ if __name__ == '__main__':
                  imag_horizon=t.imag_horizon, layer_norm=False), steps=2,
             full_grads=('wm.core.cell.z_mlp.weight', 'wm.core.cell.post_mlp_h.weight', 'wm.core.cell.prior_mlp.bias',
                         'wm.decoder.reward.model.model.12.weight', 'ac.actor.model.12.weight', 'ac.critic.model.12.weight'))
+    if 'gaussian' in which:
+        # SURVEY 8(a) variant: stoch_discrete = 0 - Gaussian latents (rssm.py:103-117,195-203, functions.py:46-56): z is
+        # stoch_dim wide, prior / posterior heads emit (mean, std) and Normal.rsample / the Normal KL replace the categorical
+        t = O.tiny_conf()
+        run('tiny_gaussian_latents', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=0,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon), steps=2,
+            full_grads=('wm.core.cell.z_mlp.weight', 'wm.core.cell.post_mlp.weight', 'wm.core.cell.prior_mlp.bias',
+                        'ac.actor.model.12.weight'))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()
