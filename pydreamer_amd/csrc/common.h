@@ -166,6 +166,10 @@ int dm_gru_gates_bwd_launch(int rows, int D, const float* gi, const float* gh, c
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                             const int32_t* forced, float* onehot, int ldo, int32_t* idx, float* z_next,
                             const uint8_t* next_reset, hipStream_t st);
+// Gaussian latents (C = 0 in the sampler / KL launchers: parameter rows are (mean[S] | raw std[S]), std = 2 sigmoid + 0.1):
+// backward of z = mean + std * eps into the parameter gradient (eps recovered from z)
+int dm_gauss_sample_bwd_launch(int rows, int S, const float* par, int ldp, const float* z, int ldz, const float* dz,
+                               int lddz, float* dpar, int lddp, int accum, hipStream_t st);
 int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* prior, float* kl, float* ep, float* eq,
                      hipStream_t st);
 int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* prior, float sp, float sq, float* dpost,

@@ -394,7 +394,7 @@ struct DecGeom {
   explicit DecGeom(const dm_shape* s) {
     N = s->T * s->B * (s->I > 0 ? s->I : 1);
     ch = s->img_ch; d = s->cnn_depth;
-    F = s->D + s->S * s->C;
+    F = s->D + s->S * (s->C ? s->C : 1);      // Gaussian latents (C = 0) are S wide
     const int kk[5] = {0, 5, 5, 6, 6};
     const int ci[5] = {0, 32 * d, 4 * d, 2 * d, d};
     const int co[5] = {0, 4 * d, 2 * d, d, ch};

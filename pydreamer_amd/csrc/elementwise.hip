@@ -1062,10 +1062,104 @@ __global__ void __launch_bounds__(256) sample_onehot_lane32_kernel(int rows, int
   if (idx_out) idx_out[i] = idx;
 }
 
+// ---- Gaussian latents (stoch_discrete = 0; rssm.py:195-203, functions.py:46-56 diag_normal): a row of parameters is
+// (mean[S] | raw[S]) with std = 2 sigmoid(raw) + 0.1; z = mean + std * eps (Normal.rsample, eps standard normal).
+__device__ __forceinline__ float dm_gauss_std(float raw) { return 2.0f * dm_sigmoid(raw) + 0.1f; }
+__global__ void __launch_bounds__(256) gauss_sample_kernel(int rows, int S, const float* __restrict__ par, int ldp,
+                                                           const float* __restrict__ eps, float* __restrict__ z, int ldz,
+                                                           float* __restrict__ z_next,
+                                                           const uint8_t* __restrict__ next_reset) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / S, s = i % S;
+    const float* pr = par + (size_t)r * ldp;
+    const float v = pr[s] + dm_gauss_std(pr[S + s]) * eps[i];
+    z[(size_t)r * ldz + s] = v;
+    if (z_next) z_next[i] = (next_reset && next_reset[r]) ? 0.f : v;
+  }
+}
+// backward of the reparameterised sample: dmean (+)= dz ; draw (+)= dz * eps * dstd/draw, eps = (z - mean) / std
+__global__ void __launch_bounds__(256) gauss_sample_bwd_kernel(int rows, int S, const float* __restrict__ par, int ldp,
+                                                               const float* __restrict__ z, int ldz,
+                                                               const float* __restrict__ dz, int lddz,
+                                                               float* __restrict__ dpar, int lddp, int accum) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / S, s = i % S;
+    const float* pr = par + (size_t)r * ldp;
+    const float sg = dm_sigmoid(pr[S + s]);
+    const float sd = 2.0f * sg + 0.1f;
+    const float e = (z[(size_t)r * ldz + s] - pr[s]) / sd;
+    const float g = dz[(size_t)r * lddz + s];
+    float* dp = dpar + (size_t)r * lddp;
+    const float gm = g, gr = g * e * 2.0f * sg * (1.0f - sg);
+    if (accum) { dp[s] += gm; dp[S + s] += gr; }
+    else { dp[s] = gm; dp[S + s] = gr; }
+  }
+}
+int dm_gauss_sample_bwd_launch(int rows, int S, const float* par, int ldp, const float* z, int ldz, const float* dz,
+                               int lddz, float* dpar, int lddp, int accum, hipStream_t st) {
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(gauss_sample_bwd_kernel, dim3(ew_blocks((size_t)rows * S)), dim3(256), 0, st, rows, S, par, ldp, z, ldz,
+                     dz, lddz, dpar, lddp, accum);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+// KL(N(m1,s1) || N(m2,s2)) summed over S, and the two entropies (0.5 log(2 pi e) + log std per dimension)
+__global__ void __launch_bounds__(256) gauss_kl_fwd_kernel(int rows, int S, const float* __restrict__ post,
+                                                           const float* __restrict__ prior, float* __restrict__ kl,
+                                                           float* __restrict__ ent_post, float* __restrict__ ent_prior) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* a = post + (size_t)row * 2 * S;
+  const float* b = prior + (size_t)row * 2 * S;
+  float akl = 0.f, aep = 0.f, aeq = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float s1 = dm_gauss_std(a[S + s]), s2 = dm_gauss_std(b[S + s]);
+    const float d = a[s] - b[s];
+    akl += logf(s2 / s1) + (s1 * s1 + d * d) / (2.0f * s2 * s2) - 0.5f;
+    aep += 1.4189385332046727f + logf(s1);
+    aeq += 1.4189385332046727f + logf(s2);
+  }
+  akl = dm_wave_sum(akl); aep = dm_wave_sum(aep); aeq = dm_wave_sum(aeq);
+  if (lane == 0) {
+    kl[row] = akl;
+    if (ent_post) ent_post[row] = aep;
+    if (ent_prior) ent_prior[row] = aeq;
+  }
+}
+__global__ void __launch_bounds__(256) gauss_kl_bwd_kernel(int rows, int S, const float* __restrict__ post,
+                                                           const float* __restrict__ prior, float sp, float sq,
+                                                           float* __restrict__ dpost, float* __restrict__ dprior) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / S, s = i % S;
+    const size_t o = (size_t)r * 2 * S;
+    const float g1 = dm_sigmoid(post[o + S + s]), g2 = dm_sigmoid(prior[o + S + s]);
+    const float s1 = 2.0f * g1 + 0.1f, s2 = 2.0f * g2 + 0.1f;
+    const float d = post[o + s] - prior[o + s];
+    const float i22 = 1.0f / (s2 * s2);
+    dpost[o + s] = sp * d * i22;
+    dpost[o + S + s] = sp * (s1 * i22 - 1.0f / s1) * 2.0f * g1 * (1.0f - g1);
+    dprior[o + s] = -sq * d * i22;
+    dprior[o + S + s] = sq * (1.0f / s2 - (s1 * s1 + d * d) * i22 / s2) * 2.0f * g2 * (1.0f - g2);
+  }
+}
+
 int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                             const int32_t* forced, float* onehot, int ldo, int32_t* idx, float* z_next,
                             const uint8_t* next_reset, hipStream_t st) {
   if (rows <= 0) return DM_OK;
+  if (C == 0) {       // Gaussian latents: `logits` rows are (mean | raw std), `u` holds standard-normal draws, `onehot` gets z
+    DM_REQUIRE(u && !forced, DM_E_NULL, "sample: Gaussian latents need their noise (and cannot be index-forced)");
+    hipLaunchKernelGGL(gauss_sample_kernel, dim3(ew_blocks((size_t)rows * groups)), dim3(256), 0, st, rows, groups, logits,
+                       ldl, u, onehot, ldo, z_next, next_reset);
+    DM_LAUNCH_CHECK();
+    if (idx && hipMemsetAsync(idx, 0, (size_t)rows * groups * sizeof(int32_t), st) != hipSuccess)
+      return dm_fail(DM_E_HIP, "sample: memset failed");
+    return DM_OK;
+  }
   const size_t tg = (size_t)rows * groups;
   if (C == 32 && (ldl & 3) == 0 && (ldo & 3) == 0 &&
       (((uintptr_t)logits | (uintptr_t)onehot | (uintptr_t)z_next) & 15) == 0) {
@@ -1092,7 +1186,7 @@ int dm_sample_onehot_launch(int rows, int groups, int C, const float* logits, in
 extern "C" int dm_sample_onehot(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                                 const int32_t* forced_idx, float* onehot, int ldo, int32_t* idx, void* stream) {
   DM_REQUIRE(logits && onehot && (u || forced_idx), DM_E_NULL, "sample_onehot: null pointer");
-  DM_REQUIRE(C >= 1 && groups >= 1, DM_E_SHAPE, "sample_onehot: bad groups/C");
+  DM_REQUIRE(C >= 0 && groups >= 1, DM_E_SHAPE, "sample_onehot: bad groups/C");       // C = 0: Gaussian latents
   return dm_sample_onehot_launch(rows, groups, C, logits, ldl, u, forced_idx, onehot, ldo, idx, nullptr, nullptr,
                                  (hipStream_t)stream);
 }
@@ -1337,6 +1431,11 @@ __global__ void __launch_bounds__(256) st_softmax_bwd_kernel(int rows, int group
 int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* prior, float* kl, float* ep, float* eq,
                      hipStream_t st) {
   if (rows <= 0) return DM_OK;
+  if (C == 0) {
+    hipLaunchKernelGGL(gauss_kl_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, S, post, prior, kl, ep, eq);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   hipLaunchKernelGGL(kl_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, S, C, post, prior, kl, ep, eq);
   DM_LAUNCH_CHECK();
   return DM_OK;
@@ -1344,6 +1443,12 @@ int dm_kl_fwd_launch(int rows, int S, int C, const float* post, const float* pri
 int dm_kl_bwd_launch(int rows, int S, int C, const float* post, const float* prior, float sp, float sq, float* dpost,
                      float* dprior, hipStream_t st) {
   if (rows <= 0) return DM_OK;
+  if (C == 0) {
+    hipLaunchKernelGGL(gauss_kl_bwd_kernel, dim3(ew_blocks((size_t)rows * S)), dim3(256), 0, st, rows, S, post, prior, sp, sq,
+                       dpost, dprior);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(ew_blocks((size_t)rows * S)), dim3(256), 0, st, rows, S, C, post, prior, sp, sq,
                      dpost, dprior);
   DM_LAUNCH_CHECK();

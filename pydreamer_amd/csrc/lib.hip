@@ -53,7 +53,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (!s) return 0;
   const size_t N = (size_t)s->T * s->B * (s->I > 0 ? s->I : 1);
   const size_t d = (size_t)s->cnn_depth, ch = (size_t)s->img_ch;
-  const size_t D = s->D, Hd = s->Hd, Z = (size_t)s->S * s->C, A = s->A;
+  const size_t D = s->D, Hd = s->Hd, Z = (size_t)s->S * (s->C ? s->C : 2), A = s->A;    // C = 0 (Gaussian latents): parameters are 2S wide, z is S
   const size_t Hm = s->mlp_hidden, L = s->mlp_layers, H = s->H > 0 ? s->H : 1;
   const size_t SK = DM_SPLITK_FLOATS;
   // encoder backward: ga (N*31*31*d) + gb (N*14*14*2d) + dwr (8d*64d) + dxcol (max patch matrix, l>=1)

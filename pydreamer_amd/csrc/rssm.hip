@@ -22,7 +22,7 @@ static inline int rssm_gru_layers(const dm_shape* s) {
   return 1 + ((s->flags & DM_FLAG_GRU_LAYERS_MASK) >> DM_FLAG_GRU_LAYERS_SHIFT);
 }
 static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
-  const size_t N = (size_t)s->T * s->B, Hd = s->Hd, D = s->D, Z = (size_t)s->S * s->C;
+  const size_t N = (size_t)s->T * s->B, Hd = s->Hd, D = s->D, Z = (size_t)s->S * (s->C ? s->C : 1);   // width of z
   DmArena ar(base, (size_t)1 << 62);
   RssmActs t;
   t.ea = ar.take(N * Hd); t.ee = ar.take(N * Hd);
@@ -43,7 +43,7 @@ extern "C" size_t dm_rssm_acts_floats(const dm_shape* shp) {
 
 static int rssm_check(const dm_shape* s) {
   DM_REQUIRE(s->I == 1, DM_E_SHAPE, "rssm: iwae_samples=%d unsupported (only 1)", s->I);
-  DM_REQUIRE(s->T >= 1 && s->B >= 1 && s->D >= 4 && s->Hd >= 4 && s->S >= 1 && s->C >= 2 && s->A >= 1 && s->E >= 1,
+  DM_REQUIRE(s->T >= 1 && s->B >= 1 && s->D >= 4 && s->Hd >= 4 && s->S >= 1 && (s->C >= 2 || s->C == 0) && s->A >= 1 && s->E >= 1,
              DM_E_SHAPE, "rssm: bad shape");
   DM_REQUIRE((s->D & 3) == 0, DM_E_SHAPE, "rssm: deter_dim must be a multiple of 4 (got %d)", s->D);
   DM_REQUIRE(rssm_gru_kind(s) <= 2, DM_E_SHAPE, "rssm: unknown recurrent cell kind %d", rssm_gru_kind(s));
@@ -184,7 +184,11 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   if (t0 == t1) return DM_OK;
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "rssm_sequence_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
+  // Z: width of z (S one-hot groups of C, or S Gaussian dimensions when C = 0); ZP: width of the posterior / prior
+  // parameters (logits, or mean | raw std - rssm.py:112,117)
+  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * (C ? C : 1), ZP = S * (C ? C : 2);
+  const int F = D + Z, E = s->E, A = s->A;
+  const bool gauss = C == 0;
   (void)T;
   const int N = (t1 - t0) * B;                        // rows of this range
   const size_t q0 = (size_t)t0 * B;                   // its first row
@@ -212,7 +216,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   const bool normed = p[DM_RSSM_IN_G] != nullptr;      // layer_norm=False: all three norms are NoNorm (null parameters)
   DM_REQUIRE((p[DM_RSSM_POST_G] != nullptr) == normed && (p[DM_RSSM_PRIOR_G] != nullptr) == normed, DM_E_NULL,
              "rssm: the cell's three norms must be all LayerNorm or all NoNorm");
-  const bool fuse_ln = normed && !stacked && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (Z >= 64 * 1024 / Hd);
+  const bool fuse_ln = normed && !stacked && !gauss && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, ZP, Hd) &&
+                       (ZP >= 64 * 1024 / Hd);
   static const int no_fuse_sample = getenv("DM_RSSM_NO_FUSE_SAMPLE") ? 1 : 0;      // A/B switch
   const bool fuse_sample = !no_fuse_sample && fuse_ln && C == 32 && (Z & 31) == 0 && (F & 3) == 0 && (D & 3) == 0 &&
                            (((uintptr_t)feat | (uintptr_t)a.zin) & 15) == 0;
@@ -228,7 +233,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   // a dense vector and keeps the product.
   static const int no_embed = getenv("DM_RSSM_NO_Z_EMBED") ? 1 : 0;        // A/B switch
   float* wzt = nullptr;
-  if (!no_embed && idx && t1 - t0 > 1 && dm_z_embed_ok(Hd)) {
+  if (!no_embed && !gauss && idx && t1 - t0 > 1 && dm_z_embed_ok(Hd)) {
     const size_t mark = ar.off;
     float* w = ar.take((size_t)Z * Hd);
     if (ar.ok) {
@@ -311,8 +316,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     }
     if (fuse_ln) {
       DmGemm pq;      // post = post_mlp(ELU(post_norm(x2))), LayerNorm in the prologue
-      pq.M = B; pq.N = Z; pq.K = Hd; pq.A = a.x2 + r0 * Hd; pq.lda = Hd; pq.B = p[DM_RSSM_POST_W]; pq.ldb = Hd;
-      pq.C = post + r0 * Z; pq.ldc = Z; pq.bias = p[DM_RSSM_POST_OB];
+      pq.M = B; pq.N = ZP; pq.K = Hd; pq.A = a.x2 + r0 * Hd; pq.lda = Hd; pq.B = p[DM_RSSM_POST_W]; pq.ldb = Hd;
+      pq.C = post + r0 * ZP; pq.ldc = ZP; pq.bias = p[DM_RSSM_POST_OB];
       pq.ln_g = p[DM_RSSM_POST_G]; pq.ln_b = p[DM_RSSM_POST_B]; pq.ln_eps = 1e-3f;
       pq.A_frag = x2f;
       if (fuse_sample) {   // ... and z ~ OneHotCategoricalStraightThrough(post) in the epilogue        rssm.py:147-148
@@ -327,11 +332,11 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     } else {
       DM_TRY(norm_elu_fwd(B, Hd, a.x2 + r0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + r0 * Hd,
                                   Hd, a.st2 + r0 * 2, st));
-      DM_TRY(linear(st, ws, skb, B, Z, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
-                    post + r0 * Z, Z));
+      DM_TRY(linear(st, ws, skb, B, ZP, Hd, a.pin + r0 * Hd, Hd, p[DM_RSSM_POST_W], p[DM_RSSM_POST_OB], nullptr, 0,
+                    post + r0 * ZP, ZP));
     }
     // z ~ OneHotCategoricalStraightThrough(post)                                       rssm.py:147-148
-    DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * Z, Z, u ? u + r0 * S : nullptr,
+    DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * ZP, ZP, u ? u + r0 * S : nullptr,
                                    forced_idx ? forced_idx + r0 * S : nullptr, feat + r0 * F + D, F,
                                    idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
   }
@@ -346,8 +351,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
                 a.x3 + q0 * Hd, Hd));
   DM_TRY(norm_elu_fwd(N, Hd, a.x3 + q0 * Hd, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, a.prin + q0 * Hd,
                               Hd, a.st3 + q0 * 2, st));
-  DM_TRY(linear(st, ws, skb, N, Z, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
-                prior + q0 * Z, Z));
+  DM_TRY(linear(st, ws, skb, N, ZP, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
+                prior + q0 * ZP, ZP));
   return DM_OK;
 }
 extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
@@ -368,7 +373,9 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DmPrecisionScope prec(s->flags & DM_FLAG_BF16);
   DM_TRY(rssm_check(s));
   hipStream_t st = (hipStream_t)stream;
-  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, E = s->E, A = s->A;
+  const int T = s->T, B = s->B, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * (C ? C : 1), ZP = S * (C ? C : 2);
+  const int F = D + Z, E = s->E, A = s->A;        // Z: width of z, ZP: width of its distribution's parameters (see above)
+  const bool gauss = C == 0;
   const int N = T * B;
   RssmActs a;
   rssm_carve(s, const_cast<float*>(acts), &a);
@@ -385,7 +392,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   float* dgh = ar.take((size_t)N * 3 * D);
   float* dza = ar.take((size_t)N * Hd);
   float* dx1 = ar.take((size_t)N * Hd);
-  float* wt_post = ar.take((size_t)Z * Hd);
+  float* wt_post = ar.take((size_t)ZP * Hd);
   float* wt_post_h = ar.take((size_t)Hd * D);
   float* wt_ih = ar.take((size_t)3 * D * Hd);
   float* wt_hh = ar.take((size_t)3 * D * D);
@@ -400,9 +407,9 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
   // ---- prior branch, batched over all rows
-  DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dprior, Z, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
-  DM_TRY(dm_colsum_launch(N, Z, dprior, Z, g[DM_RSSM_PRIOR_OB], sk, skb, st));
-  DM_TRY(dgrad(st, sk, skb, N, Z, Hd, dprior, Z, p[DM_RSSM_PRIOR_W], dprin, Hd, 0, nullptr));
+  DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dprior, ZP, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
+  DM_TRY(dm_colsum_launch(N, ZP, dprior, ZP, g[DM_RSSM_PRIOR_OB], sk, skb, st));
+  DM_TRY(dgrad(st, sk, skb, N, ZP, Hd, dprior, ZP, p[DM_RSSM_PRIOR_W], dprin, Hd, 0, nullptr));
   DM_TRY(norm_elu_bwd_dx(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, p[DM_RSSM_PRIOR_G], dprin, Hd, dx3, Hd, st));
   DM_TRY(norm_elu_bwd_params(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
                                      g[DM_RSSM_PRIOR_B], sk, skb, st));
@@ -412,7 +419,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
 
   // ---- BPTT.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
   // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
-  DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, Z, Hd));
+  DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, ZP, Hd));
   DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
   GruStack gk;
   DM_TRY(gru_stack(s, p, g, &gk));
@@ -426,7 +433,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = p[DM_RSSM_IN_G] != nullptr && !stacked && kind == 0 && dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  const bool fuse_b = p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
+                      dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
   // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
   // backward epilogue, read by the two products that follow it
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;
@@ -438,17 +446,18 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
-    float* dpt = dpost + r0 * Z;
-    // straight-through sample: dpost += softmax'(post)^T dz'
-    DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * Z, Z, dft + D, F, dpt, Z, 1, st));
+    float* dpt = dpost + r0 * ZP;
+    // straight-through sample: dpost += softmax'(post)^T dz'   (Gaussian: the reparameterised sample's (dmean, draw std))
+    if (gauss) DM_TRY(dm_gauss_sample_bwd_launch(B, S, post + r0 * ZP, ZP, feat + r0 * F + D, F, dft + D, F, dpt, ZP, 1, st));
+    else DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * ZP, ZP, dft + D, F, dpt, ZP, 1, st));
     // post_mlp, post_norm+ELU, post_mlp_h
     if (fuse_b) {
       DmGemm q3;   // dpin = dpost Wpost
-      q3.M = B; q3.N = Hd; q3.K = Z; q3.A = dpt; q3.lda = Z; q3.B = wt_post; q3.ldb = Z; q3.C = dpin + r0 * Hd; q3.ldc = Hd;
+      q3.M = B; q3.N = Hd; q3.K = ZP; q3.A = dpt; q3.lda = ZP; q3.B = wt_post; q3.ldb = ZP; q3.C = dpin + r0 * Hd; q3.ldc = Hd;
       q3.C_frag = dpinf;
       DM_TRY(dm_gemm_launch(q3, sk, skb, st));
     } else {
-      DM_TRY(dgrad_t(st, sk, skb, B, Z, Hd, dpt, Z, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
+      DM_TRY(dgrad_t(st, sk, skb, B, ZP, Hd, dpt, ZP, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
     }
     if (fuse_b) {
       const uint8_t* rz = reset + r0;
@@ -531,8 +540,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     DM_TRY(norm_elu_bwd_dx(N, Hd, a.x1, Hd, a.za, Hd, a.st1, p[DM_RSSM_IN_G], dza, Hd, dx1, Hd, st));
   }
   // ---- weight / bias / LayerNorm gradients, batched over all rows
-  DM_TRY(wgrad(st, sk, skb, N, Z, Hd, dpost, Z, a.pin, Hd, g[DM_RSSM_POST_W]));
-  DM_TRY(dm_colsum_launch(N, Z, dpost, Z, g[DM_RSSM_POST_OB], sk, skb, st));
+  DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dpost, ZP, a.pin, Hd, g[DM_RSSM_POST_W]));
+  DM_TRY(dm_colsum_launch(N, ZP, dpost, ZP, g[DM_RSSM_POST_OB], sk, skb, st));
   DM_TRY(norm_elu_bwd_params(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, dpin, Hd, g[DM_RSSM_POST_G], g[DM_RSSM_POST_B],
                                      sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx2, Hd, feat, F, g[DM_RSSM_POST_H_W]));
@@ -589,7 +598,8 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   DM_TRY(rssm_check(s));
   DM_REQUIRE(M >= 1 && s->H >= 1, DM_E_SHAPE, "dream_rollout: M=%d H=%d", M, s->H);
   hipStream_t st = (hipStream_t)stream;
-  const int H = s->H, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * C, F = D + Z, A = s->A;
+  const int H = s->H, D = s->D, Hd = s->Hd, S = s->S, C = s->C, Z = S * (C ? C : 1), ZP = S * (C ? C : 2);   // see fwd_steps
+  const int F = D + Z, A = s->A;
   const int Hm = s->mlp_hidden, L = s->mlp_layers;
   const int adist = s->flags & 3;                 // 0 onehot, 1 tanh_normal, 2 normal_tanh
   DM_REQUIRE(adist <= 2, DM_E_SHAPE, "dream_rollout: unknown actor distribution %d", adist);
@@ -608,7 +618,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   float* stats = ar.take((size_t)M * 2);
   float* gi = ar.take((size_t)M * 3 * D);
   float* gh = ar.take((size_t)M * 3 * D);
-  float* prior = ar.take((size_t)M * Z);
+  float* prior = ar.take((size_t)M * ZP);
   const int kind = rssm_gru_kind(s);
   float* gsw = ar.take(kind ? (size_t)M * 3 * D : 0);
   float* gstw = ar.take(kind ? (size_t)M * 6 : 0);
@@ -624,7 +634,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   static const int no_embed = getenv("DM_RSSM_NO_Z_EMBED") ? 1 : 0;        // A/B switch
   float *wzt = nullptr, *wat = nullptr;
   int32_t *pidx = nullptr, *aidx = nullptr;
-  if (!no_embed && H > 1 && dm_z_embed_ok(Hd)) {
+  if (!no_embed && C != 0 && H > 1 && dm_z_embed_ok(Hd)) {
     const size_t mark = ar.off;
     float* w = ar.take((size_t)Z * Hd);
     float* w2 = ar.take((size_t)A * Hd);
@@ -690,8 +700,8 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     else DM_TRY(dm_gru_norm_fwd_launch(kind, M, D, gi, gh, cur, F, lng, lnb, nxt, F, gsw, gstw, nullptr, nullptr, st));
     DM_TRY(linear(st, sk, skb, M, Hd, D, nxt, F, p[DM_RSSM_PRIOR_H_W], p[DM_RSSM_PRIOR_H_B], nullptr, 0, x1, Hd));
     DM_TRY(norm_elu_fwd(M, Hd, x1, Hd, p[DM_RSSM_PRIOR_G], p[DM_RSSM_PRIOR_B], 1e-3f, za, Hd, stats, st));
-    DM_TRY(linear(st, sk, skb, M, Z, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, Z));
-    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, Z, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
+    DM_TRY(linear(st, sk, skb, M, ZP, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, ZP));
+    DM_TRY(dm_sample_onehot_launch(M, S, C, prior, ZP, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
                                    nullptr, st));
   }
   return DM_OK;

@@ -288,22 +288,22 @@ class RSSMCell(_Params):
 
     def __init__(self, embed_dim, action_dim, deter_dim, stoch_dim, stoch_discrete, hidden_dim, gru_layers, gru_type, layer_norm):
         super().__init__()
-        if not stoch_discrete:
-            raise NotImplementedError('continuous latents (stoch_discrete=0) are not built in the HIP path')
         norm = LayerNormP if layer_norm else (lambda n: _Slot())       # NoNorm (common.py:68-74): no parameters
         self.stoch_dim, self.stoch_discrete, self.deter_dim = stoch_dim, stoch_discrete, deter_dim
-        Z = stoch_dim * stoch_discrete
+        # discrete latents: stoch_dim one-hot groups of stoch_discrete; Gaussian latents (stoch_discrete = 0): z is stoch_dim
+        # wide and the prior / posterior heads emit (mean | raw std)                                 (rssm.py:103,112,117)
+        Z, ZP = stoch_dim * (stoch_discrete or 1), stoch_dim * (stoch_discrete or 2)
         self.z_mlp = LinearP(Z, hidden_dim)
         self.a_mlp = LinearP(action_dim, hidden_dim, bias=False)
         self.in_norm = norm(hidden_dim)
         self.gru = GRUCellStack(hidden_dim, deter_dim, gru_layers, gru_type)
         self.prior_mlp_h = LinearP(deter_dim, hidden_dim)
         self.prior_norm = norm(hidden_dim)
-        self.prior_mlp = LinearP(hidden_dim, Z)
+        self.prior_mlp = LinearP(hidden_dim, ZP)
         self.post_mlp_h = LinearP(deter_dim, hidden_dim)
         self.post_mlp_e = LinearP(embed_dim, hidden_dim, bias=False)
         self.post_norm = norm(hidden_dim)
-        self.post_mlp = LinearP(hidden_dim, Z)
+        self.post_mlp = LinearP(hidden_dim, ZP)
 
     def ordered(self):
         """Tensors in the DM_RSSM_* order of include/dreamer_hip.h (None for slots this cell type does not have)."""
@@ -313,7 +313,7 @@ class RSSMCell(_Params):
     def init_state(self, batch_size):
         dev = self.z_mlp.weight.device
         return (torch.zeros((batch_size, self.deter_dim), device=dev),
-                torch.zeros((batch_size, self.stoch_dim * self.stoch_discrete), device=dev))
+                torch.zeros((batch_size, self.stoch_dim * (self.stoch_discrete or 1)), device=dev))
 
 
 class RSSMCore(_Params):
@@ -703,7 +703,11 @@ class WorldModel(_Params):
         I = int(iwae)
         BI, NE = B * I, T * B
         N, dev = T * B * I, image.device
-        D_, Z, F_, E = c.deter_dim, c.stoch_dim * c.stoch_discrete, self.features_dim, self.encoder.out_dim
+        D_, F_, E = c.deter_dim, self.features_dim, self.encoder.out_dim
+        gauss = not c.stoch_discrete         # Gaussian latents: z is stoch_dim wide, its parameters (mean | raw std) twice that
+        Z, ZP = c.stoch_dim * (c.stoch_discrete or 1), c.stoch_dim * (c.stoch_discrete or 2)
+        if gauss and (I > 1 or forced_idx is not None):
+            raise NotImplementedError('Gaussian latents (stoch_discrete=0): iwae_samples > 1 and forced indices are not built')
         shp = self.shape(T, B, imag_horizon)
         shp.I = I
         ws = self.workspace(shp, dev)
@@ -739,7 +743,8 @@ class WorldModel(_Params):
         if bad:
             raise ValueError('training_step input shapes (got, expected): ' + ', '.join(f'{k}: {v[0]} != {v[1]}' for k, v in bad.items()))
         if u_post is None and forced_idx is None:
-            u_post = torch.rand(T, BI, c.stoch_dim, device=dev)
+            # uniforms for the categorical inverse-CDF rule; standard-normal eps of Normal.rsample for Gaussian latents
+            u_post = (torch.randn if gauss else torch.rand)(T, BI, c.stoch_dim, device=dev)
         lib = H.lib()
         shp_e = shp_r = shp
         if I > 1:
@@ -767,8 +772,8 @@ class WorldModel(_Params):
             rssm_p = H.rssm_struct(po)
         rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp_r))), device=dev)
         feat = torch.empty(N, F_, device=dev)
-        post = torch.empty(N, Z, device=dev)
-        prior = torch.empty(N, Z, device=dev)
+        post = torch.empty(N, ZP, device=dev)
+        prior = torch.empty(N, ZP, device=dev)
         idx = torch.empty(N, c.stoch_dim, dtype=torch.int32, device=dev)
         fidx = forced_idx.to(torch.int32).contiguous() if forced_idx is not None else None
         u_post = u_post.contiguous() if u_post is not None else None
@@ -879,8 +884,8 @@ class WorldModel(_Params):
                     ac.update_critic_target()
                 ac.train_steps += 1
             rows = (T - 1) * B
-            value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False, sparse_cols=Z)
-            value, aux_acts = ac.critic.fwd(feat, F_, N, ws, sparse_cols=Z)
+            value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False, sparse_cols=0 if gauss else Z)
+            value, aux_acts = ac.critic.fwd(feat, F_, N, ws, sparse_cols=0 if gauss else Z)
             adv, agae, vtgt, wgt = (torch.empty(T - 1, B, device=dev) for _ in range(4))
             H.call('dm_gae_losses', T - 1, B, ac.gamma, ac.lambda_, H.fptr(reward_t), H.fptr(terminal_t), H.fptr(value_t),
                    H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
@@ -957,7 +962,7 @@ class WorldModel(_Params):
         NE, N = T * B, T * B * I
         iw = pk.get('iw')          # IWAE importance weights (N,) or None: every per-sample gradient of loss_model carries them
         feat, dev = pk['feat'], pk['feat'].device
-        F_, Z, E = self.features_dim, c.stoch_dim * c.stoch_discrete, self.encoder.out_dim
+        F_, Z, E = self.features_dim, c.stoch_dim * (c.stoch_discrete or 2), self.encoder.out_dim   # Z: parameter width here
         plist = self._param_order()
         flat, views, direct = _flat_views(plist, dev, getattr(self, '_fused', None), scratch)
         gof = {id(p): v for p, v in zip(plist, views)}
@@ -1030,11 +1035,11 @@ class WorldModel(_Params):
         lib = H.lib()
         with torch.no_grad():
             if u_pred is None:
-                u_pred = torch.rand(N, S, device=dev)
+                u_pred = (torch.rand if C else torch.randn)(N, S, device=dev)
             u_pred = u_pred.reshape(N, S).contiguous()
             fp = feat.clone()                                                 # feature_replace_z: [h | prior sample]
             idx = torch.empty(N, S, dtype=torch.int32, device=dev)
-            H.call('dm_sample_onehot', N, S, C, H.fptr(pk['prior']), S * C, H.fptr(u_pred), None,
+            H.call('dm_sample_onehot', N, S, C, H.fptr(pk['prior']), S * (C or 2), H.fptr(u_pred), None,
                    ctypes.c_void_p(fp.data_ptr() + 4 * D_), F_, H.ptr(idx), H.stream())
             dl = dec.image.layers()
             dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
@@ -1326,7 +1331,7 @@ class Dreamer(nn.Module):
         if tuple(u_act.shape) != ((Hh, M) if kind == 0 else (Hh, M, A)):
             raise ValueError(f'actor noise has shape {tuple(u_act.shape)}, expected {(Hh, M) if kind == 0 else (Hh, M, A)}')
         if u_prior is None:
-            u_prior = torch.rand(Hh, M, S, device=dev)
+            u_prior = (torch.rand if c.stoch_discrete else torch.randn)(Hh, M, S, device=dev)
         feats = torch.empty(Hh + 1, M, F_, device=dev)
         actions = torch.empty(Hh, M, A, device=dev)
         act_idx = torch.empty(Hh, M, dtype=torch.int32, device=dev)

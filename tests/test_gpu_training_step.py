@@ -381,8 +381,9 @@ def _check_pair(r, oconf, free_running=True):
             assert torch.equal(r['xh']['act_idx'].cpu().long(), r['xo']['act_idx']), 'dream action index mismatch'
         else:
             _close(r['xh']['actions'], r['xo']['actions'], 1e-4, 1e-5, 'dream continuous actions')
-        lat_h = r['xh']['dream_features'][1:, :, oconf.deter_dim:].reshape(oconf.imag_horizon, -1, S, oconf.stoch_discrete).argmax(-1).cpu()
-        assert torch.equal(lat_h, r['xo']['lat_idx']), 'dream latent index mismatch'
+        if oconf.stoch_discrete:
+            lat_h = r['xh']['dream_features'][1:, :, oconf.deter_dim:].reshape(oconf.imag_horizon, -1, S, oconf.stoch_discrete).argmax(-1).cpu()
+            assert torch.equal(lat_h, r['xo']['lat_idx']), 'dream latent index mismatch'
     names = ('loss_model', 'loss_probe', 'loss_actor', 'loss_critic')
     for n, a, b in zip(names, r['lh'], r['lo']):
         assert _rel(a, b) < 2e-5 or abs(float(a) - float(b)) < 2e-6, (n, float(a), float(b))
@@ -392,7 +393,10 @@ def _check_pair(r, oconf, free_running=True):
     for k, v in r['to'].items():
         _close(r['th'][k], v, 1e-4, 1e-4 * max(1.0, float(v.abs().max())), f'tensor {k}')
     _close(r['st_h'][0], r['st_o'][0], 0, 1e-5, 'out_state h')
-    assert torch.equal(r['st_h'][1].cpu(), r['st_o'][1]), 'out_state z'
+    if oconf.stoch_discrete:
+        assert torch.equal(r['st_h'][1].cpu(), r['st_o'][1]), 'out_state z'
+    else:       # Gaussian latents: z is a float sample
+        _close(r['st_h'][1], r['st_o'][1], 0, 2e-5, 'out_state z')
     worst = ('', 0.0)
     for k, g in r['go'].items():
         e = _rel_l2(r['gh'][k], g)
@@ -444,13 +448,26 @@ def test_training_step_no_layernorm_vs_oracle(hip, kw):
         _check_pair(r, oconf)
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(layer_norm=False, gru_type='gru_layernorm_dv2'),
+                                dict(actor_dist='tanh_normal', action_dim=4, entropy=1.0e-4, kl_balance=0.5, gru_layers=2)])
+def test_training_step_gaussian_latents_vs_oracle(hip, kw):
+    """stoch_discrete = 0 (rssm.py:103-117,195-203; functions.py:46-56): Gaussian latents - reparameterised posterior and
+    prior samples, the Normal KL (balanced and plain), entropies, BPTT through mean and std - two consecutive steps, every
+    loss, metric and per-parameter gradient."""
+    oconf = O.tiny_conf(stoch_discrete=0, **kw)
+    for r in _run_pair(oconf, 2):
+        _check_pair(r, oconf)
+
+
 def test_training_step_matches_reference_goldens(hip):
     """Directly against the fixtures written by the real reference (tests/golden/tiny.npz, debug_literal.npz, tiny_dmc.npz,
     the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz, and the auxiliary critic
     of dreamer.py:267-279,347-358: tiny_aux_critic.npz, and the 3-layer GRUCellStack of rnn.py:40-67: tiny_gru_layers3.npz -
-    SURVEY 8(f) N4; layer_norm=False, common.py:68-74 NoNorm: tiny_no_layernorm.npz)."""
+    SURVEY 8(f) N4; layer_norm=False, common.py:68-74 NoNorm: tiny_no_layernorm.npz; Gaussian latents, stoch_discrete=0,
+    rssm.py:195-203: tiny_gaussian_latents.npz)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
-                        ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2)):
+                        ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2),
+                        ('tiny_gaussian_latents', 2)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)

@@ -71,7 +71,8 @@ def test_state_dict_keys_match_reference_table():
     from pydreamer_amd.models import Dreamer
     for oconf in (O.tiny_conf(), O.atari_literal_conf(), O.tiny_conf(gru_type='gru_layernorm'),
                   O.tiny_conf(gru_type='gru_layernorm_dv2'), O.tiny_conf(aux_critic=True), O.tiny_conf(gru_layers=2),
-                  O.atari_literal_conf(gru_layers=3), O.tiny_conf(layer_norm=False), O.tiny_conf(layer_norm=False, aux_critic=True)):
+                  O.atari_literal_conf(gru_layers=3), O.tiny_conf(layer_norm=False), O.tiny_conf(layer_norm=False, aux_critic=True),
+                  O.tiny_conf(stoch_discrete=0), O.atari_literal_conf(stoch_discrete=0)):
         shapes = O.param_shapes(oconf)
         conf = config.load_config('defaults', 'atari', **vars(oconf))
         with torch.device('meta'):
@@ -85,7 +86,7 @@ def test_unsupported_configs_fail_loudly():
     from pydreamer_amd.models import Dreamer
     for kw in (dict(aux_critic=True, iwae_samples=2), dict(gru_layers=5, deter_dim=1000), dict(gru_layers=2, gru_type='gru_layernorm'), dict(gru_layers=3, deter_dim=1002),
                dict(gru_type='bogus'), dict(actor_dist='bogus'), dict(actor_grad='dynamics'),
-               dict(image_size=32), dict(stoch_discrete=0)):
+               dict(image_size=32)):
         conf = config.load_config('defaults', 'atari', **kw)
         with pytest.raises(NotImplementedError):
             Dreamer(conf)
