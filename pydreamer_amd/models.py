@@ -8,7 +8,7 @@ model, actor, critic — so each of the 4 returned losses supports an independen
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
 Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type in {gru, gru_layernorm,
-gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0, layer_norm True or False,
+gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0 or 0 (Gaussian latents), layer_norm True or False,
 aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
 probe_model='none', no vecobs / reward_input.
 """
