@@ -153,8 +153,8 @@ def test_oracle_matches_reference_no_layernorm():
 def test_oracle_matches_reference_gaussian_latents():
     """SURVEY 8(a) variant: stoch_discrete = 0 - Gaussian latents (rssm.py:103-117,195-203; functions.py:46-56 diag_normal:
     std = 2 sigmoid(.) + 0.1): reparameterised samples, the Normal KL with balancing, entropies, the rollout's prior
-    samples; two training steps incl. the gradient direction of every parameter.  (Oracle only so far: the HIP path
-    raises NotImplementedError for this configuration)"""
+    samples; two training steps incl. the gradient direction of every parameter.  (The HIP path is checked against the
+    same fixture in tests/test_gpu_training_step.py.)"""
     g, conf, results = _replay('tiny_gaussian_latents', 2)
     assert conf.stoch_discrete == 0 and O.feature_dim(conf) == conf.deter_dim + conf.stoch_dim
     for res in results:
