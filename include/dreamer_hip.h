@@ -63,6 +63,7 @@ typedef struct dm_shape {
  * LayerNorm, losses and storage stay fp32.  Precision is a per-call argument (here, dm_mlp_params.precision, DM_GEMM_BF16);
  * there is no process-wide switch. */
 #define DM_FLAG_BF16 128
+/* dm_shape.C = 0: Gaussian latents - z is S wide, the prior / posterior parameter rows 2*S wide (mean | raw std). */
 /* bits 8-9: gru_layers - 1 (GRUCellStack depth, rnn.py:40-67; up to 4 layers, plain GRU cells only) */
 #define DM_FLAG_GRU_LAYERS_SHIFT 8
 #define DM_FLAG_GRU_LAYERS_MASK (3 << DM_FLAG_GRU_LAYERS_SHIFT)
@@ -112,11 +113,15 @@ int dm_gru_gates_bwd(int rows, int D, const float* gi, const float* gh, const fl
 /* OneHotCategorical(StraightThrough) sample (rssm.py:147-148,195-201; dreamer.py:198-200):
  * per group of C logits: p = softmax(logits); cdf = sequential fp32 cumsum(p);
  * idx = #{k : cdf_k <= u*cdf_{C-1}} clamped to C-1 (the inverse-CDF rule the oracle patches into torch.multinomial);
- * if forced_idx != NULL it is used instead of sampling.  onehot (rows, groups*C) with leading dim ldo. */
+ * if forced_idx != NULL it is used instead of sampling.  onehot (rows, groups*C) with leading dim ldo.
+ * C = 0 selects Gaussian latents (stoch_discrete = 0; rssm.py:202-203, functions.py:46-56 diag_normal): a `logits` row is
+ * (mean[groups] | raw[groups]), std = 2 sigmoid(raw) + 0.1, `u` holds STANDARD-NORMAL draws and `onehot` receives
+ * z = mean + std * u (Normal.rsample), groups wide; forced_idx must be NULL, idx (if given) is zero-filled. */
 int dm_sample_onehot(int rows, int groups, int C, const float* logits, int ldl, const float* u,
                      const int32_t* forced_idx, float* onehot, int ldo, int32_t* idx, void* stream);
 
-/* KL(post||prior), entropies (dreamer.py:326-343,369-379; torch/distributions/kl.py:248-252). */
+/* KL(post||prior), entropies (dreamer.py:326-343,369-379; torch/distributions/kl.py:248-252).  C = 0: rows of Gaussian
+ * parameters (mean[S] | raw std[S]) and the Normal-Normal KL / entropies (torch/distributions/kl.py kl_normal_normal). */
 int dm_kl_balance_fwd(int rows, int S, int C, const float* post, const float* prior,
                       float* kl, float* ent_post, float* ent_prior, void* stream);
 /* dpost = scale_post * dKL/dpost, dprior = scale_prior * dKL/dprior (overwrite). */
