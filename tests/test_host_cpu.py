@@ -72,7 +72,8 @@ def test_state_dict_keys_match_reference_table():
     for oconf in (O.tiny_conf(), O.atari_literal_conf(), O.tiny_conf(gru_type='gru_layernorm'),
                   O.tiny_conf(gru_type='gru_layernorm_dv2'), O.tiny_conf(aux_critic=True), O.tiny_conf(gru_layers=2),
                   O.atari_literal_conf(gru_layers=3), O.tiny_conf(layer_norm=False), O.tiny_conf(layer_norm=False, aux_critic=True),
-                  O.tiny_conf(stoch_discrete=0), O.atari_literal_conf(stoch_discrete=0)):
+                  O.tiny_conf(stoch_discrete=0), O.atari_literal_conf(stoch_discrete=0),
+                  O.tiny_conf(stoch_discrete=0, aux_critic=True, layer_norm=False, gru_layers=2, actor_dist='tanh_normal', action_dim=4)):
         shapes = O.param_shapes(oconf)
         conf = config.load_config('defaults', 'atari', **vars(oconf))
         with torch.device('meta'):
