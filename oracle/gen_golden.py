@@ -419,6 +419,18 @@ if __name__ == '__main__':
                  imag_horizon=t.imag_horizon), steps=2,
             full_grads=('wm.core.cell.z_mlp.weight', 'wm.core.cell.post_mlp.weight', 'wm.core.cell.prior_mlp.bias',
                         'ac.actor.model.12.weight'))
+    if 'corners' in which:
+        # corners the HIP path does not build yet; the oracle is pinned for them ahead of the product:
+        # Gaussian latents with iwae_samples = 2 (sampled Normal log-density KL, dreamer.py:340-343) and a 2-layer stack of
+        # NormGRUCell (rnn.py:40-67 with rnn.py:95-114)
+        t = O.tiny_conf()
+        base = dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, cnn_depth=t.cnn_depth,
+                    action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size, imag_horizon=t.imag_horizon)
+        run('tiny_gaussian_iwae', ['defaults', 'atari'], dict(base, stoch_discrete=0, iwae_samples=2), steps=1,
+            full_grads=('wm.core.cell.post_mlp.weight',))
+        run('tiny_gru_layernorm_layers2', ['defaults', 'atari'],
+            dict(base, stoch_discrete=t.stoch_discrete, gru_type='gru_layernorm', gru_layers=2), steps=1,
+            full_grads=('wm.core.cell.gru.layers.1.ln_update.weight',))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

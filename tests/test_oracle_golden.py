@@ -161,6 +161,15 @@ def test_oracle_matches_reference_gaussian_latents():
         _check_step(g, conf, res)
 
 
+@pytest.mark.parametrize('name', ['tiny_gaussian_iwae', 'tiny_gru_layernorm_layers2'])
+def test_oracle_matches_reference_corners_ahead_of_the_product(name):
+    """Two corners the HIP path still refuses, pinned in the oracle ahead of it: Gaussian latents with
+    iwae_samples = 2 (the sampled Normal log-density KL, dreamer.py:340-343) and a 2-layer stack of NormGRUCell
+    (rnn.py:40-67,95-114)."""
+    g, conf, results = _replay(name, 1)
+    _check_step(g, conf, results[0])
+
+
 def test_oracle_matches_reference_aux_critic():
     """aux_critic (dreamer.py:267-279,347-358), two training steps."""
     g, conf, results = _replay('tiny_aux_critic', 2)
