@@ -350,6 +350,8 @@ def main():
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
+                    fp32_products=('split-bf16 x3 pieces / 6 MFMA products, fp32 accumulate (DM_FP32_SPLIT=1)' if hip.lib().dm_fp32_mode() else 'fp32 MFMA'),
+                    chain_graphs=hip.chain_graph_stats(),
                     step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
                     **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),
                     roofline=roof, cpu_baseline=cpu)

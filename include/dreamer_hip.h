@@ -347,8 +347,21 @@ int dm_mlp_chain_min_rows(int rows);
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
 /* Per-launch rows of the armed region (call before dm_prof_end): rows[i*8 + {0..7}] = {kind, M, N, K, split count, flags
- * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands), flops, milliseconds}; returns the row count. */
+ * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands, 16 split-bf16 fp32 products), flops, milliseconds};
+ * returns the row count. */
 int dm_prof_rows(double* rows, int max_rows);
+/* The launch chains (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout: hundreds of small dependent kernels on one stream) are
+ * stream-captured once per distinct argument set and replayed as ONE linear hipGraph afterwards (csrc/chain_graph.hip;
+ * bit-identical to the eager launch sequence; A/B switch DM_CHAIN_GRAPH=0).  No reference counterpart: it removes the host
+ * launch cost the reference pays per ATen op.
+ * dm_chain_graph_stats: out[3*i + {0,1,2}] = {replays, captures, switched off (arguments never repeat)} per chain in
+ * first-use order; returns the number of chains.  dm_chain_graph_reset drops every cached graph. */
+int dm_chain_graph_stats(long long* out, int max_chains);
+int dm_chain_graph_reset(void);
+/* 0 = fp32 contractions run on the fp32 MFMA (default); 1 = as split-bf16 products (each fp32 operand = three bf16 pieces,
+ * six MFMA products, fp32 accumulation: fp32-class results, csrc/gemm.hip; experimental environment switch DM_FP32_SPLIT=1,
+ * read once). */
+int dm_fp32_mode(void);
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
 

@@ -214,15 +214,19 @@ def preprocess(raw, conf, device='cpu'):
                 terminal=torch.from_numpy(raw['terminal']).to(device), reset=torch.from_numpy(raw['reset']).to(device))
 
 
-def make_noise(conf, seed=777):
+def make_noise(conf, seed=777, eval_iwae=None):
     """Uniforms in reference call order: T posterior draws (B*I*S), then H x [actor (M), prior (M*S)].
     Gaussian latents (stoch_discrete = 0): the latent arrays (u_post, u_prior, u_pred, u_prior_log) hold STANDARD-NORMAL
-    draws instead - the eps of Normal.rsample (z = mean + std * eps)."""
+    draws instead - the eps of Normal.rsample (z = mean + std * eps).
+    eval_iwae = I: the evaluation call shape (train.py:353-359,380-385 pass iwae_samples=eval_samples to a model whose own
+    conf.iwae_samples is 1): every per-sample array is sized for I samples, the do_dream_tensors log dream for the B first
+    states (dreamer.py:170: states[0, :, 0])."""
     T, B, S, H = conf.batch_length, conf.batch_size, conf.stoch_dim, conf.imag_horizon
-    M = T * B * conf.iwae_samples
+    Isamp = int(eval_iwae or conf.iwae_samples)
+    M = T * B * Isamp
     rs = np.random.RandomState(seed)
     lat = (lambda *shape: rs.rand(*shape)) if conf.stoch_discrete else (lambda *shape: rs.randn(*shape))
-    out = dict(u_post=torch.tensor(lat(T, B * conf.iwae_samples, S), dtype=torch.float32),
+    out = dict(u_post=torch.tensor(lat(T, B * Isamp, S), dtype=torch.float32),
                u_act=torch.tensor(rs.rand(H, M), dtype=torch.float32),
                u_prior=torch.tensor(lat(H, M, S), dtype=torch.float32))
     # continuous actors draw normal noise instead (torch.normal in Normal.sample): x = mean + std * eps.  The noise is
@@ -232,8 +236,10 @@ def make_noise(conf, seed=777):
     out['eps_act'] = torch.tensor(0.25 * rs.randn(H, M, conf.action_dim), dtype=torch.float32)
     # logging variants (drawn AFTER everything above, so the streams of the plain step are unchanged):
     #   do_image_pred: one prior sample per (t,b) (dreamer.py:383); do_dream_tensors: a (T-1)-step dream from the B first states
-    Bi = B * conf.iwae_samples
+    Bi = B * Isamp
     out['u_pred'] = torch.tensor(lat(T, Bi, S), dtype=torch.float32)
+    if eval_iwae:
+        Bi = B
     out['u_act_log'] = torch.tensor(rs.rand(T - 1, Bi), dtype=torch.float32)
     out['u_prior_log'] = torch.tensor(lat(T - 1, Bi, S), dtype=torch.float32)
     out['eps_act_log'] = torch.tensor(0.25 * rs.randn(T - 1, Bi, conf.action_dim), dtype=torch.float32)
@@ -510,16 +516,15 @@ def wm_training_step(p, conf, obs, in_state, u_post, forced_idx=None, u_pred=Non
             metrics.update(loss_critic_aux=aux[0]['loss_critic'], policy_value_aux=aux[0]['policy_value_im'])
     extras = dict(post_idx=torch.stack(idxs), post=posts.detach(), prior=priors.detach(), embed=embed.detach())
     if u_pred is not None:                                                    # do_image_pred, dreamer.py:381-394
-        assert I == 1, 'the oracle restates do_image_pred for iwae_samples = 1'
-        with torch.no_grad():
+        with torch.no_grad():      # I > 1: the decoders reduce TBI => TB by -logavgexp(-loss) / mean (decoders.py:170-171,277-278,312-313)
             z_prior, pred_idx = st_sample(conf, priors.detach(), u_pred)      # zdistr(prior).sample()
             fp = torch.cat((hs, z_prior), -1).reshape(T, B, I, -1).detach()   # feature_replace_z
             dec_p = conv_decoder(p, fp)
-            li = 0.5 * torch.square(dec_p - target).sum(dim=[-1, -2, -3]).squeeze(2)
+            li = lae(0.5 * torch.square(dec_p - target).sum(dim=[-1, -2, -3]))
             mu_p = mlp(p, 'wm.decoder.reward.model.model', fp, conf.reward_decoder_layers)
-            lr = (-D.Normal(mu_p, torch.ones_like(mu_p) * std).log_prob(obs['reward'].unsqueeze(2)) * std ** 2).squeeze(2)
+            lr = lae(-D.Normal(mu_p, torch.ones_like(mu_p) * std).log_prob(obs['reward'].unsqueeze(2)) * std ** 2)
             td = D.Bernoulli(logits=mlp(p, 'wm.decoder.terminal.model.model', fp, conf.terminal_decoder_layers).float())
-            lt = (-td.log_prob(obs['terminal'].unsqueeze(2))).squeeze(2)
+            lt = lae(-td.log_prob(obs['terminal'].unsqueeze(2)))
             tensors.update(logprob_image=li, logprob_reward=lr, logprob_terminal=lt, image_pred=dec_p.mean(2),
                            reward_pred=mu_p.mean(2), terminal_pred=td.mean.mean(2))
             metrics.update(logprob_image=li.mean(), logprob_reward=lr.mean(), logprob_terminal=lt.mean())

@@ -237,9 +237,11 @@ def run_amp(name, sections, overrides):
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
-def run_eval(name, sections, overrides, do_open_loop=False):
+def run_eval(name, sections, overrides, do_open_loop=False, iwae_samples=None):
     """Logging variants of training_step (train.py:353-359,380-385 call it with do_image_pred / do_dream_tensors):
-    one forward with both flags; inputs, extra uniforms and every extra output are stored."""
+    one forward with both flags; inputs, extra uniforms and every extra output are stored.
+    iwae_samples = I: the call shape of evaluate() itself, which passes iwae_samples=eval_samples TOGETHER with the flags to
+    a model whose conf.iwae_samples stays 1 (train.py:353-359,380-385)."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     sys.path.insert(0, REF)
@@ -253,7 +255,8 @@ def run_eval(name, sections, overrides, do_open_loop=False):
     T, B, S, H = rconf.batch_length, rconf.batch_size, rconf.stoch_dim, rconf.imag_horizon
     raw = O.synthetic_batch(oconf, seed=4321, first=True)
     obs = O.preprocess(raw, oconf)
-    noise = O.make_noise(oconf, seed=999)
+    Ie = int(iwae_samples or 1)
+    noise = O.make_noise(oconf, seed=999, eval_iwae=iwae_samples)
     onehot = rconf.actor_dist == 'onehot'
     with MultinomialPatch() as mp:
         mp.queue = [noise['u_post'][t] for t in range(T)] + [noise['u_pred'].reshape(-1, S)]
@@ -267,9 +270,10 @@ def run_eval(name, sections, overrides, do_open_loop=False):
                 mp.eps_queue.append(noise['eps_act_log'][i])
         with torch.no_grad():
             losses, new_state, metrics, tensors, dream_tensors = model.training_step(
-                obs, model.init_state(B), do_image_pred=True, do_dream_tensors=True, do_open_loop=do_open_loop)
+                obs, model.init_state(B * Ie), iwae_samples=iwae_samples, do_image_pred=True, do_dream_tensors=True,
+                do_open_loop=do_open_loop)
         assert not mp.queue and not mp.eps_queue
-        pred_idx = mp.idx[T].reshape(T, B, S)
+        pred_idx = mp.idx[T].reshape(T, B * Ie, S)
         tail = mp.idx[T + 1 + (2 if onehot else 1) * H:]
         log_act = torch.stack(tail[0::2]) if onehot else torch.zeros(T - 1, B, dtype=torch.long)
         log_lat = torch.stack(tail[1::2] if onehot else tail).reshape(T - 1, B, S)
@@ -293,7 +297,9 @@ def run_eval(name, sections, overrides, do_open_loop=False):
             out['dream_image_pred_frame'] = v[-1:, :1].numpy()
         else:
             out['dream_' + k] = v.detach().numpy()
-    out['idx_post'] = torch.stack(mp.idx[:T]).reshape(T, B, S).numpy().astype(np.uint8)
+    out['idx_post'] = torch.stack(mp.idx[:T]).reshape(T, B * Ie, S).numpy().astype(np.uint8)
+    if iwae_samples:
+        out['iwae_samples'] = np.array(Ie)
     out['out_state_h'] = new_state[0].numpy()
     out['idx_pred'] = pred_idx.numpy().astype(np.uint8)
     out['idx_log_act'] = log_act.numpy().astype(np.uint8)
@@ -371,6 +377,15 @@ if __name__ == '__main__':
                  dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
                       cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                       imag_horizon=t.imag_horizon), do_open_loop=True)
+    if 'eval_iwae' in which:
+        # evaluate()'s own call shape (train.py:353-359,380-385): iwae_samples=eval_samples WITH do_image_pred /
+        # do_dream_tensors (closed loop) and WITH do_open_loop (open loop): the I > 1 reductions of decoders.py:85-106,170-171
+        t = O.tiny_conf()
+        base = dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                    cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                    imag_horizon=t.imag_horizon)
+        run_eval('tiny_eval_iwae', ['defaults', 'atari'], base, iwae_samples=3)
+        run_eval('tiny_open_loop_iwae', ['defaults', 'atari'], base, do_open_loop=True, iwae_samples=3)
     if 'amp' in which:
         t = O.tiny_conf()
         run_amp('tiny_amp', ['defaults', 'atari'],

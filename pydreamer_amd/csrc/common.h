@@ -50,6 +50,7 @@ struct DmArena {
 // different host threads / streams with different precisions do not interact.  0 = fp32, 1 = bf16 operands (RNE) with
 // fp32 accumulation.
 int dm_cur_precision();
+int dm_fp32_split();      // gemm.hip: 1 = fp32 products run as split-bf16 (3 pieces, 6 MFMA products; DM_FP32_SPLIT=1), 0 = fp32 MFMA (default)
 struct DmPrecisionScope {
   int prev;
   explicit DmPrecisionScope(int p);
@@ -227,6 +228,46 @@ int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const
 
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
 void dm_prof_slot_end(int slot, hipStream_t st);
+bool dm_prof_active();                                                             // the per-launch profiler is recording
+
+// ---- linear hipGraph replay of a launch chain (chain_graph.hip) -----------------------------------------------------
+// The key: every value the chain's kernel arguments are computed from.
+struct DmChainKey {
+  uint64_t w[144];
+  int n = 0;
+  bool overflow = false;                               // more words than the key holds: the chain then runs eagerly
+  DmChainKey& add(const void* p) { if (n < 144) w[n++] = (uint64_t)(uintptr_t)p; else overflow = true; return *this; }
+  DmChainKey& add(long long v) { if (n < 144) w[n++] = (uint64_t)v; else overflow = true; return *this; }
+  DmChainKey& add_words(const void* p, size_t bytes) {   // a struct of pointers / 8-byte words (zero-padded tail)
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < bytes; i += 8) {
+      uint64_t v = 0;
+      for (size_t j = 0; j < 8 && i + j < bytes; ++j) v |= (uint64_t)b[i + j] << (8 * j);
+      add((long long)v);
+    }
+    return *this;
+  }
+  DmChainKey& add(const dm_shape* s) {
+    const int32_t* f = reinterpret_cast<const int32_t*>(s);
+    for (size_t i = 0; i + 1 < sizeof(dm_shape) / 4; i += 2) add((long long)(((uint64_t)(uint32_t)f[i] << 32) | (uint32_t)f[i + 1]));
+    return *this;
+  }
+};
+class DmChainGraph {
+ public:
+  DmChainGraph(const char* tag, const DmChainKey& key, hipStream_t st);
+  ~DmChainGraph();
+  bool replay_only() const { return mode_ == 1; }      // a cached graph exists: skip the launch sequence
+  hipStream_t launch_stream() const { return mode_ == 2 ? cap_ : st_; }   // where the launch sequence must go
+  int finish();                                        // replay it / close the capture, instantiate and launch
+ private:
+  const char* tag_;
+  DmChainKey key_;
+  hipStream_t st_;
+  hipStream_t cap_ = nullptr;
+  hipGraphExec_t exec_ = nullptr;
+  int mode_ = 0;                                       // 0 eager, 1 replay, 2 capturing
+};
 
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;

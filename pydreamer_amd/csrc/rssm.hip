@@ -197,6 +197,15 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   rssm_carve(s, acts, &a);
   const float* const* p = P->p;
 
+  // the whole launch sequence below depends on nothing but these values: replayed as one linear hipGraph (chain_graph.hip)
+  DmChainKey ck;
+  ck.add(s).add((long long)t0).add((long long)t1).add(embed).add(action).add(reset).add(h0).add(z0).add(u).add(forced_idx)
+      .add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(prior).add(idx).add(ws).add((long long)ws_bytes)
+      .add((long long)dm_cur_precision());
+  DmChainGraph cg("rssm_sequence_fwd", ck, st);
+  if (cg.replay_only()) return cg.finish();
+  st = cg.launch_stream();
+
   DM_TRY(linear(st, ws, skb, N, Hd, A, action + q0 * A, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea + q0 * Hd, Hd));
   DM_TRY(linear(st, ws, skb, N, Hd, E, embed + q0 * E, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee + q0 * Hd, Hd));
 
@@ -353,7 +362,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
                               Hd, a.st3 + q0 * 2, st));
   DM_TRY(linear(st, ws, skb, N, ZP, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
                 prior + q0 * ZP, ZP));
-  return DM_OK;
+  return cg.finish();
 }
 extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
                                     const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
@@ -405,6 +414,13 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+
+  DmChainKey ck;
+  ck.add(s).add(embed).add(action).add(reset).add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(dfeat).add(dpost)
+      .add(dprior).add_words(G, sizeof(*G)).add(dembed).add(ws).add((long long)ws_bytes).add((long long)dm_cur_precision());
+  DmChainGraph cg("rssm_sequence_bwd", ck, st);
+  if (cg.replay_only()) return cg.finish();
+  st = cg.launch_stream();
 
   // ---- prior branch, batched over all rows
   DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dprior, ZP, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
@@ -584,7 +600,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx1, Hd, g[DM_RSSM_Z_B], sk, skb, st));
   DM_TRY(wgrad(st, sk, skb, N, Hd, A, dx1, Hd, action, A, g[DM_RSSM_A_W]));
-  return DM_OK;
+  return cg.finish();
 }
 
 // ---------------------------------------------------------------- imagination -------------------
@@ -626,6 +642,13 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  DmChainKey ck;
+  ck.add(s).add((long long)M).add(start).add_words(P, sizeof(*P)).add_words(actor, sizeof(*actor)).add(u_act).add(u_prior)
+      .add(feats).add(actions).add(act_idx).add(actor_acts).add(actor_logits).add(ws).add((long long)ws_bytes)
+      .add((long long)dm_cur_precision());
+  DmChainGraph cg("dream_rollout", ck, st);
+  if (cg.replay_only()) return cg.finish();
+  st = cg.launch_stream();
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
   GruStack gk;
   DM_TRY(gru_stack(s, p, nullptr, &gk));
@@ -704,5 +727,5 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(dm_sample_onehot_launch(M, S, C, prior, ZP, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
                                    nullptr, st));
   }
-  return DM_OK;
+  return cg.finish();
 }

@@ -7,7 +7,7 @@ calls the C-ABI of libdreamer_hip.so (pydreamer_amd/hip.py) through three `torch
 model, actor, critic — so each of the 4 returned losses supports an independent `.backward()` exactly like the
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
-Supported configuration (everything else raises NotImplementedError): iwae_samples>=1, gru_type in {gru, gru_layernorm,
+Supported configuration (everything else raises NotImplementedError): iwae_samples>=1 (also with the logging flags), gru_type in {gru, gru_layernorm,
 gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0 or 0 (Gaussian latents), layer_norm True or False,
 aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
 probe_model='none', no vecobs / reward_input.
@@ -1026,10 +1026,13 @@ class WorldModel(_Params):
     def _image_pred(self, pk, obs, u_pred):
         """do_image_pred (dreamer.py:381-394): decode from a PRIOR sample instead of the posterior sample and report the
         reconstruction losses as logprob_* / *_pred (decoders.py:50-108 with extra_metrics).  Logging variant, no grads.
-        The NaN-masked sign / terminal splits (decoders.py:94-105) are (T,B) torch expressions."""
+        iwae_samples = I > 1 (the call shape of evaluate(), train.py:353-359,380-385): one prior sample per (t,b,i) row; the
+        decoders reduce TBI => TB by -logavgexp(-loss) for the losses and a mean for the predictions
+        (decoders.py:170-171,277-278,312-313).  The NaN-masked sign / terminal splits (decoders.py:94-105) are (T,B) torch
+        expressions."""
         c, dec = self.conf, self.decoder
-        T, B, feat, shp = pk['T'], pk['B'], pk['feat'], pk['shp']
-        N, dev = T * B, feat.device
+        T, B, I, feat, shp = pk['T'], pk['B'], pk.get('I', 1), pk['feat'], pk['shp']
+        NE, N, dev = T * B, T * B * I, feat.device
         D_, S, C, F_ = c.deter_dim, c.stoch_dim, c.stoch_discrete, self.features_dim
         ws = self.workspace(shp, dev)
         lib = H.lib()
@@ -1045,20 +1048,32 @@ class WorldModel(_Params):
             dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
             acts = torch.empty(int(lib.dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
             li = torch.empty(N, device=dev)
-            image_pred = torch.empty(T, B, c.image_channels, c.image_size, c.image_size, device=dev)
+            image_pred = torch.empty(T, B, I, c.image_channels, c.image_size, c.image_size, device=dev)
             H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(fp), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
                    H.fptr(acts), H.fptr(li), H.fptr(image_pred), H.ptr(ws), ws.numel(), H.stream())
             mu, _ = dec.reward.model.fwd(fp, F_, N, ws, save_acts=False)
             tl, _ = dec.terminal.model.fwd(fp, F_, N, ws, save_acts=False)
             lr, lt, rp, tp, scratch = (torch.empty(N, device=dev) for _ in range(5))
             loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
-            H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(obs['reward'].float().contiguous()), 0.0, loss_const, H.fptr(lr),
+            reward_t, terminal_t = obs['reward'].float().contiguous(), obs['terminal'].float().contiguous()
+            if I > 1:                              # targets expanded over I (decoders.py:270,305: insert_dim)
+                reward_t = reward_t.repeat_interleave(I, dim=1).contiguous()
+                terminal_t = terminal_t.repeat_interleave(I, dim=1).contiguous()
+            H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), 0.0, loss_const, H.fptr(lr),
                    H.fptr(scratch), H.fptr(rp), H.stream())
-            H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(obs['terminal'].float().contiguous()), 0.0, 0.0, H.fptr(lt),
+            H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), 0.0, 0.0, H.fptr(lt),
                    H.fptr(scratch), H.fptr(tp), H.stream())
+            if I > 1:                              # TBI => TB
+                red = torch.empty(5, NE, device=dev)
+                for j, (x, mode) in enumerate(((li, 1), (lr, 1), (lt, 1), (rp, 0), (tp, 0))):
+                    H.call('dm_reduce_i', NE, I, 1, H.fptr(x), mode, H.fptr(red[j]), None, H.stream())
+                li, lr, lt, rp, tp = (red[j] for j in range(5))
+                image_pred = image_pred.mean(2)                               # decoded.mean(dim=2), decoders.py:171
+            else:
+                image_pred = image_pred[:, :, 0]
             tb = lambda x: x.view(T, B)
             tensors = dict(logprob_image=tb(li), logprob_reward=tb(lr), logprob_terminal=tb(lt),
-                           image_pred=image_pred.view(T, B, *image_pred.shape[-3:]), reward_pred=tb(rp), terminal_pred=tb(tp))
+                           image_pred=image_pred, reward_pred=tb(rp), terminal_pred=tb(tp))
             metrics = dict(logprob_image=li.mean(), logprob_reward=lr.mean(), logprob_terminal=lt.mean())
             nan = torch.full((), float('nan'), device=dev)
             nanmean = lambda x: torch.nansum(x) / (~torch.isnan(x)).sum()     # functions.py:149-150
@@ -1073,8 +1088,6 @@ class WorldModel(_Params):
                       u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
         I = int(iwae_samples)
-        if I > 1 and (do_image_pred or do_open_loop):
-            raise NotImplementedError('do_image_pred / do_open_loop are built for iwae_samples = 1')
         if do_open_loop and torch.is_grad_enabled():
             raise NotImplementedError('do_open_loop is an evaluation variant: call it under torch.no_grad() like '
                                       'train.py:353-359 does (its backward is not built)')
@@ -1367,8 +1380,6 @@ class Dreamer(nn.Module):
         T, B = obs['action'].shape[:2]
         noise = noise or {}
         I = iwae_samples
-        if I > 1 and do_dream_tensors:
-            raise NotImplementedError('do_dream_tensors is built for iwae_samples = 1')
         u_post = noise.get('u_post')
         if u_post is not None:
             u_post = u_post.reshape(T, B * I, -1)
@@ -1437,12 +1448,13 @@ class Dreamer(nn.Module):
         if do_dream_tensors:
             with torch.no_grad():
                 kind, dpk2 = self.ac.dist_kind, {}
+                # states[0, :, 0] (dreamer.py:170): the first of the I samples of every batch column at t = 0 = rows b*I
                 f2, a2, r2, t2 = self._dream_from_features(
-                    pk['feat'][:B].contiguous(), T - 1,
+                    pk['feat'][:B * I:I].contiguous(), T - 1,
                     noise.get('u_act_log') if kind == 0 else noise.get('eps_act_log'), noise.get('u_prior_log'), _pack=dpk2)
                 dl = self.wm.decoder.image.layers()
                 dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
-                shp, dev = pk['shp'], pk['feat'].device
+                shp, dev = pk['shp_e'], pk['feat'].device          # (T,B,1): the log dream has one row per (step, column)
                 acts = torch.empty(int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=dev)
                 image_dream = torch.empty(T, B, self.conf.image_channels, self.conf.image_size, self.conf.image_size, device=dev)
                 ws = self.wm.workspace(shp, dev)

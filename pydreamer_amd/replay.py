@@ -216,7 +216,9 @@ class DeviceRing:
     consumer asks for the batch after next (so the previous batch stays valid while the current step runs)."""
 
     def __init__(self, source, device, depth=4):
-        self.source, self.device, self.depth = iter(source), torch.device(device), max(2, depth)
+        # depth >= 3: next() keeps the current and the previous batch and frees the one before (a ring of 2 would deadlock:
+        # the third next() waits for a filled slot while the producer waits for a free one)
+        self.source, self.device, self.depth = iter(source), torch.device(device), max(3, depth)
         self.stream = torch.cuda.Stream(self.device)
         self.free = queue.Queue()
         self.ready = queue.Queue(maxsize=self.depth)
@@ -245,6 +247,10 @@ class DeviceRing:
                     if i is None:
                         return
                     host, dev, ev, done = self.slots[i]
+                    # HOST-side wait for this slot's previous H2D copy: the copy stream may still be parked behind
+                    # wait_event(done) (the step path never syncs, so the host runs ahead), and rewriting the pinned
+                    # buffer under a pending asynchronous copy would hand the model a half-overwritten batch
+                    ev.synchronize()
                     for k, v in batch.items():
                         host[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
                     if done[0] is not None:         # the steps that read this slot's previous batch must have finished on the GPU
@@ -254,14 +260,23 @@ class DeviceRing:
                             dev[k].copy_(host[k], non_blocking=True)
                         ev.record(self.stream)
                     self.ready.put(i)
+            self.ready.put(None)        # source exhausted: next() raises StopIteration after the last batch
         except Exception as e:          # surfaced by next()
             self.error = e
             self.ready.put(None)
 
+    def __iter__(self):
+        return self
+
+    __next__ = lambda self: self.next()
+
     def next(self):
         i = self.ready.get()
         if i is None:
-            raise RuntimeError('replay producer failed') from self.error
+            self.ready.put(None)        # stay exhausted / failed for later calls
+            if self.error is not None:
+                raise RuntimeError('replay producer failed') from self.error
+            raise StopIteration
         host, dev, ev, done = self.slots[i]
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)

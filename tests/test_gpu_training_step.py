@@ -1002,19 +1002,23 @@ def test_uint8_ingest_matches_float_path(hip):
     assert torch.equal(dst, obs_f['image'])
 
 
-def test_logging_variants_match_reference_golden(hip):
+@pytest.mark.parametrize('name', ['tiny_eval', 'tiny_eval_iwae'])
+def test_logging_variants_match_reference_golden(hip, name):
     """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394) through the HIP path against
-    tests/golden/tiny_eval.npz written by the real reference (called under no_grad like train.py:353-359)."""
-    g = np.load(os.path.join(GOLD, 'tiny_eval.npz'))
+    tests/golden/tiny_eval.npz written by the real reference (called under no_grad like train.py:353-359).
+    tiny_eval_iwae: evaluate()'s own call shape - iwae_samples=3 passed together with the flags (train.py:380-385)."""
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    Ie = int(g['iwae_samples']) if 'iwae_samples' in g.files else None
     oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
     raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
     noise = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
     model = _build(oconf, O.make_params(oconf, seed=0))
     with torch.no_grad():
         losses, st, metrics, tensors, dt = model.training_step(_to_dev(O.preprocess(raw, oconf)),
-                                                               model.init_state(oconf.batch_size), noise=noise,
-                                                               do_image_pred=True, do_dream_tensors=True)
-    T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
+                                                               model.init_state(oconf.batch_size * (Ie or 1)), noise=noise,
+                                                               iwae_samples=Ie, do_image_pred=True, do_dream_tensors=True)
+    T, B, S = oconf.batch_length, oconf.batch_size * (Ie or 1), oconf.stoch_dim
+    assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_post'])
     assert np.array_equal(model.last_extras['pred_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_pred'])
     assert np.array_equal(model.last_extras['dream_log_act_idx'].cpu().numpy().astype(np.uint8), g['idx_log_act'])
     for i, l in enumerate(losses):
@@ -1035,21 +1039,25 @@ def test_logging_variants_match_reference_golden(hip):
     np.testing.assert_allclose(dt['image_pred'][-1:, :1].cpu().numpy(), g['dream_image_pred_frame'], rtol=0, atol=3e-5)
 
 
-def test_open_loop_matches_reference_golden(hip):
+@pytest.mark.parametrize('name', ['tiny_open_loop', 'tiny_open_loop_iwae'])
+def test_open_loop_matches_reference_golden(hip, name):
     """do_open_loop (rssm.py:50-53: every step is forward_prior) + the logging variants, against
-    tests/golden/tiny_open_loop.npz written by the real reference; evaluation only (no_grad)."""
-    g = np.load(os.path.join(GOLD, 'tiny_open_loop.npz'))
+    tests/golden/tiny_open_loop.npz written by the real reference; evaluation only (no_grad).
+    tiny_open_loop_iwae: with iwae_samples=3, the call of train.py:353-359."""
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    Ie = int(g['iwae_samples']) if 'iwae_samples' in g.files else None
     oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
     raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
     noise = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
     model = _build(oconf, O.make_params(oconf, seed=0))
     obs = _to_dev(O.preprocess(raw, oconf))
     with pytest.raises(NotImplementedError):
-        model.training_step(obs, model.init_state(oconf.batch_size), noise=noise, do_open_loop=True)
+        model.training_step(obs, model.init_state(oconf.batch_size * (Ie or 1)), noise=noise, iwae_samples=Ie, do_open_loop=True)
     with torch.no_grad():
-        losses, st, metrics, tensors, dt = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise,
-                                                               do_image_pred=True, do_dream_tensors=True, do_open_loop=True)
-    T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
+        losses, st, metrics, tensors, dt = model.training_step(obs, model.init_state(oconf.batch_size * (Ie or 1)), noise=noise,
+                                                               iwae_samples=Ie, do_image_pred=True, do_dream_tensors=True,
+                                                               do_open_loop=True)
+    T, B, S = oconf.batch_length, oconf.batch_size * (Ie or 1), oconf.stoch_dim
     assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_post'])
     assert np.array_equal(model.last_extras['pred_idx'].cpu().numpy().astype(np.uint8).reshape(T, B, S), g['idx_pred'])
     np.testing.assert_allclose(st[0].cpu().numpy(), g['out_state_h'], rtol=0, atol=5e-6)
@@ -1061,6 +1069,8 @@ def test_open_loop_matches_reference_golden(hip):
             assert torch.isnan(metrics[k]), k
         else:
             assert _rel(metrics[k], ref) < 1e-4 or abs(float(metrics[k]) - ref) < 5e-6, (k, float(metrics[k]), ref)
+    for k in [f[7:] for f in g.files if f.startswith('tensor_') and not f.endswith(('_sum', '_frame'))]:
+        np.testing.assert_allclose(tensors[k].cpu().numpy(), g['tensor_' + k], rtol=1e-4, atol=2e-5, equal_nan=True, err_msg=k)
     for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
         np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
 

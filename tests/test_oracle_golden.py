@@ -266,19 +266,22 @@ def test_oracle_matches_reference_at_dmc_native():
         assert _rel(metrics[k], float(g['s0_metric_' + k])) < 2e-5, k
 
 
-@pytest.mark.parametrize('name,open_loop', [('tiny_eval', False), ('tiny_open_loop', True)])
+@pytest.mark.parametrize('name,open_loop', [('tiny_eval', False), ('tiny_open_loop', True),
+                                            ('tiny_eval_iwae', False), ('tiny_open_loop_iwae', True)])
 def test_oracle_logging_variants_match_reference(name, open_loop):
     """do_image_pred + do_dream_tensors (dreamer.py:163-180,381-394; called by train.py:353-359,380-385), without and
-    with do_open_loop (rssm.py:50-53), against the fixtures written by the real reference."""
+    with do_open_loop (rssm.py:50-53), against the fixtures written by the real reference.  The *_iwae fixtures are
+    evaluate()'s own call shape: iwae_samples=3 passed TOGETHER with the flags to a model whose conf.iwae_samples is 1."""
     g = _load(name)
     conf = _conf_from(g)
+    Ie = int(g['iwae_samples']) if 'iwae_samples' in g.files else None
     raw = {k: g['in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
     noise = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('in_u_') or k.startswith('in_eps_')}
     model = O.OracleDreamer(conf, O.make_params(conf, seed=0))
     with torch.no_grad():
-        losses, st, metrics, tensors, ex = model.training_step(O.preprocess(raw, conf), model.init_state(conf.batch_size),
+        losses, st, metrics, tensors, ex = model.training_step(O.preprocess(raw, conf), model.init_state(conf.batch_size * (Ie or 1)),
                                                                noise, do_image_pred=True, do_dream_tensors=True,
-                                                               do_open_loop=open_loop)
+                                                               do_open_loop=open_loop, iwae_samples=Ie)
     assert np.array_equal(ex['post_idx'].numpy().astype(np.uint8).reshape(g['idx_post'].shape), g['idx_post'])
     np.testing.assert_allclose(st[0].numpy(), g['out_state_h'], rtol=0, atol=2e-6)
     assert np.array_equal(ex['pred_idx'].numpy().astype(np.uint8).reshape(g['idx_pred'].shape), g['idx_pred'])
