@@ -350,14 +350,16 @@ int dm_prof_end(double* out, int nkinds);
  * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands, 16 split-bf16 fp32 products), flops, milliseconds};
  * returns the row count. */
 int dm_prof_rows(double* rows, int max_rows);
-/* The launch chains (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout: hundreds of small dependent kernels on one stream) are
+/* The launch chains (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout: hundreds of small dependent kernels on one stream) can be
  * stream-captured once per distinct argument set and replayed as ONE linear hipGraph afterwards (csrc/chain_graph.hip;
- * bit-identical to the eager launch sequence; A/B switch DM_CHAIN_GRAPH=0).  No reference counterpart: it removes the host
- * launch cost the reference pays per ATen op.
+ * bit-identical to the eager launch sequence).  Off by default - measured on MI355X the chains are GPU-latency-bound, the
+ * replay only removes host time (~9 us -> ~0.3 us per launch); DM_CHAIN_GRAPH=1 or dm_chain_graph_enable(1) switches it on.
+ * No reference counterpart: it removes the host launch cost the reference pays per ATen op.
  * dm_chain_graph_stats: out[3*i + {0,1,2}] = {replays, captures, switched off (arguments never repeat)} per chain in
  * first-use order; returns the number of chains.  dm_chain_graph_reset drops every cached graph. */
 int dm_chain_graph_stats(long long* out, int max_chains);
 int dm_chain_graph_reset(void);
+int dm_chain_graph_enable(int on);   /* on >= 0: set the switch (A/B, tests), returns the previous value; on < 0: query */
 /* 0 = fp32 contractions run on the fp32 MFMA (default); 1 = as split-bf16 products (each fp32 operand = three bf16 pieces,
  * six MFMA products, fp32 accumulation: fp32-class results, csrc/gemm.hip; experimental environment switch DM_FP32_SPLIT=1,
  * read once). */

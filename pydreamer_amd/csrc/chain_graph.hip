@@ -13,13 +13,24 @@
 //
 // The key holds every value a kernel argument is computed from (all pointers, the shape, the precision and the step
 // range); the torch caching allocator hands a steady-state training loop the same addresses step after step, so the
-// cache settles on a handful of entries.  A cache that keeps missing (addresses that never repeat) switches itself off
-// for that chain - capture + instantiate costs more than the eager launches it would save.
+// cache settles on a handful of entries (pydreamer_amd/models.py keeps the chains' buffers in a per-model arena for this).  A
+// cache that keeps missing (addresses that never repeat) switches itself off for that chain - capture + instantiate costs
+// more than the eager launches it would save.
 //
 // What is captured is exactly the eager launch sequence (same kernels, same order, same stream), so results are
-// bit-identical; the graph is linear (no branches): the dependent-kernel boundary of a replayed node is the stream's.
-// Off under the per-launch profiler (events would be captured as nodes) and inside an outer capture (graph.py).
-// Switch: DM_CHAIN_GRAPH=0 (A/B).
+// bit-identical; the graph is linear (no branches).  Never under the per-launch profiler (events would be captured as nodes)
+// or inside an outer capture (graph.py).
+//
+// Measured on MI355X / ROCm 7.2 (scripts/chain_graph_bench.py, profiles/r03_chain_graph.txt), idle GPU, one stream:
+//   posterior chain B=50 (255 launches): host 2.28 ms eager -> 0.08 ms replay, GPU 3.81 ms either way (15 us per dependent
+//   launch); B=7: host 1.21 -> 0.08 ms, GPU 2.00 ms either way; rollout B=50: host 0.95 -> 0.05 ms, GPU 7.0 ms either way.
+//   A replayed node costs the GPU what an eager launch costs (the dependent-kernel boundary is the stream's); the host cost
+//   drops from ~9 us per launch to ~0.3 us per node.
+// In the training step the chains are GPU-latency-bound, not host-bound (the step: 38.5 ms either way, the 7-column shard
+// 11.7 ms either way, host enqueue 10.4 -> 9.7 ms), and graph launches issued CONCURRENTLY on two streams from two host threads
+// (the pre-launched BPTT chain beside the rollout chain) collapse: 7-column shard 11.7 -> 28.8 ms, full batch 38.5 -> 54.7 ms.
+// So the replay is OFF by default; DM_CHAIN_GRAPH=1 / dm_chain_graph_enable(1) switches it on (host-bound deployments:
+// small models, slow hosts), DM_CHAIN_GRAPH_ONLY=<names> restricts it to some chains.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -27,6 +38,7 @@
 #include <mutex>
 #include <vector>
 
+static std::mutex g_mu;
 struct ChainEntry {
   const char* tag;
   DmChainKey key;
@@ -38,15 +50,20 @@ struct ChainTagState {
   uint64_t hits, misses;
   bool off;
 };
-static std::mutex g_mu;
 static std::vector<ChainEntry> g_cache;
 static std::vector<ChainTagState> g_tags;
 static uint64_t g_clock = 0;
 static const size_t CHAIN_CACHE_CAP = 48;
 
-static int chain_graph_enabled() {
-  static const int on = getenv("DM_CHAIN_GRAPH") ? atoi(getenv("DM_CHAIN_GRAPH")) : 1;
-  return on;
+static int g_chain_graph_on = getenv("DM_CHAIN_GRAPH") ? atoi(getenv("DM_CHAIN_GRAPH")) : 0;
+static int chain_graph_enabled() { return g_chain_graph_on; }
+// on >= 0 sets the switch (tests / A-B runs: the eager launch sequence and the replay must agree bit for bit); returns the
+// previous value.  on < 0 queries.
+extern "C" int dm_chain_graph_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int prev = g_chain_graph_on;
+  if (on >= 0) g_chain_graph_on = on ? 1 : 0;
+  return prev;
 }
 static ChainTagState& tag_state(const char* tag) {      // g_mu held
   for (auto& t : g_tags)
@@ -57,6 +74,8 @@ static ChainTagState& tag_state(const char* tag) {      // g_mu held
 
 DmChainGraph::DmChainGraph(const char* tag, const DmChainKey& key, hipStream_t st) : tag_(tag), key_(key), st_(st) {
   if (!chain_graph_enabled() || dm_prof_active() || key.overflow) return;
+  static const char* only = getenv("DM_CHAIN_GRAPH_ONLY");      // A/B: comma-separated chain names that may be replayed
+  if (only && !strstr(only, tag)) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();

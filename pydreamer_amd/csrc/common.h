@@ -228,6 +228,7 @@ int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const
 
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
 void dm_prof_slot_end(int slot, hipStream_t st);
+extern "C" int dm_mlp_chain_min_rows(int rows);                                    // mlp_chain.hip: rows < 1 queries
 bool dm_prof_active();                                                             // the per-launch profiler is recording
 
 // ---- linear hipGraph replay of a launch chain (chain_graph.hip) -----------------------------------------------------

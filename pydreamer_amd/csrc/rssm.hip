@@ -645,7 +645,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   DmChainKey ck;
   ck.add(s).add((long long)M).add(start).add_words(P, sizeof(*P)).add_words(actor, sizeof(*actor)).add(u_act).add(u_prior)
       .add(feats).add(actions).add(act_idx).add(actor_acts).add(actor_logits).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision());
+      .add((long long)dm_cur_precision()).add((long long)dm_mlp_chain_min_rows(0));      // + the one mutable dispatch threshold
   DmChainGraph cg("dream_rollout", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();

@@ -178,6 +178,7 @@ _SIGNATURES = {
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
     'dm_chain_graph_stats': (c_int, [POINTER(ctypes.c_longlong), c_int]),
     'dm_chain_graph_reset': (c_int, []),
+    'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_fp32_mode': (c_int, []),
 }
 

@@ -565,6 +565,50 @@ class _Done:
         return self.value
 
 
+class _StepArena:
+    """Buffers of everything the library's launch chains read or write (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout).
+    With the chains' hipGraph replay switched on (csrc/chain_graph.hip, DM_CHAIN_GRAPH=1 / dm_chain_graph_enable) they are
+    PERSISTENT per geometry, because a replayed graph is keyed by its pointer arguments and the caching allocator does not
+    hand a training loop the same addresses step after step (measured: 0 replays in 24 steps): `get(name, shape)` then
+    returns the same tensor for the same (name, shape, dtype, device) on every step; the two most recent geometries per name
+    are kept (training / evaluation batch shapes alternate).  Consequence in that mode: the buffers are overwritten by the NEXT
+    training_step(); nothing in them is handed to the caller (features / states are cloned on the way out of
+    WorldModel.training_step, Dreamer.last_extras documents its own lifetime) and a backward() on the losses of an older
+    step is refused (the generation stamp).  With the replay off (the default) `get` is torch.empty and nothing is shared."""
+
+    KEEP = 2
+
+    def __init__(self):
+        self.bufs = {}
+        self.gens = {}                     # geometry -> generation of the step whose activations the buffers hold
+        self.on = False
+
+    def begin_step(self, geometry):
+        self.on = H.lib().dm_chain_graph_enable(-1) == 1
+        if not self.on:
+            self.bufs.clear()
+            return None
+        self.gens[geometry] = self.gens.get(geometry, 0) + 1
+        return geometry, self.gens[geometry]
+
+    def current(self, stamp):
+        return stamp is None or self.gens.get(stamp[0]) == stamp[1]
+
+    def get(self, name, shape, dtype=torch.float32, device=None):
+        shape = tuple(int(x) for x in shape)
+        if not self.on:
+            return torch.empty(shape, dtype=dtype, device=device)
+        key = (shape, dtype, str(device))
+        slot = self.bufs.setdefault(name, {})
+        t = slot.pop(key, None)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            while len(slot) >= self.KEEP:
+                slot.pop(next(iter(slot)))
+        slot[key] = t                      # most recently used last
+        return t
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise H.DreamerHipError(f'{what} is on {t.device}: pydreamer_amd has no CPU path (the HIP library is the product)')
@@ -631,6 +675,7 @@ class WorldModel(_Params):
             init_weights_tf2(m)
         self._ws = None
         self._pipe = None
+        self._arena = _StepArena()
         # Forward time-chunk pipeline over 3 streams (encoder chunk i+1 | posterior steps of chunk i | decoder chunk i-1).
         # OFF by default: measured on MI355X / ROCm 7.2 it LOSES (61.9 vs 47.7 ms per step at B=50, 33.1 vs 16.5 ms at
         # B=7): the loop's 1024-thread workgroups starve behind the conv GEMMs of the other streams and every cross-stream
@@ -688,7 +733,7 @@ class WorldModel(_Params):
         with torch.no_grad():
             pk = self._forward(obs, in_state, u_post, None, forward_only=True)
         T, B = obs['action'].shape[:2]
-        return pk['feat'].view(T, B, 1, -1), pk['out_state']
+        return (pk['feat'].clone() if self._arena.on else pk['feat']).view(T, B, 1, -1), pk['out_state']
 
     # ---- forward through the C-ABI
     def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False, mbuf=None,
@@ -742,9 +787,22 @@ class WorldModel(_Params):
         bad = {k: (got[k], want[k]) for k in want if got[k] != want[k]}
         if bad:
             raise ValueError('training_step input shapes (got, expected): ' + ', '.join(f'{k}: {v[0]} != {v[1]}' for k, v in bad.items()))
-        if u_post is None and forced_idx is None:
+        # Everything the posterior chain touches lives in the step arena (stable addresses -> the chain's hipGraph is replayed)
+        ar = self._arena
+        gen = ar.begin_step((T, B, I))
+        u_buf = None
+        if forced_idx is None or u_post is not None:
             # uniforms for the categorical inverse-CDF rule; standard-normal eps of Normal.rsample for Gaussian latents
-            u_post = (torch.randn if gauss else torch.rand)(T, BI, c.stoch_dim, device=dev)
+            u_buf = ar.get('u_post', (T, BI, c.stoch_dim), device=dev)
+            if u_post is not None:
+                u_buf.copy_(u_post.reshape(T, BI, c.stoch_dim))
+            elif gauss:
+                u_buf.normal_()
+            else:
+                u_buf.uniform_()
+        u_post = u_buf
+        h0 = ar.get('h0', (BI, D_), device=dev).copy_(h0)
+        z0 = ar.get('z0', (BI, Z), device=dev).copy_(z0)
         lib = H.lib()
         shp_e = shp_r = shp
         if I > 1:
@@ -756,7 +814,7 @@ class WorldModel(_Params):
         enc = self.encoder.encoder_image
         enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
         enc_acts = torch.empty(int(lib.dm_conv_encoder_acts_floats(ctypes.byref(shp_e))), device=dev)
-        embed = torch.empty(NE, E, device=dev)
+        embed = ar.get('embed', (NE, E), device=dev)
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         if open_loop:
@@ -770,13 +828,14 @@ class WorldModel(_Params):
                              ('post_mlp.weight', 'prior_mlp.weight'), ('post_mlp.bias', 'prior_mlp.bias')):
                 po[ix[dst]] = po[ix[src]]
             rssm_p = H.rssm_struct(po)
-        rssm_acts = torch.empty(int(lib.dm_rssm_acts_floats(ctypes.byref(shp_r))), device=dev)
-        feat = torch.empty(N, F_, device=dev)
-        post = torch.empty(N, ZP, device=dev)
-        prior = torch.empty(N, ZP, device=dev)
-        idx = torch.empty(N, c.stoch_dim, dtype=torch.int32, device=dev)
-        fidx = forced_idx.to(torch.int32).contiguous() if forced_idx is not None else None
-        u_post = u_post.contiguous() if u_post is not None else None
+        rssm_acts = ar.get('rssm_acts', (int(lib.dm_rssm_acts_floats(ctypes.byref(shp_r))),), device=dev)
+        feat = ar.get('feat', (N, F_), device=dev)
+        post = ar.get('post', (N, ZP), device=dev)
+        prior = ar.get('prior', (N, ZP), device=dev)
+        idx = ar.get('idx', (N, c.stoch_dim), torch.int32, device=dev)
+        fidx = None
+        if forced_idx is not None:
+            fidx = ar.get('forced_idx', (T, BI, c.stoch_dim), torch.int32, device=dev).copy_(forced_idx)
         u_ptr = H.fptr(u_post) if u_post is not None else None
         dec = self.decoder
         dl = dec.image.layers()
@@ -787,15 +846,20 @@ class WorldModel(_Params):
             image_rec = None          # materialised lazily from the decoder's saved prediction (see LazyTensors)
 
         chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop and I == 1) else 1
-        embed_x, action_x, reset_x = embed, action, reset
+        # rssm.py:35-41: (T,B,X) -> (T,B*I,X), pure data movement - into the arena (I = 1: a plain copy of the caller's tensors)
+        A_ = c.action_dim
+        action_x = ar.get('action_x', (T, BI, A_), device=dev)
+        action_x.view(T, B, I, A_).copy_(action.view(T, B, 1, A_).expand(T, B, I, A_))
+        reset_x = ar.get('reset_x', (T, BI), torch.uint8, device=dev)
+        reset_x.view(T, B, I).copy_(reset.view(T, B, 1).expand(T, B, I))
+        embed_x = embed
         if chunks <= 1:
             H.call('dm_conv_encoder_fwd', ctypes.byref(shp_e), H.ptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
                    H.fptr(embed), H.ptr(ws), ws.numel(), H.stream())
-            if I > 1:       # rssm.py:35-41: (T,B,X) -> (T,B*I,X); pure data movement
-                embed_x = embed.view(T, B, E).repeat_interleave(I, dim=1).contiguous().view(N, E)
-                action_x = action.repeat_interleave(I, dim=1).contiguous()
-                reset_x = reset.repeat_interleave(I, dim=1).contiguous()
-            embed_rssm = torch.zeros_like(embed_x) if open_loop else embed_x
+            if I > 1:
+                embed_x = ar.get('embed_x', (N, E), device=dev)
+                embed_x.view(T, B, I, E).copy_(embed.view(T, B, 1, E).expand(T, B, I, E))
+            embed_rssm = ar.get('embed_zero', tuple(embed_x.shape), device=dev).zero_() if open_loop else embed_x
             H.call('dm_rssm_sequence_fwd', ctypes.byref(shp_r), H.fptr(embed_rssm), H.fptr(action_x), H.ptr(reset_x), H.fptr(h0),
                    H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
@@ -825,8 +889,8 @@ class WorldModel(_Params):
                     pp['ev_enc'][i].record(s_enc)
                 pp['s_chain'].wait_event(pp['ev_enc'][i])
                 with torch.cuda.stream(pp['s_chain']):
-                    H.call('dm_rssm_sequence_fwd_steps', ctypes.byref(shp), t0, t1, H.fptr(embed), H.fptr(action),
-                           H.ptr(reset), H.fptr(h0), H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p),
+                    H.call('dm_rssm_sequence_fwd_steps', ctypes.byref(shp), t0, t1, H.fptr(embed), H.fptr(action_x),
+                           H.ptr(reset_x), H.fptr(h0), H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p),
                            H.fptr(rssm_acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(pp['ws_chain']),
                            pp['ws_chain'].numel(), H.stream())
                     pp['ev_chain'][i].record(pp['s_chain'])
@@ -843,7 +907,7 @@ class WorldModel(_Params):
         last = feat[(T - 1) * BI:]
         out_state = (last[:, :D_].clone(), last[:, D_:].clone())                  # detached by construction (rssm.py:77)
         pk = dict(shp=shp, shp_e=shp_e, shp_r=shp_r, T=T, B=B, I=I, feat=feat, post=post, prior=prior, idx=idx,
-                  out_state=out_state, embed=embed, embed_x=embed_x, action_x=action_x, reset_x=reset_x)
+                  out_state=out_state, embed=embed, embed_x=embed_x, action_x=action_x, reset_x=reset_x, gen=gen)
         if forward_only:
             return pk
 
@@ -963,12 +1027,17 @@ class WorldModel(_Params):
         iw = pk.get('iw')          # IWAE importance weights (N,) or None: every per-sample gradient of loss_model carries them
         feat, dev = pk['feat'], pk['feat'].device
         F_, Z, E = self.features_dim, c.stoch_dim * (c.stoch_discrete or 2), self.encoder.out_dim   # Z: parameter width here
+        if not self._arena.current(pk.get('gen')):
+            raise RuntimeError('the activations saved by this training_step() were overwritten by a later training_step() '
+                               '(they live in per-model buffers with stable addresses); call backward() after each '
+                               'training_step()')
+        ar = self._arena
         plist = self._param_order()
         flat, views, direct = _flat_views(plist, dev, getattr(self, '_fused', None), scratch)
         gof = {id(p): v for p, v in zip(plist, views)}
         dec = self.decoder
 
-        dfeat = torch.zeros(N, F_, device=dev)
+        dfeat = ar.get('dfeat', (N, F_), device=dev).zero_()
         # dense heads (decoders.py:73-83)
         if iw is not None and not pk.get('iw_applied'):
             for dout in (pk['dmu'], pk['dtl']):
@@ -989,8 +1058,8 @@ class WorldModel(_Params):
                H.fptr(pk['dec_acts']), dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws),
                ws.numel(), H.stream())
         # KL (dreamer.py:334-343)
-        dpost = torch.empty(N, Z, device=dev)
-        dprior = torch.empty(N, Z, device=dev)
+        dpost = ar.get('dpost', (N, Z), device=dev)
+        dprior = ar.get('dprior', (N, Z), device=dev)
         if iw is not None:         # sampled KL of the IWAE bound
             H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
                    H.ptr(pk['idx']), self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
@@ -1005,7 +1074,7 @@ class WorldModel(_Params):
         cell = self.core.cell
         rssm_p = H.rssm_struct(cell.ordered())
         rssm_g = H.rssm_struct([None if p is None else gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
-        dembed = torch.empty(N, E, device=dev)
+        dembed = ar.get('dembed', (N, E), device=dev)
         H.call('dm_rssm_sequence_bwd', ctypes.byref(pk['shp_r']), H.fptr(pk['embed_x']), H.fptr(pk['action_x']),
                H.ptr(pk['reset_x']), ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']),
                H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(),
@@ -1085,7 +1154,7 @@ class WorldModel(_Params):
         return metrics, tensors, idx
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
-                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None):
+                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None, _internal=False):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
         I = int(iwae_samples)
         if do_open_loop and torch.is_grad_enabled():
@@ -1099,7 +1168,9 @@ class WorldModel(_Params):
                            iwae=I)
         loss = _WMStep.apply(self, pk, *self._param_order())
         D_ = self.deter_dim
-        feat = pk['feat']
+        # the feature matrix lives in the step arena (overwritten by the next step): callers get their own copy, except
+        # Dreamer.training_step, which consumes it before returning (_internal)
+        feat = pk['feat'] if (_internal or not self._arena.on) else pk['feat'].clone()
         features = feat.view(T, B, I, -1)
         states = (feat[:, :D_].view(T, B, I, -1), feat[:, D_:].view(T, B, I, -1))
         self._last_pack = pk
@@ -1331,7 +1402,7 @@ class Dreamer(nn.Module):
         start = torch.cat((h, z), -1).contiguous()           # to_feature (rssm.py:83-84)
         return self._dream_from_features(start, Hh, u_act, u_prior, _pack)
 
-    def _dream_from_features(self, start, Hh, u_act=None, u_prior=None, _pack=None):
+    def _dream_from_features(self, start, Hh, u_act=None, u_prior=None, _pack=None, _start_in_arena=False):
         """start: (M,F) rows [h|z] (the world model's feature matrix is passed as is, no concat copy)."""
         c = self.conf
         M, dev = start.shape[0], start.device
@@ -1339,23 +1410,41 @@ class Dreamer(nn.Module):
         shp = self.wm.shape(1, M, Hh)                        # T*B = M rows for workspace sizing
         ws = self.wm.workspace(shp, dev)
         kind = self.ac.dist_kind
-        if u_act is None:     # uniforms for the one-hot actor, standard-normal noise for continuous actors
-            u_act = torch.rand(Hh, M, device=dev) if kind == 0 else torch.randn(Hh, M, A, device=dev)
-        if tuple(u_act.shape) != ((Hh, M) if kind == 0 else (Hh, M, A)):
-            raise ValueError(f'actor noise has shape {tuple(u_act.shape)}, expected {(Hh, M) if kind == 0 else (Hh, M, A)}')
-        if u_prior is None:
-            u_prior = (torch.rand if c.stoch_discrete else torch.randn)(Hh, M, S, device=dev)
-        feats = torch.empty(Hh + 1, M, F_, device=dev)
-        actions = torch.empty(Hh, M, A, device=dev)
-        act_idx = torch.empty(Hh, M, dtype=torch.int32, device=dev)
+        # the rollout chain's buffers live in the world model's step arena (stable addresses -> its hipGraph is replayed);
+        # uniforms for the one-hot actor / the categorical latents, standard-normal noise for continuous actors / Gaussian latents
+        ar = self.wm._arena
+        ua_shape = (Hh, M) if kind == 0 else (Hh, M, A)
+        if u_act is not None and tuple(u_act.shape) != ua_shape:
+            raise ValueError(f'actor noise has shape {tuple(u_act.shape)}, expected {ua_shape}')
+        ua = ar.get('u_act', ua_shape, device=dev)
+        up = ar.get('u_prior', (Hh, M, S), device=dev)
+        if u_act is not None:
+            ua.copy_(u_act)
+        elif kind == 0:
+            ua.uniform_()
+        else:
+            ua.normal_()
+        if u_prior is not None:
+            up.copy_(u_prior.reshape(Hh, M, S))
+        elif c.stoch_discrete:
+            up.uniform_()
+        else:
+            up.normal_()
+        u_act, u_prior = ua, up
+        if ar.on and not _start_in_arena:
+            start = ar.get('dream_start', tuple(start.shape), device=dev).copy_(start)
+        start = start.contiguous()
+        feats = ar.get('dream_feats', (Hh + 1, M, F_), device=dev)
+        actions = ar.get('dream_actions', (Hh, M, A), device=dev)
+        act_idx = ar.get('dream_act_idx', (Hh, M), torch.int32, device=dev)
         cell_p = H.rssm_struct(self.wm.core.cell.ordered())
         actor_p = self.ac.actor.struct()
         a_acts = a_logits = None
         if _pack is not None:          # training: keep the actor activations of all H steps for the policy-gradient backward
-            a_acts = torch.empty(self.ac.actor.acts_floats(Hh * M), device=dev)
-            a_logits = torch.empty(Hh * M, self.ac.actor.out_dim, device=dev)
+            a_acts = ar.get('dream_actor_acts', (self.ac.actor.acts_floats(Hh * M),), device=dev)
+            a_logits = ar.get('dream_actor_logits', (Hh * M, self.ac.actor.out_dim), device=dev)
         H.call('dm_dream_rollout', ctypes.byref(shp), M, H.fptr(start), ctypes.byref(cell_p), ctypes.byref(actor_p),
-               H.fptr(u_act.contiguous()), H.fptr(u_prior.contiguous()), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
+               H.fptr(u_act), H.fptr(u_prior), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
                H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
         rows = (Hh + 1) * M
         f2 = feats.view(rows, F_)
@@ -1384,13 +1473,18 @@ class Dreamer(nn.Module):
         if u_post is not None:
             u_post = u_post.reshape(T, B * I, -1)
 
+        if self._overlap is not None:
+            # pre-launched backward passes of a step whose losses were never backpropagated may still be reading the arena
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._overlap.s_wm)
+            cur.wait_stream(self._overlap.s_ac)
         # every loss / metric scalar of this step lands in ONE device buffer (METRIC_SLOTS)
         mbuf = torch.zeros(METRIC_BUF_FLOATS, device=obs['action'].device)
         self.metric_buffer = mbuf
         loss_model, features, states, out_state, metrics, tensors = \
             self.wm.training_step(obs, in_state, iwae_samples=iwae_samples, do_open_loop=do_open_loop,
                                   do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
-                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf)
+                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf, _internal=True)
         pk = self.wm._last_pack
         ov = None
         if self.overlap_backward and torch.is_grad_enabled():
@@ -1420,7 +1514,7 @@ class Dreamer(nn.Module):
         features_dream, actions_dream, rewards_dream, terminals_dream = \
             self._dream_from_features(pk['feat'], imag_horizon,
                                       noise.get('u_act') if self.ac.dist_kind == 0 else noise.get('eps_act'),
-                                      noise.get('u_prior'), _pack=dpk)
+                                      noise.get('u_prior'), _pack=dpk, _start_in_arena=True)
         (loss_actor, loss_critic), metrics_ac, tensors_ac = \
             self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
                                   act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
@@ -1440,8 +1534,10 @@ class Dreamer(nn.Module):
             pv = torch.empty(T, B, device=pk['feat'].device)
             H.call('dm_reduce_i', T * B, I, 1, H.fptr(tensors_ac['value'][0].contiguous()), 0, H.fptr(pv), None, H.stream())
             tensors.update(policy_value=pv)
-        self.last_extras = dict(post_idx=pk['idx'].view(T, B * I, -1), act_idx=dpk['act_idx'], actions=actions_dream,
-                                dream_features=features_dream,
+        # Diagnostics for tests / debugging (not part of the reference API).  The index tensors are copies; `actions`,
+        # `dream_features`, `post` and `prior` are views of the step arena: valid until the next training_step().
+        self.last_extras = dict(post_idx=pk['idx'].view(T, B * I, -1).clone(), act_idx=dpk['act_idx'].clone(),
+                                actions=actions_dream, dream_features=features_dream,
                                 ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'], pred_idx=pk.get('pred_idx'))
         # Dream for a log sample (dreamer.py:163-180): T-1 imagined steps from the B first states, decoded to images
         dream_tensors = {}
@@ -1466,7 +1562,7 @@ class Dreamer(nn.Module):
                 dream_tensors = dict(action_pred=torch.cat([obs['action'][:1].float(), a2]), reward_pred=r2.mean,
                                      terminal_pred=t2.mean, image_pred=image_dream.view(T, B, *image_dream.shape[-3:]),
                                      **t_ac2)
-                self.last_extras.update(dream_log_act_idx=dpk2['act_idx'])
+                self.last_extras.update(dream_log_act_idx=dpk2['act_idx'].clone())
         losses = (loss_model, loss_probe, loss_actor, loss_critic)
         return losses, out_state, metrics, tensors, dream_tensors
 

@@ -363,7 +363,9 @@ def _run_pair(oconf, steps, forced=False, seed=0):
         gh = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None and v.requires_grad}
         for opt in opts:
             opt.step()
-        out.append(dict(lo=lo, lh=lh, mo={**mo, **gmo}, mh={**mh, **gmh}, to=to, th=th, xo=xo, xh=model.last_extras,
+        # last_extras' large entries are views of the model's step arena (valid until the next step): snapshot them
+        xh = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model.last_extras.items()}
+        out.append(dict(lo=lo, lh=lh, mo={**mo, **gmo}, mh={**mh, **gmh}, to=to, th=th, xo=xo, xh=xh,
                         go=go, gh=gh, st_o=st_o2, st_h=st_h2,
                         po={k: v.detach().clone() for k, v in ora.p.items()},
                         ph={k: v.detach().clone() for k, v in model.state_dict().items()}))
@@ -1073,6 +1075,80 @@ def test_open_loop_matches_reference_golden(hip, name):
         np.testing.assert_allclose(tensors[k].cpu().numpy(), g['tensor_' + k], rtol=1e-4, atol=2e-5, equal_nan=True, err_msg=k)
     for k in [f[6:] for f in g.files if f.startswith('dream_') and not f.startswith('dream_image_pred')]:
         np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('cfg', ['tiny', 'shard'])
+def test_chain_graphs_replay_bit_identical(hip, cfg):
+    """csrc/chain_graph.hip: dm_rssm_sequence_fwd / _bwd and dm_dream_rollout are stream-captured once per argument set and
+    replayed as linear hipGraphs.  Six optimizer steps with the replay on equal the same steps with eager launches bit for
+    bit (losses of every step, parameters after the last one), and the chains really are replayed (the step arena keeps
+    their pointer arguments stable).  'shard': the 7-column data-parallel shard of Atari-literal (fused 5-launch T steps)."""
+    oconf = O.tiny_conf() if cfg == 'tiny' else O.atari_literal_conf(batch_size=7, batch_length=6, imag_horizon=3)
+    conf = _hip_conf(oconf)
+    params = O.make_params(oconf, seed=5)
+    batches = [_to_dev(O.preprocess(O.synthetic_batch(oconf, seed=40 + i, first=(i == 0)), oconf)) for i in range(2)]
+    noises = [{k: v.to(DEV) for k, v in O.make_noise(oconf, seed=60 + s).items()} for s in range(6)]
+
+    def run():
+        model = _build(oconf, params)
+        opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+        state, out = model.init_state(oconf.batch_size), []
+        for s_ in range(6):
+            losses, state, metrics, tensors, _ = model.training_step(batches[s_ % 2], state, noise=noises[s_])
+            for opt in opts:
+                opt.zero_grad()
+            for loss in losses:
+                loss.backward()
+            model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+            for opt in opts:
+                opt.step()
+            out.append(torch.stack([l.detach().reshape(()) for l in losses] + [metrics['loss_kl'].reshape(())]))
+        return torch.stack(out).cpu(), opts[0].flat_param.clone().cpu(), opts[2].flat_param.clone().cpu()
+    prev = hip.lib().dm_chain_graph_enable(1)
+    try:
+        hip.call('dm_chain_graph_reset')
+        a = run()
+        stats = hip.chain_graph_stats()
+        hip.lib().dm_chain_graph_enable(0)
+        b = run()
+    finally:
+        hip.lib().dm_chain_graph_enable(prev)
+        hip.call('dm_chain_graph_reset')
+    assert torch.isfinite(a[0]).all()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert len(stats) == 3 and all(st['replays'] >= 2 and not st['off'] for st in stats), stats
+
+
+def test_backward_on_overwritten_activations_is_refused(hip):
+    """With the chains' hipGraph replay on, their buffers live in a per-model arena with stable addresses: with overlap_backward off (gradients computed inside
+    backward()), a backward() on the losses of an OLDER training_step() must fail loudly, not use the newer step's activations."""
+    oconf = O.tiny_conf()
+    model = _build(oconf, O.make_params(oconf, seed=1))
+    model.overlap_backward = False
+    opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+    obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=3, first=True), oconf))
+    st = model.init_state(oconf.batch_size)
+    prev = hip.lib().dm_chain_graph_enable(1)          # the arena (and with it this refusal) exists only with the replay on
+    try:
+        losses1, *_ = model.training_step(obs, st)
+        losses2, *_ = model.training_step(obs, st)
+        for opt in opts:
+            opt.zero_grad()
+        with pytest.raises(RuntimeError, match='overwritten'):
+            losses1[0].backward()
+        for loss in losses2:
+            loss.backward()
+    finally:
+        hip.lib().dm_chain_graph_enable(prev)
+        hip.call('dm_chain_graph_reset')
+    # replay off (the default): every step owns its buffers, an older step's losses can still be backpropagated
+    losses1, *_ = model.training_step(obs, st)
+    losses2, *_ = model.training_step(obs, st)
+    for opt in opts:
+        opt.zero_grad()
+    for loss in losses1:
+        loss.backward()
 
 
 def test_stale_prelaunched_gradients_are_refused(hip):
