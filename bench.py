@@ -10,7 +10,12 @@ Workload: BASELINE.json configs[1] "Atari defaults" at B=50,T=50,H=15, deter=600
 replay already resident in HBM (a ring of pre-generated batches).  With N>1 the GLOBAL batch stays 50 and is sharded on
 the batch axis (7,7,6,6,6,6,6,6 at N=8) with one RCCL all-reduce per optimizer group -> "scaling": "strong".
 
+Other workloads (diagnostic lines, marked as such): --workload atari-native = pydreamer's own `defaults+atari` (B=32, T=48,
+deter 1024: what the reference's README measured), --workload dmc = BASELINE configs[4] at one GPU (defaults+dmc, B=T=50).
+
 The JSON line also carries
+  h2d_included : the same step fed from HOST memory through pydreamer_amd.replay.DeviceRing (pinned uint8 frames, copy
+                 stream) - SURVEY 8(d) asks for it next to `value`, which keeps the replay resident in HBM.
   roofline     : the GEMM kernel family (every dense contraction of the step runs on it), algorithmic 2MNK flops per
                  launch / HIP-event launch durations recorded on the launch stream in a profiled pass of the same steps
                  that directly follows the timed region (events are kept out of the timed region so `value` is unperturbed);
@@ -32,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = 'grad-steps/sec (world-model+AC) at B=50,T=50,H=15, 64×64 obs, 1/2/4/8 GPU'
+ORACLE_VS_REF = 'r03_oracle_vs_reference.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_oracle_vs_reference.json')) else 'r02_oracle_vs_reference.json'
 
 
 def make_ring(conf, b_local, n_batches, device, seed):
@@ -43,8 +49,11 @@ def make_ring(conf, b_local, n_batches, device, seed):
         u8 = torch.randint(0, 256, (T, b_local, conf.image_size, conf.image_size, conf.image_channels), generator=g,
                            device=device, dtype=torch.uint8)
         image = u8.float().div_(255.0).sub_(0.5).permute(0, 1, 4, 2, 3).contiguous()
-        act = torch.randint(0, A, (T, b_local), generator=g, device=device)
-        action = torch.nn.functional.one_hot(act, A).float()
+        if conf.actor_dist == 'onehot':
+            act = torch.randint(0, A, (T, b_local), generator=g, device=device)
+            action = torch.nn.functional.one_hot(act, A).float()
+        else:                                          # continuous control (DMC): U(-1, 1) actions
+            action = torch.rand(T, b_local, A, generator=g, device=device) * 2 - 1
         reward = torch.tanh(torch.randn(T, b_local, generator=g, device=device))
         terminal = (torch.rand(T, b_local, generator=g, device=device) < 0.005).float()
         reset = torch.zeros(T, b_local, dtype=torch.bool, device=device)
@@ -53,6 +62,46 @@ def make_ring(conf, b_local, n_batches, device, seed):
             reset[0, 0] = True
         ring.append(dict(image=image, action=action, reward=reward, terminal=terminal, reset=reset))
     return ring
+
+
+def make_host_ring(conf, b_local, n_batches, seed):
+    """The same synthetic replay as numpy batches in HOST memory, in the replay's native layout (uint8 (T,B,H,W,C) frames):
+    what DeviceRing stages through pinned memory for the H2D-included leg."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    T, A = conf.batch_length, conf.action_dim
+    ring = []
+    for i in range(n_batches):
+        act = rs.randint(0, A, (T, b_local))
+        reset = np.zeros((T, b_local), bool)
+        reset[0] = rs.rand(b_local) < 1.0 / 200
+        ring.append(dict(image=rs.randint(0, 256, (T, b_local, conf.image_size, conf.image_size, conf.image_channels)).astype(np.uint8),
+                         action=np.eye(A, dtype=np.float32)[act], reward=np.tanh(rs.randn(T, b_local)).astype(np.float32),
+                         terminal=(rs.rand(T, b_local) < 0.005).astype(np.float32), reset=reset))
+    return ring
+
+
+class GlobalNoise:
+    """Sampler uniforms drawn in the GLOBAL batch layout with a generator every rank seeds identically, then sliced to the
+    rank's batch columns: a sharded run draws, column for column, what the unsharded run draws."""
+
+    def __init__(self, conf, B, lo, hi, device, seed):
+        self.g = torch.Generator(device=device).manual_seed(seed)
+        self.T, self.B, self.lo, self.hi, self.dev = conf.batch_length, B, lo, hi, device
+        self.S, self.H, self.A = conf.stoch_dim, conf.imag_horizon, conf.action_dim
+        self.onehot = conf.actor_dist == 'onehot'
+        self.gauss = not conf.stoch_discrete
+
+    def draw(self):
+        T, B, S, H, A, lo, hi = self.T, self.B, self.S, self.H, self.A, self.lo, self.hi
+        lat = (lambda *sh: torch.randn(*sh, generator=self.g, device=self.dev)) if self.gauss else \
+              (lambda *sh: torch.rand(*sh, generator=self.g, device=self.dev))
+        n = dict(u_post=lat(T, B, S)[:, lo:hi], u_prior=lat(H, T, B, S)[:, :, lo:hi].reshape(H, -1, S))
+        if self.onehot:
+            n['u_act'] = torch.rand(H, T, B, generator=self.g, device=self.dev)[:, :, lo:hi].reshape(H, -1)
+        else:
+            n['eps_act'] = torch.randn(H, T, B, A, generator=self.g, device=self.dev)[:, :, lo:hi].reshape(H, -1, A)
+        return n
 
 
 def _effective_cores():
@@ -127,10 +176,11 @@ def cpu_baseline(sample_batch=50, threads_cap=32, timeout_s=200):
         # representativeness of the port: oracle / reference wall time per grad step, MEASURED in the build
         # container by oracle/time_vs_reference.py against the reference's own loop and committed under profiles/
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r02_oracle_vs_reference.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', ORACLE_VS_REF)) as f:
                 m = json.load(f)
             res['oracle_over_reference_time'] = m['oracle_over_reference_time']
-            res['oracle_over_reference_source'] = (f"profiles/r02_oracle_vs_reference.json: oracle {m['oracle_s_per_step']:.2f} s vs reference "
+            res['representative'] = bool(abs(m['oracle_over_reference_time'] - 1.0) <= 0.10)      # within +-10 %
+            res['oracle_over_reference_source'] = (f"profiles/{ORACLE_VS_REF}: oracle {m['oracle_s_per_step']:.2f} s vs reference "
                                                    f"{m['reference_s_per_step']:.2f} s per step, {m['batch_columns']} columns, {m['threads']} threads, "
                                                    f"build container")
         except (OSError, KeyError, ValueError):
@@ -175,6 +225,11 @@ def main():
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
+    ap.add_argument('--workload', choices=('atari-literal', 'atari-native', 'dmc'), default='atari-literal',
+                    help="atari-literal = BASELINE configs[1] (the metric); atari-native = pydreamer's own defaults+atari (B=32, T=48, deter 1024; "
+                         "README.md:90-97); dmc = configs[4] at one GPU (defaults+dmc, actor_grad=reinforce, action_dim 6, B=T=50); the last two are diagnostic lines")
+    ap.add_argument('--no-h2d-leg', action='store_true', help='skip the H2D-included leg (DeviceRing from host memory)')
+    ap.add_argument('--h2d-steps', type=int, default=20)
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
 
@@ -201,19 +256,27 @@ def main():
     from pydreamer_amd.models import Dreamer
     hip.call('dm_device_check')
 
-    gconf = config.atari_literal()
+    def make_conf(**kw):
+        if args.workload == 'atari-native':
+            return config.load_config('defaults', 'atari', action_dim=18, **kw)
+        if args.workload == 'dmc':
+            return config.load_config('defaults', 'dmc', **{**dict(action_dim=6, actor_grad='reinforce', batch_size=50, batch_length=50), **kw})
+        return config.atari_literal(**kw)
+    gconf = make_conf()
     B = gconf.batch_size
     lo, hi = DP.shard_bounds(B, world, rank)
     if args.emulate_world > 1 and world == 1:
         lo, hi = DP.shard_bounds(B, args.emulate_world, 0)
-    conf = config.atari_literal(batch_size=hi - lo, amp=(args.dtype == 'bf16'))
+    conf = make_conf(batch_size=hi - lo, amp=(args.dtype == 'bf16'))
+    # algorithmic TFLOP per grad step (2 MAC, dense as the reference executes, backward = 2x forward)
+    alg_tflop = {'atari-literal': 2.76, 'atari-native': 2.00, 'dmc': 4.83}[args.workload]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
     model.overlap_backward = not args.no_overlap
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-    DP.attach(opts, hi - lo, B)
+    DP.attach(opts, hi - lo, B, model=model)           # the B_r/B weight rides in the backward kernels' scale arguments
     ring = make_ring(conf, hi - lo, args.ring, dev, 1234 + rank)
-    torch.manual_seed(777 + rank)                      # sampler uniforms
+    noise = GlobalNoise(conf, B, lo, hi, dev, 777)     # global-layout sampler uniforms, the rank's columns sliced out
     state = {'s': model.init_state(hi - lo)}
 
     graphed = None
@@ -227,7 +290,7 @@ def main():
             losses, new_state, metrics, tensors, _ = graphed(obs, state['s'])
             state['s'] = new_state                      # keep_state (train.py:177-178)
         else:
-            losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'])
+            losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'], noise=noise.draw())
             state['s'] = new_state
             for opt in opts:
                 opt.zero_grad()
@@ -254,11 +317,77 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)
+        rank_ms = [1e3 * float(x.item()) / args.steps for x in per_rank]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_model = float(metrics['loss_model'])
+    dist_info = None
+    if world > 1:
+        # per-rank numbers (before the MAX) and the stand-alone cost of the step's all-reduces on this fabric
+        mine = torch.tensor([1e3 * t_enqueued / args.steps], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        host_ms = [float(x.item()) for x in allr]
+        ar_ms = {}
+        for name, opt in zip(('wm', 'probe', 'actor', 'critic'), opts):
+            buf = torch.zeros_like(opt.flat_grad)
+            for _ in range(2):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms[name] = dict(bytes=4 * buf.numel(), ms=e0.elapsed_time(e1) / 5)
+        try:
+            rccl = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), rccl_version=rccl,
+                         ms_per_step_per_rank=rank_ms, host_enqueue_ms_per_rank=host_ms, allreduce_standalone=ar_ms,
+                         note='all-reduce of each optimizer group\'s flat fp32 gradient buffer, timed alone (in the step the world-model '
+                              'group\'s is overlapped with the actor / critic backward)')
+
+    # H2D-included leg: the same step fed from host memory through the DeviceRing (pinned uint8 frames, own copy stream)
+    h2d = None
+    if world == 1 and not args.no_h2d_leg and args.emulate_world <= 1 and not args.graph:
+        from pydreamer_amd.replay import DeviceRing
+        import itertools
+        host_ring = make_host_ring(conf, hi - lo, 4, 4321)
+        dring = DeviceRing(itertools.cycle(host_ring), dev, depth=4)
+        hstate = model.init_state(hi - lo)
+
+        def hstep():
+            nonlocal hstate
+            obs = dring.next()
+            losses, hstate, *_ = model.training_step(obs, hstate, noise=noise.draw())
+            for opt in opts:
+                opt.zero_grad()
+            for loss in losses:
+                loss.backward()
+            model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+            for opt in opts:
+                opt.step()
+        for _ in range(3):
+            hstep()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(args.h2d_steps):
+            hstep()
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th
+        dring.close()
+        nbytes = sum(v.nbytes for v in host_ring[0].values())
+        h2d = dict(value=args.h2d_steps / th, unit='grad-steps/s', ms_per_step=1e3 * th / args.h2d_steps, steps=args.h2d_steps,
+                   host_bytes_per_step=nbytes, note='uint8 (T,B,64,64,3) frames + actions / rewards / flags from pinned host memory through '
+                   'pydreamer_amd.replay.DeviceRing (depth 4, own copy stream); x/255-0.5 and HWC->CHW happen inside the first conv\'s loader')
 
     # profiled pass: HIP events around every GEMM launch on the launch stream (same steps, right after the timed region)
     roof = None
@@ -333,7 +462,7 @@ def main():
                     kinds=kinds, note='HIP events on the launch stream around every GEMM launch, eager (un-graphed) pass of the same steps right after the timed region')
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'atari-literal':
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -341,18 +470,24 @@ def main():
         line = dict(metric=METRIC, value=args.steps / elapsed, unit='grad-steps/s', n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None,
                     dtype='f32' if args.dtype == 'f32' else 'bf16 (MFMA operands; fp32 accumulate, fp32 storage and non-GEMM math)', data='synthetic',
-                    config=dict(workload='atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
-                                         'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ' + ('fp32' if args.dtype == 'f32' else 'amp/bf16') + '; '
+                    config=dict(workload={'atari-literal': 'atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
+                                         'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ',
+                                          'atari-native': 'atari-native (pydreamer README.md:90-97): defaults+atari as shipped, batch_size 32, batch_length 48, imag_horizon 15, '
+                                         'deter_dim 1024, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ',
+                                          'dmc': 'dmc (BASELINE configs[4] at one GPU): defaults+dmc, batch_size 50, batch_length 50, imag_horizon 15, deter_dim 2048, '
+                                         'action_dim 6, tanh_normal actor, actor_grad reinforce, '}[args.workload] + ('fp32' if args.dtype == 'f32' else 'amp/bf16') + '; '
                                          'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('; fwd+bwd section replayed as one hipGraph' if args.graph else ''),
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
-                                algorithmic_tflop_per_step=2.76),
+                                algorithmic_tflop_per_step=alg_tflop),
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     fp32_products=('split-bf16 x3 pieces / 6 MFMA products, fp32 accumulate (DM_FP32_SPLIT=1)' if hip.lib().dm_fp32_mode() else 'fp32 MFMA'),
                     chain_graphs=hip.chain_graph_stats(),
-                    step_tflops=2.76 / (ms * 1e-3), step_frac_of_fp32_peak=2.76 / (ms * 1e-3) / 157.3,
+                    step_tflops=alg_tflop / (ms * 1e-3), step_frac_of_fp32_peak=alg_tflop / (ms * 1e-3) / 157.3,
+                    h2d_included=h2d, distributed=dist_info,
+                    **({} if args.workload == 'atari-literal' else {'INVALID_diagnostic_workload': args.workload}),
                     **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))

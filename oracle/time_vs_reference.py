@@ -1,6 +1,6 @@
 """Wall-time ratio oracle / reference for one gradient step (build container only: imports /root/reference).
 
-    python oracle/time_vs_reference.py [batch_columns=10] [steps=3]  ->  profiles/r02_oracle_vs_reference.json
+    python oracle/time_vs_reference.py [batch_columns=10] [steps=3] [out.json]  ->  profiles/r03_oracle_vs_reference.json
 
 SURVEY 8(d): the CPU baseline that bench.py times on the GPU box is the oracle (kind "port"; the reference's Python never
 travels).  Its representativeness is established HERE by running the reference's own loop (train.py:165-198: forward under
@@ -69,7 +69,7 @@ def main():
                threads=threads, host='build container (no GPU)', warmup_steps_excluded=1,
                note='reference = /root/reference pydreamer.models.Dreamer driven by the train.py:165-198 section; same batch, '
                     'same weights, same torch build; within +-10 % means the oracle is a representative CPU baseline (SURVEY 8(d))')
-    path = os.path.join(ROOT, 'profiles', 'r02_oracle_vs_reference.json')
+    path = os.path.join(ROOT, 'profiles', sys.argv[3] if len(sys.argv) > 3 else 'r03_oracle_vs_reference.json')
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))

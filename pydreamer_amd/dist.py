@@ -24,31 +24,66 @@ def shard_obs(obs, world, rank):
     return {k: v[:, lo:hi].contiguous() for k, v in obs.items()}, (lo, hi)
 
 
-def attach(optimizers, local_batch, global_batch, group=None):
-    """Enable gradient all-reduce inside FusedAdamW.clip_grad_norm for every optimizer group."""
+def attach(optimizers, local_batch, global_batch, group=None, model=None):
+    """Enable gradient all-reduce inside FusedAdamW.clip_grad_norm for every optimizer group.
+    model (a pydreamer_amd Dreamer whose init_optimizers() produced `optimizers`): the B_r/B weight is FOLDED into the scale
+    argument every backward entry point already takes (models.WorldModel / ActorCritic.grad_weight), so the rank's gradient
+    buffers come out of the backward kernels already weighted and no extra pass over the 92 MB buffer runs per step; without
+    it (or for a group fed by autograd, the 1-element probe group) the buffer is multiplied before the collective."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     w = float(local_batch) / float(global_batch)
+    folded = set()
+    if model is not None and getattr(model, '_opt', None) is not None:
+        model.wm.grad_weight = w
+        model.ac.grad_weight = w
+        folded = {id(model._opt[k]) for k in ('wm', 'actor', 'critic')}
     for opt in optimizers:
         opt.dp = (group, w)
+        opt.dp_folded = id(opt) in folded
+
+
+_inflight = []      # futures of launcher-thread jobs that may issue collectives (models._Overlap.submit)
+
+
+def track(fut):
+    if dist.is_available() and dist.is_initialized():
+        _inflight.append(fut)
+
+
+def drain():
+    """Collectives must be issued in the same order on every rank.  The pre-launched backward passes issue theirs from the
+    launcher thread (allreduce_scratch_async); before the MAIN thread issues one (the accumulation path of
+    FusedAdamW.adopt_scratch, clip_grad_norm for a group without an early reduce) every launcher job of the step has to have
+    issued its own - otherwise two ranks can interleave them differently and RCCL pairs mismatched buffers."""
+    while _inflight:
+        fut = _inflight.pop(0)
+        try:
+            fut.result()
+        except Exception:      # surfaced by the backward() that owns the future
+            pass
+
+
+def _weight(opt, buf):
+    group, w = opt.dp
+    if w != 1.0 and not getattr(opt, 'dp_folded', False):
+        buf.mul_(w)
+    return group
 
 
 def allreduce_scratch_async(opt):
     """Called on the side stream right after a pre-launched backward pass has been enqueued there (SURVEY.md 8(e):
-    "issued as soon as each backward finishes (wm first, overlapped with actor/critic backward)"): weights the rank's
-    gradient by B_r/B and starts the SUM all-reduce of the group's buffer; the handle is waited for in loss.backward()
-    (FusedAdamW.adopt_scratch), so grad_clip() finds the global-batch gradient already in place."""
+    "issued as soon as each backward finishes (wm first, overlapped with actor/critic backward)"): starts the SUM all-reduce
+    of the group's (B_r/B-weighted) buffer; the handle is waited for in loss.backward() (FusedAdamW.adopt_scratch), so
+    grad_clip() finds the global-batch gradient already in place."""
     if opt.dp is None:
         return
-    group, w = opt.dp
-    if w != 1.0:
-        opt.scratch.mul_(w)
+    group = _weight(opt, opt.scratch)
     opt.early_reduce = dist.all_reduce(opt.scratch, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def allreduce_grads(opt):
     """grad <- sum_r (B_r/B) grad_r, in place on the flat buffer (one collective per optimizer group)."""
-    group, w = opt.dp
-    if w != 1.0:
-        opt.flat_grad.mul_(w)
+    drain()
+    group = _weight(opt, opt.flat_grad)
     dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=group)

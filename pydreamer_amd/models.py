@@ -486,7 +486,10 @@ class _Overlap:
                 stream.wait_event(wait_event)
                 with torch.cuda.stream(stream):
                     return fn()
-        return self.pool.submit(job)
+        fut = self.pool.submit(job)
+        from . import dist as D
+        D.track(fut)              # a main-thread collective must not overtake the collectives this job may issue
+        return fut
 
 
 def pack_metrics(*dicts):
@@ -922,9 +925,11 @@ class WorldModel(_Params):
         loss_terminal, dtl, terminal_rec = (torch.empty(N, device=dev) for _ in range(3))
         # -Normal(mu, std).log_prob(y) * std^2 = 0.5 (mu-y)^2 + std^2 (log std + log sqrt(2 pi))   (decoders.py:296-304)
         loss_const = REWARD_STD ** 2 * (math.log(REWARD_STD) + math.log(math.sqrt(2 * math.pi)))
-        H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), dec.reward_weight / NE, loss_const, H.fptr(loss_reward),
+        # gw: the data-parallel shard weight B_r/B (dist.attach), folded into every gradient scale; loss values are unaffected
+        gw = float(getattr(self, 'grad_weight', 1.0))
+        H.call('dm_head_loss', 0, N, H.fptr(mu), H.fptr(reward_t), gw * dec.reward_weight / NE, loss_const, H.fptr(loss_reward),
                H.fptr(dmu), H.fptr(reward_rec), H.stream())
-        H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), dec.terminal_weight / NE, 0.0, H.fptr(loss_terminal),
+        H.call('dm_head_loss', 1, N, H.fptr(tl), H.fptr(terminal_t), gw * dec.terminal_weight / NE, 0.0, H.fptr(loss_terminal),
                H.fptr(dtl), H.fptr(terminal_rec), H.stream())
 
         # KL + entropies (dreamer.py:326-343,369-379)
@@ -943,10 +948,11 @@ class WorldModel(_Params):
             # the "dream", the batch's own actions / rewards / terminals; only loss_critic is kept.  Its actor forward and
             # policy loss are computed by the reference and then thrown away, so they are simply not run here.
             ac = self.ac_aux
-            if torch.is_grad_enabled():
-                if ac.train_steps % ac.target_interval == 0:
-                    ac.update_critic_target()
-                ac.train_steps += 1
+            # a2c.py:76-79 via dreamer.py:349: ac_aux.training_step runs with log_only=False also under no_grad evaluation,
+            # so the target refresh and the counter advance on EVERY call (the reference's behaviour, mirrored)
+            if ac.train_steps % ac.target_interval == 0:
+                ac.update_critic_target()
+            ac.train_steps += 1
             rows = (T - 1) * B
             value_t, _ = ac.critic_target.fwd(feat, F_, N, ws, save_acts=False, sparse_cols=0 if gauss else Z)
             value, aux_acts = ac.critic.fwd(feat, F_, N, ws, sparse_cols=0 if gauss else Z)
@@ -955,7 +961,7 @@ class WorldModel(_Params):
                    H.fptr(adv), H.fptr(agae), H.fptr(vtgt), H.fptr(wgt), H.stream())
             lc = torch.empty(rows, device=dev)
             dvalue = torch.zeros(N, device=dev)                      # value[-1] gets no gradient
-            H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), self.aux_critic_weight / rows, H.fptr(lc),
+            H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), gw * self.aux_critic_weight / rows, H.fptr(lc),
                    H.fptr(dvalue), H.stream())
             _multi_sum([(lc, 1.0 / rows), (value.view(T, B)[:-1], 1.0 / rows)], dev, out=mbuf[24:26])
             aux = dict(acts=aux_acts, dvalue=dvalue, value=value, lc=lc, rows=rows)
@@ -1037,6 +1043,7 @@ class WorldModel(_Params):
         gof = {id(p): v for p, v in zip(plist, views)}
         dec = self.decoder
 
+        gw = float(getattr(self, 'grad_weight', 1.0))          # data-parallel shard weight B_r/B (dist.attach)
         dfeat = ar.get('dfeat', (N, F_), device=dev).zero_()
         # dense heads (decoders.py:73-83)
         if iw is not None and not pk.get('iw_applied'):
@@ -1055,19 +1062,19 @@ class WorldModel(_Params):
         dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
         dec_g = H.conv_struct([gof[id(m.weight)] for m in dl], [gof[id(m.bias)] for m in dl], cls=H.dm_conv_grads)
         H.call('dm_conv_decoder_mse_bwd_rows', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
-               H.fptr(pk['dec_acts']), dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws),
+               H.fptr(pk['dec_acts']), gw * dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws),
                ws.numel(), H.stream())
         # KL (dreamer.py:334-343)
         dpost = ar.get('dpost', (N, Z), device=dev)
         dprior = ar.get('dprior', (N, Z), device=dev)
         if iw is not None:         # sampled KL of the IWAE bound
             H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
-                   H.ptr(pk['idx']), self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
+                   H.ptr(pk['idx']), gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
         else:
             if self.kl_balance is None:
-                sp = sq = self.kl_weight / N
+                sp = sq = gw * self.kl_weight / N
             else:
-                sp, sq = self.kl_weight * (1 - self.kl_balance) / N, self.kl_weight * self.kl_balance / N
+                sp, sq = gw * self.kl_weight * (1 - self.kl_balance) / N, gw * self.kl_weight * self.kl_balance / N
             H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
                    H.fptr(dpost), H.fptr(dprior), H.stream())
         # RSSM BPTT
@@ -1268,16 +1275,17 @@ class ActorCritic(_Params):
         rows = Hh * M
         lc = torch.empty(rows, device=dev)
         dvalue = torch.zeros(J * M, device=dev)                      # value[-1] gets no gradient
-        H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), 1.0 / rows, H.fptr(lc), H.fptr(dvalue),
+        gw = float(getattr(self, 'grad_weight', 1.0))          # data-parallel shard weight B_r/B (dist.attach), gradients only
+        H.call('dm_critic_loss', rows, H.fptr(value), H.fptr(vtgt), H.fptr(wgt), gw / rows, H.fptr(lc), H.fptr(dvalue),
                H.stream())
         la, ent = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
         dlogits = torch.empty(rows, self.actor.out_dim, device=dev)
         if self.dist_kind == 0:
             H.call('dm_actor_loss', rows, A, H.fptr(logits), H.ptr(act_idx), H.fptr(agae), H.fptr(wgt), self.entropy_weight,
-                   1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits), H.stream())
+                   gw / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits), H.stream())
         else:
             H.call('dm_actor_loss_continuous', self.dist_kind, rows, A, H.fptr(logits), H.fptr(actions.contiguous()),
-                   H.fptr(agae), H.fptr(wgt), self.entropy_weight, 1.0 / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits),
+                   H.fptr(agae), H.fptr(wgt), self.entropy_weight, gw / rows, H.fptr(la), H.fptr(ent), H.fptr(dlogits),
                    H.stream())
         value2d = value.view(J, M)
         reward1 = rewards.view(J, M)[1:]
@@ -1365,13 +1373,13 @@ class Dreamer(nn.Module):
                     grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_critic')))
 
     def packed_metrics(self):
-        """(names, buffer): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
-        has run) as ONE 1-D device tensor - `dict(zip(names, buffer[idx].tolist()))` replaces the trainer's ~20 `.item()`
-        syncs per logged step (train.py:204-214) with a single copy.  No kernel runs here: the kernels of the step wrote
-        their results straight into this buffer."""
+        """(names, buffer, idx): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
+        has run) sits in ONE 1-D device tensor `buffer`; `idx` (a python list) are the slots of `names` in it, so
+        `vals = buffer.tolist(); dict(zip(names, (vals[i] for i in idx)))` replaces the trainer's ~20 `.item()` syncs per
+        logged step (train.py:204-214) with a single device-to-host copy.  No kernel runs here: the kernels of the step
+        wrote their results straight into this buffer."""
         names = list(METRIC_SLOTS)
-        idx = torch.tensor([METRIC_SLOTS[n] for n in names])
-        return names, self.metric_buffer, idx
+        return names, self.metric_buffer, [METRIC_SLOTS[n] for n in names]
 
     def init_state(self, batch_size):
         return self.wm.init_state(batch_size)

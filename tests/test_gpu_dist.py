@@ -44,7 +44,7 @@ def _one_step(model, conf, opts, obs, noise, steps=2):
     return out
 
 
-def _worker(rank, world, port, overlap, out):
+def _worker(rank, world, port, overlap, fold, out):
     import torch.distributed as dist
     from oracle import dreamer_oracle as O
     from pydreamer_amd import config
@@ -71,8 +71,8 @@ def _worker(rank, world, port, overlap, out):
         model = model.to(dev)
         model.overlap_backward = overlap
         opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-        DP.attach(opts, hi - lo, B)
-        assert opts[0].dp is not None
+        DP.attach(opts, hi - lo, B, model=model if fold else None)    # fold: B_r/B inside the backward kernels' scales
+        assert opts[0].dp is not None and opts[0].dp_folded == fold and not opts[1].dp_folded
         shard, _ = DP.shard_obs(obs, world, rank)
         gm, idx = _one_step(model, conf, opts, shard, _slice_noise(noise, T, B, S, Hh, lo, hi))
         torch.cuda.synchronize()
@@ -82,8 +82,8 @@ def _worker(rank, world, port, overlap, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap', [True, False])
-def test_two_rank_step_equals_one_rank(hip, overlap):
+@pytest.mark.parametrize('overlap,fold', [(True, True), (False, True), (True, False)])
+def test_two_rank_step_equals_one_rank(hip, overlap, fold):
     import torch.multiprocessing as mp
     from oracle import dreamer_oracle as O
     from pydreamer_amd import config
@@ -91,7 +91,7 @@ def test_two_rank_step_equals_one_rank(hip, overlap):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), overlap, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), overlap, fold, out), nprocs=world, join=True)
     res = dict(out)
     assert set(res) == {0, 1}
     # the single-process run of the whole batch
@@ -141,4 +141,7 @@ def test_bench_multi_rank_code_path_smoke(hip):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['cpu_baseline'] is None
     assert d['value'] > 0 and abs(d['ms_per_step'] * d['value'] - 1e3) < 1e-6 * 1e3
     assert '[25, 25]' in d['config']['parallelism']
+    dd = d['distributed']
+    assert dd['world_size'] == 2 and len(dd['ms_per_step_per_rank']) == 2 and set(dd['allreduce_standalone']) == {'wm', 'probe', 'actor', 'critic'}
+    assert dd['allreduce_standalone']['wm']['bytes'] > 80e6 and dd['allreduce_standalone']['wm']['ms'] > 0
     assert np.isfinite(d['loss_model_last']) and d['roofline'] is not None and d['roofline']['frac'] > 0

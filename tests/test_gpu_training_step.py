@@ -799,8 +799,9 @@ def test_training_step_matches_reference_at_atari_literal(hip):
     (tests/golden/atari_literal.npz; inputs regenerated from the same seeds and fingerprinted).
     117 500 categorical draws depend on fp32 logits summed in a different order than torch's CPU kernels, so a draw whose
     uniform lies within ~1 ulp of a CDF edge may legitimately differ and then changes that row's later states; the bar is
-    therefore: every index of the first 10 time steps identical, >= 99.9 % of all posterior indices identical, loss_model
-    within 1e-3 absolute, the other losses within 1e-3 relative.  Measured on MI355X (round 1): all 80 000 posterior
+    therefore: every index of the first 25 time steps identical, >= 99.99 % of all posterior indices identical, loss_model
+    within 1e-3 absolute, the other losses within 1e-3 relative, per-parameter gradient norms within 3e-3 and gradient
+    projections within 5e-3 of the parameter's gradient norm (bars ~10x the measured values).  Measured on MI355X (round 1): all 80 000 posterior
     indices identical, loss_model 523.5302124 = reference to the last printed digit, loss_actor 2e-4 / loss_critic 3e-5
     relative, worst per-parameter gradient-norm error 3.1e-4."""
     g = np.load(os.path.join(GOLD, 'atari_literal.npz'))
@@ -822,11 +823,12 @@ def test_training_step_matches_reference_at_atari_literal(hip):
     same = (got == ref)
     print('atari-literal posterior indices equal:', same.mean(), 'first mismatch t:',
           int(np.argmax(~same.all(axis=(1, 2)))) if not same.all() else None)
-    assert same[:10].all()
-    assert same.mean() >= 0.999
+    # bars ~10x the measured values: measured 100 % / 100 %
+    assert same[:25].all()
+    assert same.mean() >= 0.9999
     act_same = model.last_extras['act_idx'].cpu().numpy().astype(np.uint8) == g['s0_idx_act']
     print('imagination actor indices equal:', act_same.mean())
-    assert act_same.mean() >= 0.995      # a draw within an ulp of a CDF edge may flip and that row then diverges
+    assert act_same.mean() >= 0.999      # a draw within an ulp of a CDF edge may flip and that row then diverges
     # the north-star bar: world-model loss within 1e-3 (absolute) of the reference on the fixed full-size batch
     assert abs(float(losses[0]) - g['s0_losses'][0]) < 1e-3
     for i, l in enumerate(losses):
@@ -840,22 +842,22 @@ def test_training_step_matches_reference_at_atari_literal(hip):
     named = dict(model.named_parameters())
     worst = max(abs(float(named[n].grad.double().norm()) - r) / max(r, 1e-7) for n, r in zip(names, g['s0_grad_norms']))
     print('worst per-parameter grad-norm rel err', worst)
-    assert worst < 2e-2
+    assert worst < 3e-3          # measured 3.1e-4 (Atari-literal) / 9.3e-4 (DMC-native)
     if 's0_grad_proj' in g.files:      # gradient DIRECTIONS: projections onto two closed-form directions per parameter
         wp = 0.0
         for i, (n, r, pr) in enumerate(zip(names, g['s0_grad_norms'], g['s0_grad_proj'])):
             got = O.grad_probe(named[n].grad, i)
             wp = max(wp, max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) / max(r, 1e-7))
         print('worst per-parameter gradient-projection error / norm', wp)
-        assert wp < 1e-2
+        assert wp < 5e-3         # measured 2.7e-3 / 1.8e-3
 
 
 def test_training_step_matches_reference_at_dmc_native(hip):
     """BASELINE.json configs[4] at its native width - defaults+dmc (deter_dim 2048, hidden 1000, tanh_normal actor on 6
     continuous action dims, actor_grad=reinforce) at B=50, T=50, H=15, fp32 - against the slim golden written by the real
-    reference (tests/golden/dmc_native.npz).  Bars as for Atari-literal: first 10 time steps of posterior indices
-    identical, >= 99.9 % overall, loss_model within 1e-3 absolute, other losses / metrics within 1e-3 .. 5e-3 relative,
-    per-parameter gradient norms within 2e-2."""
+    reference (tests/golden/dmc_native.npz).  Bars as for Atari-literal: first 25 time steps of posterior indices
+    identical, >= 99.99 % overall, loss_model within 1e-3 absolute, other losses / metrics within 1e-3 .. 5e-3 relative,
+    per-parameter gradient norms within 3e-3, gradient projections within 5e-3."""
     g = np.load(os.path.join(GOLD, 'dmc_native.npz'))
     oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
     assert oconf.deter_dim == 2048 and oconf.actor_dist == 'tanh_normal' and oconf.action_dim == 6
@@ -878,7 +880,7 @@ def test_training_step_matches_reference_at_dmc_native(hip):
     gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
     same = model.last_extras['post_idx'].cpu().numpy().astype(np.uint8) == g['s0_idx_post']
     print('dmc-native posterior indices equal:', same.mean())
-    assert same[:10].all() and same.mean() >= 0.999
+    assert same[:25].all() and same.mean() >= 0.9999
     assert abs(float(losses[0]) - g['s0_losses'][0]) < 1e-3
     for i, l in enumerate(losses):
         r = g['s0_losses'][i]
@@ -891,14 +893,14 @@ def test_training_step_matches_reference_at_dmc_native(hip):
     named = dict(model.named_parameters())
     worst = max(abs(float(named[n].grad.double().norm()) - r) / max(r, 1e-7) for n, r in zip(names, g['s0_grad_norms']))
     print('worst per-parameter grad-norm rel err', worst)
-    assert worst < 2e-2
+    assert worst < 3e-3          # measured 3.1e-4 (Atari-literal) / 9.3e-4 (DMC-native)
     if 's0_grad_proj' in g.files:      # gradient DIRECTIONS: projections onto two closed-form directions per parameter
         wp = 0.0
         for i, (n, r, pr) in enumerate(zip(names, g['s0_grad_norms'], g['s0_grad_proj'])):
             got = O.grad_probe(named[n].grad, i)
             wp = max(wp, max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) / max(r, 1e-7))
         print('worst per-parameter gradient-projection error / norm', wp)
-        assert wp < 1e-2
+        assert wp < 5e-3         # measured 2.7e-3 / 1.8e-3
 
 
 def test_dmc_native_bf16_step_tracks_the_fp32_reference(hip):
@@ -1077,6 +1079,107 @@ def test_open_loop_matches_reference_golden(hip, name):
         np.testing.assert_allclose(dt[k].cpu().numpy(), g['dream_' + k], rtol=1e-4, atol=2e-5, err_msg=k)
 
 
+@pytest.mark.parametrize('amp', [False, True])
+def test_literal_trainer_section(hip, amp):
+    """BASELINE north-star: "train.py drives it unchanged".  The statement sequence of train.py:165-198, verbatim in structure
+    - autocast(enabled=conf.amp) around training_step, GradScaler(enabled=conf.amp), zero_grad x4, scaler.scale(loss).backward()
+    x4, scaler.unscale_(opt) x4, model.grad_clip, scaler.step(opt) x4, scaler.update() - against the plain sequence
+    (backward / clip / step) on an identical model, for amp False and True.  Two steps with carried state: every parameter
+    identical bit for bit (a disabled scaler is a pass-through; an enabled one multiplies the four losses by 2^16 and the
+    gradients by 2^-16, both exact in fp32).  Then, amp only, an overflow step: an inf planted in one world-model gradient
+    makes scaler.step skip THAT optimizer (its parameters and moments stay put), the others step, and update() halves the scale."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from torch.cuda.amp import GradScaler, autocast
+    oconf = O.tiny_conf()
+    conf = _hip_conf(oconf)
+    conf.amp = amp
+    params = O.make_params(oconf, seed=6)
+    from pydreamer_amd.models import Dreamer
+
+    def build():
+        m = Dreamer(conf)
+        m.load_state_dict(params, strict=True)
+        m = m.to(DEV)
+        return m, m.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+    batches = [_to_dev(O.preprocess(O.synthetic_batch(oconf, seed=70 + i, first=(i == 0)), oconf)) for i in range(3)]
+    noises = [{k: v.to(DEV) for k, v in O.make_noise(oconf, seed=80 + i).items()} for i in range(3)]
+
+    model, optimizers = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        scaler = GradScaler(enabled=conf.amp)
+    states, wid = {}, 0
+    for i in range(2):                                   # ---- train.py:165-198
+        obs = batches[i]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ctx = autocast(enabled=conf.amp)
+        with ctx:
+            state = states.get(wid)
+            if state is None:
+                state = model.init_state(conf.batch_size * conf.iwae_samples)
+            losses, new_state, loss_metrics, tensors, dream_tensors = \
+                model.training_step(obs, state, do_image_pred=(i == 1), do_dream_tensors=(i == 1), noise=noises[i])
+            if conf.keep_state:
+                states[wid] = new_state
+        for opt in optimizers:
+            opt.zero_grad()
+        for loss in losses:
+            scaler.scale(loss).backward()
+        for opt in optimizers:
+            scaler.unscale_(opt)
+        grad_metrics = model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+        for opt in optimizers:
+            scaler.step(opt)
+        scaler.update()
+        assert all(np.isfinite(v.item()) for v in grad_metrics.values())
+        assert i == 0 or ('image_pred' in tensors and 'image_pred' in dream_tensors)
+
+    plain, popts = build()
+    st = plain.init_state(conf.batch_size)
+    for i in range(2):
+        losses_p, st, _, _, _ = plain.training_step(batches[i], st, do_image_pred=(i == 1), do_dream_tensors=(i == 1), noise=noises[i])
+        for opt in popts:
+            opt.zero_grad()
+        for loss in losses_p:
+            loss.backward()
+        gm_p = plain.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+        for opt in popts:
+            opt.step()
+    for (k, a), (_, b) in zip(model.state_dict().items(), plain.state_dict().items()):
+        assert torch.equal(a, b), k
+    for k in gm_p:
+        assert torch.equal(grad_metrics[k], gm_p[k]), k
+    for a, b in zip(losses, losses_p):
+        assert torch.equal(a.detach(), b.detach())
+
+    if not amp:
+        assert scaler.get_scale() == 1.0
+        return
+    # ---- overflow step: GradScaler must skip the optimizer whose gradients hold an inf, and only that one
+    scale0 = scaler.get_scale()
+    before = [o.flat_param.clone() for o in optimizers]
+    moments = optimizers[0].exp_avg.clone()
+    with autocast(enabled=True):
+        losses, new_state, *_ = model.training_step(batches[2], states[wid], noise=noises[2])
+    for opt in optimizers:
+        opt.zero_grad()
+    for loss in losses:
+        scaler.scale(loss).backward()
+    model.wm.core.cell.z_mlp.weight.grad.view(-1)[3] = float('inf')
+    for opt in optimizers:
+        scaler.unscale_(opt)
+    model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
+    for opt in optimizers:
+        scaler.step(opt)
+    scaler.update()
+    assert torch.equal(optimizers[0].flat_param, before[0]) and torch.equal(optimizers[0].exp_avg, moments)      # wm: skipped
+    assert not torch.equal(optimizers[2].flat_param, before[2]) and not torch.equal(optimizers[3].flat_param, before[3])
+    assert scaler.get_scale() == scale0 * 0.5
+
+
 @pytest.mark.parametrize('cfg', ['tiny', 'shard'])
 def test_chain_graphs_replay_bit_identical(hip, cfg):
     """csrc/chain_graph.hip: dm_rssm_sequence_fwd / _bwd and dm_dream_rollout are stream-captured once per argument set and
@@ -1243,7 +1346,8 @@ def test_metric_buffer_and_lazy_tensors(hip):
         loss.backward()
     gm = model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
     names, buf, idx = model.packed_metrics()
-    vals = dict(zip(names, buf[idx.to(buf.device)].tolist()))          # ONE device->host copy for everything
+    host = buf.tolist()                                                # ONE device->host copy for everything
+    vals = dict(zip(names, (host[i] for i in idx)))
     ora = O.OracleDreamer(oconf, params)
     ora.init_optimizers()
     lo, _, mo, to, _ = ora.training_step(obs, ora.init_state(oconf.batch_size), noise)
