@@ -191,6 +191,18 @@ int dm_col2im_s2_launch(int n, int hb, int wb, int c, int k, const float* col, c
 int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                        hipStream_t st);
 
+// direct small-channel convolutions (conv_direct.hip): encoder layer 1 (3 -> d, k4 s2) and decoder layer 4 (d -> 3, k6 s2)
+bool dm_enc_l1_direct_ok(int ch, int d, int img);
+int dm_enc_l1_fwd_launch(int frames, int d, int u8, const void* image, const float* w, const float* bias, float* wt, float* y,
+                         hipStream_t st);
+size_t dm_enc_l1_wgrad_part_floats(int frames, int d);
+int dm_enc_l1_wgrad_launch(int frames, int d, int u8, const void* image, const float* G, float* part, float* dW, void* ws,
+                           size_t ws_bytes, hipStream_t st);
+bool dm_dec_l4_direct_ok(int ch, int d, int hs, int k);
+size_t dm_dec_l4_w4_floats(int d);
+int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, const float* bias, float* w4, float* out,
+                         hipStream_t st);
+
 // fused MLP (mlp.hip)
 // chain_wpack (optional): fragment-major weights already packed by the caller (dm_mlp_chain_pack_launch) for the whole-MLP
 // kernel; null: packed here, per call, into the workspace

@@ -367,9 +367,11 @@ struct EncGeom {
   int N, ch, d;
   int hb[4], hs[4], cin[4], cout[4];
   size_t rows[4], kdim[4];
+  bool direct0;      // layer 1 runs as a direct convolution (conv_direct.hip): no explicit patch matrix
   explicit EncGeom(const dm_shape* s) {
     N = s->T * s->B * (s->I > 0 ? s->I : 1);
     ch = s->img_ch; d = s->cnn_depth;
+    direct0 = dm_enc_l1_direct_ok(ch, d, s->img);
     int h = s->img;
     const int ci[4] = {ch, d, 2 * d, 4 * d};
     const int co[4] = {d, 2 * d, 4 * d, 8 * d};
@@ -423,7 +425,7 @@ static size_t enc_carve(const EncGeom& g, float* base, size_t cap_floats, EncAct
   DmArena ar(base, cap_floats * sizeof(float));
   for (int l = 0; l < 4; ++l) {
     float* w = ar.take(l == 0 ? 0 : (size_t)g.cout[l] * g.kdim[l]);
-    float* xc = ar.take(l == 0 ? g.rows[l] * g.kdim[l] : 0);
+    float* xc = ar.take(l == 0 && !g.direct0 ? g.rows[l] * g.kdim[l] : 0);
     float* ro = ar.take(l == 0 ? 0 : g.rows[l]);
     float* ko = ar.take(l == 0 ? 0 : g.kdim[l]);
     float* yy = ar.take(g.rows[l] * g.cout[l]);
@@ -478,6 +480,17 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
   if (n == 0) return DM_OK;
   for (int l = 0; l < 4; ++l) {
     const size_t r0 = (size_t)n0 * g.hs[l] * g.hs[l];          // first patch row of the range in layer l
+    if (l == 0 && g.direct0) {      // 3 -> d channels: one direct kernel on the frame, no patch matrix (conv_direct.hip)
+      DmArena ar(ws, ws_bytes);
+      ar.take(DM_SPLITK_FLOATS);
+      float* wt = ar.take((size_t)48 * g.d);
+      DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small for the layer-1 weights");
+      const size_t frame = (size_t)g.ch * g.hb[0] * g.hb[0];
+      const void* img = shape_u8(shp) ? (const void*)((const uint8_t*)image + (size_t)n0 * frame)
+                                      : (const void*)(image + (size_t)n0 * frame);
+      DM_TRY(dm_enc_l1_fwd_launch(n, g.d, shape_u8(shp) ? 1 : 0, img, p->w[0], p->b[0], wt, a.y[0] + r0 * g.cout[0], st));
+      continue;
+    }
     if (l == 0) {
       const size_t frame = (size_t)g.ch * g.hb[0] * g.hb[0];
       if (shape_u8(shp)) {
@@ -518,7 +531,6 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
                                    const float* dembed, const dm_conv_grads* gr, void* ws, size_t ws_bytes, void* stream) {
   DM_REQUIRE(shp && p && acts && dembed && gr && ws, DM_E_NULL, "conv_encoder_bwd: null pointer");
   DmPrecisionScope prec(shp->flags & DM_FLAG_BF16);
-  (void)image;
   EncGeom g(shp);
   DM_REQUIRE(g.valid(shp), DM_E_SHAPE, "conv_encoder: unsupported geometry");
   hipStream_t st = (hipStream_t)stream;
@@ -560,6 +572,12 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
   for (int l = 3; l >= 0; --l) {
     const int rows = (int)g.rows[l], co = g.cout[l], kd = (int)g.kdim[l];
     DM_TRY(dm_colsum_launch(rows, co, G, co, gr->b[l], splitk, skb, st));
+    if (l == 0 && g.direct0) {      // patches re-gathered from the frame inside the weight-gradient kernel (conv_direct.hip)
+      DM_REQUIRE(image, DM_E_NULL, "conv_encoder_bwd: the direct layer-1 weight gradient reads the image");
+      DM_REQUIRE(dm_enc_l1_wgrad_part_floats(g.N, g.d) <= xcmax, DM_E_WORKSPACE, "conv_encoder_bwd: partial buffer too small");
+      DM_TRY(dm_enc_l1_wgrad_launch(g.N, g.d, shape_u8(shp) ? 1 : 0, image, G, dxcol, gr->w[0], splitk, skb, st));
+      continue;
+    }
     DmGemm q;   // dWr[o][kidx] = sum_rows G[row][o] * Xcol[row][kidx]
     q.a_layout = 1; q.b_layout = 1;
     q.M = co; q.N = kd; q.K = rows;
@@ -694,12 +712,14 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
   if (n == 0) return DM_OK;
   DmArena ar(ws, ws_bytes);
   float* splitk = ar.take(DM_SPLITK_FLOATS);
+  const bool direct4 = dm_dec_l4_direct_ok(g.ch, g.d, g.hsm[4], g.k[4]);      // d -> 3 channels: conv_direct.hip, no column matrix
   size_t colmax = 0;
-  for (int l = 1; l <= 4; ++l) {
+  for (int l = 1; l <= (direct4 ? 3 : 4); ++l) {
     const size_t c = (size_t)n * g.hsm[l] * g.hsm[l] * g.k[l] * g.k[l] * g.cout[l];
     if (c > colmax) colmax = c;
   }
   float* ycol = ar.take(colmax);
+  float* w4 = ar.take(direct4 ? dm_dec_l4_w4_floats(g.d) : 0);
   // gather-form layers: zero-padded input copy, gather / scatter tables, class-concatenated weights
   size_t padmax = 0, tabmax = 0, wcmax = 0;
   for (int l = 1; l <= 4; ++l)
@@ -730,6 +750,10 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
     const int kk = g.k[l] * g.k[l];
     const float* xin = l == 1 ? a.x[0] + (size_t)n0 * g.cin[1]
                               : a.x[l - 1] + (size_t)n0 * g.hbg[l - 1] * g.hbg[l - 1] * g.cout[l - 1];
+    if (l == 4 && direct4) {
+      DM_TRY(dm_dec_l4_fwd_launch(n, g.d, xin, p->w[4], p->b[4], w4, a.x[4] + (size_t)n0 * g.hbg[4] * g.hbg[4] * g.cout[4], st));
+      continue;
+    }
     if (convt_gather_ok(g.k[l], g.cin[l], g.cout[l], g.hsm[l], (size_t)n)) {
       const int ta = g.k[l] / 2, hs = g.hsm[l], hb = g.hbg[l], Hc = hs + ta - 1, kdim = ta * ta * g.cin[l];
       DM_REQUIRE(kdim <= 9 * 1024, DM_E_SHAPE, "conv_decoder_fwd: gather-form K %d exceeds the offset table", kdim);

@@ -1,0 +1,295 @@
+// Direct small-channel convolutions: the two ends of the image stack, where one side of the layer has 3 channels.
+//
+//   encoder layer 1  (encoders.py:80-83)    Conv2d(3 -> d, k4, s2) + ELU on the 64x64 frame
+//   decoder layer 4  (decoders.py:154-155)  ConvTranspose2d(d -> 3, k6, s2) onto the 64x64 frame
+//
+// As GEMMs these two have K = 48 resp. N = 108 and need an explicit patch / column matrix, because a 3-channel pixel is
+// neither a 16-byte gather nor an MFMA-sized operand: N*31^2 x 48 floats (461 MB at Atari-literal) written by im2col and read
+// twice, N*30^2 x 108 floats (972 MB) written by the product and read by col2im - 3.5 GB of HBM traffic and ~1.2 ms per step
+// around ~25 GFLOP of work.  Here each is ONE kernel that reads the frame / the NHWC activation directly:
+//
+//   enc_l1_fwd_kernel    lane = output pixel, all d channels in registers; the 48 x d weights are wave-uniform -> scalar loads,
+//                        the FMAs take them as SGPR operands (no LDS, no weight VGPRs); bias + ELU in the epilogue;
+//                        float NCHW frames or the replay's uint8 HWC frames (x/255 - 0.5 in the loader)
+//   enc_l1_wgrad_kernel  dW[o][tap] = sum_pixels G[pixel][o] patch[pixel][tap] on v_mfma_f32_16x16x4_f32 (K = pixels): the
+//                        patch operand is gathered straight from the frame (tap block = input channel, lane&15 = (ky,kx));
+//                        per-wave partials, summed in fixed order by dm_colsum_launch (deterministic)
+//   dec_l4_fwd_kernel    lane = output pixel of ONE parity class (2yy+py, 2xx+px): an even-k stride-2 transposed convolution
+//                        is, per class, a 3x3 convolution over the input; the class's 9 x d x 3 weights are wave-uniform
+//                        (scalar loads), the input pixel vectors are 16-byte loads
+// fp32 VALU arithmetic (v_fmac with an SGPR operand); bound: VALU issue (13 / 5.5 GFMA-lanes) and the output write.
+#include "common.h"
+#include <stdlib.h>
+
+static inline int grid_for_px(size_t total, int per_block) { return (int)((total + per_block - 1) / per_block); }
+
+bool dm_conv_direct_enabled() {
+  static const int off = getenv("DM_CONV_NO_DIRECT") ? 1 : 0;      // A/B switch: the explicit patch / column matrices
+  return !off;
+}
+
+// ---------------------------------------------------------------- encoder layer 1, forward --------
+// wt: (48 taps, CO) with tap = c*16 + ky*4 + kx (the torch weight (CO,3,4,4) transposed once per call)
+template <int CO, bool U8>
+__global__ void __launch_bounds__(256) enc_l1_fwd_kernel(int npix, const void* __restrict__ image_,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ y) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = p < npix;
+  const int pc = ok ? p : npix - 1;
+  const int n = pc / 961, r = pc - n * 961, py = r / 31, px = r - py * 31;
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = bias[o];
+#pragma unroll 1
+  for (int cy = 0; cy < 12; ++cy) {               // (c, ky) pairs; the 4 kx taps of a pair are 4 consecutive pixels of one row
+    const int c = cy >> 2, ky = cy & 3;
+    float v[4];
+    if (U8) {
+      const uint8_t* img = (const uint8_t*)image_ + (size_t)n * 12288 + ((size_t)(2 * py + ky) * 64 + 2 * px) * 3 + c;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) v[kx] = (float)img[kx * 3] / 255.0f - 0.5f;      // preprocessing.py:21-29, as im2col_s2_u8hwc
+    } else {
+      const float* img = (const float*)image_ + (size_t)n * 12288 + (size_t)c * 4096 + (2 * py + ky) * 64 + 2 * px;
+      const float2 a = *reinterpret_cast<const float2*>(img), b = *reinterpret_cast<const float2*>(img + 2);   // 2*px: 8-byte aligned
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+    const float* w = wt + (size_t)(c * 16 + ky * 4) * CO;        // wave-uniform: scalar loads
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[kx], w[kx * CO + o], acc[o]);
+  }
+  if (ok) {
+    float4* dst = reinterpret_cast<float4*>(y + (size_t)p * CO);
+#pragma unroll
+    for (int o = 0; o < CO; o += 4)
+      dst[o >> 2] = make_float4(dm_elu(acc[o]), dm_elu(acc[o + 1]), dm_elu(acc[o + 2]), dm_elu(acc[o + 3]));
+  }
+}
+
+__global__ void __launch_bounds__(256) enc_l1_wt_kernel(int co, const float* __restrict__ w, float* __restrict__ wt) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                // wt[t][o] = w[o][t], t = c*16 + ky*4 + kx
+  if (e < co * 48) wt[e] = w[(size_t)(e % co) * 48 + e / co];
+}
+
+bool dm_enc_l1_direct_ok(int ch, int d, int img) {
+  return dm_conv_direct_enabled() && ch == 3 && img == 64 && (d == 8 || d == 16 || d == 32 || d == 48 || d == 64);
+}
+// y (frames*961, d) NHWC post-ELU; wt: scratch of 48*d floats (the transposed weights, written here)
+int dm_enc_l1_fwd_launch(int frames, int d, int u8, const void* image, const float* w, const float* bias, float* wt,
+                         float* y, hipStream_t st) {
+  if (frames <= 0) return DM_OK;
+  hipLaunchKernelGGL(enc_l1_wt_kernel, dim3(grid_for_px((size_t)d * 48, 256)), dim3(256), 0, st, d, w, wt);
+  DM_LAUNCH_CHECK();
+  const int npix = frames * 961;
+  const dim3 grid(grid_for_px((size_t)npix, 256)), blk(256);
+#define DM_ENC_L1(CO_)                                                                                              \
+  if (d == CO_) {                                                                                                   \
+    if (u8) hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, true>), grid, blk, 0, st, npix, image, wt, bias, y);           \
+    else hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, false>), grid, blk, 0, st, npix, image, wt, bias, y);             \
+  }
+  DM_ENC_L1(8) DM_ENC_L1(16) DM_ENC_L1(32) DM_ENC_L1(48) DM_ENC_L1(64)
+#undef DM_ENC_L1
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ---------------------------------------------------------------- encoder layer 1, weight gradient
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+constexpr int ENC_LD = 68;       // LDS row stride of the staged frame (floats): 16-byte aligned rows, the 16 taps of a pixel on 16 banks
+// part[wave][o][48]: this wave's sum over its pixels of G[pixel][o] * patch[pixel][tap]   (o < CO).
+// A workgroup stages one frame at a time in LDS (3 x 64 rows, converted to float once: coalesced 16-byte / 4-byte global
+// reads instead of a 4-byte gather per MFMA operand - the first version, gathering from global memory, ran 542 us against
+// 226 us for the product on the explicit patch matrix); its 4 waves split the frame's 961 output pixels in chunks of 64.
+template <int OB, bool U8>
+__global__ void __launch_bounds__(256) enc_l1_wgrad_kernel(int frames, int CO, const void* __restrict__ image_,
+                                                           const float* __restrict__ G, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float img[3 * 64 * ENC_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  f32x4c acc[OB][3];
+#pragma unroll
+  for (int i = 0; i < OB; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+  const int tapoff = (l15 >> 2) * ENC_LD + (l15 & 3);           // this lane's tap (ky, kx) inside a channel plane
+  for (int n = blockIdx.x; n < frames; n += gridDim.x) {
+    __syncthreads();                                             // the previous frame's readers are done
+    if (U8) {      // (64,64,3) bytes -> three float planes
+      const uint8_t* src = (const uint8_t*)image_ + (size_t)n * 12288;
+      for (int e = tid; e < 12288; e += 256) {
+        const int c = e % 3, pix = e / 3;
+        img[(c * 64 + (pix >> 6)) * ENC_LD + (pix & 63)] = (float)src[e] / 255.0f - 0.5f;
+      }
+    } else {
+      const float4* src = reinterpret_cast<const float4*>((const float*)image_ + (size_t)n * 12288);
+      for (int e = tid; e < 3072; e += 256) {                    // 3 x 64 rows x 16 float4
+        const int row = e >> 4, c4 = e & 15;
+        *reinterpret_cast<float4*>(&img[row * ENC_LD + 4 * c4]) = src[e];
+      }
+    }
+    __syncthreads();
+    const float* Gn = G + (size_t)n * 961 * CO;
+    for (int p0 = wave * 64; p0 < 961; p0 += 256) {
+      // all 16 k-steps' G operands first, unconditionally (clamped addresses, zeroed by a multiply): one latency per
+      // 64-pixel chunk instead of one per k-step (a conditional load became a branch with the wait right behind it)
+      float a[16][OB];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {                          // 4 pixels per MFMA k-step: pixel = p0 + 4*ks + (lane>>4)
+        const int p = p0 + 4 * ks + q;
+        const int pc = p < 961 ? p : 960;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+          const int o = ob * 16 + l15;
+          a[ks][ob] = Gn[(size_t)pc * CO + (o < CO ? o : CO - 1)] * ((p < 961 && o < CO) ? 1.f : 0.f);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int p = p0 + 4 * ks + q;
+        const int pc = p < 961 ? p : 960;                        // a pixel past the frame multiplies a zeroed G row
+        const int py = pc / 31, px = pc - py * 31;
+        const float* base = &img[2 * py * ENC_LD + 2 * px + tapoff];
+        float b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b[c] = base[c * 64 * ENC_LD];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[ob][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][ob], b[c], acc[ob][c], 0, 0, 0);
+      }
+    }
+  }
+  // C/D map of the 16x16 MFMA: row (o) = 4*(lane>>4) + r, col (tap) = lane & 15
+  float* dst = part + (size_t)(blockIdx.x * 4 + wave) * CO * 48;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ob * 16 + 4 * q + r;
+        if (o < CO) dst[(size_t)o * 48 + c * 16 + l15] = acc[ob][c][r];
+      }
+}
+
+static int enc_l1_wgrad_blocks(int frames) { return frames > 512 ? 512 : frames; }      // <= 2048 waves, whole frames per workgroup
+size_t dm_enc_l1_wgrad_part_floats(int frames, int d) { return (size_t)enc_l1_wgrad_blocks(frames) * 4 * d * 48; }
+// dW (d, 3, 4, 4) = sum over all pixels; G (frames*961, d) = dY0 * ELU'(Y0); part: dm_enc_l1_wgrad_part_floats(frames, d) of scratch
+int dm_enc_l1_wgrad_launch(int frames, int d, int u8, const void* image, const float* G, float* part, float* dW, void* ws,
+                           size_t ws_bytes, hipStream_t st) {
+  if (frames <= 0) return DM_OK;
+  const int blocks = enc_l1_wgrad_blocks(frames);
+  const dim3 grid(blocks), blk(256);
+  const int OB = (d + 15) / 16;
+  DM_REQUIRE(OB >= 1 && OB <= 4, DM_E_SHAPE, "enc_l1_wgrad: cnn_depth %d", d);
+#define DM_ENC_WG(OB_)                                                                                               \
+  if (OB == OB_) {                                                                                                   \
+    if (u8) hipLaunchKernelGGL((enc_l1_wgrad_kernel<OB_, true>), grid, blk, 0, st, frames, d, image, G, part);         \
+    else hipLaunchKernelGGL((enc_l1_wgrad_kernel<OB_, false>), grid, blk, 0, st, frames, d, image, G, part);           \
+  }
+  DM_ENC_WG(1) DM_ENC_WG(2) DM_ENC_WG(3) DM_ENC_WG(4)
+#undef DM_ENC_WG
+  DM_LAUNCH_CHECK();
+  return dm_colsum_launch(blocks * 4, d * 48, part, d * 48, dW, ws, ws_bytes, st);
+}
+
+// ---------------------------------------------------------------- decoder layer 4, forward --------
+// w4[cls][a*3+b][c][4] = W[c][o][py+2a][px+2b] (o < 3, slot 3 = 0), cls = py*2 + px; W is the torch (d, 3, 6, 6) tensor
+__global__ void __launch_bounds__(256) dec_l4_repack_kernel(int d, const float* __restrict__ w, float* __restrict__ w4) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 4 * 9 * d * 4) return;
+  const int o = e & 3, c = (e >> 2) % d, ab = (e / (4 * d)) % 9, cls = e / (36 * d);
+  const int ky = (cls >> 1) + 2 * (ab / 3), kx = (cls & 1) + 2 * (ab % 3);
+  w4[e] = o < 3 ? w[(((size_t)c * 3 + o) * 6 + ky) * 6 + kx] : 0.f;
+}
+// out[n, 2yy+py, 2xx+px, o] = b[o] + sum_{a,b<3} sum_c x[n, yy-a, xx-b, c] * W[c][o][py+2a][px+2b]     (x: (n,30,30,d) NHWC)
+// Workgroup = (frame, 8 class rows yy0 .. yy0+7); wave = parity class (py,px); lane = (column xx, half rh) and computes the
+// FOUR pixels (yy0 + 4 rh + j, xx), j < 4.  The 10 input rows yy0-2 .. yy0+7 are staged in LDS with coalesced 16-byte reads
+// (zero rows / columns outside the image, pixel stride d+4 floats: conflict-free ds_read_b128).  Measured history of this
+// kernel at Atari-literal (the column-matrix path it replaces: 0.97 ms): pixel vectors read from global memory, 64 lanes x
+// 16 B at a 192-byte stride per load: 4.1 ms (address-coalescing bound); LDS-staged input, one pixel per lane: 1.95 ms - the
+// class's weights are wave-uniform, but behind a barrier the compiler does not scalarise global loads, so they arrive as
+// vector loads, 4 per 12 FMAs; four pixels per lane share each weight load (4 per 48 FMAs).
+constexpr int DEC_ROWS = 10, DEC_COLS = 34;
+template <int D>
+__global__ void __launch_bounds__(256) dec_l4_fwd_kernel(int frames, const float* __restrict__ x, const float* __restrict__ w4,
+                                                         const float* __restrict__ bias, float* __restrict__ out) {
+  constexpr int LDP = D + 4, D4 = D / 4;
+  extern __shared__ __attribute__((aligned(16))) float rows[];      // [10 rows][34 columns (ix = -2 .. 31)][D + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x >> 2, yy0 = (blockIdx.x & 3) * 8;
+  for (int e = tid; e < DEC_ROWS * DEC_COLS * D4; e += 256) {     // D4 is a constant: the index split is multiply-shift
+    const int c4 = e % D4, col = (e / D4) % DEC_COLS, r = e / (D4 * DEC_COLS);
+    const int iy = yy0 - 2 + r, ix = col - 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < 30 && ix >= 0 && ix < 30) v = *reinterpret_cast<const float4*>(x + (((size_t)n * 30 + iy) * 30 + ix) * D + 4 * c4);
+    *reinterpret_cast<float4*>(&rows[(r * DEC_COLS + col) * LDP + 4 * c4]) = v;
+  }
+  __syncthreads();
+  const int py = cls >> 1, px = cls & 1;
+  const int rh = lane >> 5, xx = lane & 31;
+  // outputs as two float2 pairs per pixel, (o0, o1) and (o2, pad): every FMA is a v_pk_fma_f32 with the input value broadcast
+  dm_f32x2 a01[4], a23[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a01[j] = (dm_f32x2){bias[0], bias[1]}; a23[j] = (dm_f32x2){bias[2], 0.f}; }
+#pragma unroll 1
+  for (int ab = 0; ab < 9; ++ab) {
+    // LDS row of pixel j: (yy0 + 4 rh + j) - a - (yy0 - 2) = 4 rh + j + 2 - a
+    const float* src = &rows[((4 * rh + 2 - ab / 3) * DEC_COLS + (xx + 2 - ab % 3)) * LDP];
+    const float4* wv = reinterpret_cast<const float4*>(w4 + ((size_t)(cls * 9 + ab) * D) * 4);
+#pragma unroll 2
+    for (int c4 = 0; c4 < D4; ++c4) {
+      dm_f32x2 wlo[4], whi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 w = wv[c4 * 4 + i];
+        wlo[i] = (dm_f32x2){w.x, w.y}; whi[i] = (dm_f32x2){w.z, w.w};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)j * DEC_COLS * LDP + 4 * c4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const dm_f32x2 b = {vv[i], vv[i]};
+          a01[j] = __builtin_elementwise_fma(b, wlo[i], a01[j]);
+          a23[j] = __builtin_elementwise_fma(b, whi[i], a23[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float* dst = out + (((size_t)n * 64 + 2 * (yy0 + 4 * rh + j) + py) * 64 + 2 * xx + px) * 3;
+    dst[0] = a01[j].x; dst[1] = a01[j].y; dst[2] = a23[j].x;
+  }
+}
+
+bool dm_dec_l4_direct_ok(int ch, int d, int hs, int k) {
+  return dm_conv_direct_enabled() && ch == 3 && hs == 30 && k == 6 && (d == 8 || d == 16 || d == 32 || d == 48 || d == 64);
+}
+size_t dm_dec_l4_w4_floats(int d) { return (size_t)4 * 9 * d * 4; }
+int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, const float* bias, float* w4, float* out,
+                         hipStream_t st) {
+  if (frames <= 0) return DM_OK;
+  hipLaunchKernelGGL(dec_l4_repack_kernel, dim3(grid_for_px(dm_dec_l4_w4_floats(d), 256)), dim3(256), 0, st, d, w, w4);
+  DM_LAUNCH_CHECK();
+  const size_t lds = (size_t)DEC_ROWS * DEC_COLS * (d + 4) * sizeof(float);       // 70.7 KB at d = 48: above the 64 KB default
+#define DM_DEC_L4(D_)                                                                                                  \
+  if (d == D_) {                                                                                                       \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      if (hipFuncSetAttribute((const void*)dec_l4_fwd_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return dm_fail(DM_E_HIP, "dec_l4_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((dec_l4_fwd_kernel<D_>), dim3(frames * 4), dim3(256), lds, st, frames, x, w4, bias, out);         \
+  }
+  DM_DEC_L4(8) DM_DEC_L4(16) DM_DEC_L4(32) DM_DEC_L4(48) DM_DEC_L4(64)
+#undef DM_DEC_L4
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

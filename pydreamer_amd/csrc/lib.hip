@@ -69,7 +69,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   size_t col = N * 25 * 4 * d;
   if (N * 25 * 25 * 2 * d > col) col = N * 25 * 25 * 2 * d;
   if (N * 169 * 36 * d > col) col = N * 169 * 36 * d;
-  if (N * 900 * 36 * ch > col) col = N * 900 * 36 * ch;
+  if (!dm_dec_l4_direct_ok((int)ch, (int)d, 30, 6) && N * 900 * 36 * ch > col) col = N * 900 * 36 * ch;   // layer 4 runs as a direct kernel otherwise
   size_t gmax = N * 25 * 4 * d;
   if (N * 169 * 2 * d > gmax) gmax = N * 169 * 2 * d;
   if (N * 900 * d > gmax) gmax = N * 900 * d;
@@ -84,7 +84,8 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   size_t gpad = N * 17 * 17 * 2 * d;
   if (N * 34 * 34 * d > gpad) gpad = N * 34 * 34 * d;
   const size_t gtab = N * 32 * 32;
-  const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) + 1024;
+  const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) +
+                         pad64(144 * d) + 1024;      // + the direct layer-4 kernel's class-ordered weights
   const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024;   // + gather tables, padded image-layer weights
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg
