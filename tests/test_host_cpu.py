@@ -105,7 +105,8 @@ def test_workspace_and_acts_sizing():
     enc = int(lib.dm_conv_encoder_acts_floats(ctypes.byref(lit))) * 4
     dec = int(lib.dm_conv_decoder_acts_floats(ctypes.byref(lit))) * 4
     rssm = int(lib.dm_rssm_acts_floats(ctypes.byref(lit))) * 4
-    assert 0.9e9 < enc < 2e9 and 0.5e9 < dec < 1.5e9 and 0.1e9 < rssm < 0.3e9, (enc, dec, rssm)   # patch matrices are implicit
+    # patch matrices are implicit; the encoder's layer-1 patch matrix (461 MB) is gone too since layer 1 is a direct kernel
+    assert 0.6e9 < enc < 1.0e9 and 0.5e9 < dec < 1.5e9 and 0.1e9 < rssm < 0.3e9, (enc, dec, rssm)
     assert int(lib.dm_mlp_acts_floats(2500, 400, 4)) >= 2500 * (400 * 2 + 2) * 4
 
 
