@@ -216,7 +216,7 @@ def main():
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--pmc-json', default=os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'),
+    ap.add_argument('--pmc-json', default=os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'),
                     help='per-kernel HBM traffic from two rocprofv3 PMC passes of THIS command (scripts/pmc_traffic.py); it carries a '
                          'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
     ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '

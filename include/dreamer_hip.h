@@ -70,7 +70,8 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 4 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots) */
+int dm_version(void);                 /* ABI version, currently 5 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+                                         v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -137,6 +138,13 @@ int dm_kl_sampled_fwd(int rows, int S, int C, const float* post, const float* pr
 /* dpost = scale*row_w[n]*(onehot - softmax(post)), dprior = -scale*row_w[n]*(onehot - softmax(prior)); row_w nullable. */
 int dm_kl_sampled_bwd(int rows, int S, int C, const float* post, const float* prior, const int32_t* idx, float scale,
                       const float* row_w, float* dpost, float* dprior, void* stream);
+/* The same for Gaussian latents (stoch_discrete = 0, rssm.py:202-203): post / prior rows are (mean | raw std), z (rows, S; row
+ * stride ldz) is the reparameterised posterior sample, through which a gradient flows too: dz (row stride lddz) is
+ * ACCUMULATED with scale*row_w[n]*d(log q - log p)/dz, dpost / dprior receive the explicit parameter gradients. */
+int dm_kl_sampled_gauss_fwd(int rows, int S, const float* post, const float* prior, const float* z, int ldz, float* out,
+                            void* stream);
+int dm_kl_sampled_gauss_bwd(int rows, int S, const float* post, const float* prior, const float* z, int ldz, float scale,
+                            const float* row_w, float* dpost, float* dprior, float* dz, int lddz, void* stream);
 /* x (TB,I,W) -> out (TB,W): mode 0 mean over I, mode 2 sum, mode 1 (W = 1) -logavgexp(-x) (functions.py:97-102) with the
  * optional importance weights w_out (TB,I) = softmax_i(-x) = d out/d x_i. */
 int dm_reduce_i(int TB, int I, int W, const float* x, int mode, float* out, float* w_out, void* stream);

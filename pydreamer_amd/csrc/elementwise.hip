@@ -1314,6 +1314,74 @@ extern "C" int dm_kl_sampled_bwd(int rows, int S, int C, const float* post, cons
   return DM_OK;
 }
 
+// Gaussian latents (stoch_discrete = 0) under IWAE: loss_kl[n] = log q(z_n) - log p(z_n) with q = N(m1, s1), p = N(m2, s2)
+// diagonal (rssm.py:202-203 diag_normal, std = 2 sigmoid(raw) + 0.1) and z the REPARAMETERISED posterior sample
+// (Normal.rsample: z = m1 + s1 eps), so - unlike the one-hot case above - a gradient also flows through z itself:
+//   per dimension  f = -log s1 - (z - m1)^2 / (2 s1^2) + log s2 + (z - m2)^2 / (2 s2^2)
+//   df/dm1 = (z - m1)/s1^2     df/ds1 = -1/s1 + (z - m1)^2/s1^3     df/dm2 = -(z - m2)/s2^2     df/ds2 = 1/s2 - (z - m2)^2/s2^3
+//   df/dz  = -(z - m1)/s1^2 + (z - m2)/s2^2     (added to the sample's gradient; the BPTT pass carries it into (m1, s1))
+__global__ void __launch_bounds__(256) gauss_kl_sampled_fwd_kernel(int rows, int S, const float* __restrict__ post,
+                                                                   const float* __restrict__ prior, const float* __restrict__ z,
+                                                                   int ldz, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* a = post + (size_t)row * 2 * S;
+  const float* b = prior + (size_t)row * 2 * S;
+  float acc = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float s1 = dm_gauss_std(a[S + s]), s2 = dm_gauss_std(b[S + s]);
+    const float zz = z[(size_t)row * ldz + s];
+    const float d1 = (zz - a[s]) / s1, d2 = (zz - b[s]) / s2;
+    acc += (-logf(s1) - 0.5f * d1 * d1) - (-logf(s2) - 0.5f * d2 * d2);
+  }
+  acc = dm_wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+__global__ void __launch_bounds__(256) gauss_kl_sampled_bwd_kernel(int rows, int S, const float* __restrict__ post,
+                                                                   const float* __restrict__ prior, const float* __restrict__ z,
+                                                                   int ldz, float scale, const float* __restrict__ row_w,
+                                                                   float* __restrict__ dpost, float* __restrict__ dprior,
+                                                                   float* __restrict__ dz, int lddz) {
+  const int total = rows * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int r = i / S, s = i % S;
+    const size_t o = (size_t)r * 2 * S;
+    const float g1 = dm_sigmoid(post[o + S + s]), g2 = dm_sigmoid(prior[o + S + s]);
+    const float s1 = 2.0f * g1 + 0.1f, s2 = 2.0f * g2 + 0.1f;
+    const float zz = z[(size_t)r * ldz + s];
+    const float e1 = zz - post[o + s], e2 = zz - prior[o + s];
+    const float w = scale * (row_w ? row_w[r] : 1.f);
+    const float i11 = 1.0f / (s1 * s1), i22 = 1.0f / (s2 * s2);
+    dpost[o + s] = w * e1 * i11;
+    dpost[o + S + s] = w * (-1.0f / s1 + e1 * e1 * i11 / s1) * 2.0f * g1 * (1.0f - g1);
+    dprior[o + s] = -w * e2 * i22;
+    dprior[o + S + s] = w * (1.0f / s2 - e2 * e2 * i22 / s2) * 2.0f * g2 * (1.0f - g2);
+    dz[(size_t)r * lddz + s] += w * (-e1 * i11 + e2 * i22);
+  }
+}
+extern "C" int dm_kl_sampled_gauss_fwd(int rows, int S, const float* post, const float* prior, const float* z, int ldz,
+                                       float* out, void* stream) {
+  DM_REQUIRE(post && prior && z && out, DM_E_NULL, "kl_sampled_gauss_fwd: null pointer");
+  if (rows <= 0) return DM_OK;
+  hipLaunchKernelGGL(gauss_kl_sampled_fwd_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, S, post, prior,
+                     z, ldz, out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+extern "C" int dm_kl_sampled_gauss_bwd(int rows, int S, const float* post, const float* prior, const float* z, int ldz,
+                                       float scale, const float* row_w, float* dpost, float* dprior, float* dz, int lddz,
+                                       void* stream) {
+  DM_REQUIRE(post && prior && z && dpost && dprior && dz, DM_E_NULL, "kl_sampled_gauss_bwd: null pointer");
+  if (rows <= 0) return DM_OK;
+  int blocks = dm_cdiv((size_t)rows * S, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gauss_kl_sampled_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, S, post, prior, z, ldz,
+                     scale, row_w, dpost, dprior, dz, lddz);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // Reductions over the I samples of every (t,b): x (TB, I, W) -> out (TB, W).
 //   mode 0: mean_i x        mode 2: sum_i x
 //   mode 1 (W = 1): -logavgexp_i(-x) = -(logsumexp_i(-x) - log I)  (functions.py:97-102), and optionally the importance

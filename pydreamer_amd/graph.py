@@ -1,10 +1,11 @@
 """hipGraph capture of the trainer's inner section (reference train.py:171-192: training_step -> zero_grad -> backward x4).
 
-One Atari-literal gradient step is ~8000 kernel launches, most of them the 50-row products of the sequential T-step,
-BPTT and imagination chains; fed launch by launch the host needs ~45 ms to enqueue a step that the GPU executes in
-~55 ms, and every latency-bound chain runs at host-launch speed.  Capturing the section once and replaying it removes
-the host from the loop.  What is captured is exactly the eager code path (same kernels, same order, same side streams
-for the overlapped backward passes), so results are bit-identical to the eager step.
+One Atari-literal gradient step is ~1 000 kernel launches, a quarter of them the 50-row products of the sequential T-step,
+BPTT and imagination chains.  Capturing the section once and replaying it removes the host from the loop; what is captured is
+exactly the eager code path (same kernels, same order, same side streams for the overlapped backward passes), so results are
+bit-identical to the eager step.  Measured on MI355X / ROCm 7.2 it is SLOWER than eager (a graph with concurrent branches
+replays at ~11 us per node) and therefore optional; the library-level alternative - linear graphs of the three
+launch chains only, csrc/chain_graph.hip - is GPU-neutral and saves host time only.
 
 Left outside the graph on purpose:
   * the critic-target refresh (a2c.py:68-70: every `target_interval` steps, host-side condition) - done eagerly by

@@ -121,6 +121,8 @@ _SIGNATURES = {
     'dm_mask_rows': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_int, _P]),
     'dm_kl_sampled_fwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'dm_kl_sampled_bwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P]),
+    'dm_kl_sampled_gauss_fwd': (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    'dm_kl_sampled_gauss_bwd': (c_int, [c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, _P, c_int, _P]),
     'dm_reduce_i': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
     'dm_combine_rows': (c_int, [c_int, c_int64, POINTER(c_void_p), POINTER(c_float), _P, _P]),
     'dm_scale_rows': (c_int, [c_int64, c_int, _P, c_int, _P, c_float, _P]),

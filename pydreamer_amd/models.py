@@ -8,7 +8,7 @@ model, actor, critic — so each of the 4 returned losses supports an independen
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
 Supported configuration (everything else raises NotImplementedError): iwae_samples>=1 (also with the logging flags), gru_type in {gru, gru_layernorm,
-gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0 or 0 (Gaussian latents), layer_norm True or False,
+gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0 or 0 (Gaussian latents, also with iwae_samples>1), layer_norm True or False,
 aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
 probe_model='none', no vecobs / reward_input.
 """
@@ -754,8 +754,8 @@ class WorldModel(_Params):
         D_, F_, E = c.deter_dim, self.features_dim, self.encoder.out_dim
         gauss = not c.stoch_discrete         # Gaussian latents: z is stoch_dim wide, its parameters (mean | raw std) twice that
         Z, ZP = c.stoch_dim * (c.stoch_discrete or 1), c.stoch_dim * (c.stoch_discrete or 2)
-        if gauss and (I > 1 or forced_idx is not None):
-            raise NotImplementedError('Gaussian latents (stoch_discrete=0): iwae_samples > 1 and forced indices are not built')
+        if gauss and forced_idx is not None:
+            raise NotImplementedError('Gaussian latents (stoch_discrete=0) have no indices to force')
         shp = self.shape(T, B, imag_horizon)
         shp.I = I
         ws = self.workspace(shp, dev)
@@ -793,19 +793,24 @@ class WorldModel(_Params):
         # Everything the posterior chain touches lives in the step arena (stable addresses -> the chain's hipGraph is replayed)
         ar = self._arena
         gen = ar.begin_step((T, B, I))
-        u_buf = None
-        if forced_idx is None or u_post is not None:
-            # uniforms for the categorical inverse-CDF rule; standard-normal eps of Normal.rsample for Gaussian latents
-            u_buf = ar.get('u_post', (T, BI, c.stoch_dim), device=dev)
-            if u_post is not None:
-                u_buf.copy_(u_post.reshape(T, BI, c.stoch_dim))
-            elif gauss:
-                u_buf.normal_()
-            else:
-                u_buf.uniform_()
-        u_post = u_buf
-        h0 = ar.get('h0', (BI, D_), device=dev).copy_(h0)
-        z0 = ar.get('z0', (BI, Z), device=dev).copy_(z0)
+        if ar.on:
+            u_buf = None
+            if forced_idx is None or u_post is not None:
+                # uniforms for the categorical inverse-CDF rule; standard-normal eps of Normal.rsample for Gaussian latents
+                u_buf = ar.get('u_post', (T, BI, c.stoch_dim), device=dev)
+                if u_post is not None:
+                    u_buf.copy_(u_post.reshape(T, BI, c.stoch_dim))
+                elif gauss:
+                    u_buf.normal_()
+                else:
+                    u_buf.uniform_()
+            u_post = u_buf
+            h0 = ar.get('h0', (BI, D_), device=dev).copy_(h0)
+            z0 = ar.get('z0', (BI, Z), device=dev).copy_(z0)
+        elif u_post is not None:
+            u_post = u_post.reshape(T, BI, c.stoch_dim).float().contiguous()
+        elif forced_idx is None:
+            u_post = (torch.randn if gauss else torch.rand)(T, BI, c.stoch_dim, device=dev)
         lib = H.lib()
         shp_e = shp_r = shp
         if I > 1:
@@ -838,7 +843,8 @@ class WorldModel(_Params):
         idx = ar.get('idx', (N, c.stoch_dim), torch.int32, device=dev)
         fidx = None
         if forced_idx is not None:
-            fidx = ar.get('forced_idx', (T, BI, c.stoch_dim), torch.int32, device=dev).copy_(forced_idx)
+            fidx = (ar.get('forced_idx', (T, BI, c.stoch_dim), torch.int32, device=dev).copy_(forced_idx) if ar.on
+                    else forced_idx.to(torch.int32).contiguous())
         u_ptr = H.fptr(u_post) if u_post is not None else None
         dec = self.decoder
         dl = dec.image.layers()
@@ -851,10 +857,13 @@ class WorldModel(_Params):
         chunks = min(self.pipeline_chunks, T) if (T >= 4 and not forward_only and not open_loop and I == 1) else 1
         # rssm.py:35-41: (T,B,X) -> (T,B*I,X), pure data movement - into the arena (I = 1: a plain copy of the caller's tensors)
         A_ = c.action_dim
-        action_x = ar.get('action_x', (T, BI, A_), device=dev)
-        action_x.view(T, B, I, A_).copy_(action.view(T, B, 1, A_).expand(T, B, I, A_))
-        reset_x = ar.get('reset_x', (T, BI), torch.uint8, device=dev)
-        reset_x.view(T, B, I).copy_(reset.view(T, B, 1).expand(T, B, I))
+        if ar.on or I > 1:
+            action_x = ar.get('action_x', (T, BI, A_), device=dev)
+            action_x.view(T, B, I, A_).copy_(action.view(T, B, 1, A_).expand(T, B, I, A_))
+            reset_x = ar.get('reset_x', (T, BI), torch.uint8, device=dev)
+            reset_x.view(T, B, I).copy_(reset.view(T, B, 1).expand(T, B, I))
+        else:
+            action_x, reset_x = action, reset
         embed_x = embed
         if chunks <= 1:
             H.call('dm_conv_encoder_fwd', ctypes.byref(shp_e), H.ptr(image), ctypes.byref(enc_p), H.fptr(enc_acts),
@@ -984,8 +993,12 @@ class WorldModel(_Params):
             # the logged tensors are -logavgexp_i(-x) of the per-sample losses (decoders.py:170,277,312), means over I for the
             # entropies and the reconstructions (dreamer.py:371-372, decoders.py:171,278,313)
             kl_s = torch.empty(N, device=dev)
-            H.call('dm_kl_sampled_fwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(post), H.fptr(prior), H.ptr(idx), H.fptr(kl_s),
-                   H.stream())
+            if gauss:      # Normal log-densities of the reparameterised sample z = feat[:, D:] (rssm.py:202-203)
+                H.call('dm_kl_sampled_gauss_fwd', N, c.stoch_dim, H.fptr(post), H.fptr(prior),
+                       ctypes.c_void_p(feat.data_ptr() + 4 * D_), F_, H.fptr(kl_s), H.stream())
+            else:
+                H.call('dm_kl_sampled_fwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(post), H.fptr(prior), H.ptr(idx), H.fptr(kl_s),
+                       H.stream())
             l_tbi = torch.empty(N, device=dev)
             ptrs = (ctypes.c_void_p * 4)(kl_s.data_ptr(), loss_image.data_ptr(), loss_reward.data_ptr(), loss_terminal.data_ptr())
             H.call('dm_combine_rows', 4, N, ptrs, w, H.fptr(l_tbi), H.stream())
@@ -1067,7 +1080,12 @@ class WorldModel(_Params):
         # KL (dreamer.py:334-343)
         dpost = ar.get('dpost', (N, Z), device=dev)
         dprior = ar.get('dprior', (N, Z), device=dev)
-        if iw is not None:         # sampled KL of the IWAE bound
+        if iw is not None and not c.stoch_discrete:      # sampled Normal KL: explicit parameter gradients + the path through z
+            D_ = c.deter_dim
+            H.call('dm_kl_sampled_gauss_bwd', N, c.stoch_dim, H.fptr(pk['post']), H.fptr(pk['prior']),
+                   ctypes.c_void_p(feat.data_ptr() + 4 * D_), F_, gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost),
+                   H.fptr(dprior), ctypes.c_void_p(dfeat.data_ptr() + 4 * D_), F_, H.stream())
+        elif iw is not None:         # sampled KL of the IWAE bound
             H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
                    H.ptr(pk['idx']), gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
         else:
@@ -1424,21 +1442,28 @@ class Dreamer(nn.Module):
         ua_shape = (Hh, M) if kind == 0 else (Hh, M, A)
         if u_act is not None and tuple(u_act.shape) != ua_shape:
             raise ValueError(f'actor noise has shape {tuple(u_act.shape)}, expected {ua_shape}')
-        ua = ar.get('u_act', ua_shape, device=dev)
-        up = ar.get('u_prior', (Hh, M, S), device=dev)
-        if u_act is not None:
-            ua.copy_(u_act)
-        elif kind == 0:
-            ua.uniform_()
+        if ar.on:
+            ua = ar.get('u_act', ua_shape, device=dev)
+            up = ar.get('u_prior', (Hh, M, S), device=dev)
+            if u_act is not None:
+                ua.copy_(u_act)
+            elif kind == 0:
+                ua.uniform_()
+            else:
+                ua.normal_()
+            if u_prior is not None:
+                up.copy_(u_prior.reshape(Hh, M, S))
+            elif c.stoch_discrete:
+                up.uniform_()
+            else:
+                up.normal_()
+            u_act, u_prior = ua, up
         else:
-            ua.normal_()
-        if u_prior is not None:
-            up.copy_(u_prior.reshape(Hh, M, S))
-        elif c.stoch_discrete:
-            up.uniform_()
-        else:
-            up.normal_()
-        u_act, u_prior = ua, up
+            if u_act is None:
+                u_act = torch.rand(ua_shape, device=dev) if kind == 0 else torch.randn(ua_shape, device=dev)
+            if u_prior is None:
+                u_prior = (torch.rand if c.stoch_discrete else torch.randn)(Hh, M, S, device=dev)
+            u_act, u_prior = u_act.float().contiguous(), u_prior.reshape(Hh, M, S).float().contiguous()
         if ar.on and not _start_in_arena:
             start = ar.get('dream_start', tuple(start.shape), device=dev).copy_(start)
         start = start.contiguous()

@@ -1,29 +1,38 @@
 #!/bin/bash
-# Round profile set, run on the GPU box from the repo root:  bash scripts/collect_profiles.sh r02
+# Round profile set, run on the GPU box from the repo root:  bash scripts/collect_profiles.sh r03
 #   1. rocprofv3 --kernel-trace --stats of the default bench command's workload (short run) -> <tag>_kernel_stats.csv
 #   2. two PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass; counters only, no tracing domains besides
 #      --kernel-trace) of a 3-step single-stream run -> <tag>_pmc_traffic.json (carries the kernel-source fingerprint)
 #   3. the bench line itself, reading the fresh PMC file -> <tag>_bench.json
 # Everything lands in gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 SHA=$(python bench.py --csrc-sha)
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --prof-steps 0 > $OUT/ks_bench.json 2> $OUT/ks.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/ks_bench.json 2> $OUT/ks.err
 cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python $REPO/scripts/trace_timeline.py $(find /tmp/prof_ks -name "*kernel_trace.csv" | head -1) 2 > $OUT/${TAG}_timeline.txt 2>&1
+# the same workload on ONE stream (--no-overlap): per-kernel durations undisturbed by concurrent streams - the file the bench line's
+# roofline.achieved (HIP events in a single-stream pass) must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks_serial -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --no-overlap > $OUT/ks_serial_bench.json 2> $OUT/ks_serial.err
+cp $(find /tmp/prof_ks_serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_serial.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --prof-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/prof_WRITE_SIZE -name "*counter_collection.csv" | head -1) 3 $SHA > $OUT/${TAG}_pmc_traffic.json
 cd $REPO
 python bench.py --pmc-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
-python bench.py --dtype bf16 --no-cpu-baseline --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16.json 2>/dev/null
+for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
+DM_FP32_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg > $OUT/${TAG}_bench_fp32_split.json 2>/dev/null
+python bench.py --dtype bf16 --no-cpu-baseline --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes_bf16.txt > $OUT/${TAG}_bench_bf16.json 2>/dev/null
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
 # per-CU operand load ceilings (coalesced vs MFMA-fragment gather), see scripts/microbench/l2_stream.hip
 (cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 l2_stream.hip -o /tmp/l2_stream 2>/dev/null && \
  for kib in 2048 8192 65536; do /tmp/l2_stream $kib 8 256 4 0; /tmp/l2_stream $kib 8 1024 1 0; /tmp/l2_stream $kib 8 256 4 1; /tmp/l2_stream $kib 8 1024 1 1; done) > $OUT/${TAG}_l2_stream.txt 2>&1

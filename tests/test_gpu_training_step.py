@@ -510,6 +510,45 @@ def test_training_step_matches_reference_goldens(hip):
             np.testing.assert_allclose(sums, g[pre + 'param_abs_sums'], rtol=2e-6)
 
 
+def test_gaussian_latents_iwae_matches_reference_golden(hip):
+    """stoch_discrete = 0 WITH iwae_samples = 2 (dreamer.py:340-343 with rssm.py:202-203: the sampled KL is a difference of
+    Normal log-densities of the reparameterised sample, through which a gradient flows) against
+    tests/golden/tiny_gaussian_iwae.npz written by the real reference: losses, metrics, per-parameter gradient norms,
+    parameters after clip + AdamW."""
+    g = np.load(os.path.join(GOLD, 'tiny_gaussian_iwae.npz'))
+    oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
+    assert oconf.stoch_discrete == 0 and oconf.iwae_samples == 2
+    model = _build(oconf, O.make_params(oconf, seed=0))
+    opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+    pre = 's0_'
+    raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+    noise = {k: torch.from_numpy(g[pre + 'in_' + k]).to(DEV) for k in ('u_post', 'u_act', 'u_prior', 'eps_act') if pre + 'in_' + k in g.files}
+    losses, state, metrics, tensors, _ = model.training_step(_to_dev(O.preprocess(raw, oconf)),
+                                                             model.init_state(oconf.batch_size * oconf.iwae_samples), noise=noise)
+    for opt in opts:
+        opt.zero_grad()
+    for loss in losses:
+        loss.backward()
+    gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+    for opt in opts:
+        opt.step()
+    if oconf.actor_dist == 'onehot':
+        assert np.array_equal(model.last_extras['act_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_act'])
+    for i, l in enumerate(losses):
+        ref = g[pre + 'losses'][i]
+        assert _rel(l, ref) < 2e-5 or abs(float(l) - ref) < 2e-6, (i, float(l), ref)
+    for k, v in {**metrics, **gm}.items():
+        ref = float(g[pre + 'metric_' + k])
+        assert _rel(v, ref) < 1e-4 or abs(float(v) - ref) < 5e-6, (k, float(v), ref)
+    names = [str(n) for n in g[pre + 'grad_names']]
+    named = dict(model.named_parameters())
+    for n, ref in zip(names, g[pre + 'grad_norms']):
+        got = float(named[n].grad.double().norm())
+        assert abs(got - ref) <= 2e-3 * ref + 1e-7, (n, got, ref)
+    sums = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()])
+    np.testing.assert_allclose(sums, g[pre + 'param_abs_sums'], rtol=2e-6)
+
+
 def test_iwae_training_step_matches_reference_golden(hip):
     """SURVEY 8(f) N3 - iwae_samples = 3 (train.py:353-359,380-385 evaluate with eval_samples > 1; here as a full TRAINING
     step, gradients included) against tests/golden/tiny_iwae.npz written by the real reference: batch expansion by I
