@@ -70,8 +70,9 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 5 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
-                                         v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only) */
+int dm_version(void);                 /* ABI version, currently 6 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+                                         v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
+                                         v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -265,6 +266,11 @@ enum {
   DM_RSSM_GRU_L1_WIH, DM_RSSM_GRU_L1_WHH, DM_RSSM_GRU_L1_BIH, DM_RSSM_GRU_L1_BHH,
   DM_RSSM_GRU_L2_WIH, DM_RSSM_GRU_L2_WHH, DM_RSSM_GRU_L2_BIH, DM_RSSM_GRU_L2_BHH,
   DM_RSSM_GRU_L3_WIH, DM_RSSM_GRU_L3_WHH, DM_RSSM_GRU_L3_BIH, DM_RSSM_GRU_L3_BHH,
+  /* ... and, for a stack of LayerNorm cells (gru_layers > 1 with gru_layernorm / gru_layernorm_dv2; ABI v6), the LayerNorm
+   * parameters of layers 1..3 in the (G0,B0,G1,B1,G2,B2) order of DM_RSSM_GRU_LN_* above, D/L (dv2: 3D/L) floats each. */
+  DM_RSSM_GRU_L1_LN_G0, DM_RSSM_GRU_L1_LN_B0, DM_RSSM_GRU_L1_LN_G1, DM_RSSM_GRU_L1_LN_B1, DM_RSSM_GRU_L1_LN_G2, DM_RSSM_GRU_L1_LN_B2,
+  DM_RSSM_GRU_L2_LN_G0, DM_RSSM_GRU_L2_LN_B0, DM_RSSM_GRU_L2_LN_G1, DM_RSSM_GRU_L2_LN_B1, DM_RSSM_GRU_L2_LN_G2, DM_RSSM_GRU_L2_LN_B2,
+  DM_RSSM_GRU_L3_LN_G0, DM_RSSM_GRU_L3_LN_B0, DM_RSSM_GRU_L3_LN_G1, DM_RSSM_GRU_L3_LN_B1, DM_RSSM_GRU_L3_LN_G2, DM_RSSM_GRU_L3_LN_B2,
   DM_RSSM_NPARAMS
 };
 typedef struct dm_rssm_params { const float* p[DM_RSSM_NPARAMS]; } dm_rssm_params;

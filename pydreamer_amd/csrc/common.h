@@ -145,15 +145,18 @@ int dm_ln_elu_bwd_params_launch(int rows, int n, const float* x, int ldx, const 
                                 const float* dy, int lddy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                 hipStream_t st);
 // LayerNorm GRU cells (rnn.py:95-138): kind 1 = gru_layernorm, 2 = gru_layernorm_dv2; ln_g / ln_b: 3 pointers each
-// (kind 1: LN_reset, LN_update, LN_newval of width D; kind 2: slot 0 = the one LayerNorm of width 3D)
+// (kind 1: LN_reset, LN_update, LN_newval of width D; kind 2: slot 0 = the one LayerNorm of width 3D).  One layer of a
+// stack of such cells: D = the layer width, ldg / ldst / ldn = row strides of the gate matrices (gi, gh, gs, dgi, dgh, dg),
+// of the statistics and of h_next (0: the packed single-cell strides 3D, 6, D).
 int dm_gru_norm_fwd_launch(int kind, int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                            const float* const* ln_g, const float* const* ln_b, float* h_out, int ldo, float* gs, float* gst,
-                           float* h_next, const uint8_t* next_reset, hipStream_t st);
+                           float* h_next, const uint8_t* next_reset, hipStream_t st, int ldg = 0, int ldst = 0, int ldn = 0);
 int dm_gru_norm_bwd_launch(int kind, int rows, int D, const float* gh, const float* h_in, int ldh, const float* gs,
                            const float* gst, const float* const* ln_g, const float* const* ln_b, const float* dh_out, int lddh,
-                           float* dgi, float* dgh, float* dg, float* dh_in, int lddi, const uint8_t* row_zero, hipStream_t st);
+                           float* dgi, float* dgh, float* dg, float* dh_in, int lddi, const uint8_t* row_zero, hipStream_t st,
+                           int ldg = 0, int ldst = 0);
 int dm_gru_norm_param_grads_launch(int kind, int rows, int D, const float* gs, const float* gst, const float* dg, float* dgam,
-                                   float* dbet, hipStream_t st);
+                                   float* dbet, hipStream_t st, int ldg = 0, int ldst = 0);
 // h_next (optional, rows x D): the NEXT step's masked state input, next_reset[r] ? 0 : h_out   (rssm.py:134)
 // h_frag / h_next_frag (optional, rows <= 64): fragment-major copies (dm_frag_off) of h_out and of h_next
 int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh, float* h_out,

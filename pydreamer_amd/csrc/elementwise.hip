@@ -444,14 +444,15 @@ __global__ void __launch_bounds__(256) gru_norm_fwd_kernel(int rows, int D, cons
                                                            const float* __restrict__ gh, const float* __restrict__ h_in,
                                                            int ldh, const GruLnParams lp, float* __restrict__ h_out, int ldo,
                                                            float* __restrict__ gs, float* __restrict__ gst,
-                                                           float* __restrict__ h_next, const uint8_t* __restrict__ next_reset) {
+                                                           float* __restrict__ h_next, const uint8_t* __restrict__ next_reset,
+                                                           int ldg, int ldst, int ldn) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float eps = 1e-3f;
-  const float* gir = gi + (size_t)row * 3 * D;
-  const float* ghr = gh + (size_t)row * 3 * D;
-  float* sr = gs + (size_t)row * 3 * D;
+  const float* gir = gi + (size_t)row * ldg;
+  const float* ghr = gh + (size_t)row * ldg;
+  float* sr = gs + (size_t)row * ldg;
   const float* hr = h_in + (size_t)row * ldh;
   float st[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (KIND == 2) {
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(256) gru_norm_fwd_kernel(int rows, int D, cons
       const float r = dm_sigmoid(g_r), u = dm_sigmoid(g_u - 1.0f), n = tanhf(r * g_n);
       const float ho = u * n + (1.f - u) * hr[d];
       h_out[(size_t)row * ldo + d] = ho;
-      if (h_next) h_next[(size_t)row * D + d] = (next_reset && next_reset[row]) ? 0.f : ho;
+      if (h_next) h_next[(size_t)row * ldn + d] = (next_reset && next_reset[row]) ? 0.f : ho;
     }
   } else {
     float s0 = 0.f, s1 = 0.f;
@@ -502,10 +503,10 @@ __global__ void __launch_bounds__(256) gru_norm_fwd_kernel(int rows, int D, cons
       const float n = tanhf((sr[2 * D + d] - m2) * r2 * lp.g[2][d] + lp.b[2][d]);
       const float ho = u * n + (1.f - u) * hr[d];
       h_out[(size_t)row * ldo + d] = ho;
-      if (h_next) h_next[(size_t)row * D + d] = (next_reset && next_reset[row]) ? 0.f : ho;
+      if (h_next) h_next[(size_t)row * ldn + d] = (next_reset && next_reset[row]) ? 0.f : ho;
     }
   }
-  if (lane < 6) gst[(size_t)row * 6 + lane] = st[lane];
+  if (lane < 6) gst[(size_t)row * ldst + lane] = st[lane];
 }
 
 // dgi, dgh (rows,3D): gradients w.r.t. the two gate products; dg (rows,3D): gradients w.r.t. the LayerNorm OUTPUTS (for
@@ -517,18 +518,18 @@ __global__ void __launch_bounds__(256) gru_norm_bwd_kernel(int rows, int D, cons
                                                            const GruLnParams lp, const float* __restrict__ dh_out, int lddh,
                                                            float* __restrict__ dgi, float* __restrict__ dgh,
                                                            float* __restrict__ dg, float* __restrict__ dh_in, int lddi,
-                                                           const uint8_t* __restrict__ row_zero) {
+                                                           const uint8_t* __restrict__ row_zero, int ldg, int ldst) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* sr = gs + (size_t)row * 3 * D;
-  const float* ghr = gh + (size_t)row * 3 * D;
+  const float* sr = gs + (size_t)row * ldg;
+  const float* ghr = gh + (size_t)row * ldg;
   const float* hr = h_in + (size_t)row * ldh;
   const float* dhr = dh_out + (size_t)row * lddh;
-  float* dgr = dg + (size_t)row * 3 * D;
-  float* dgir = dgi + (size_t)row * 3 * D;
-  float* dghr = dgh + (size_t)row * 3 * D;
-  const float* st = gst + (size_t)row * 6;
+  float* dgr = dg + (size_t)row * ldg;
+  float* dgir = dgi + (size_t)row * ldg;
+  float* dghr = dgh + (size_t)row * ldg;
+  const float* st = gst + (size_t)row * ldst;
   const bool rz = row_zero && row_zero[row];
   if (KIND == 2) {
     const float mean = st[0], rstd = st[1];
@@ -608,7 +609,8 @@ __global__ void __launch_bounds__(256) gru_norm_bwd_kernel(int rows, int D, cons
 // c are gst[r][2*(c / D)] (KIND 1: one LayerNorm per third) or gst[r][0] (KIND 2).  64 columns x 4 row lanes per block.
 __global__ void __launch_bounds__(256) gru_norm_param_grads_kernel(int kind, int rows, int D, const float* __restrict__ gs,
                                                                    const float* __restrict__ gst, const float* __restrict__ dg,
-                                                                   float* __restrict__ dgam, float* __restrict__ dbet) {
+                                                                   float* __restrict__ dgam, float* __restrict__ dbet, int ldg,
+                                                                   int ldst) {
   __shared__ float red[2][4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -616,8 +618,8 @@ __global__ void __launch_bounds__(256) gru_norm_param_grads_kernel(int kind, int
   if (col < 3 * D) {
     const int q = kind == 1 ? col / D : 0;
     for (int r = ry; r < rows; r += 4) {
-      const float v = dg[(size_t)r * 3 * D + col];
-      const float xh = (gs[(size_t)r * 3 * D + col] - gst[(size_t)r * 6 + 2 * q]) * gst[(size_t)r * 6 + 2 * q + 1];
+      const float v = dg[(size_t)r * ldg + col];
+      const float xh = (gs[(size_t)r * ldg + col] - gst[(size_t)r * ldst + 2 * q]) * gst[(size_t)r * ldst + 2 * q + 1];
       a += v * xh;
       b += v;
     }
@@ -632,39 +634,47 @@ __global__ void __launch_bounds__(256) gru_norm_param_grads_kernel(int kind, int
 
 int dm_gru_norm_fwd_launch(int kind, int rows, int D, const float* gi, const float* gh, const float* h_in, int ldh,
                            const float* const* ln_g, const float* const* ln_b, float* h_out, int ldo, float* gs, float* gst,
-                           float* h_next, const uint8_t* next_reset, hipStream_t st) {
+                           float* h_next, const uint8_t* next_reset, hipStream_t st, int ldg, int ldst, int ldn) {
   if (rows <= 0) return DM_OK;
+  if (ldg <= 0) ldg = 3 * D;
+  if (ldst <= 0) ldst = 6;
+  if (ldn <= 0) ldn = D;
   GruLnParams lp;
   for (int i = 0; i < 3; ++i) { lp.g[i] = ln_g[i]; lp.b[i] = ln_b[i]; }
   if (kind == 1)
     hipLaunchKernelGGL((gru_norm_fwd_kernel<1>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gi, gh, h_in, ldh, lp, h_out,
-                       ldo, gs, gst, h_next, next_reset);
+                       ldo, gs, gst, h_next, next_reset, ldg, ldst, ldn);
   else
     hipLaunchKernelGGL((gru_norm_fwd_kernel<2>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gi, gh, h_in, ldh, lp, h_out,
-                       ldo, gs, gst, h_next, next_reset);
+                       ldo, gs, gst, h_next, next_reset, ldg, ldst, ldn);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
 int dm_gru_norm_bwd_launch(int kind, int rows, int D, const float* gh, const float* h_in, int ldh, const float* gs,
                            const float* gst, const float* const* ln_g, const float* const* ln_b, const float* dh_out, int lddh,
-                           float* dgi, float* dgh, float* dg, float* dh_in, int lddi, const uint8_t* row_zero, hipStream_t st) {
+                           float* dgi, float* dgh, float* dg, float* dh_in, int lddi, const uint8_t* row_zero, hipStream_t st,
+                           int ldg, int ldst) {
   if (rows <= 0) return DM_OK;
+  if (ldg <= 0) ldg = 3 * D;
+  if (ldst <= 0) ldst = 6;
   GruLnParams lp;
   for (int i = 0; i < 3; ++i) { lp.g[i] = ln_g[i]; lp.b[i] = ln_b[i]; }
   if (kind == 1)
     hipLaunchKernelGGL((gru_norm_bwd_kernel<1>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gh, h_in, ldh, gs, gst, lp,
-                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero);
+                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero, ldg, ldst);
   else
     hipLaunchKernelGGL((gru_norm_bwd_kernel<2>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, D, gh, h_in, ldh, gs, gst, lp,
-                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero);
+                       dh_out, lddh, dgi, dgh, dg, dh_in, lddi, row_zero, ldg, ldst);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
 // dgam / dbet: 3D-float vectors laid out like the LayerNorm outputs ([reset | update | newval] thirds)
 int dm_gru_norm_param_grads_launch(int kind, int rows, int D, const float* gs, const float* gst, const float* dg, float* dgam,
-                                   float* dbet, hipStream_t st) {
+                                   float* dbet, hipStream_t st, int ldg, int ldst) {
+  if (ldg <= 0) ldg = 3 * D;
+  if (ldst <= 0) ldst = 6;
   hipLaunchKernelGGL(gru_norm_param_grads_kernel, dim3(dm_cdiv(3 * D, 64)), dim3(256), 0, st, kind, rows, D, gs, gst, dg, dgam,
-                     dbet);
+                     dbet, ldg, ldst);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -14,7 +14,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 5; }
+extern "C" int dm_version(void) { return 6; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -93,7 +93,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
-                       3 * pad64(N * 3 * D) + pad64(N * 6) + pad64(N * Z) +
+                       3 * pad64(N * 3 * D) + pad64(N * 6 * 4) + pad64(N * Z) +      // (LayerNorm-GRU statistics: 6 per stack layer)
                        pad64(25 * 512 * (((D + Z + 31) / 32) + (L > 0 ? L - 1 : 0) * ((Hm + 31) / 32))) +   // + fragment-major actor weights
                        pad64(Z * Hd) + pad64(A * Hd) + pad64(N * (size_t)s->S) + pad64(N);   // + z_mlp^T, a_mlp^T and the sampled indices (z_embed)
   size_t m = enc_bwd;

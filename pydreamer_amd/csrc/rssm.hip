@@ -15,7 +15,7 @@
 
 struct RssmActs {
   float *ea, *ee, *hin, *zin, *x1, *st1, *za, *gi, *gh, *x2, *st2, *pin, *x3, *st3, *prin;
-  float *gs, *gst;      // LayerNorm GRU cells: pre-LayerNorm gate sums (N,3D) and their statistics (N,6)
+  float *gs, *gst;      // LayerNorm GRU cells: pre-LayerNorm gate sums (N,3D) and their statistics (N,6 per stack layer)
 };
 static inline int rssm_gru_kind(const dm_shape* s) { return (s->flags & DM_FLAG_GRU_MASK) >> DM_FLAG_GRU_SHIFT; }
 static inline int rssm_gru_layers(const dm_shape* s) {
@@ -32,7 +32,7 @@ static size_t rssm_carve(const dm_shape* s, float* base, RssmActs* a) {
   t.x2 = ar.take(N * Hd); t.st2 = ar.take(N * 2); t.pin = ar.take(N * Hd);
   t.x3 = ar.take(N * Hd); t.st3 = ar.take(N * 2); t.prin = ar.take(N * Hd);
   const bool lncell = rssm_gru_kind(s) != 0;
-  t.gs = ar.take(lncell ? N * 3 * D : 0); t.gst = ar.take(lncell ? N * 6 : 0);
+  t.gs = ar.take(lncell ? N * 3 * D : 0); t.gst = ar.take(lncell ? N * 6 * rssm_gru_layers(s) : 0);
   if (a) *a = t;
   return ar.off;
 }
@@ -48,23 +48,36 @@ static int rssm_check(const dm_shape* s) {
   DM_REQUIRE((s->D & 3) == 0, DM_E_SHAPE, "rssm: deter_dim must be a multiple of 4 (got %d)", s->D);
   DM_REQUIRE(rssm_gru_kind(s) <= 2, DM_E_SHAPE, "rssm: unknown recurrent cell kind %d", rssm_gru_kind(s));
   const int GL = rssm_gru_layers(s);
-  DM_REQUIRE(GL == 1 || rssm_gru_kind(s) == 0, DM_E_SHAPE, "rssm: gru_layers=%d needs gru_type=gru", GL);
   DM_REQUIRE(s->D % (4 * GL) == 0, DM_E_SHAPE, "rssm: deter_dim=%d must be a multiple of 4*gru_layers (%d)", s->D, 4 * GL);
   return DM_OK;
 }
 
-// GRUCellStack (rnn.py:40-67): L plain GRU cells of width ls = D/L.  Layer i reads x_i (x_0 = the cell input, x_i = the NEW
+// GRUCellStack (rnn.py:40-67): L cells (nn.GRUCell, or one of the two LayerNorm cells) of width ls = D/L.  Layer i reads x_i (x_0 = the cell input, x_i = the NEW
 // state of layer i-1) and its own slice [i*ls, (i+1)*ls) of the incoming state, and writes the same slice of the new
-// state.  The gate products of layer i live at columns [3*ls*i, 3*ls*(i+1)) of the (rows, 3D) gi / gh matrices.
+// state.  The gate products of layer i live at columns [3*ls*i, 3*ls*(i+1)) of the (rows, 3D) gi / gh matrices (and of
+// gs / dg for the LayerNorm cells, whose statistics of layer i are columns [6i, 6i+6) of the (rows, 6L) gst matrix).
 struct GruStack {
-  int L, ls;
+  int L, ls, kind;
   const float *wih[4], *whh[4], *bih[4], *bhh[4];
   float *g_wih[4], *g_whh[4], *g_bih[4], *g_bhh[4];
+  const float *lng[4][3], *lnb[4][3];      // LayerNorm cells: (reset, update, newval) or slot 0 = the one 3*ls-wide LayerNorm
+  float *g_lng[4][3], *g_lnb[4][3];
 };
 static int gru_stack(const dm_shape* s, const float* const* p, float* const* g, GruStack* k) {
   k->L = rssm_gru_layers(s);
   k->ls = s->D / k->L;
+  k->kind = rssm_gru_kind(s);
   for (int i = 0; i < k->L; ++i) {
+    const int lb = i == 0 ? DM_RSSM_GRU_LN_G0 : DM_RSSM_GRU_L1_LN_G0 + 6 * (i - 1);
+    for (int q = 0; q < 3; ++q) {
+      k->lng[i][q] = p[lb + 2 * q]; k->lnb[i][q] = p[lb + 2 * q + 1];
+      k->g_lng[i][q] = g ? g[lb + 2 * q] : nullptr; k->g_lnb[i][q] = g ? g[lb + 2 * q + 1] : nullptr;
+      const bool need = k->kind == 1 || (k->kind == 2 && q == 0);
+      DM_REQUIRE(!need || (k->lng[i][q] && k->lnb[i][q]), DM_E_NULL, "rssm: LayerNorm GRU layer %d without LayerNorm parameter %d",
+                 i, q);
+      DM_REQUIRE(!need || !g || (k->g_lng[i][q] && k->g_lnb[i][q]), DM_E_NULL,
+                 "rssm: LayerNorm GRU layer %d without LayerNorm gradient slot %d", i, q);
+    }
     const int b = i == 0 ? DM_RSSM_GRU_WIH : DM_RSSM_GRU_L1_WIH + 4 * (i - 1);
     k->wih[i] = p[b]; k->whh[i] = p[b + 1]; k->bih[i] = p[b + 2]; k->bhh[i] = p[b + 3];
     const bool biased = rssm_gru_kind(s) == 0;      // the LayerNorm cells have no gate biases (rnn.py:99-100)
@@ -154,15 +167,20 @@ static int transpose(hipStream_t st, const float* W, float* Wt, int rows, int co
 // One step of the stack, forward: 3 launches per layer.  `hout` may alias nothing of `hin`.
 static int gru_stack_fwd(hipStream_t st, void* sk, size_t skb, const GruStack& k, int rows, int Hd, int D, const float* x0,
                          const float* hin, int ldh, float* gi, float* gh, float* hout, int ldo, float* h_next,
-                         const uint8_t* next_reset) {
+                         const uint8_t* next_reset, float* gs, float* gst) {
   const int ls = k.ls;
   for (int i = 0; i < k.L; ++i) {
     const float* x = i == 0 ? x0 : hout + (size_t)(i - 1) * ls;
     const int ldx = i == 0 ? Hd : ldo, kin = i == 0 ? Hd : ls;
     DM_TRY(linear(st, sk, skb, rows, 3 * ls, kin, x, ldx, k.wih[i], k.bih[i], nullptr, 0, gi + 3 * ls * i, 3 * D));
     DM_TRY(linear(st, sk, skb, rows, 3 * ls, ls, hin + i * ls, ldh, k.whh[i], k.bhh[i], nullptr, 0, gh + 3 * ls * i, 3 * D));
-    DM_TRY(dm_gru_gates_fwd_launch(rows, ls, gi + 3 * ls * i, gh + 3 * ls * i, hin + i * ls, ldh, hout + i * ls, ldo,
-                                   h_next ? h_next + i * ls : nullptr, next_reset, nullptr, nullptr, st, 3 * D, D));
+    if (k.kind == 0)
+      DM_TRY(dm_gru_gates_fwd_launch(rows, ls, gi + 3 * ls * i, gh + 3 * ls * i, hin + i * ls, ldh, hout + i * ls, ldo,
+                                     h_next ? h_next + i * ls : nullptr, next_reset, nullptr, nullptr, st, 3 * D, D));
+    else
+      DM_TRY(dm_gru_norm_fwd_launch(k.kind, rows, ls, gi + 3 * ls * i, gh + 3 * ls * i, hin + i * ls, ldh, k.lng[i], k.lnb[i],
+                                    hout + i * ls, ldo, gs + 3 * ls * i, gst + 6 * i, h_next ? h_next + i * ls : nullptr,
+                                    next_reset, st, 3 * D, 6 * k.L, D));
   }
   return DM_OK;
 }
@@ -294,7 +312,8 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     // h = GRUCell(za, h_in)                                                             rssm.py:141
     if (stacked) {
       DM_TRY(gru_stack_fwd(st, ws, skb, gk, B, Hd, D, a.za + r0 * Hd, hin, D, a.gi + r0 * 3 * D, a.gh + r0 * 3 * D,
-                           feat + r0 * F, F, hin_next, reset_next));
+                           feat + r0 * F, F, hin_next, reset_next, kind ? a.gs + r0 * 3 * D : nullptr,
+                           kind ? a.gst + r0 * 6 * gk.L : nullptr));
     } else {
       DmGemm gi_q, gh_q;
       gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
@@ -520,9 +539,15 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       for (int i = gk.L - 1; i >= 0; --i) {
         float* dgi_i = dgi + r0 * 3 * D + 3 * ls * i;
         float* dgh_i = dgh + r0 * 3 * D + 3 * ls * i;
-        DM_TRY(dm_gru_gates_bwd_launch(B, ls, a.gi + r0 * 3 * D + 3 * ls * i, a.gh + r0 * 3 * D + 3 * ls * i,
-                                       a.hin + r0 * D + i * ls, D, dft + i * ls, F, dgi_i, dgh_i,
-                                       dprev ? dprev + i * ls : nullptr, F, 1, rz, st, 3 * D));
+        if (kind == 0)
+          DM_TRY(dm_gru_gates_bwd_launch(B, ls, a.gi + r0 * 3 * D + 3 * ls * i, a.gh + r0 * 3 * D + 3 * ls * i,
+                                         a.hin + r0 * D + i * ls, D, dft + i * ls, F, dgi_i, dgh_i,
+                                         dprev ? dprev + i * ls : nullptr, F, 1, rz, st, 3 * D));
+        else
+          DM_TRY(dm_gru_norm_bwd_launch(kind, B, ls, a.gh + r0 * 3 * D + 3 * ls * i, a.hin + r0 * D + i * ls, D,
+                                        a.gs + r0 * 3 * D + 3 * ls * i, a.gst + r0 * 6 * gk.L + 6 * i, gk.lng[i], gk.lnb[i],
+                                        dft + i * ls, F, dgi_i, dgh_i, dgl + r0 * 3 * D + 3 * ls * i,
+                                        dprev ? dprev + i * ls : nullptr, F, rz, st, 3 * D, 6 * gk.L));
         if (i > 0) DM_TRY(dgrad(st, sk, skb, B, 3 * ls, ls, dgi_i, 3 * D, gk.wih[i], dft + (i - 1) * ls, F, 1, nullptr));
         else DM_TRY(dgrad(st, sk, skb, B, 3 * ls, Hd, dgi_i, 3 * D, gk.wih[0], dza + r0 * Hd, Hd, 0, nullptr));
         if (dprev) DM_TRY(dgrad(st, sk, skb, B, 3 * ls, ls, dgh_i, 3 * D, gk.whh[i], dprev + i * ls, F, 1, rz));
@@ -571,8 +596,19 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       const int ldx = i == 0 ? Hd : F, kin = i == 0 ? Hd : ls;
       DM_TRY(wgrad(st, sk, skb, N, 3 * ls, kin, dgi + 3 * ls * i, 3 * D, x, ldx, gk.g_wih[i]));
       DM_TRY(wgrad(st, sk, skb, N, 3 * ls, ls, dgh + 3 * ls * i, 3 * D, a.hin + i * ls, D, gk.g_whh[i]));
-      DM_TRY(dm_colsum_launch(N, 3 * ls, dgi + 3 * ls * i, 3 * D, gk.g_bih[i], sk, skb, st));
-      DM_TRY(dm_colsum_launch(N, 3 * ls, dgh + 3 * ls * i, 3 * D, gk.g_bhh[i], sk, skb, st));
+      if (kind == 0) {
+        DM_TRY(dm_colsum_launch(N, 3 * ls, dgi + 3 * ls * i, 3 * D, gk.g_bih[i], sk, skb, st));
+        DM_TRY(dm_colsum_launch(N, 3 * ls, dgh + 3 * ls * i, 3 * D, gk.g_bhh[i], sk, skb, st));
+      } else {      // the layer's LayerNorm parameters: one column pass over its 3*ls gate columns of all rows
+        DM_TRY(dm_gru_norm_param_grads_launch(kind, N, ls, a.gs + 3 * ls * i, a.gst + 6 * i, dgl + 3 * ls * i, lnpg, lnpb, st,
+                                              3 * D, 6 * gk.L));
+        const int parts = kind == 1 ? 3 : 1;
+        const size_t len = (size_t)(kind == 1 ? ls : 3 * ls) * sizeof(float);
+        for (int q = 0; q < parts; ++q)
+          if (hipMemcpyAsync(gk.g_lng[i][q], lnpg + (size_t)q * ls, len, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(gk.g_lnb[i][q], lnpb + (size_t)q * ls, len, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return dm_fail(DM_E_HIP, "rssm_sequence_bwd: gradient copy failed");
+      }
     }
   } else {
     DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
@@ -637,7 +673,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   float* prior = ar.take((size_t)M * ZP);
   const int kind = rssm_gru_kind(s);
   float* gsw = ar.take(kind ? (size_t)M * 3 * D : 0);
-  float* gstw = ar.take(kind ? (size_t)M * 6 : 0);
+  float* gstw = ar.take(kind ? (size_t)M * 6 * rssm_gru_layers(s) : 0);
   const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
@@ -713,7 +749,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
       DM_TRY(norm_elu_fwd(M, Hd, x1, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, za, Hd, stats, st));
     }
     if (gk.L > 1) {
-      DM_TRY(gru_stack_fwd(st, sk, skb, gk, M, Hd, D, za, cur, F, gi, gh, nxt, F, nullptr, nullptr));
+      DM_TRY(gru_stack_fwd(st, sk, skb, gk, M, Hd, D, za, cur, F, gi, gh, nxt, F, nullptr, nullptr, gsw, gstw));
     } else {
       DM_TRY(linear(st, sk, skb, M, 3 * D, Hd, za, Hd, p[DM_RSSM_GRU_WIH], p[DM_RSSM_GRU_BIH], nullptr, 0, gi, 3 * D));
       DM_TRY(linear(st, sk, skb, M, 3 * D, D, cur, F, p[DM_RSSM_GRU_WHH], p[DM_RSSM_GRU_BHH], nullptr, 0, gh, 3 * D));

@@ -35,9 +35,8 @@ GRU_KINDS = {'gru': 0, 'gru_layernorm': 1, 'gru_layernorm_dv2': 2}
 DM_FLAG_GRU_SHIFT = 5
 _LN_SLOTS = {
     'gru': [None] * 6,
-    'gru_layernorm': ['gru.layers.0.ln_reset.weight', 'gru.layers.0.ln_reset.bias', 'gru.layers.0.ln_update.weight',
-                      'gru.layers.0.ln_update.bias', 'gru.layers.0.ln_newval.weight', 'gru.layers.0.ln_newval.bias'],
-    'gru_layernorm_dv2': ['gru.layers.0.lnorm.weight', 'gru.layers.0.lnorm.bias', None, None, None, None],
+    'gru_layernorm': ['ln_reset.weight', 'ln_reset.bias', 'ln_update.weight', 'ln_update.bias', 'ln_newval.weight', 'ln_newval.bias'],
+    'gru_layernorm_dv2': ['lnorm.weight', 'lnorm.bias', None, None, None, None],
 }
 
 
@@ -52,13 +51,17 @@ def rssm_param_names(gru_type='gru', gru_layers=1):
         ren = {'gru.layers.0.weight_ih': 'gru.layers.0.weight_ih.weight', 'gru.layers.0.weight_hh': 'gru.layers.0.weight_hh.weight',
                'gru.layers.0.bias_ih': None, 'gru.layers.0.bias_hh': None}
         names = [ren.get(n, n) for n in names]
-    names = names + _LN_SLOTS[gru_type]
+    ln = lambda i: [n and f'gru.layers.{i}.{n}' for n in _LN_SLOTS[gru_type]]
+    names = names + ln(0)
+    cell = ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh') if gru_type == 'gru' else ('weight_ih.weight', 'weight_hh.weight', None, None)
     for i in range(1, DM_MAX_GRU_LAYERS):       # GRUCellStack layers 1..3 (rnn.py:56): DM_RSSM_GRU_L{i}_{WIH,WHH,BIH,BHH}
-        names += [f'gru.layers.{i}.{n}' if i < gru_layers else None for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        names += [f'gru.layers.{i}.{n}' if (n and i < gru_layers) else None for n in cell]
+    for i in range(1, DM_MAX_GRU_LAYERS):       # ... and DM_RSSM_GRU_L{i}_LN_* of a stack of LayerNorm cells
+        names += ln(i) if i < gru_layers else [None] * 6
     return names
 
 
-DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER) + 6 + 4 * (DM_MAX_GRU_LAYERS - 1)
+DM_RSSM_NPARAMS = len(RSSM_PARAM_ORDER) + 6 + (4 + 6) * (DM_MAX_GRU_LAYERS - 1)
 
 
 class DreamerHipError(RuntimeError):
@@ -185,6 +188,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+DM_ABI_VERSION = 6      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():
@@ -200,6 +204,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        if handle.dm_version() != DM_ABI_VERSION:
+            raise DreamerHipError(f'{LIB_PATH} has ABI version {handle.dm_version()}, this binding is written for '
+                                  f'{DM_ABI_VERSION}: rebuild it (`make -C pydreamer_amd/csrc`)')
         _lib = handle
     return _lib
 
@@ -292,7 +299,7 @@ def cu_masked_stream(words, device):
 
 
 def rssm_struct(tensors, cls=dm_rssm_params):
-    """tensors: one per slot (rssm_param_names order); trailing slots (the 6 LayerNorm-GRU ones, the 12 of the stack's
+    """tensors: one per slot (rssm_param_names order); trailing slots (the 6 LayerNorm-GRU ones, the 12 + 18 of the stack's
     layers 1..3) may be omitted, absent slots are None."""
     tensors = list(tensors) + [None] * (DM_RSSM_NPARAMS - len(tensors))
     assert len(tensors) == DM_RSSM_NPARAMS

@@ -8,7 +8,7 @@ model, actor, critic — so each of the 4 returned losses supports an independen
 reference (train.py:184-187).  There is no CPU path: tensors must live on a gfx950 device.
 
 Supported configuration (everything else raises NotImplementedError): iwae_samples>=1 (also with the logging flags), gru_type in {gru, gru_layernorm,
-gru_layernorm_dv2}, gru_layers 1..4 for gru (1 for the LayerNorm cells), stoch_discrete>0 or 0 (Gaussian latents, also with iwae_samples>1), layer_norm True or False,
+gru_layernorm_dv2}, gru_layers 1..4, stoch_discrete>0 or 0 (Gaussian latents, also with iwae_samples>1), layer_norm True or False,
 aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
 probe_model='none', no vecobs / reward_input.
 """
@@ -266,13 +266,13 @@ class NormGRUCellLateResetP(_Params):
 
 
 class GRUCellStack(_Params):
-    """rnn.py:40-67; cell_type in {gru, gru_layernorm, gru_layernorm_dv2}.  Up to 4 layers of plain GRU cells (the
-    LayerNorm cells are built for num_layers=1 only): layer i owns columns [i*layer_size, (i+1)*layer_size) of the state."""
+    """rnn.py:40-67; cell_type in {gru, gru_layernorm, gru_layernorm_dv2}, up to 4 layers of any of them: layer i owns
+    columns [i*layer_size, (i+1)*layer_size) of the state."""
 
     def __init__(self, input_size, hidden_size, num_layers, cell_type):
         super().__init__()
         cells = dict(gru=GRUCellP, gru_layernorm=NormGRUCellP, gru_layernorm_dv2=NormGRUCellLateResetP)
-        if cell_type not in cells or not 1 <= num_layers <= H.DM_MAX_GRU_LAYERS or (num_layers > 1 and cell_type != 'gru'):
+        if cell_type not in cells or not 1 <= num_layers <= H.DM_MAX_GRU_LAYERS:
             raise NotImplementedError(f'gru_type={cell_type!r}, gru_layers={num_layers} not built in the HIP path')
         layer_size = hidden_size // num_layers
         assert layer_size * num_layers == hidden_size, 'Must be divisible'

@@ -441,6 +441,16 @@ def test_training_step_gru_cell_stack_vs_oracle(hip, layers, deter):
         _check_pair(r, oconf)
 
 
+@pytest.mark.parametrize('gru_type,layers,deter', [('gru_layernorm', 2, 64), ('gru_layernorm_dv2', 2, 64), ('gru_layernorm', 3, 96),
+                                                   ('gru_layernorm_dv2', 4, 96)])
+def test_training_step_layernorm_cell_stack_vs_oracle(hip, gru_type, layers, deter):
+    """GRUCellStack of the LayerNorm cells (rnn.py:51-57 with rnn.py:95-138): per-layer LayerNorm parameters, no gate biases;
+    every loss, metric and per-parameter gradient of two consecutive steps."""
+    oconf = O.tiny_conf(gru_type=gru_type, gru_layers=layers, deter_dim=deter)
+    for r in _run_pair(oconf, 2):
+        _check_pair(r, oconf)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(actor_dist='tanh_normal', action_dim=4, entropy=1.0e-4), dict(gru_type='gru_layernorm')])
 def test_training_step_no_layernorm_vs_oracle(hip, kw):
     """layer_norm=False (common.py:68-74 NoNorm in every MLP head and in the RSSM cell's three norms; the GRU cell's own
@@ -466,10 +476,10 @@ def test_training_step_matches_reference_goldens(hip):
     the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz, and the auxiliary critic
     of dreamer.py:267-279,347-358: tiny_aux_critic.npz, and the 3-layer GRUCellStack of rnn.py:40-67: tiny_gru_layers3.npz -
     SURVEY 8(f) N4; layer_norm=False, common.py:68-74 NoNorm: tiny_no_layernorm.npz; Gaussian latents, stoch_discrete=0,
-    rssm.py:195-203: tiny_gaussian_latents.npz)."""
+    rssm.py:195-203: tiny_gaussian_latents.npz; a 2-layer stack of NormGRUCells: tiny_gru_layernorm_layers2.npz)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
                         ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2),
-                        ('tiny_gaussian_latents', 2)):
+                        ('tiny_gaussian_latents', 2), ('tiny_gru_layernorm_layers2', 1)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)
