@@ -94,6 +94,11 @@ int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                 const float* bias, const float* add, int ldadd, int flags,
                 void* ws, size_t ws_bytes, void* stream);
+/* The same product with operands STORED as bf16 (conf.amp's weight / activation twins: train.py:166 autocast casts them per
+ * call, here they live in HBM in that format): fp32 accumulation, fp32 C and an optional bf16 twin C_h of it (same ldc).
+ * Leading dimensions in elements; minor extents in multiples of 8, rows 16-byte aligned. */
+int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
+                  float* C, int ldc, uint16_t* C_h, const float* bias, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
 int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,

@@ -90,6 +90,11 @@ struct DmGemm {
   // fills C_frag with a pack launch, so callers may set them unconditionally.
   const float* A_frag = nullptr;
   float* C_frag = nullptr;
+  // bf16-STORAGE operands (both or neither; same layouts, gather tables and leading dimensions, in elements): the product
+  // reads these instead of A / B (gemm_h_kernel).  C_h: optional bf16 twin of the result (same ldc), any operand format.
+  const unsigned short* A_h = nullptr;
+  const unsigned short* B_h = nullptr;
+  unsigned short* C_h = nullptr;
 };
 // Fragment-major layout of a <= 64-row block X[row][k]: the 16 B a lane of v_mfma_f32_16x16x4_f32 loads for a 16-k chunk
 // (lane l: row 16*mb + (l&15), k = 16*c + 4*(l>>4) .. +3) sit at ((c*4 + mb)*4 + (l>>4))*16 + (l&15) in units of 16 B, so

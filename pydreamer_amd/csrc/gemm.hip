@@ -52,6 +52,7 @@ struct GemmKArgs {
   int n_tiles, n_items;
   int tiles_n, n_fast;
   int a_vec, b_vec;
+  unsigned short* Ch;         // optional bf16 twin of C (same ldc), written with the final value
 };
 
 // Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).  Branch-free: out-of-range
@@ -356,6 +357,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MB][NB], const GemmK
               if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
               if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[at]);
               g.C[at] = v;
+              if (g.Ch) g.Ch[at] = (unsigned short)dm_f2bf(v);
             }
           } else if (g.nsplit > 1) {
             g.partial[((size_t)cur.split * g.M + row) * g.N + col] = v;
@@ -368,6 +370,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MB][NB], const GemmK
             if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
             if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
             *c = v;
+            if (g.Ch) g.Ch[(size_t)row * g.ldc + col] = (unsigned short)dm_f2bf(v);
           }
         }
       }
@@ -781,6 +784,180 @@ __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
   gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half);
 }
 
+// ---- bf16-STORAGE tile kernel (conf.amp with operands that already live in HBM as bf16: weight twins kept by the optimizer,
+// activation twins written by the producing epilogue).  The fp32-storage bf16 kernels above run at the rate their fp32 operands
+// arrive (17-18 B/clk/CU = half that in elements); here a k-tile is 64 elements = the same 128 bytes per row and per load
+// instruction pattern, so every byte that arrives carries twice the MACs and nothing is converted on the way:
+//   * layout 0 (k contiguous): 16-byte chunks (8 bf16) go from global memory to the [row][k] LDS image as they are;
+//   * layout 1 (row index contiguous): a chunk is 8 rows at one k; a thread owns NCH consecutive k of the same 8 rows and
+//     transposes them in registers (v_perm) into one 8- / 4-byte LDS write per row;
+//   * two LDS slots, one barrier per k-tile: the chunks of tile t+1 (in registers since the middle of step t-1) are written
+//     between the two halves of step t's MFMAs and the loads of tile t+2 are issued right behind them;
+//   * edge rows read a clamped row, k groups past the end read a page of zeros (K % 8 == 0): no masks.
+// LDS row stride 72 bf16 (144 bytes): the ds_read_b128 fragment reads of 16 consecutive rows tile the 64 banks exactly.
+// The 16-byte k-chunks of a row are XOR-swizzled with bits 4-6 of the row index (hswz): the transposing writes of a layout-1
+// operand come from lanes 8 rows apart (8 * 144 B = 32 banks), which without the swizzle land 8-way on two bank groups.
+constexpr int LDH = 72;
+typedef unsigned int dm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int hswz(int row, int k) { return (k & 7) | ((((k >> 3) ^ (row >> 4)) & 7) << 3); }   // k in [0,64)
+template <int ROWS, int LAYOUT, bool GATHER>
+struct HOperand {
+  static constexpr int NCH = ROWS * 8 / 256;                 // 16-byte chunks per thread per 64-k tile
+  static constexpr int CPK = ROWS / 8;                       // layout 1: chunks per k
+  static constexpr bool KSEQ = LAYOUT == 1 && 256 % CPK == 0 && (256 / CPK) * NCH == 64 && (NCH == 2 || NCH == 4);
+  const unsigned short* P;
+  const int* tvar;
+  int ld;
+  int off[NCH], kin[NCH];
+  __device__ __forceinline__ void init(const unsigned short* P_, int ld_, int row0, int nrows, const int* tmaj, const int* tmin,
+                                       int tid) {
+    P = P_; ld = ld_;
+    tvar = LAYOUT == 0 ? tmin : tmaj;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int f = tid + i * 256;
+      if (LAYOUT == 0) {
+        const int row = min(row0 + (f >> 3), nrows - 1);
+        kin[i] = (f & 7) << 3;
+        off[i] = GATHER ? tmaj[row] : row * ld + kin[i];
+      } else {
+        kin[i] = KSEQ ? (tid / CPK) * NCH + i : f / CPK;
+        const int col = min(row0 + (((KSEQ ? tid : f) % CPK) << 3), nrows - 8);
+        off[i] = GATHER ? tmin[col] : kin[i] * ld + col;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(dm_u32x4 (&r)[NCH], int k0, int kend, bool nt = false) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const bool ok = k0 + kin[i] < kend;
+      size_t at;
+      if (LAYOUT == 0) at = GATHER ? (size_t)off[i] + (size_t)tvar[ok ? k0 + kin[i] : 0] : (size_t)off[i] + (size_t)k0;
+      else at = GATHER ? (size_t)off[i] + (size_t)tvar[ok ? k0 + kin[i] : 0] : (size_t)k0 * ld + (size_t)off[i];
+      typedef const __attribute__((address_space(1))) dm_u32x4* gptr4;
+      const uintptr_t src = ok ? (uintptr_t)(P + at) : (uintptr_t)dm_zero_page;
+      if (nt) r[i] = __builtin_nontemporal_load(reinterpret_cast<gptr4>(src));
+      else r[i] = *reinterpret_cast<gptr4>(src);
+    }
+  }
+  __device__ __forceinline__ void stash(const dm_u32x4 (&r)[NCH], unsigned short* S, int tid) const {
+    if (LAYOUT == 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int f = tid + i * 256;
+        *reinterpret_cast<dm_u32x4*>(&S[(f >> 3) * LDH + hswz(f >> 3, (f & 7) << 3)]) = r[i];
+      }
+    } else if (KSEQ) {       // r[i][p] = rows (r8 + 2p, r8 + 2p + 1) at k = kq + i
+      const int kq = (tid / CPK) * NCH, r8 = (tid % CPK) << 3;
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        unsigned short* d0 = &S[(r8 + 2 * p2) * LDH + hswz(r8, kq)];      // rows r8 .. r8+7 share row >> 4
+        const unsigned lo01 = __builtin_amdgcn_perm(r[NCH > 1 ? 1 : 0][p2], r[0][p2], 0x05040100u);
+        const unsigned hi01 = __builtin_amdgcn_perm(r[NCH > 1 ? 1 : 0][p2], r[0][p2], 0x07060302u);
+        if (NCH == 4) {
+          const unsigned lo23 = __builtin_amdgcn_perm(r[NCH - 1][p2], r[NCH > 2 ? 2 : 0][p2], 0x05040100u);
+          const unsigned hi23 = __builtin_amdgcn_perm(r[NCH - 1][p2], r[NCH > 2 ? 2 : 0][p2], 0x07060302u);
+          *reinterpret_cast<uint2*>(d0) = make_uint2(lo01, lo23);
+          *reinterpret_cast<uint2*>(d0 + LDH) = make_uint2(hi01, hi23);
+        } else {
+          *reinterpret_cast<unsigned*>(d0) = lo01;
+          *reinterpret_cast<unsigned*>(d0 + LDH) = hi01;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int f = tid + i * 256;
+        const int kk = f / CPK, r8 = (f % CPK) << 3;
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          S[(r8 + 2 * p2) * LDH + hswz(r8, kk)] = (unsigned short)(r[i][p2] & 0xFFFFu);
+          S[(r8 + 2 * p2 + 1) * LDH + hswz(r8, kk)] = (unsigned short)(r[i][p2] >> 16);
+        }
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int AL, int BL, bool GA, bool GB, int WGM, int WGN, bool SC>
+__global__ void __launch_bounds__(256, 2) gemm_h_kernel(const GemmKArgs g) {
+  static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
+  constexpr int BK = 64;
+  constexpr int MB = BM / (32 * WGM), NB = BN / (32 * WGN);
+  constexpr int SLOT = (BM + BN) * LDH;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * SLOT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const GemmItem cur = gemm_decode<BM, BN>(g, blockIdx.x);
+  const int nkt = cur.kend > cur.kbeg ? (cur.kend - cur.kbeg + BK - 1) / BK : 0;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    typedef HOperand<BM, AL, GA> OA;
+    typedef HOperand<BN, BL, GB> OB;
+    OA sa;
+    OB sb;
+    sa.init(reinterpret_cast<const unsigned short*>(g.A), g.lda, cur.m0, g.M, g.a_maj, g.a_min, tid);
+    sb.init(reinterpret_cast<const unsigned short*>(g.B), g.ldb, cur.n0, g.N, g.b_maj, g.b_min, tid);
+    dm_u32x4 ra[OA::NCH], rb[OB::NCH];
+    const bool nt = (g.flags & (1 << 20)) != 0;        // experiment switch DM_GEMM_H_NT: non-temporal operand loads
+    sa.load(ra, cur.kbeg, cur.kend, nt);
+    sb.load(rb, cur.kbeg, cur.kend, nt);
+    sa.stash(ra, smem, tid);
+    sb.stash(rb, smem + BM * LDH, tid);
+    if (nkt > 1) {
+      sa.load(ra, cur.kbeg + BK, cur.kend, nt);
+      sb.load(rb, cur.kbeg + BK, cur.kend, nt);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const unsigned short* Ah = smem + (kt & 1) * SLOT;
+      const unsigned short* Bh = Ah + BM * LDH;
+      unsigned short* Aw = smem + ((kt & 1) ^ 1) * SLOT;
+      unsigned short* Bw = Aw + BM * LDH;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 a8[MB], b8[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          a8[mb] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * (BM / WGM) + mb * 32 + l31) * LDH +
+                                                        hswz(wm * (BM / WGM) + mb * 32 + l31, ks * 16 + half * 8)]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          b8[nb] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / WGN) + nb * 32 + l31) * LDH +
+                                                        hswz(wn * (BN / WGN) + nb * 32 + l31, ks * 16 + half * 8)]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mb], b8[nb], acc[mb][nb], 0, 0, 0);
+        if (ks == 1) {      // middle of the step: tile kt+1 registers -> the other slot, then the loads of tile kt+2
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt + 1 < nkt) {
+            sa.stash(ra, Aw, tid);
+            sb.stash(rb, Bw, tid);
+          }
+          if (kt + 2 < nkt) {
+            sa.load(ra, cur.kbeg + (kt + 2) * BK, cur.kend, nt);
+            sb.load(rb, cur.kbeg + (kt + 2) * BK, cur.kend, nt);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half);
+}
+
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs g) {
   const size_t total = (size_t)g.M * g.N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -807,6 +984,7 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs
     if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
     if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
     *c = v;
+    if (g.Ch) g.Ch[(size_t)row * g.ldc + col] = (unsigned short)dm_f2bf(v);
   }
 }
 
@@ -919,6 +1097,31 @@ static int gemm_pipe_tiles(int tc, const GemmKArgs& a, int al, int bl, int gathe
   return gemm_pipe_dispatch<64, 64, 2, 2, PR>(a, al, bl, gather, grid, stream);
 }
 
+template <int BM, int BN, int WGM, int WGN>
+static int gemm_h_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
+  if (a.c_tab) {
+    if (gather != 1 || al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0)");
+    hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 0, 0, true, false, WGM, WGN, true>), grid, dim3(256), 0, stream, a);
+  } else if (gather == 1) {
+    if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
+    hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 0, 0, true, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  } else if (gather == 2) {
+    if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
+    hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 1, 1, false, true, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 0, 0, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 0, 1, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 1, 0, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_h_kernel<BM, BN, 1, 1, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  return DM_OK;
+}
+static int gemm_h_tiles(int tc, const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
+  if (tc == 0) return gemm_h_dispatch<128, 128, 2, 2>(a, al, bl, gather, grid, stream);
+  if (tc == 1) return gemm_h_dispatch<128, 64, 2, 2>(a, al, bl, gather, grid, stream);
+  if (tc == 3) return gemm_h_dispatch<128, 96, 4, 1>(a, al, bl, gather, grid, stream);
+  if (tc == 4) return gemm_h_dispatch<96, 128, 1, 4>(a, al, bl, gather, grid, stream);
+  return gemm_h_dispatch<64, 64, 2, 2>(a, al, bl, gather, grid, stream);
+}
+
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
 template <int BM, int BN, bool V, int WGM = 2, int WGN = 2, int BF = 0>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
@@ -959,7 +1162,8 @@ DmPrecisionScope::~DmPrecisionScope() { tl_precision = prev; }
 int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t stream) {
   DM_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1, DM_E_SHAPE, "gemm: bad dims M=%d N=%d K=%d (K must be >= 1)", q.M, q.N, q.K);
   if (q.M == 0 || q.N == 0) return DM_OK;
-  DM_REQUIRE(q.A && q.B && q.C, DM_E_NULL, "gemm: null operand");
+  DM_REQUIRE(((q.A && q.B) || (q.A_h && q.B_h)) && q.C, DM_E_NULL, "gemm: null operand");
+  DM_REQUIRE((q.A_h == nullptr) == (q.B_h == nullptr), DM_E_NULL, "gemm: bf16-storage operands come in pairs");
   DM_REQUIRE((unsigned)q.a_layout < 2 && (unsigned)q.b_layout < 2, DM_E_SHAPE, "gemm: bad layout");
   DM_REQUIRE(q.a_maj || q.lda >= (q.a_layout == 0 ? q.K : q.M), DM_E_SHAPE, "gemm: lda %d too small", q.lda);
   DM_REQUIRE(q.b_maj || q.ldb >= (q.b_layout == 0 ? q.K : q.N), DM_E_SHAPE, "gemm: ldb %d too small", q.ldb);
@@ -969,13 +1173,21 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   DM_REQUIRE(!q.add || q.ldadd >= q.N, DM_E_SHAPE, "gemm: ldadd %d < N %d", q.ldadd, q.N);
 
   {   // <= 64-row products of the sequential RSSM chains: one-launch skinny kernel (gemm_skinny.hip)
-    const int sk = dm_gemm_skinny_try(q, stream);
+    const int sk = (q.A_h || q.C_h) ? 0 : dm_gemm_skinny_try(q, stream);
     if (sk < 0) return sk;
     if (sk == 1) return DM_OK;
   }
   DM_REQUIRE(!q.ln_g && !q.lnb_x && !q.gates, DM_E_SHAPE,
              "gemm: LayerNorm prologues / the gates epilogue are built for the <= 64-row skinny products only (M=%d K=%d)", q.M, q.K);
+  // bf16-storage operands (both or neither): 16-byte chunks of 8 elements along the minor axis
+  const bool hstore = q.A_h && q.B_h;
+  DM_REQUIRE(!hstore || ((((uintptr_t)q.A_h | (uintptr_t)q.B_h) & 15) == 0 && ((q.K & 7) == 0 || (q.a_layout == 1 && q.b_layout == 1)) &&
+                         (q.a_maj ? q.a_tab_vec >= 8 : (q.lda & 7) == 0) && (q.b_maj ? q.b_tab_vec >= 8 : (q.ldb & 7) == 0) &&
+                         (q.a_layout == 0 || ((q.M & 7) == 0 && q.M >= 8)) && (q.b_layout == 0 || ((q.N & 7) == 0 && q.N >= 8))),
+             DM_E_SHAPE, "gemm: bf16-storage operands need 16-byte aligned rows and extents in multiples of 8 (M=%d N=%d K=%d)",
+             q.M, q.N, q.K);
   GemmKArgs a;
+  a.Ch = q.C_h;
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.mulref = q.mulref; a.row_zero = q.row_zero; a.partial = nullptr;
   a.M = q.M; a.N = q.N; a.K = q.K;
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
@@ -984,11 +1196,16 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.c_tab = q.c_tab; a.sc_cout = q.sc_cout; a.sc_wpitch = q.sc_wpitch; a.bias_mod = q.bias_mod;
   DM_REQUIRE(!q.c_tab || (q.sc_cout > 0 && q.N % q.sc_cout == 0 && q.N / q.sc_cout == 4 && !q.add && !(q.flags & DM_GEMM_ACCUM)),
              DM_E_SHAPE, "gemm: scatter epilogue needs N = 4 * sc_cout, no addend, no accumulate");
+  if (hstore) {
+    a.A = reinterpret_cast<const float*>(q.A_h); a.B = reinterpret_cast<const float*>(q.B_h);
+    static const int h_nt = getenv("DM_GEMM_H_NT") ? 1 : 0;
+    if (h_nt) a.flags |= 1 << 20;
+  }
   // 16-byte load path: aligned base, rows a multiple of 4 floats apart, and the vectorised (minor) extent a multiple
   // of 4 so that no group of 4 straddles the edge.  Minor extent: K for layout 0, M (resp. N) for layout 1.
-  a.a_vec = (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0) &&
+  a.a_vec = hstore ? 1 : (((uintptr_t)q.A & 15) == 0 && (q.a_maj ? q.a_tab_vec != 0 : (q.lda & 3) == 0) &&
              (((q.a_layout == 0 ? q.K : q.M) & 3) == 0)) ? 1 : 0;
-  a.b_vec = (((uintptr_t)q.B & 15) == 0 && (q.b_maj ? q.b_tab_vec != 0 : (q.ldb & 3) == 0) &&
+  a.b_vec = hstore ? 1 : (((uintptr_t)q.B & 15) == 0 && (q.b_maj ? q.b_tab_vec != 0 : (q.ldb & 3) == 0) &&
              (((q.b_layout == 0 ? q.K : q.N) & 3) == 0)) ? 1 : 0;
 
   // ---- tile / split-K selection (deterministic in the shape only) ------------------------------------------------
@@ -1116,7 +1333,8 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   static const int no_pipe = getenv("DM_GEMM_NO_PIPE") ? 1 : 0;      // A/B switch: the single-stage loop for the bf16-pipe modes
   // the pipelined kernel clamps edge rows instead of masking them: it needs >= 1 full row (layout 0) / >= 4 (layout 1 groups)
   const bool pipe_ok = vec && !no_pipe && (q.a_layout == 0 ? q.M >= 1 : q.M >= 4) && (q.b_layout == 0 ? q.N >= 1 : q.N >= 4);
-  if (pipe_ok && q.bf16) rc = gemm_pipe_tiles<1>(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
+  if (hstore) rc = gemm_h_tiles(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
+  else if (pipe_ok && q.bf16) rc = gemm_pipe_tiles<1>(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
   else if (pipe_ok && dm_fp32_split() && gather == 0 && q.a_layout == 0 && q.b_layout == 0)      // where the pipelined split wins
     rc = gemm_pipe_tiles<2>(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
   else if (vec && q.bf16) {
@@ -1166,5 +1384,21 @@ extern "C" int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K, cons
   g.M = M; g.N = N; g.K = K;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.add = add; g.ldadd = ldadd; g.flags = flags & ~DM_GEMM_BF16;
+  return dm_gemm_launch(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// bf16-STORAGE product (operands already bf16 in HBM; fp32 accumulation and fp32 result, optional bf16 twin of the result):
+// the primitive behind conf.amp's weight / activation twins.  Same layouts and leading-dimension meaning (in elements) as
+// dm_gemm_f32; extents along the minor axis in multiples of 8, 16-byte aligned rows.
+extern "C" int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
+                             int ldb, float* C, int ldc, uint16_t* C_h, const float* bias, int flags, void* ws, size_t ws_bytes,
+                             void* stream) {
+  DmPrecisionScope prec(1);
+  DmGemm g;
+  g.a_layout = a_layout; g.b_layout = b_layout;
+  g.M = M; g.N = N; g.K = K;
+  g.A_h = A; g.lda = lda; g.B_h = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.C_h = C_h;
+  g.bias = bias;
+  g.flags = flags & ~DM_GEMM_BF16;
   return dm_gemm_launch(g, ws, ws_bytes, (hipStream_t)stream);
 }

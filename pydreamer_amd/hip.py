@@ -112,6 +112,7 @@ _SIGNATURES = {
     'dm_stream_destroy': (c_int, [_P]),
     'dm_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int,
                             _P, c_size_t, _P]),
+    'dm_gemm_bf16h': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     'dm_ln_elu_fwd': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_float, _P, c_int, _P, _P]),
     'dm_ln_elu_bwd': (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_size_t, _P]),
     'dm_colsum': (c_int, [c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
