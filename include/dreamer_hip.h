@@ -99,6 +99,11 @@ int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
  * Leading dimensions in elements; minor extents in multiples of 8, rows 16-byte aligned. */
 int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
                   float* C, int ldc, uint16_t* C_h, const float* bias, int flags, void* ws, size_t ws_bytes, void* stream);
+/* Calls with DM_FLAG_BF16 keep bf16 twins of their activations / per-call weight copies and feed them to dm_gemm_bf16h's
+ * kernel (activation arenas of such calls are larger: the *_acts_floats functions account for it; acts handed to a backward
+ * entry point must come from a forward call with the same flags).  1 / 0 switches that path on / off, -1 queries; returns
+ * the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
+int dm_bf16_twins_enable(int on);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
 int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,

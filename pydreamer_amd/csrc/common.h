@@ -57,6 +57,31 @@ struct DmPrecisionScope {
   ~DmPrecisionScope();
 };
 
+// ---- bf16 twins (conf.amp: operands STORED as bf16, gemm.hip gemm_h_kernel) ---------------------------------------------
+// A composite entry point running in bf16 mode opens a DmTwinScope and registers, for each fp32 buffer it wants a bf16 copy
+// of, the range and the twin's storage (scratch of its workspace, or a region of its activation arena when the backward
+// pass needs the copy too).  dm_gemm_launch then (a) writes the twin of any result that lands in a registered range from its
+// epilogue and marks it valid, (b) reads twins instead of fp32 operands when BOTH operands of a product have a valid one.
+// Other producers (direct convolutions, pad / col2im / loss kernels) write their twin themselves and call dm_twin_mark.
+// The map is thread-local and dies with the scope: nothing is remembered between calls (a backward entry point re-registers
+// the arena twins its forward wrote as valid - acts must come from a forward call with the same dm_shape.flags).
+// DM_BF16_NO_TWINS=1 (A/B switch) makes every scope inactive: the fp32-storage bf16 products of rounds 1-2.
+struct DmTwinScope {
+  bool active, opened;
+  explicit DmTwinScope(bool bf16_mode);
+  ~DmTwinScope();
+};
+bool dm_twins_on();                       // a scope is active on this thread
+void dm_twin_add(const float* base, size_t n, unsigned short* twin, bool valid);
+void dm_twin_mark(const float* p);        // the range holding p now has a complete twin
+unsigned short* dm_twin_of(const float* p, bool need_valid);      // twin address of element p, or nullptr
+// dst[i] = bf16(src[i]) for up to 8 segments in one launch (weights of a call, small activations)
+struct DmCvtSeg { const float* src; unsigned short* dst; size_t n; };
+int dm_to_bf16_multi_launch(const DmCvtSeg* segs, int count, hipStream_t st);
+static inline size_t dm_half_floats(size_t elems) { return (elems + 1) / 2; }      // floats that hold `elems` bf16
+constexpr int DM_HSTORE_MIN_K = 1024;     // k-contiguous gathered / scattered products shorter than this stay on the fp32-storage kernels (gemm.hip)
+constexpr int DM_HSTORE_MIN_K_DENSE = 400;
+
 // ---- internal (C++) entry points shared between translation units -------------------------------
 struct DmGatesBwd;
 struct DmGemm {
@@ -74,6 +99,7 @@ struct DmGemm {
   // of the layout (row for layout 0, k for layout 1); *_tab_vec: 4 consecutive minors are 4 aligned consecutive floats
   const int* a_maj = nullptr; const int* a_min = nullptr; int a_tab_vec = 0;
   const int* b_maj = nullptr; const int* b_min = nullptr; int b_tab_vec = 0;
+  int a_tab_vec8 = 0, b_tab_vec8 = 0;             // ... and 8 consecutive minors are 8 consecutive, 16-byte aligned bf16 of the twin
   int flags = 0;
   // scatter epilogue of the class-concatenated transposed convolution (see gemm.hip SC / conv.hip): c_tab[row] = {float
   // offset of the row's class-(0,0) output pixel, bit 1: odd output row exists, bit 0: odd output column exists}
@@ -95,6 +121,7 @@ struct DmGemm {
   const unsigned short* A_h = nullptr;
   const unsigned short* B_h = nullptr;
   unsigned short* C_h = nullptr;
+  bool no_twin = false;                           // do not write the result's twin even if the call's twin map has room for it
 };
 // Fragment-major layout of a <= 64-row block X[row][k]: the 16 B a lane of v_mfma_f32_16x16x4_f32 loads for a 16-k chunk
 // (lane l: row 16*mb + (l&15), k = 16*c + 4*(l>>4) .. +3) sit at ((c*4 + mb)*4 + (l>>4))*16 + (l&15) in units of 16 B, so
@@ -202,7 +229,7 @@ int dm_permute4_launch(const float* src, float* dst, int d0, int d1, int d2, int
 // direct small-channel convolutions (conv_direct.hip): encoder layer 1 (3 -> d, k4 s2) and decoder layer 4 (d -> 3, k6 s2)
 bool dm_enc_l1_direct_ok(int ch, int d, int img);
 int dm_enc_l1_fwd_launch(int frames, int d, int u8, const void* image, const float* w, const float* bias, float* wt, float* y,
-                         hipStream_t st);
+                         unsigned short* y_h, hipStream_t st);
 size_t dm_enc_l1_wgrad_part_floats(int frames, int d);
 int dm_enc_l1_wgrad_launch(int frames, int d, int u8, const void* image, const float* G, float* part, float* dW, void* ws,
                            size_t ws_bytes, hipStream_t st);

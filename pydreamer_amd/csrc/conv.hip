@@ -73,7 +73,7 @@ template <int VEC>
 __global__ void __launch_bounds__(256) col2im_s2_kernel(int n, int hb, int wb, int c, int k, int hs, int ws,
                                                         const float* __restrict__ col, const float* __restrict__ bias,
                                                         int flags, const float* __restrict__ elu_ref,
-                                                        float* __restrict__ big) {
+                                                        float* __restrict__ big, unsigned short* __restrict__ big_h) {
   const int cv = c / VEC;
   const size_t total = (size_t)n * hb * wb * cv;
   const size_t rowlen = (size_t)k * k * c;
@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) col2im_s2_kernel(int n, int hb, int wb, i
       if (flags & DM_C2I_ELU) v = dm_elu(v);
       if (elu_ref) v *= dm_elu_grad_from_y(elu_ref[dst + q]);
       big[dst + q] = v;
+      if (big_h) big_h[dst + q] = (unsigned short)dm_f2bf(v);
     }
   }
 }
@@ -145,12 +146,14 @@ int dm_col2im_s2_launch(int n, int hb, int wb, int c, int k, const float* col, c
   const int hs = (hb - k) / 2 + 1, ws = (wb - k) / 2 + 1;
   const size_t total = (size_t)n * hb * wb * c;
   if (total == 0) return DM_OK;
+  unsigned short* big_h = dm_twin_of(big, false);      // bf16 mode: the result's twin (common.h DmTwinScope), written here
+  if (big_h) dm_twin_mark(big);
   if ((c & 3) == 0 && (((uintptr_t)big | (uintptr_t)col) & 15) == 0) {
     hipLaunchKernelGGL((col2im_s2_kernel<4>), dim3(grid_for(total / 4)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, col,
-                       bias, flags, elu_ref, big);
+                       bias, flags, elu_ref, big, big_h);
   } else {
     hipLaunchKernelGGL((col2im_s2_kernel<1>), dim3(grid_for(total)), dim3(256), 0, st, n, hb, wb, c, k, hs, ws, col, bias,
-                       flags, elu_ref, big);
+                       flags, elu_ref, big, big_h);
   }
   DM_LAUNCH_CHECK();
   return DM_OK;
@@ -246,6 +249,21 @@ __global__ void __launch_bounds__(256) convt_pad_kernel(int n, int hs, int ws, i
     xp[e] = in ? x[(((size_t)i * hs + yy) * ws + xx) * c4 + cc] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+// The same zero-padded copy written as bf16 (the gathered operand of a bf16-storage product, common.h DmTwinScope)
+__global__ void __launch_bounds__(256) convt_pad_h_kernel(int n, int hs, int ws, int c4, int P, const float4* __restrict__ x,
+                                                          uint2* __restrict__ xp) {
+  const int hp = hs + 2 * P, wp = ws + 2 * P;
+  const size_t total = (size_t)n * hp * wp * c4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    size_t t = e;
+    const int cc = (int)(t % c4); t /= c4;
+    const int xx = (int)(t % wp) - P; t /= wp;
+    const int yy = (int)(t % hp) - P; t /= hp;
+    const int i = (int)t;
+    const bool in = yy >= 0 && yy < hs && xx >= 0 && xx < ws;
+    xp[e] = in ? dm_pack_bf16x4(x[(((size_t)i * hs + yy) * ws + xx) * c4 + cc]) : make_uint2(0u, 0u);
+  }
+}
 // rowoff[(n,yy,xx)] = offset of padded pixel (yy+P, xx+P);  koff[(a,b,i)] = -(a*wp + b)*cin + i;
 // ctab[(n,yy,xx)] = {offset of big[n, 2yy, 2xx, 0], bit 1: 2yy+1 < hb, bit 0: 2xx+1 < wb}
 __global__ void __launch_bounds__(256) convt_tables_kernel(int n, int hs, int ws, int cin, int ta, int hb, int wb, int cout,
@@ -299,7 +317,7 @@ __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const flo
                                                         const void* __restrict__ target_, int tdiv, float scale,
                                                         const float* __restrict__ row_scale,
                                                         float* __restrict__ loss, float* __restrict__ dpred, int dpad,
-                                                        float* __restrict__ rec) {
+                                                        float* __restrict__ rec, unsigned short* __restrict__ dpred_h) {
   __shared__ float red[4];
   const int i = blockIdx.x;
   const int per = hw * c;
@@ -319,6 +337,12 @@ __global__ void __launch_bounds__(256) mse_image_kernel(int hw, int c, const flo
       dp[cc] = scale * d;
       if (cc == c - 1)
         for (int q = c; q < dpad; ++q) dp[q] = 0.f;
+      if (dpred_h) {      // bf16 twin of the gradient (common.h DmTwinScope)
+        unsigned short* dh = dpred_h + ((size_t)i * hw + pix) * dpad;
+        dh[cc] = (unsigned short)dm_f2bf(scale * d);
+        if (cc == c - 1)
+          for (int q = c; q < dpad; ++q) dh[q] = 0;
+      }
     }
     if (rec) rec[(size_t)i * per + (size_t)cc * hw + pix] = pv;
   }
@@ -356,8 +380,10 @@ extern "C" int dm_preprocess_image_u8(int64_t n, int hw, int c, const uint8_t* s
 static inline bool shape_u8(const dm_shape* s) { return (s->flags & DM_FLAG_IMAGE_U8) != 0; }
 static int mse_launch(bool u8, int n, int hw, int c, const float* pred, const void* target, int tdiv, float scale,
                       const float* row_scale, float* loss, float* dpred, int dpad, float* rec, hipStream_t st) {
-  if (u8) hipLaunchKernelGGL((mse_image_kernel<true>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec);
-  else hipLaunchKernelGGL((mse_image_kernel<false>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec);
+  unsigned short* dh = dpred ? dm_twin_of(dpred, false) : nullptr;      // bf16 mode: the gradient's twin, written here
+  if (dh) dm_twin_mark(dpred);
+  if (u8) hipLaunchKernelGGL((mse_image_kernel<true>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec, dh);
+  else hipLaunchKernelGGL((mse_image_kernel<false>), dim3(n), dim3(256), 0, st, hw, c, pred, target, tdiv, scale, row_scale, loss, dpred, dpad, rec, dh);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -368,7 +394,9 @@ struct EncGeom {
   int hb[4], hs[4], cin[4], cout[4];
   size_t rows[4], kdim[4];
   bool direct0;      // layer 1 runs as a direct convolution (conv_direct.hip): no explicit patch matrix
+  bool twins;        // bf16 mode: the arena also holds bf16 twins of y[0..2] and of the repacked weights (common.h DmTwinScope)
   explicit EncGeom(const dm_shape* s) {
+    twins = (s->flags & DM_FLAG_BF16) != 0;
     N = s->T * s->B * (s->I > 0 ? s->I : 1);
     ch = s->img_ch; d = s->cnn_depth;
     direct0 = dm_enc_l1_direct_ok(ch, d, s->img);
@@ -393,7 +421,9 @@ struct DecGeom {
   int N, ch, d, F;
   int k[5], hsm[5], hbg[5], cin[5], cout[5];   // index 1..4
   size_t rows_s[5], rows_b[5];
+  bool twins;       // bf16 mode: the arena also holds bf16 twins of x[0..2] and wr[1..4] (common.h DmTwinScope)
   explicit DecGeom(const dm_shape* s) {
+    twins = (s->flags & DM_FLAG_BF16) != 0;
     N = s->T * s->B * (s->I > 0 ? s->I : 1);
     ch = s->img_ch; d = s->cnn_depth;
     F = s->D + s->S * (s->C ? s->C : 1);      // Gaussian latents (C = 0) are S wide
@@ -420,6 +450,8 @@ struct EncActs {
   int* rowoff[4];  // implicit-im2col tables (l>=1), see conv_tables_kernel
   int* koff[4];
   float* y[4];     // post-ELU NHWC outputs
+  unsigned short* yh[4];    // bf16 mode: twins of y[0..2] and wr[1..3], behind everything else (fp32 offsets do not move)
+  unsigned short* wrh[4];
 };
 static size_t enc_carve(const EncGeom& g, float* base, size_t cap_floats, EncActs* a) {
   DmArena ar(base, cap_floats * sizeof(float));
@@ -431,7 +463,17 @@ static size_t enc_carve(const EncGeom& g, float* base, size_t cap_floats, EncAct
     float* yy = ar.take(g.rows[l] * g.cout[l]);
     if (a) { a->wr[l] = w; a->xcol[l] = xc; a->rowoff[l] = (int*)ro; a->koff[l] = (int*)ko; a->y[l] = yy; }
   }
+  for (int l = 0; l < 4; ++l) {
+    float* yh = ar.take(g.twins && l < 3 ? dm_half_floats(g.rows[l] * g.cout[l]) : 0);
+    float* wh = ar.take(g.twins && l > 0 ? dm_half_floats((size_t)g.cout[l] * g.kdim[l]) : 0);
+    if (a) { a->yh[l] = (unsigned short*)yh; a->wrh[l] = (unsigned short*)wh; }
+  }
   return ar.off;
+}
+static void enc_register_twins(const EncGeom& g, const EncActs& a, bool acts_valid, bool weights_valid) {
+  if (!dm_twins_on()) return;
+  for (int l = 0; l < 3; ++l) dm_twin_add(a.y[l], g.rows[l] * g.cout[l], a.yh[l], acts_valid);
+  for (int l = 1; l < 4; ++l) dm_twin_add(a.wr[l], (size_t)g.cout[l] * g.kdim[l], a.wrh[l], weights_valid);
 }
 extern "C" size_t dm_conv_encoder_acts_floats(const dm_shape* shp) {
   if (!shp) return 0;
@@ -471,10 +513,17 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
   EncActs a;
   enc_carve(g, acts, (size_t)1 << 60, &a);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small");
+  DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
+  enc_register_twins(g, a, false, !prepare);
   if (prepare) {
     for (int l = 1; l < 4; ++l) {
       DM_TRY(conv_tables_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, a.rowoff[l], a.koff[l], st));
       DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cout[l], g.cin[l], 4, 4, 0, 2, 3, 1, st));
+    }
+    if (dm_twins_on()) {
+      DmCvtSeg sg[3];
+      for (int l = 1; l < 4; ++l) { sg[l - 1] = DmCvtSeg{a.wr[l], a.wrh[l], (size_t)g.cout[l] * g.kdim[l]}; dm_twin_mark(a.wr[l]); }
+      DM_TRY(dm_to_bf16_multi_launch(sg, 3, st));
     }
   }
   if (n == 0) return DM_OK;
@@ -488,7 +537,9 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
       const size_t frame = (size_t)g.ch * g.hb[0] * g.hb[0];
       const void* img = shape_u8(shp) ? (const void*)((const uint8_t*)image + (size_t)n0 * frame)
                                       : (const void*)(image + (size_t)n0 * frame);
-      DM_TRY(dm_enc_l1_fwd_launch(n, g.d, shape_u8(shp) ? 1 : 0, img, p->w[0], p->b[0], wt, a.y[0] + r0 * g.cout[0], st));
+      unsigned short* y0h = dm_twin_of(a.y[0] + r0 * g.cout[0], false);
+      DM_TRY(dm_enc_l1_fwd_launch(n, g.d, shape_u8(shp) ? 1 : 0, img, p->w[0], p->b[0], wt, a.y[0] + r0 * g.cout[0], y0h, st));
+      if (y0h) dm_twin_mark(a.y[0]);
       continue;
     }
     if (l == 0) {
@@ -507,7 +558,10 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
     q.a_layout = 0; q.b_layout = 0;
     q.M = n * g.hs[l] * g.hs[l]; q.N = g.cout[l]; q.K = (int)g.kdim[l];
     if (l == 0) { q.A = a.xcol[0] + r0 * g.kdim[0]; q.lda = q.K; }
-    else { q.A = a.y[l - 1]; q.a_maj = a.rowoff[l] + r0; q.a_min = a.koff[l]; q.a_tab_vec = (g.cin[l] & 3) == 0; }
+    else {
+      q.A = a.y[l - 1]; q.a_maj = a.rowoff[l] + r0; q.a_min = a.koff[l];
+      q.a_tab_vec = (g.cin[l] & 3) == 0; q.a_tab_vec8 = (g.cin[l] & 7) == 0;
+    }
     q.B = l == 0 ? p->w[0] : a.wr[l]; q.ldb = q.K;
     q.C = a.y[l] + r0 * g.cout[l]; q.ldc = q.N;
     q.bias = p->b[l];
@@ -559,8 +613,18 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
   int2* t_ctab = (int2*)ar.take(2 * tabmax);
   int* t_koff = (int*)ar.take(wcmax ? 4 * 1024 : 0);
   float* wcat = ar.take(wcmax);
+  // bf16 mode: twins of the two gradient ping-pong buffers and of the class-concatenated weights; the zero-padded gradient
+  // copy is written as bf16 only (it lives in the fp32 copy's storage)
+  DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
+  const bool tw_on = dm_twins_on();
+  unsigned short* ga_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(gmax) : 0);
+  unsigned short* gb_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(g.rows[1] * g.cout[1]) : 0);
+  unsigned short* wcat_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wcmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_encoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  enc_register_twins(g, a, true, true);
+  dm_twin_add(ga, gmax, ga_h, false);
+  dm_twin_add(gb, g.rows[1] * g.cout[1], gb_h, false);
 
   // dY3 (NHWC) = permute(dembed) ; G = dY3 * ELU'(Y3)
   float* G = gb;      // layer-3 grads are small; ping-pong between ga / gb going down
@@ -569,6 +633,11 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
                      0);
   DM_LAUNCH_CHECK();
   DM_TRY(dm_mul_elu_grad_launch(tot3, G, a.y[3], G, st));
+  if (tw_on) {
+    const DmCvtSeg sg = {G, dm_twin_of(G, false), tot3};
+    DM_TRY(dm_to_bf16_multi_launch(&sg, 1, st));
+    dm_twin_mark(G);
+  }
   for (int l = 3; l >= 0; --l) {
     const int rows = (int)g.rows[l], co = g.cout[l], kd = (int)g.kdim[l];
     DM_TRY(dm_colsum_launch(rows, co, G, co, gr->b[l], splitk, skb, st));
@@ -583,7 +652,10 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
     q.M = co; q.N = kd; q.K = rows;
     q.A = G; q.lda = co;
     if (l == 0) { q.B = a.xcol[0]; q.ldb = kd; }
-    else { q.B = a.y[l - 1]; q.b_maj = a.rowoff[l]; q.b_min = a.koff[l]; q.b_tab_vec = (g.cin[l] & 3) == 0; }
+    else {
+      q.B = a.y[l - 1]; q.b_maj = a.rowoff[l]; q.b_min = a.koff[l];
+      q.b_tab_vec = (g.cin[l] & 3) == 0; q.b_tab_vec8 = (g.cin[l] & 7) == 0;
+    }
     q.C = (l == 0) ? gr->w[0] : dwr; q.ldc = kd;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
     if (l > 0 && convt_gather_ok(4, co, g.cin[l], g.hs[l], (size_t)g.N)) {
@@ -595,25 +667,36 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
       float* Gn = (G == ga) ? gb : ga;
       if (l == 1) Gn = ga;   // layer-0 output grads are the largest buffer
       const size_t padn = (size_t)g.N * (hs + 2) * (hs + 2) * (co / 4);
-      hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, g.N, hs, hs, co / 4, 1, (const float4*)G,
-                         (float4*)gpad);
+      const bool hpath = tw_on && (co & 7) == 0 && kdim4 >= DM_HSTORE_MIN_K;      // bf16-storage product: padded gradient + weights as bf16
+      if (hpath) hipLaunchKernelGGL(convt_pad_h_kernel, dim3(grid_for(padn)), dim3(256), 0, st, g.N, hs, hs, co / 4, 1, (const float4*)G,
+                                    (uint2*)gpad);
+      else hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, g.N, hs, hs, co / 4, 1, (const float4*)G,
+                              (float4*)gpad);
       DM_LAUNCH_CHECK();
       hipLaunchKernelGGL(convt_tables_kernel, dim3(grid_for((size_t)g.N * Hc * Hc + kdim4)), dim3(256), 0, st, g.N, hs, hs, co, 2,
                          hb, hb, ci, t_rowoff, t_koff, t_ctab);
       DM_LAUNCH_CHECK();
       hipLaunchKernelGGL(convt_repack_kernel, dim3(grid_for((size_t)4 * ci * kdim4)), dim3(256), 0, st, co, ci, 4, p->w[l], wcat);
       DM_LAUNCH_CHECK();
+      if (hpath) {
+        const DmCvtSeg sg = {wcat, wcat_h, (size_t)4 * ci * kdim4};
+        DM_TRY(dm_to_bf16_multi_launch(&sg, 1, st));
+      }
       if (2 * Hc != hb) {      // odd input extent (31): the last row / column is reached by no window - its gradient is zero
         hipError_t e = hipMemsetAsync(Gn, 0, (size_t)g.N * hb * hb * ci * sizeof(float), st);
+        if (e == hipSuccess && dm_twin_of(Gn, false))
+          e = hipMemsetAsync(dm_twin_of(Gn, false), 0, (size_t)g.N * hb * hb * ci * sizeof(unsigned short), st);
         if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_encoder_bwd: %s", hipGetErrorString(e));
       }
       DmGemm d;
       d.M = g.N * Hc * Hc; d.N = 4 * ci; d.K = kdim4;
-      d.A = gpad; d.a_maj = t_rowoff; d.a_min = t_koff; d.a_tab_vec = 1;
+      d.A = gpad; d.a_maj = t_rowoff; d.a_min = t_koff; d.a_tab_vec = 1; d.a_tab_vec8 = 1;
+      if (hpath) { d.A = nullptr; d.A_h = (const unsigned short*)gpad; d.B_h = wcat_h; }
       d.B = wcat; d.ldb = kdim4;
       d.C = Gn;
       d.c_tab = t_ctab; d.sc_cout = ci; d.sc_wpitch = hb * ci;
       d.mulref = a.y[l - 1];
+      d.no_twin = l == 1;      // the layer-0 gradient is read by the direct weight-gradient kernel and the bias sum only (fp32)
       DM_TRY(dm_gemm_launch(d, splitk, skb, st));
       G = Gn;
     } else if (l > 0) {
@@ -660,7 +743,11 @@ __global__ void __launch_bounds__(256) convt_unpad_cout_kernel(int I, int O, int
 struct DecActs {
   float* wr[5];
   float* x[5];     // x[0] = fc output (N,32d); x[l] = NHWC activations after layer l (x[4] = prediction)
+  unsigned short* xh[5];     // bf16 mode: twins of x[0..2] and wr[1..4], behind everything else (dm_conv_decoder_pred_offset holds)
+  unsigned short* wrh[5];
 };
+static inline size_t dec_x_elems(const DecGeom& g, int l) { return l == 0 ? (size_t)g.N * g.cin[1] : g.rows_b[l] * g.cout[l]; }
+static inline size_t dec_w_elems(const DecGeom& g, int l) { return (size_t)g.cin[l] * g.k[l] * g.k[l] * g.cout[l]; }
 static size_t dec_carve(const DecGeom& g, float* base, size_t cap_floats, DecActs* a) {
   DmArena ar(base, cap_floats * sizeof(float));
   float* x0 = ar.take((size_t)g.N * g.cin[1]);
@@ -670,7 +757,18 @@ static size_t dec_carve(const DecGeom& g, float* base, size_t cap_floats, DecAct
     float* xx = ar.take(g.rows_b[l] * g.cout[l]);
     if (a) { a->wr[l] = w; a->x[l] = xx; }
   }
+  for (int l = 0; l <= 4; ++l) {
+    float* xh = ar.take(g.twins && l < 3 ? dm_half_floats(dec_x_elems(g, l)) : 0);
+    float* wh = ar.take(g.twins && l > 0 ? dm_half_floats(dec_w_elems(g, l)) : 0);
+    if (a) { a->xh[l] = (unsigned short*)xh; a->wrh[l] = (unsigned short*)wh; }
+  }
   return ar.off;
+}
+static void dec_register_twins(const DecGeom& g, const DecActs& a, bool acts_valid, bool weights_valid) {
+  if (!dm_twins_on()) return;
+  // (x[3], the 30x30xd input of the image layer, gets none: writing it costs more than its one reader, that layer's weight gradient, gains)
+  for (int l = 0; l < 3; ++l) dm_twin_add(a.x[l], dec_x_elems(g, l), a.xh[l], acts_valid);
+  for (int l = 1; l <= 4; ++l) dm_twin_add(a.wr[l], dec_w_elems(g, l), a.wrh[l], weights_valid);
 }
 extern "C" size_t dm_conv_decoder_acts_floats(const dm_shape* shp) {
   if (!shp) return 0;
@@ -706,9 +804,18 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
   hipStream_t st = (hipStream_t)stream;
   DecActs a;
   dec_carve(g, acts, (size_t)1 << 60, &a);
-  if (prepare)
+  DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
+  const bool tw_on = dm_twins_on();
+  dec_register_twins(g, a, false, !prepare);
+  if (prepare) {
     for (int l = 1; l <= 4; ++l)
       DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cin[l], g.cout[l], g.k[l], g.k[l], 0, 2, 3, 1, st));
+    if (tw_on) {
+      DmCvtSeg sg[4];
+      for (int l = 1; l <= 4; ++l) { sg[l - 1] = DmCvtSeg{a.wr[l], a.wrh[l], dec_w_elems(g, l)}; dm_twin_mark(a.wr[l]); }
+      DM_TRY(dm_to_bf16_multi_launch(sg, 4, st));
+    }
+  }
   if (n == 0) return DM_OK;
   DmArena ar(ws, ws_bytes);
   float* splitk = ar.take(DM_SPLITK_FLOATS);
@@ -735,6 +842,7 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
   int2* t_ctab = (int2*)ar.take(2 * tabmax);
   int* t_koff = (int*)ar.take(wcmax ? 9 * 1024 : 0);
   float* wcat = ar.take(wcmax);
+  unsigned short* wcat_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wcmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_fwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   {
@@ -758,8 +866,11 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
       const int ta = g.k[l] / 2, hs = g.hsm[l], hb = g.hbg[l], Hc = hs + ta - 1, kdim = ta * ta * g.cin[l];
       DM_REQUIRE(kdim <= 9 * 1024, DM_E_SHAPE, "conv_decoder_fwd: gather-form K %d exceeds the offset table", kdim);
       const size_t padn = (size_t)n * (hs + 2 * (ta - 1)) * (hs + 2 * (ta - 1)) * (g.cin[l] / 4);
-      hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, n, hs, hs, g.cin[l] / 4, ta - 1,
-                         (const float4*)xin, (float4*)xpad);
+      const bool hpath = tw_on && (g.cin[l] & 7) == 0 && kdim >= DM_HSTORE_MIN_K;       // bf16-storage product: padded input + weights as bf16
+      if (hpath) hipLaunchKernelGGL(convt_pad_h_kernel, dim3(grid_for(padn)), dim3(256), 0, st, n, hs, hs, g.cin[l] / 4, ta - 1,
+                                    (const float4*)xin, (uint2*)xpad);
+      else hipLaunchKernelGGL(convt_pad_kernel, dim3(grid_for(padn)), dim3(256), 0, st, n, hs, hs, g.cin[l] / 4, ta - 1,
+                              (const float4*)xin, (float4*)xpad);
       DM_LAUNCH_CHECK();
       hipLaunchKernelGGL(convt_tables_kernel, dim3(grid_for((size_t)n * Hc * Hc + kdim)), dim3(256), 0, st, n, hs, hs, g.cin[l],
                          ta, hb, hb, g.cout[l], t_rowoff, t_koff, t_ctab);
@@ -767,9 +878,14 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
       hipLaunchKernelGGL(convt_repack_kernel, dim3(grid_for((size_t)4 * g.cout[l] * kdim)), dim3(256), 0, st, g.cin[l], g.cout[l],
                          g.k[l], p->w[l], wcat);
       DM_LAUNCH_CHECK();
+      if (hpath) {
+        const DmCvtSeg sg = {wcat, wcat_h, (size_t)4 * g.cout[l] * kdim};
+        DM_TRY(dm_to_bf16_multi_launch(&sg, 1, st));
+      }
       DmGemm q;   // big[n, 2yy+py, 2xx+px, o] = act( b[o] + patch(n,yy,xx) . Wcat[(py,px,o)] )
       q.M = n * Hc * Hc; q.N = 4 * g.cout[l]; q.K = kdim;
-      q.A = xpad; q.a_maj = t_rowoff; q.a_min = t_koff; q.a_tab_vec = 1;
+      q.A = xpad; q.a_maj = t_rowoff; q.a_min = t_koff; q.a_tab_vec = 1; q.a_tab_vec8 = 1;
+      if (hpath) { q.A = nullptr; q.A_h = (const unsigned short*)xpad; q.B_h = wcat_h; }
       q.B = wcat; q.ldb = kdim;
       q.C = a.x[l] + (size_t)n0 * hb * hb * g.cout[l];
       q.c_tab = t_ctab; q.sc_cout = g.cout[l]; q.sc_wpitch = hb * g.cout[l];
@@ -867,8 +983,18 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
   }
   int* rowoff = (int*)ar.take(romax);
   int* koff = (int*)ar.take(komax);
+  // bf16 mode: twins of the two gradient ping-pong buffers and of the padded image-layer weights
+  DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
+  const bool tw_on = dm_twins_on();
+  unsigned short* ga_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(gmax) : 0);
+  unsigned short* gb_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(gmax) : 0);
+  unsigned short* wpad_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wpadmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
+  dec_register_twins(g, a, true, true);
+  dm_twin_add(ga, gmax, ga_h, false);
+  dm_twin_add(gb, gmax, gb_h, false);
+  dm_twin_add(wpad, wpadmax, wpad_h, false);
 
   // G4 = scale * (pred - target), NHWC with co4[4] channels per pixel
   float* G = ga;
@@ -887,6 +1013,11 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
       hipLaunchKernelGGL(convt_pad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * ncol)), dim3(256), 0, st, g.cin[l], g.cout[l], co,
                          g.k[l], p->w[l], wpad);
       DM_LAUNCH_CHECK();
+      if (tw_on) {
+        const DmCvtSeg sg = {wpad, wpad_h, (size_t)g.cin[l] * ncol};
+        DM_TRY(dm_to_bf16_multi_launch(&sg, 1, st));
+        dm_twin_mark(wpad);
+      }
     } else {
       DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, gr->b[l], splitk, skb, st));
     }
@@ -897,6 +1028,7 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     q.M = g.cin[l]; q.N = ncol; q.K = rows_s;
     q.A = a.x[l - 1]; q.lda = g.cin[l];
     q.B = G; q.b_maj = rowoff; q.b_min = koff; q.b_tab_vec = 1;
+    q.b_tab_vec8 = (co & 7) == 0 || (co == 4 && (g.k[l] & 1) == 0);      // 8 minors = 8 channels, or 2 pixels x 4 channels of an even-width window
     q.C = dwr; q.ldc = ncol;
     DM_TRY(dm_gemm_launch(q, splitk, skb, st));
     if (padded) {
@@ -911,6 +1043,7 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     d.a_layout = 0; d.b_layout = 0;
     d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
     d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1;
+    d.a_tab_vec8 = (co & 7) == 0 || (co == 4 && (g.k[l] & 1) == 0);
     d.B = padded ? wpad : a.wr[l]; d.ldb = ncol;
     d.C = Gn; d.ldc = g.cin[l];
     if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }

@@ -33,7 +33,7 @@ bool dm_conv_direct_enabled() {
 template <int CO, bool U8>
 __global__ void __launch_bounds__(256) enc_l1_fwd_kernel(int npix, const void* __restrict__ image_,
                                                          const float* __restrict__ wt, const float* __restrict__ bias,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, unsigned short* __restrict__ y_h) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   const bool ok = p < npix;
   const int pc = ok ? p : npix - 1;
@@ -65,6 +65,12 @@ __global__ void __launch_bounds__(256) enc_l1_fwd_kernel(int npix, const void* _
 #pragma unroll
     for (int o = 0; o < CO; o += 4)
       dst[o >> 2] = make_float4(dm_elu(acc[o]), dm_elu(acc[o + 1]), dm_elu(acc[o + 2]), dm_elu(acc[o + 3]));
+    if (y_h) {      // bf16 twin of the activations (conf.amp: the next layer's gathered operand, common.h DmTwinScope)
+      uint2* dh = reinterpret_cast<uint2*>(y_h + (size_t)p * CO);
+#pragma unroll
+      for (int o = 0; o < CO; o += 4)
+        dh[o >> 2] = dm_pack_bf16x4(make_float4(dm_elu(acc[o]), dm_elu(acc[o + 1]), dm_elu(acc[o + 2]), dm_elu(acc[o + 3])));
+    }
   }
 }
 
@@ -78,7 +84,7 @@ bool dm_enc_l1_direct_ok(int ch, int d, int img) {
 }
 // y (frames*961, d) NHWC post-ELU; wt: scratch of 48*d floats (the transposed weights, written here)
 int dm_enc_l1_fwd_launch(int frames, int d, int u8, const void* image, const float* w, const float* bias, float* wt,
-                         float* y, hipStream_t st) {
+                         float* y, unsigned short* y_h, hipStream_t st) {
   if (frames <= 0) return DM_OK;
   hipLaunchKernelGGL(enc_l1_wt_kernel, dim3(grid_for_px((size_t)d * 48, 256)), dim3(256), 0, st, d, w, wt);
   DM_LAUNCH_CHECK();
@@ -86,8 +92,8 @@ int dm_enc_l1_fwd_launch(int frames, int d, int u8, const void* image, const flo
   const dim3 grid(grid_for_px((size_t)npix, 256)), blk(256);
 #define DM_ENC_L1(CO_)                                                                                              \
   if (d == CO_) {                                                                                                   \
-    if (u8) hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, true>), grid, blk, 0, st, npix, image, wt, bias, y);           \
-    else hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, false>), grid, blk, 0, st, npix, image, wt, bias, y);             \
+    if (u8) hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, true>), grid, blk, 0, st, npix, image, wt, bias, y, y_h);      \
+    else hipLaunchKernelGGL((enc_l1_fwd_kernel<CO_, false>), grid, blk, 0, st, npix, image, wt, bias, y, y_h);        \
   }
   DM_ENC_L1(8) DM_ENC_L1(16) DM_ENC_L1(32) DM_ENC_L1(48) DM_ENC_L1(64)
 #undef DM_ENC_L1

@@ -10,11 +10,13 @@
 template <bool CACHE>
 __global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, float* __restrict__ y, int ldy, float* __restrict__ stats) {
+                                                         float eps, float* __restrict__ y, int ldy, float* __restrict__ stats,
+                                                         unsigned short* __restrict__ y_h) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
+  unsigned short* yh = y_h ? y_h + (size_t)row * ldy : nullptr;      // bf16 twin of y, same leading dimension (common.h DmTwinScope)
   float xc[16];
   float s = 0.f;
   if (CACHE) {
@@ -48,10 +50,18 @@ __global__ void __launch_bounds__(256) ln_elu_fwd_kernel(int rows, int n, const 
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int c = lane + 64 * j;
-      if (c < n) yr[c] = dm_elu((xc[j] - mean) * rstd * gamma[c] + beta[c]);
+      if (c < n) {
+        const float o = dm_elu((xc[j] - mean) * rstd * gamma[c] + beta[c]);
+        yr[c] = o;
+        if (yh) yh[c] = (unsigned short)dm_f2bf(o);
+      }
     }
   } else {
-    for (int c = lane; c < n; c += 64) yr[c] = dm_elu((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+    for (int c = lane; c < n; c += 64) {
+      const float o = dm_elu((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+      yr[c] = o;
+      if (yh) yh[c] = (unsigned short)dm_f2bf(o);
+    }
   }
   if (lane == 0) {
     stats[2 * row] = mean;
@@ -260,12 +270,14 @@ int dm_colsum_launch(int rows, int n, const float* x, int ld, float* out, void* 
 int dm_ln_elu_fwd_launch(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,
                          float* y, int ldy, float* stats, hipStream_t st) {
   if (rows <= 0) return DM_OK;
+  unsigned short* y_h = dm_twin_of(y, false);        // bf16 mode: y's twin, written here
+  if (y_h) dm_twin_mark(y);
   if (n <= 1024)
     hipLaunchKernelGGL((ln_elu_fwd_kernel<true>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta,
-                       eps, y, ldy, stats);
+                       eps, y, ldy, stats, y_h);
   else
     hipLaunchKernelGGL((ln_elu_fwd_kernel<false>), dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, x, ldx, gamma, beta,
-                       eps, y, ldy, stats);
+                       eps, y, ldy, stats, y_h);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -367,7 +379,7 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
                                                             float* __restrict__ h_next,
                                                             const uint8_t* __restrict__ next_reset,
                                                             float* __restrict__ h_frag, float* __restrict__ h_next_frag,
-                                                            int ldg, int ldn) {
+                                                            int ldg, int ldn, unsigned short* __restrict__ h_out_h) {
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / D), d = (int)(i % D);
@@ -379,6 +391,7 @@ __global__ void __launch_bounds__(256) gru_gates_fwd_kernel(int rows, int D, con
     const float h = h_in[(size_t)r * ldh + d];
     const float ho = (h - ng) * ug + ng;
     h_out[(size_t)r * ldo + d] = ho;
+    if (h_out_h) h_out_h[(size_t)r * ldo + d] = (unsigned short)dm_f2bf(ho);      // bf16 twin, same leading dimension
     const float hn = (next_reset && next_reset[r]) ? 0.f : ho;
     if (h_next) h_next[(size_t)r * ldn + d] = hn;
     if (h_frag) h_frag[dm_frag_off(r, d)] = ho;
@@ -700,7 +713,8 @@ __global__ void __launch_bounds__(256) z_embed_kernel(int rows, int n, int S, in
                                                       const float* __restrict__ Wt2, float* __restrict__ x, int ldx,
                                                       float* __restrict__ x_frag,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, float* __restrict__ y, int ldy) {
+                                                      float eps, float* __restrict__ y, int ldy,
+                                                      unsigned short* __restrict__ y_h) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -807,6 +821,7 @@ __global__ void __launch_bounds__(256) z_embed_kernel(int rows, int n, int S, in
       o.z = dm_elu((acc[j].z - mean) * rstd * g.z + b.z);
       o.w = dm_elu((acc[j].w - mean) * rstd * g.w + b.w);
       *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+      if (y_h) *reinterpret_cast<uint2*>(y_h + (size_t)row * ldy + c) = dm_pack_bf16x4(o);      // bf16 twin (common.h DmTwinScope)
     }
 }
 // x[r][:] = sum_e z[r][e] * Wt[e][:] over the NON-ZERO e of row r: a sparse-row product, exact for any z and cheap when z is
@@ -878,8 +893,10 @@ int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const u
   DM_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0, DM_E_SHAPE, "z_embed: leading dims must be multiples of 4");
   DM_REQUIRE(!x_frag || rows <= 64, DM_E_SHAPE, "z_embed: the fragment-major copy needs rows <= 64");
   DM_REQUIRE(!y || (gamma != nullptr) == (beta != nullptr), DM_E_NULL, "z_embed: LayerNorm gain without its bias");
+  unsigned short* y_h = (y && gamma) ? dm_twin_of(y, false) : nullptr;      // bf16 mode: the LayerNorm+ELU output's twin
+  if (y_h) dm_twin_mark(y);
   hipLaunchKernelGGL(z_embed_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, S, C, idx, row_zero, Wt, bias, add,
-                     ldadd, idx2, Wt2, x, ldx, x_frag, gamma, beta, eps, y, ldy);
+                     ldadd, idx2, Wt2, x, ldx, x_frag, gamma, beta, eps, y, ldy, y_h);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -896,8 +913,10 @@ int dm_gru_gates_fwd_launch(int rows, int D, const float* gi, const float* gh, c
                             hipStream_t st, int ldg, int ldn) {
   if (rows <= 0) return DM_OK;
   DM_REQUIRE((!h_frag && !h_next_frag) || rows <= 64, DM_E_SHAPE, "gru_gates_fwd: fragment-major copies need rows <= 64");
+  unsigned short* h_out_h = dm_twin_of(h_out, false);      // bf16 mode: the new state's twin, written here
+  if (h_out_h) dm_twin_mark(h_out);
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(ew_blocks((size_t)rows * D)), dim3(256), 0, st, rows, D, gi, gh, h_in,
-                     ldh, h_out, ldo, h_next, next_reset, h_frag, h_next_frag, ldg > 0 ? ldg : 3 * D, ldn > 0 ? ldn : D);
+                     ldh, h_out, ldo, h_next, next_reset, h_frag, h_next_frag, ldg > 0 ? ldg : 3 * D, ldn > 0 ? ldn : D, h_out_h);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -1921,6 +1940,44 @@ extern "C" int dm_actor_loss_continuous(int kind, int rows, int A, const float* 
   if (rows <= 0) return DM_OK;
   hipLaunchKernelGGL(actor_loss_continuous_kernel, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, kind, rows, A,
                      params, actions, adv_gae, weight, ent_w, scale, loss, entropy, dparams);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ---- fp32 -> bf16 (RNE) copies of up to 8 buffers in one launch: the weight twins of a bf16-mode call (common.h DmTwinScope)
+struct CvtArgs { DmCvtSeg seg[8]; size_t start[9]; };      // start[i]: first 4-element group of segment i in the flat group index
+__global__ void __launch_bounds__(256) to_bf16_multi_kernel(const CvtArgs a, int count) {
+  const size_t total = a.start[count];
+  for (size_t gidx = (size_t)blockIdx.x * 256 + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * 256) {
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) sidx += (i < count && gidx >= a.start[i]) ? 1 : 0;
+    const DmCvtSeg sg = a.seg[sidx];
+    const size_t e = (gidx - a.start[sidx]) * 4;
+    if (e + 4 <= sg.n && ((((uintptr_t)sg.src) & 15) == 0) && ((((uintptr_t)sg.dst) & 7) == 0)) {
+      const float4 v = *reinterpret_cast<const float4*>(sg.src + e);
+      *reinterpret_cast<uint2*>(sg.dst + e) = dm_pack_bf16x4(v);
+    } else {
+      for (size_t j = e; j < sg.n && j < e + 4; ++j) sg.dst[j] = (unsigned short)dm_f2bf(sg.src[j]);
+    }
+  }
+}
+int dm_to_bf16_multi_launch(const DmCvtSeg* segs, int count, hipStream_t st) {
+  DM_REQUIRE(count >= 0 && count <= 8, DM_E_SHAPE, "to_bf16: %d segments (max 8)", count);
+  CvtArgs a;
+  size_t groups = 0;
+  int n = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!segs[i].src || !segs[i].dst || segs[i].n == 0) continue;
+    a.seg[n] = segs[i];
+    a.start[n] = groups;
+    groups += (segs[i].n + 3) / 4;
+    ++n;
+  }
+  if (n == 0) return DM_OK;
+  for (int i = n; i <= 8; ++i) a.start[i] = groups;
+  a.start[n] = groups;
+  hipLaunchKernelGGL(to_bf16_multi_kernel, dim3(ew_blocks(groups)), dim3(256), 0, st, a, n);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -328,9 +328,14 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
 }
 
 // Epilogue shared by the tile kernels: `acc` holds the (BM/WGM) x (BN/WGN) block of this wave in the 32x32 MFMA C/D layout.
+// `stage` (optional): 32 x 40 bf16 of LDS owned by this wave; the bf16 twin of a dense result then leaves as 16-byte
+// stores of 8 columns (a 32 x 32 block = 2 store instructions instead of 16 two-byte ones - the two-byte form cost
+// 170 us on a 2.25 M x 48 result).  The caller guarantees nobody else reads that LDS any more.
+constexpr int EPI_STAGE_LD = 40;
 template <int BM, int BN, int WGM, int WGN, bool SC, int MB, int NB>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MB][NB], const GemmKArgs& g, const GemmItem& cur, int wm, int wn,
-                                              int l31, int half) {
+                                              int l31, int half, unsigned short* stage = nullptr) {
+  const bool staged = !SC && stage && g.Ch && g.nsplit <= 1 && (g.ldc & 7) == 0 && (((uintptr_t)g.Ch) & 15) == 0;
   // C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -370,9 +375,29 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MB][NB], const GemmK
             if (g.flags & DM_GEMM_ELU) v = dm_elu(v);
             if (g.mulref) v *= dm_elu_grad_from_y(g.mulref[(size_t)row * g.ldmul + col]);
             *c = v;
-            if (g.Ch) g.Ch[(size_t)row * g.ldc + col] = (unsigned short)dm_f2bf(v);
+            if (staged) stage[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_STAGE_LD + l31] = (unsigned short)dm_f2bf(v);
+            else if (g.Ch) g.Ch[(size_t)row * g.ldc + col] = (unsigned short)dm_f2bf(v);
           }
         }
+      }
+      if (staged) {      // this wave's 32 x 32 block: lane -> (row lane >> 1, 16 columns), two 16-byte stores
+        __builtin_amdgcn_wave_barrier();
+        const int lane = half * 32 + l31;
+        const int rl = lane >> 1, c0 = (lane & 1) * 16;
+        const int row = cur.m0 + wm * (BM / WGM) + mb * 32 + rl;
+        const int colb = cur.n0 + wn * (BN / WGN) + nb * 32 + c0;
+        if (row < g.M) {
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            const int cc = colb + h8 * 8;
+            const unsigned short* sp = &stage[rl * EPI_STAGE_LD + c0 + h8 * 8];
+            unsigned short* dp = g.Ch + (size_t)row * g.ldc + cc;
+            if (cc + 8 <= g.N) *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+            else
+              for (int j = 0; j < 8 && cc + j < g.N; ++j) dp[j] = sp[j];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -527,7 +552,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half);
+  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half,
+                                              reinterpret_cast<unsigned short*>(smem) + wave * 32 * EPI_STAGE_LD);
 }
 
 // ---- software-pipelined tile kernel for the bf16-pipe modes (PR 1: bf16 operands, PR 2: split-bf16 fp32 products) -------
@@ -781,7 +807,12 @@ __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
     }
     step(no, no, kt & 1, (kt & 1) ^ 1, 0);                 // last tile
   }
-  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half);
+  unsigned short* stage = nullptr;
+  if (g.Ch) {      // (uniform) the twin leaves through LDS: every wave must be done reading its fragments first
+    __syncthreads();
+    stage = smem + wave * 32 * EPI_STAGE_LD;
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half, stage);
 }
 
 // ---- bf16-STORAGE tile kernel (conf.amp with operands that already live in HBM as bf16: weight twins kept by the optimizer,
@@ -955,7 +986,7 @@ __global__ void __launch_bounds__(256, 2) gemm_h_kernel(const GemmKArgs g) {
       __syncthreads();
     }
   }
-  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half);
+  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half, smem + wave * 32 * EPI_STAGE_LD);
 }
 
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmKArgs g) {
@@ -1153,6 +1184,46 @@ int dm_fp32_split() {
 }
 extern "C" int dm_fp32_mode(void) { return dm_fp32_split(); }
 // operand precision of the call in progress on this host thread (common.h: DmPrecisionScope)
+// ---- bf16 twin map of the composite call in progress (common.h DmTwinScope)
+struct TwinRange { const float* base; size_t n; unsigned short* twin; bool valid; };
+static thread_local TwinRange tl_twins[48];
+static thread_local int tl_ntwins = 0;
+static thread_local bool tl_twins_on = false;
+static int g_twins_enabled = getenv("DM_BF16_NO_TWINS") ? 0 : 1;
+// 1 / 0: switch the bf16-storage operand path of bf16-mode calls on / off (A/B and parity tests), -1: query.  Returns the state.
+extern "C" int dm_bf16_twins_enable(int on) {
+  if (on >= 0) g_twins_enabled = on ? 1 : 0;
+  return g_twins_enabled;
+}
+DmTwinScope::DmTwinScope(bool bf16_mode) {
+  opened = !tl_twins_on;               // composite calls do not nest; an inner scope leaves the outer one's map alone
+  active = bf16_mode && g_twins_enabled;
+  if (opened) { tl_twins_on = active; tl_ntwins = 0; }
+}
+DmTwinScope::~DmTwinScope() {
+  if (opened) { tl_twins_on = false; tl_ntwins = 0; }
+}
+bool dm_twins_on() { return tl_twins_on; }
+void dm_twin_add(const float* base, size_t n, unsigned short* twin, bool valid) {
+  if (!tl_twins_on || !base || !twin || n == 0 || tl_ntwins >= 48) return;
+  tl_twins[tl_ntwins++] = TwinRange{base, n, twin, valid};
+}
+static TwinRange* twin_find(const float* p) {
+  if (!tl_twins_on || !p) return nullptr;
+  for (int i = tl_ntwins - 1; i >= 0; --i)
+    if (p >= tl_twins[i].base && p < tl_twins[i].base + tl_twins[i].n) return &tl_twins[i];
+  return nullptr;
+}
+void dm_twin_mark(const float* p) {
+  TwinRange* r = twin_find(p);
+  if (r) r->valid = true;
+}
+unsigned short* dm_twin_of(const float* p, bool need_valid) {
+  TwinRange* r = twin_find(p);
+  if (!r || (need_valid && !r->valid)) return nullptr;
+  return r->twin + (p - r->base);
+}
+
 static thread_local int tl_precision = 0;
 int dm_cur_precision() { return tl_precision; }
 DmPrecisionScope::DmPrecisionScope(int p) : prev(tl_precision) { tl_precision = p ? 1 : 0; }
@@ -1175,19 +1246,52 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   {   // <= 64-row products of the sequential RSSM chains: one-launch skinny kernel (gemm_skinny.hip)
     const int sk = (q.A_h || q.C_h) ? 0 : dm_gemm_skinny_try(q, stream);
     if (sk < 0) return sk;
-    if (sk == 1) return DM_OK;
+    if (sk == 1) {
+      // the skinny kernel keeps fp32 operands and writes no twin: a registered result gets its twin by a copy pass (dense
+      // results only; otherwise the twin stays invalid and consumers read the fp32 values)
+      unsigned short* t = (q.bf16 && dm_twins_on()) ? dm_twin_of(q.C, false) : nullptr;
+      if (t && q.ldc == q.N) {
+        const DmCvtSeg sg = {q.C, t, (size_t)q.M * q.N};
+        DM_TRY(dm_to_bf16_multi_launch(&sg, 1, stream));
+        dm_twin_mark(q.C);
+      }
+      return DM_OK;
+    }
   }
   DM_REQUIRE(!q.ln_g && !q.lnb_x && !q.gates, DM_E_SHAPE,
              "gemm: LayerNorm prologues / the gates epilogue are built for the <= 64-row skinny products only (M=%d K=%d)", q.M, q.K);
-  // bf16-storage operands (both or neither): 16-byte chunks of 8 elements along the minor axis
-  const bool hstore = q.A_h && q.B_h;
-  DM_REQUIRE(!hstore || ((((uintptr_t)q.A_h | (uintptr_t)q.B_h) & 15) == 0 && ((q.K & 7) == 0 || (q.a_layout == 1 && q.b_layout == 1)) &&
-                         (q.a_maj ? q.a_tab_vec >= 8 : (q.lda & 7) == 0) && (q.b_maj ? q.b_tab_vec >= 8 : (q.ldb & 7) == 0) &&
+  // bf16-storage operands: given explicitly (both or neither), or found in the call's twin map (common.h DmTwinScope) when
+  // BOTH operands have a valid twin and the shape meets the 16-byte chunk rules (8 elements along the minor axis); the
+  // result's twin is written whenever the map has storage for it.
+  const unsigned short* Ah = q.A_h;
+  const unsigned short* Bh = q.B_h;
+  unsigned short* Chh = q.C_h;
+  if (q.bf16 && dm_twins_on()) {
+    if (!Ah && !Bh) {
+      const unsigned short* ta = dm_twin_of(q.A, true);
+      const unsigned short* tb = dm_twin_of(q.B, true);
+      const bool fits = ta && tb && ((((uintptr_t)ta | (uintptr_t)tb) & 15) == 0) &&
+                        ((q.K & 7) == 0 || (q.a_layout == 1 && q.b_layout == 1)) &&
+                        (q.a_maj ? q.a_tab_vec8 != 0 : (q.lda & 7) == 0) && (q.b_maj ? q.b_tab_vec8 != 0 : (q.ldb & 7) == 0) &&
+                        (q.a_layout == 0 || ((q.M & 7) == 0 && q.M >= 8)) && (q.b_layout == 0 || ((q.N & 7) == 0 && q.N >= 8));
+      // measured on the step's convolution products (profiles/r03_bf16_storage.txt): weight gradients (both operands
+      // row-contiguous, K = pixels) gain 1.1-1.9x, k-contiguous products gain from K ~ 1000 up and lose below it (a 64-k tile
+      // halves the k-steps that amortise a tile's prologue and epilogue)
+      // ...; dense k-contiguous products (the 2 500-row imagination cell) gain from K ~ 400
+      const int min_k = (q.a_maj || q.b_maj || q.c_tab) ? DM_HSTORE_MIN_K : DM_HSTORE_MIN_K_DENSE;
+      if (fits && ((q.a_layout == 1 && q.b_layout == 1) || q.K >= min_k)) { Ah = ta; Bh = tb; }
+    }
+    if (!Chh && !q.no_twin) Chh = dm_twin_of(q.C, false);
+    if (Chh) dm_twin_mark(q.C);
+  }
+  const bool hstore = Ah && Bh;
+  DM_REQUIRE(!hstore || ((((uintptr_t)Ah | (uintptr_t)Bh) & 15) == 0 && ((q.K & 7) == 0 || (q.a_layout == 1 && q.b_layout == 1)) &&
+                         (q.a_maj ? q.a_tab_vec8 != 0 : (q.lda & 7) == 0) && (q.b_maj ? q.b_tab_vec8 != 0 : (q.ldb & 7) == 0) &&
                          (q.a_layout == 0 || ((q.M & 7) == 0 && q.M >= 8)) && (q.b_layout == 0 || ((q.N & 7) == 0 && q.N >= 8))),
              DM_E_SHAPE, "gemm: bf16-storage operands need 16-byte aligned rows and extents in multiples of 8 (M=%d N=%d K=%d)",
              q.M, q.N, q.K);
   GemmKArgs a;
-  a.Ch = q.C_h;
+  a.Ch = Chh;
   a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias; a.add = q.add; a.mulref = q.mulref; a.row_zero = q.row_zero; a.partial = nullptr;
   a.M = q.M; a.N = q.N; a.K = q.K;
   a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.ldmul = q.ldmul;
@@ -1197,7 +1301,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   DM_REQUIRE(!q.c_tab || (q.sc_cout > 0 && q.N % q.sc_cout == 0 && q.N / q.sc_cout == 4 && !q.add && !(q.flags & DM_GEMM_ACCUM)),
              DM_E_SHAPE, "gemm: scatter epilogue needs N = 4 * sc_cout, no addend, no accumulate");
   if (hstore) {
-    a.A = reinterpret_cast<const float*>(q.A_h); a.B = reinterpret_cast<const float*>(q.B_h);
+    a.A = reinterpret_cast<const float*>(Ah); a.B = reinterpret_cast<const float*>(Bh);
     static const int h_nt = getenv("DM_GEMM_H_NT") ? 1 : 0;
     if (h_nt) a.flags |= 1 << 20;
   }
@@ -1326,7 +1430,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   if (slot >= 0) {
     long long* sh = &g_prof.shape[5 * (size_t)slot];
     sh[0] = q.M; sh[1] = q.N; sh[2] = q.K; sh[3] = nsplit; sh[4] = (q.a_maj ? 1 : 0) | (q.b_maj ? 2 : 0) | (q.c_tab ? 4 : 0) | (q.bf16 ? 8 : 0) |
-            ((!q.bf16 && a.a_vec && a.b_vec && dm_fp32_split()) ? 16 : 0);
+            ((!q.bf16 && a.a_vec && a.b_vec && dm_fp32_split()) ? 16 : 0) | (hstore ? 32 : 0);
   }
   int rc;
   const bool vec = a.a_vec && a.b_vec;

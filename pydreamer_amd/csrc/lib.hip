@@ -63,8 +63,11 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   // + gather-form data gradient: zero-padded copies of the 14x14x2d / 6x6x4d gradients, tables, class-concatenated weights
   size_t epad = N * 16 * 16 * 2 * d;
   if (N * 8 * 8 * 4 * d > epad) epad = N * 8 * 8 * 4 * d;
+  // bf16 mode (DM_FLAG_BF16): + bf16 twins of gradient ping-pong buffers and per-call weight copies (common.h DmTwinScope)
+  const size_t tw = (s->flags & DM_FLAG_BF16) ? 1 : 0;
   const size_t enc_bwd = SK + pad64(N * 961 * d) + pad64(N * 196 * 2 * d) + pad64(8 * d * 64 * d) + pad64(xc) + pad64(epad) +
-                         3 * pad64(N * 225) + pad64(4 * 1024) + pad64(16 * 2 * d * 4 * d) + 1024;
+                         3 * pad64(N * 225) + pad64(4 * 1024) + pad64(16 * 2 * d * 4 * d) + 1024 +
+                         tw * (pad64(N * 961 * d / 2 + 1) + pad64(N * 196 * d + 1) + pad64(8 * 2 * d * 4 * d + 1));
   // decoder: column matrices rows_small * k*k*cout for layers 1..4
   size_t col = N * 25 * 4 * d;
   if (N * 25 * 25 * 2 * d > col) col = N * 25 * 25 * 2 * d;
@@ -85,8 +88,10 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   if (N * 34 * 34 * d > gpad) gpad = N * 34 * 34 * d;
   const size_t gtab = N * 32 * 32;
   const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) +
-                         pad64(144 * d) + 1024;      // + the direct layer-4 kernel's class-ordered weights
-  const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024;   // + gather tables, padded image-layer weights
+                         pad64(144 * d) + 1024 +      // + the direct layer-4 kernel's class-ordered weights
+                         tw * pad64(2 * 2 * d * 9 * 2 * d + 1);
+  const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024 +   // + gather tables, padded image-layer weights
+                         tw * (2 * pad64(gmax / 2 + 1) + pad64((wmax + 36 * 4 * d) / 2 + 1));
   const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg
                           2 * pad64((3 * D + 15) / 16 * 1024) + 2 * pad64((Hd + 15) / 16 * 1024);   // + fragment-major dgi / dgh / dpin / dza
@@ -95,7 +100,9 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +
                        3 * pad64(N * 3 * D) + pad64(N * 6 * 4) + pad64(N * Z) +      // (LayerNorm-GRU statistics: 6 per stack layer)
                        pad64(25 * 512 * (((D + Z + 31) / 32) + (L > 0 ? L - 1 : 0) * ((Hm + 31) / 32))) +   // + fragment-major actor weights
-                       pad64(Z * Hd) + pad64(A * Hd) + pad64(N * (size_t)s->S) + pad64(N);   // + z_mlp^T, a_mlp^T and the sampled indices (z_embed)
+                       pad64(Z * Hd) + pad64(A * Hd) + pad64(N * (size_t)s->S) + pad64(N) +   // + z_mlp^T, a_mlp^T and the sampled indices (z_embed)
+                       tw * (pad64(3 * D * Hd / 2 + 1) + pad64(3 * D * D / 2 + 1) + pad64(Hd * D / 2 + 1) + pad64(Z * Hd / 2 + 1) +
+                             pad64(N * Hd / 2 + 1) + pad64((H + 1) * N * (D + (size_t)s->S * (s->C ? s->C : 1)) / 2 + 1));   // + bf16 twins of the cell's weights, za and the h columns of feats
   size_t m = enc_bwd;
   if (dec_fwd > m) m = dec_fwd;
   if (dec_bwd > m) m = dec_bwd;

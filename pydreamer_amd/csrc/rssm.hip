@@ -676,18 +676,39 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   float* gstw = ar.take(kind ? (size_t)M * 6 * rssm_gru_layers(s) : 0);
   const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
+  // bf16 mode, plain single-layer GRU with LayerNorm: the cell's four 2 500-row products read bf16 twins (common.h DmTwinScope) -
+  // per-call copies of their weights, za (written by the z_embed / LayerNorm kernels that produce it) and the h columns of
+  // `feats` (written by the gates kernel; one range per step, so step 0's h, copied from `start`, stays on the fp32 path)
+  DmTwinScope tw((s->flags & DM_FLAG_BF16) != 0);
+  const bool tw_on = dm_twins_on() && kind == 0 && rssm_gru_layers(s) == 1 && p[DM_RSSM_IN_G] && p[DM_RSSM_PRIOR_G] && (F & 7) == 0;
+  unsigned short* wih_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)3 * D * Hd) : 0);
+  unsigned short* whh_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)3 * D * D) : 0);
+  unsigned short* wph_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)Hd * D) : 0);
+  unsigned short* wp_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)ZP * Hd) : 0);
+  unsigned short* za_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)M * Hd) : 0);
+  unsigned short* feats_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)(H + 1) * M * F) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   DmChainKey ck;
   ck.add(s).add((long long)M).add(start).add_words(P, sizeof(*P)).add_words(actor, sizeof(*actor)).add(u_act).add(u_prior)
       .add(feats).add(actions).add(act_idx).add(actor_acts).add(actor_logits).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision()).add((long long)dm_mlp_chain_min_rows(0));      // + the one mutable dispatch threshold
+      .add((long long)dm_cur_precision()).add((long long)dm_mlp_chain_min_rows(0))       // + the one mutable dispatch threshold
+      .add((long long)tw_on);
   DmChainGraph cg("dream_rollout", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
   GruStack gk;
   DM_TRY(gru_stack(s, p, nullptr, &gk));
+  if (tw_on) {
+    const DmCvtSeg sg[4] = {{p[DM_RSSM_GRU_WIH], wih_h, (size_t)3 * D * Hd}, {p[DM_RSSM_GRU_WHH], whh_h, (size_t)3 * D * D},
+                            {p[DM_RSSM_PRIOR_H_W], wph_h, (size_t)Hd * D}, {p[DM_RSSM_PRIOR_W], wp_h, (size_t)ZP * Hd}};
+    DM_TRY(dm_to_bf16_multi_launch(sg, 4, st));
+    for (int i = 0; i < 4; ++i) dm_twin_add(sg[i].src, sg[i].n, sg[i].dst, true);
+    dm_twin_add(za, (size_t)M * Hd, za_h, false);
+    for (int i = 1; i <= H && i < 40; ++i)
+      dm_twin_add(feats + (size_t)i * M * F, (size_t)M * F, feats_h + (size_t)i * M * F, false);
+  }
   // steps 1.. of the rollout read the z the prior sampler of the step before drew: z_mlp + in_norm + ELU become one
   // gather-sum launch over z_mlp^T (dm_z_embed_launch) instead of a (M x Hd x Z) product and a LayerNorm launch
   static const int no_embed = getenv("DM_RSSM_NO_Z_EMBED") ? 1 : 0;        // A/B switch

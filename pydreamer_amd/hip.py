@@ -186,6 +186,7 @@ _SIGNATURES = {
     'dm_chain_graph_reset': (c_int, []),
     'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_fp32_mode': (c_int, []),
+    'dm_bf16_twins_enable': (c_int, [c_int]),
 }
 
 _lib = None

@@ -108,6 +108,25 @@ print(json.dumps(out))
 """
 
 
+@pytest.mark.parametrize('al,bl,M,N,K', [(0, 0, 300, 200, 136), (0, 0, 2500, 1800, 1000), (0, 1, 257, 96, 72), (1, 0, 128, 333, 200),
+                                         (1, 1, 96, 768, 4999), (1, 1, 400, 1624, 2500), (0, 0, 70, 40, 8), (0, 0, 4096, 1024, 4096)])
+def test_gemm_bf16_storage(hip, al, bl, M, N, K):
+    """dm_gemm_bf16h: operands STORED as bf16 (64-k tiles, 16-byte chunks), fp32 accumulation; reference = fp64 product of the
+    same bf16 values; the optional bf16 twin of the result is exactly RNE(C).  Ragged M / N / K, every layout pair."""
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn((M, K) if al == 0 else (K, M), generator=g).bfloat16().to(DEV)
+    B = torch.randn((N, K) if bl == 0 else (K, N), generator=g).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.empty(M, N, device=DEV)
+    Ch = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    hip.call('dm_gemm_bf16h', al, bl, M, N, K, hip.ptr(A), A.shape[1], hip.ptr(B), B.shape[1], hip.fptr(C), N, hip.ptr(Ch),
+             hip.fptr(bias), 0, hip.ptr(ws), ws.numel(), hip.stream())
+    ref = (A.double() if al == 0 else A.double().t()) @ (B.double() if bl == 0 else B.double().t()).t() + bias.double()
+    _close(C, ref, 0, 3e-6 * np.sqrt(K) * 4, f'bf16-storage gemm {al}{bl} {M}x{N}x{K}')
+    assert torch.equal(Ch, C.bfloat16())
+
+
 def test_gemm_split_bf16_is_fp32_class(hip):
     """DM_FP32_SPLIT=1 (experimental, read once per process -> probed in subprocesses): fp32 operands as three bf16 pieces,
     six MFMA products, fp32 accumulation (csrc/gemm.hip).  Every layout, ragged edges, split-K, the software-pipelined and

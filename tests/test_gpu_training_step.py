@@ -335,6 +335,105 @@ def test_conv_decoder_mse_fwd_bwd(hip):
         assert _rel_l2(gb[i], p[f'wm.decoder.image.model.{idx}.bias'].grad) < 2e-4, f'dec layer {i} db'
 
 
+def _conv_stack_bf16(model, T, B, twins, seed=5):
+    """Encoder fwd+bwd and decoder fwd+bwd through the C-ABI with DM_FLAG_BF16, the bf16-storage operand path on / off."""
+    import ctypes
+    from pydreamer_amd import hip as H
+    H.lib().dm_bf16_twins_enable(1 if twins else 0)
+    try:
+        g = torch.Generator().manual_seed(seed)
+        shp = model.wm.shape(T, B, 1)
+        shp.flags |= H.DM_FLAG_BF16
+        ws = torch.empty(H.workspace_bytes(shp), dtype=torch.uint8, device=DEV)
+        enc = model.wm.encoder.encoder_image
+        N, E, F_ = T * B, enc.out_dim, model.wm.features_dim
+        image = (torch.rand(T, B, 3, 64, 64, generator=g) - 0.5).to(DEV)
+        feat = torch.randn(N, F_, generator=g).to(DEV)
+        dembed = torch.randn(N, E, generator=g).to(DEV)
+        enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
+        acts = torch.empty(int(H.lib().dm_conv_encoder_acts_floats(ctypes.byref(shp))), device=DEV)
+        embed = torch.empty(N, E, device=DEV)
+        H.call('dm_conv_encoder_fwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(acts), H.fptr(embed),
+               H.ptr(ws), ws.numel(), H.stream())
+        eg = [torch.empty_like(m.weight) for m in enc.convs()], [torch.empty_like(m.bias) for m in enc.convs()]
+        enc_g = H.conv_struct(eg[0], eg[1], cls=H.dm_conv_grads)
+        H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(acts), H.fptr(dembed),
+               ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
+        dl = model.wm.decoder.image.layers()
+        dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
+        dacts = torch.empty(int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=DEV)
+        loss = torch.empty(N, device=DEV)
+        rec = torch.empty(N, 3, 64, 64, device=DEV)
+        target = image.reshape(N, 3, 64, 64).contiguous()
+        H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(target), ctypes.byref(dec_p),
+               H.fptr(dacts), H.fptr(loss), H.fptr(rec), H.ptr(ws), ws.numel(), H.stream())
+        dg = [torch.empty_like(m.weight) for m in dl], [torch.empty_like(m.bias) for m in dl]
+        dec_g = H.conv_struct(dg[0], dg[1], cls=H.dm_conv_grads)
+        dfeat = torch.zeros(N, F_, device=DEV)
+        H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(target), ctypes.byref(dec_p),
+               H.fptr(dacts), 1.0 / N, ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws), ws.numel(), H.stream())
+        torch.cuda.synchronize()
+        out = dict(embed=embed, loss=loss, rec=rec, dfeat=dfeat)
+        for i in range(4):
+            out[f'enc_dw{i}'], out[f'enc_db{i}'] = eg[0][i], eg[1][i]
+        for i in range(5):
+            out[f'dec_dw{i}'], out[f'dec_db{i}'] = dg[0][i], dg[1][i]
+        return {k: v.double().cpu() for k, v in out.items()}
+    finally:
+        H.lib().dm_bf16_twins_enable(1)
+
+
+@pytest.mark.parametrize('depth,T,B', [(8, 2, 3), (48, 2, 2), (16, 3, 5)])
+def test_conv_bf16_storage_twins_match_fp32_storage(hip, depth, T, B):
+    """conf.amp convolution stack with operands STORED as bf16 (twins written by the producing kernels, gemm_h_kernel) against
+    the same bf16 products fed from fp32 storage (rounded on the way into LDS): the operand values are identical (RNE of
+    the same fp32 numbers), so results differ by fp32 summation order only - every output and gradient within 2e-5 relative."""
+    oconf = O.tiny_conf(cnn_depth=depth)
+    model = _build(oconf, O.make_params(oconf))
+    a = _conv_stack_bf16(model, T, B, twins=True)
+    b = _conv_stack_bf16(model, T, B, twins=False)
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert _rel_l2(a[k], b[k]) < 2e-5, (k, _rel_l2(a[k], b[k]))
+
+
+def test_dream_rollout_bf16_storage_twins_match_fp32_storage(hip):
+    """conf.amp imagination rollout at the Atari-literal cell width (deter 600, hidden 1000, stoch 32x32), 300 rows: the cell's
+    four products fed from bf16 twins (per-call weight copies, za and the h columns of the feature buffer written by the
+    producing kernels) against the same bf16 products fed from fp32 storage - same operand values, so the sampled actions are
+    identical and the features agree to fp32 summation order."""
+    from pydreamer_amd import config, hip as H
+    from pydreamer_amd.models import Dreamer
+    oconf = O.make_conf(deter_dim=600, hidden_dim=1000, stoch_dim=32, stoch_discrete=32, cnn_depth=8, action_dim=18,
+                        batch_size=4, batch_length=4, imag_horizon=5)
+    params = O.make_params(oconf, seed=2)
+    conf = config.load_config('defaults', 'atari', **{**{k: getattr(oconf, k) for k in vars(oconf)}, 'amp': True})
+    model = Dreamer(conf)
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV)
+    M, Hh = 300, 5
+    g = torch.Generator().manual_seed(5)
+    h = torch.tanh(torch.randn(M, 600, generator=g)).to(DEV)
+    z = F.one_hot(torch.randint(0, 32, (M, 32), generator=g), 32).float().reshape(M, -1).to(DEV)
+    u_act, u_prior = torch.rand(Hh, M, generator=g).to(DEV), torch.rand(Hh, M, 32, generator=g).to(DEV)
+    out = []
+    try:
+        for on in (1, 0):
+            H.lib().dm_bf16_twins_enable(on)
+            fh, ah, rh, th = model.dream((h, z), Hh, u_act=u_act, u_prior=u_prior)
+            out.append((fh.clone(), ah.clone()))
+    finally:
+        H.lib().dm_bf16_twins_enable(1)
+    (f1, a1), (f0, a0) = out
+    assert torch.isfinite(f1).all()
+    same = (a1 == a0).all(dim=-1).reshape(Hh, M)
+    assert float(same.float().mean()) > 0.995        # a sample within fp32 rounding of a CDF edge may flip (and changes what follows)
+    rows = same.all(dim=0)                             # trajectories with identical actions throughout
+    zsame = (f1[:, :, 600:] == f0[:, :, 600:]).all(dim=-1).all(dim=0) & rows
+    assert float(zsame.float().mean()) > 0.9
+    _close(f1[:, zsame], f0[:, zsame], 0, 2e-5, 'dream features, twins on vs off')
+
+
 # ------------------------------------------------------------------------------------------- end to end
 def _run_pair(oconf, steps, forced=False, seed=0):
     """One or more full trainer iterations (train.py:165-198) on the oracle (CPU) and the HIP model (GPU)."""
