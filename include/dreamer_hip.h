@@ -104,6 +104,13 @@ int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_
  * entry point must come from a forward call with the same flags).  1 / 0 switches that path on / off, -1 queries; returns
  * the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
 int dm_bf16_twins_enable(int on);
+/* EXPERIMENTAL, off by default (slower than the launch schedule as measured): the posterior T loop
+ * (rssm.py:38-58) as ONE persistent kernel confined to one XCD when the shape qualifies (plain GRU, LayerNorm, 32-class
+ * latents, B <= 64): five phases per step separated by a flag barrier in that XCD's L2 instead of five dependent launches;
+ * results are bit-identical to the launch schedule.  1 / 0 switches it on / off, -1 queries; returns the state.
+ * dm_rssm_persist_prof: per-phase clock ticks of its workgroup 0 (diagnostic). */
+int dm_rssm_persist_enable(int on);
+int dm_rssm_persist_prof(unsigned long long* out12, int reset);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
 int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,

@@ -275,9 +275,19 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     float* f3 = ar.take(dm_frag_floats(D)); float* f4 = ar.take(dm_frag_floats(Hd));
     if (ar.ok) { zinf = f0; x1f = f1; hinf = f2; hf = f3; x2f = f4; }
   }
+  // The fused schedule's steps after the first of a range as ONE persistent kernel on one XCD (gemm_skinny.hip
+  // rssm_persist_kernel): the first step runs as launches (its z is a dense vector from the caller) and leaves the masked
+  // inputs, fragment-major copies and indices the kernel's first step needs.
+  float* psync = nullptr;
+  if (fuse_sample && zinf && wzt && idx && t1 - t0 >= 3 && dm_rssm_persist_ok(B, D, Hd, S, C, ZP, F)) {
+    float* sy = ar.take(dm_rssm_persist_sync_floats());
+    if (ar.ok) psync = sy;
+    else ar.ok = true;
+  }
+  const int t_launch_end = psync ? t0 + 1 : t1;
   // 8 launches per step otherwise: the reset masks of step t+1 are applied by the kernels that produce h_t and z_t (only
   // the first step of a range needs the stand-alone mask kernel), and the GRU's two gate products share one launch.
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0; t < t_launch_end; ++t) {
     const size_t r0 = (size_t)t * B;
     float* hin = a.hin + r0 * D;
     float* zin = a.zin + r0 * Z;
@@ -367,6 +377,17 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     DM_TRY(dm_sample_onehot_launch(B, S, C, post + r0 * ZP, ZP, u ? u + r0 * S : nullptr,
                                    forced_idx ? forced_idx + r0 * S : nullptr, feat + r0 * F + D, F,
                                    idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
+  }
+  if (psync) {
+    DmRssmPersist pq;
+    pq.B = B; pq.D = D; pq.Hd = Hd; pq.S = S; pq.Z = Z; pq.ZP = ZP; pq.F = F; pq.t_begin = t0 + 1; pq.t_end = t1;
+    pq.idx = idx; pq.reset = reset; pq.wzt = wzt; pq.zb = p[DM_RSSM_Z_B]; pq.ea = a.ea; pq.x1 = a.x1; pq.x1f = x1f;
+    pq.wih = p[DM_RSSM_GRU_WIH]; pq.bih = p[DM_RSSM_GRU_BIH]; pq.whh = p[DM_RSSM_GRU_WHH]; pq.bhh = p[DM_RSSM_GRU_BHH];
+    pq.wph = p[DM_RSSM_POST_H_W]; pq.bph = p[DM_RSSM_POST_H_B]; pq.wpo = p[DM_RSSM_POST_W]; pq.bpo = p[DM_RSSM_POST_OB];
+    pq.in_g = p[DM_RSSM_IN_G]; pq.in_b = p[DM_RSSM_IN_B]; pq.post_g = p[DM_RSSM_POST_G]; pq.post_b = p[DM_RSSM_POST_B];
+    pq.ee = a.ee; pq.gi = a.gi; pq.gh = a.gh; pq.hin = a.hin; pq.feat = feat; pq.hf = hf; pq.hinf = hinf; pq.x2 = a.x2;
+    pq.x2f = x2f; pq.post = post; pq.zin = a.zin; pq.zinf = zinf; pq.u = u; pq.forced = forced_idx; pq.sync = psync;
+    DM_TRY(dm_rssm_persist_launch(pq, st));
   }
   if (fuse_ln) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
     DM_TRY(norm_elu_fwd(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,

@@ -187,6 +187,8 @@ _SIGNATURES = {
     'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_fp32_mode': (c_int, []),
     'dm_bf16_twins_enable': (c_int, [c_int]),
+    'dm_rssm_persist_enable': (c_int, [c_int]),
+    'dm_rssm_persist_prof': (c_int, [_P, c_int]),
 }
 
 _lib = None

@@ -434,6 +434,47 @@ def test_dream_rollout_bf16_storage_twins_match_fp32_storage(hip):
     _close(f1[:, zsame], f0[:, zsame], 0, 2e-5, 'dream features, twins on vs off')
 
 
+@pytest.mark.parametrize('B', [7, 50])
+def test_rssm_persistent_chain_matches_launch_schedule(hip, B):
+    """The posterior T loop as one persistent kernel on one XCD (five phases per step behind an L2 flag barrier) against the
+    five-launch fused schedule it replaces, at the Atari-literal cell width, T = 12: same device code per phase, so sampled
+    indices, logits, states and saved activations are bit-identical."""
+    import ctypes
+    from pydreamer_amd import hip as H
+    T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
+    oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
+                        batch_size=B, batch_length=T)
+    model = _build(oconf, O.make_params(oconf, seed=4))
+    cell = model.wm.core.cell
+    E, Z, F_ = 32 * depth, S * C, D_ + S * C
+    g = torch.Generator().manual_seed(12)
+    embed = torch.randn(T * B, E, generator=g).to(DEV)
+    action = F.one_hot(torch.randint(0, A, (T * B,), generator=g), A).float().to(DEV)
+    reset = (torch.rand(T * B, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    h0, z0 = torch.tanh(torch.randn(B, D_, generator=g)).to(DEV), torch.zeros(B, Z).to(DEV)
+    u = torch.rand(T * B, S, generator=g).to(DEV)
+    shp = model.wm.shape(T, B, 1)
+    ws = model.wm.workspace(shp, torch.device(DEV, 0))
+    P = H.rssm_struct(cell.ordered())
+    outs = []
+    try:
+        for on in (1, 0):
+            H.lib().dm_rssm_persist_enable(on)
+            acts = torch.zeros(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
+            feat, post, prior = torch.zeros(T * B, F_, device=DEV), torch.zeros(T * B, Z, device=DEV), torch.zeros(T * B, Z, device=DEV)
+            idx = torch.zeros(T * B, S, dtype=torch.int32, device=DEV)
+            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
+                   H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
+                   H.ptr(ws), ws.numel(), H.stream())
+            torch.cuda.synchronize()
+            outs.append((feat, post, prior, idx, acts))
+    finally:
+        H.lib().dm_rssm_persist_enable(1)
+    for a, b, what in zip(outs[0], outs[1], ('feat', 'post', 'prior', 'idx', 'acts')):
+        assert torch.isfinite(a.float()).all(), what
+        assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
+
+
 # ------------------------------------------------------------------------------------------- end to end
 def _run_pair(oconf, steps, forced=False, seed=0):
     """One or more full trainer iterations (train.py:165-198) on the oracle (CPU) and the HIP model (GPU)."""
