@@ -445,8 +445,8 @@ def main():
                 key = dom['kernel'].replace('>', '') + ','        # "gemm_f32_kernel<64,64,0,0" + remaining template args
                 hits = [v for k, v in pmc.items() if k.replace(' ', '').startswith(key.replace(' ', ''))]
                 if hits:
-                    n = sum(h['launches'] for h in hits)
-                    traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n, 1)
+                    n_pmc = sum(h['launches'] for h in hits)
+                    traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_pmc, 1)
                     traffic_note = (f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE in separate rocprofv3 passes of this command "
                                     f"({os.path.relpath(args.pmc_json, ROOT)}, kernel sources {pj['csrc_sha']}); whole step "
                                     f"{pj.get('total_gb_per_step')} GB")

@@ -32,6 +32,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native 
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
 DM_FP32_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg > $OUT/${TAG}_bench_fp32_split.json 2>/dev/null
 python bench.py --dtype bf16 --no-cpu-baseline --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes_bf16.txt > $OUT/${TAG}_bench_bf16.json 2>/dev/null
+DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
 # per-CU operand load ceilings (coalesced vs MFMA-fragment gather), see scripts/microbench/l2_stream.hip
 (cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 l2_stream.hip -o /tmp/l2_stream 2>/dev/null && \
