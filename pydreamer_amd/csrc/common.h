@@ -256,7 +256,10 @@ int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, cons
 // kernel; null: packed here, per call, into the workspace
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr, int sparse_cols = 0);
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr, int sparse_cols = 0,
+                      const float* chain_add0 = nullptr);
+// chain_add0 (with chain_wpack packed for k0 = in_dim - sparse_cols): the caller already has the sparse columns' contribution
+// (the imagination rollout knows the latent's indices and gathers it, rssm.hip)
 // sparse_cols > 0: the LAST sparse_cols columns of x are mostly zero (one-hot latent groups); the row-panel path then
 // multiplies only the dense columns and adds the sparse ones' contribution as a sum of weight rows (dm_sparse_rows_launch)
 
@@ -281,10 +284,13 @@ int dm_panel_colsum_final_launch(int count, const float* const* part, float* con
 bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                      const dm_mlp_params* p);
 size_t dm_mlp_chain_pack_floats(int in_dim, int layers);
-int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st);
+// k0 (0 = in_dim): layer 0 packed / multiplied over the first k0 input columns only; add0 (rows x 400): the remaining (sparse,
+// one-hot) columns' contribution, added before the LayerNorm (dm_sparse_rows_launch / dm_z_embed_launch make it)
+int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st, int k0 = 0);
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
                             float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
-                            hipStream_t st);
+                            hipStream_t st, int k0 = 0, const float* add0 = nullptr);
+bool dm_mlp_chain_sparse_ok(int in_dim, int sparse_cols);      // the sparse-tail layer 0 applies (fp32 calls, aligned split)
 
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing
 void dm_prof_slot_end(int slot, hipStream_t st);

@@ -101,6 +101,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
                        3 * pad64(N * 3 * D) + pad64(N * 6 * 4) + pad64(N * Z) +      // (LayerNorm-GRU statistics: 6 per stack layer)
                        pad64(25 * 512 * (((D + Z + 31) / 32) + (L > 0 ? L - 1 : 0) * ((Hm + 31) / 32))) +   // + fragment-major actor weights
                        pad64(Z * Hd) + pad64(A * Hd) + pad64(N * (size_t)s->S) + pad64(N) +   // + z_mlp^T, a_mlp^T and the sampled indices (z_embed)
+                       pad64((D + (size_t)s->S * (s->C ? s->C : 1)) * Hm) + pad64(N * Hm) +   // + the actor's W0^T and its sparse-tail addend
                        tw * (pad64(3 * D * Hd / 2 + 1) + pad64(3 * D * D / 2 + 1) + pad64(Hd * D / 2 + 1) + pad64(Z * Hd / 2 + 1) +
                              pad64(N * Hd / 2 + 1) + pad64((H + 1) * N * (D + (size_t)s->S * (s->C ? s->C : 1)) / 2 + 1));   // + bf16 twins of the cell's weights, za and the h columns of feats
   size_t m = enc_bwd;

@@ -47,7 +47,8 @@ extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
 // leave most CUs idle there).
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
-                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack, int sparse_cols) {
+                      void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack, int sparse_cols,
+                      const float* chain_add0) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   DM_REQUIRE(sparse_cols >= 0 && sparse_cols < in_dim, DM_E_SHAPE, "mlp: sparse_cols=%d of in_dim=%d", sparse_cols, in_dim);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
@@ -81,15 +82,35 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
   const bool panel = normed && dm_panel_ok(rows, hidden) && (in_dim & 3) == 0 && ((uintptr_t)p->w[0] & 15) == 0;
   if (!panel && dm_mlp_chain_ok(rows, in_dim, hidden, layers, out_dim, x, ldx, p)) {    // all layers + output in ONE launch
     const float* wpack = chain_wpack;
+    // Sparse trailing columns (see the row-panel path below): layer 0 multiplies the dense columns only - for the DreamerV2
+    // feature that is 58 % of the whole kernel's MFMA issue and 36 % of its weight stream - and the one-hot columns'
+    // contribution is a gathered sum of W0^T rows, added before the LayerNorm.  A caller that packed the weights itself says
+    // so by handing the addend (chain_add0) with them.
+    int k0 = 0;
+    const float* add0 = nullptr;
+    if (wpack && chain_add0 && dm_mlp_chain_sparse_ok(in_dim, sparse_cols)) { k0 = in_dim - sparse_cols; add0 = chain_add0; }
     if (!wpack) {      // pack the weights fragment-major into the (otherwise unused) split-K region of the workspace
       const size_t need = dm_mlp_chain_pack_floats(in_dim, layers);
       if (need <= DM_SPLITK_FLOATS && ws_bytes >= need * sizeof(float) && ((uintptr_t)ws & 15) == 0) {
-        DM_TRY(dm_mlp_chain_pack_launch(in_dim, layers, p, (float*)ws, st));
+        if (dm_mlp_chain_sparse_ok(in_dim, sparse_cols) && (ldx & 3) == 0) {
+          DmArena ar(ws, ws_bytes);       // scratch past the split-K region and the activation ping-pong (as the panel path)
+          ar.take(DM_SPLITK_FLOATS);
+          ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * hidden); ar.take((size_t)rows * 2);
+          float* g = ar.take((size_t)rows * hidden);
+          float* w0t = ar.take((size_t)in_dim * hidden);
+          if (ar.ok) {
+            const int dense = in_dim - sparse_cols;
+            DM_TRY(dm_permute4_launch(p->w[0], w0t, 1, 1, hidden, in_dim, 0, 1, 3, 2, st));       // W0 (hidden, in) -> W0^T (in, hidden)
+            DM_TRY(dm_sparse_rows_launch(rows, hidden, sparse_cols, x + dense, ldx, w0t + (size_t)dense * hidden, g, hidden, st));
+            k0 = dense; add0 = g;
+          }
+        }
+        DM_TRY(dm_mlp_chain_pack_launch(in_dim, layers, p, (float*)ws, st, k0));
         wpack = (const float*)ws;
       }
     }
     return dm_mlp_chain_fwd_launch(rows, in_dim, layers, out_dim, x, ldx, p, acts ? a.xpre : nullptr,
-                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, wpack, st);
+                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, wpack, st, k0, add0);
   }
   if (panel) {
     const bool fuse_out = out_dim <= 32;

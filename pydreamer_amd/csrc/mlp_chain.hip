@@ -50,6 +50,12 @@ struct ChainArgs {
   // read ONE contiguous KiB.  The row-major gather (16 rows x 64 B per instruction) is limited to 16.6 B/clk/CU by the
   // texture path whatever the cache level (scripts/microbench/l2_stream.hip), contiguous loads reach ~50.
   const float* wp[DM_MAX_MLP_LAYERS];
+  // Layer 0 with a sparse tail (the one-hot latent of a feature row, rssm.py:83-84): the product runs over the first k0
+  // input columns only (packed weights hold those k0 columns) and add0 (rows x 400, dense) - the sum of the weight rows the
+  // tail's non-zeros name, made by dm_sparse_rows_launch / dm_z_embed_launch - joins the pre-activation before the
+  // LayerNorm.  k0 = in_dim, add0 = null: the plain product.
+  int k0;
+  const float* add0;
 };
 
 __device__ __forceinline__ float chain_red16(float v) {
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
     f32x4 acc[CH_WB];
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int K = l == 0 ? g.in_dim : CH_N;
+    const int K = l == 0 ? g.k0 : CH_N;
     // all waves walk 7 blocks (wave 0 sets the pace anyway); the 7th of waves 1..3 is a dummy that re-reads the wave's
     // first block and is ignored below
     const bool packed = g.wp[l] != nullptr;
@@ -243,6 +249,15 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
     } else {
       if (l == 0) chain_layer<true, BF, 0>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
       else chain_layer<false, BF, 0>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    }
+    if (l == 0 && g.add0) {      // the sparse tail's contribution (28 more values: loaded here, not held across the k-loop)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* ar = g.add0 + (size_t)(rok[r] ? rbase + r : g.rows - 1) * CH_N + nb0 * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < CH_WB; ++i)
+          if (i < cnt) acc[i][r] += ar[i * 16];
+      }
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -376,6 +391,7 @@ struct ChainPackArgs {
   const float* w[DM_MAX_MLP_LAYERS];
   float* dst[DM_MAX_MLP_LAYERS];
   int K[DM_MAX_MLP_LAYERS];
+  int ld[DM_MAX_MLP_LAYERS];                  // row stride of the source weights (> K for layer 0 of a sparse-tail pack)
   unsigned first[DM_MAX_MLP_LAYERS + 1];      // first group of each layer (prefix sums of 25 * npairs * 128)
   int layers;
 };
@@ -391,7 +407,7 @@ __global__ void __launch_bounds__(256) mlp_chain_pack_bf16_kernel(const ChainPac
     const int l15 = r & 15, q = (r >> 4) & 3;
     const unsigned bp = r >> 6;
     const int p = bp % np, nb = bp / np;
-    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * K;
+    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * a.ld[l];
     float v[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -417,7 +433,7 @@ __global__ void __launch_bounds__(256) mlp_chain_pack_kernel(const ChainPackArgs
     const unsigned bp = r >> 7;
     const int p = bp % np, nb = bp / np;
     const int k = p * 32 + h * 16 + 4 * q;
-    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * K + k;
+    const float* src = a.w[l] + (size_t)(nb * 16 + l15) * a.ld[l] + k;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k + 3 < K) v = make_float4(src[0], src[1], src[2], src[3]);        // K % 4 == 0 (host-checked)
     reinterpret_cast<float4*>(a.dst[l])[r] = v;
@@ -438,6 +454,7 @@ extern "C" int dm_mlp_chain_min_rows(int rows) {       // rows >= 1: set; return
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static const int g_chain_nopack = getenv("DM_CHAIN_NO_PACK") ? 1 : 0;      // A/B switch
 
 bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                      const dm_mlp_params* p) {
@@ -449,25 +466,34 @@ bool dm_mlp_chain_ok(int rows, int in_dim, int hidden, int layers, int out_dim, 
   return true;
 }
 
+// fp32 calls only (with bf16 operands the product is cheaper than the gather, as measured for the row panels); the dense
+// part keeps the 16-byte operand loads
+bool dm_mlp_chain_sparse_ok(int in_dim, int sparse_cols) {
+  static const int no_sparse = getenv("DM_MLP_NO_SPARSE") ? 1 : 0;         // A/B switch (shared with the row-panel path)
+  const int dense = in_dim - sparse_cols;
+  return !no_sparse && !g_chain_nopack && !dm_cur_precision() && sparse_cols > 0 && sparse_cols < in_dim && in_dim <= 4096 &&
+         (dense & 7) == 0 && dense >= 32;
+}
 static size_t chain_pack_layer_floats(int K) { return (size_t)CH_NBLK * ((K + 31) / 32) * 512; }
 size_t dm_mlp_chain_pack_floats(int in_dim, int layers) {
   size_t n = chain_pack_layer_floats(in_dim);
   for (int l = 1; l < layers; ++l) n += chain_pack_layer_floats(CH_N);
   return n;
 }
-static const int g_chain_nopack = getenv("DM_CHAIN_NO_PACK") ? 1 : 0;      // A/B switch
 // wpack: dm_mlp_chain_pack_floats(in_dim, layers) floats, 16-byte aligned.  A caller that runs the same weights several times
 // (the H steps of a rollout) packs once.
-int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st) {
+int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st, int k0) {
   DM_REQUIRE(wpack && al16(wpack) && (in_dim & 3) == 0 && layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp_chain_pack");
+  DM_REQUIRE(k0 >= 0 && k0 <= in_dim && (k0 & 3) == 0, DM_E_SHAPE, "mlp_chain_pack: k0=%d of in_dim=%d", k0, in_dim);
+  if (k0 == 0) k0 = in_dim;
   ChainPackArgs a = {};
   a.layers = layers;
   const bool bf = dm_cur_precision() != 0;      // the copy's element type follows the precision of the call that will use it
   size_t off = 0;
   unsigned first = 0;
   for (int l = 0; l < layers; ++l) {
-    const int K = l == 0 ? in_dim : CH_N;
-    a.w[l] = p->w[l]; a.dst[l] = wpack + off; a.K[l] = K; a.first[l] = first;
+    const int K = l == 0 ? k0 : CH_N;
+    a.w[l] = p->w[l]; a.dst[l] = wpack + off; a.K[l] = K; a.ld[l] = l == 0 ? in_dim : CH_N; a.first[l] = first;
     off += chain_pack_layer_floats(K);                                         // the layer offsets are the fp32 ones in both forms
     first += (unsigned)(chain_pack_layer_floats(K) / (bf ? 8 : 4));           // 16-byte groups: half as many in bf16
   }
@@ -484,15 +510,19 @@ int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, flo
 // wpack: fragment-major weights from dm_mlp_chain_pack_launch (null: the kernel gathers from the row-major weights).
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
                             float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
-                            hipStream_t st) {
+                            hipStream_t st, int k0, const float* add0) {
   ChainArgs a = {};
+  if (k0 == 0) k0 = in_dim;
+  DM_REQUIRE(k0 == in_dim || (add0 && wpack && !g_chain_nopack && k0 >= 4 && k0 < in_dim && (k0 & 3) == 0), DM_E_SHAPE,
+             "mlp_chain: a sparse-tail layer 0 (k0=%d of %d) needs its addend and weights packed for k0", k0, in_dim);
   if (wpack && !g_chain_nopack) {
     size_t off = 0;
     for (int l = 0; l < layers; ++l) {
       a.wp[l] = wpack + off;
-      off += chain_pack_layer_floats(l == 0 ? in_dim : CH_N);
+      off += chain_pack_layer_floats(l == 0 ? k0 : CH_N);
     }
   }
+  a.k0 = k0; a.add0 = k0 < in_dim ? add0 : nullptr;
   a.x = x; a.ldx = ldx; a.in_dim = in_dim;
   a.rows = rows; a.layers = layers; a.out_dim = out_dim; a.ldout = ldout;
   for (int l = 0; l <= layers; ++l) { a.w[l] = p->w[l]; a.b[l] = p->b[l]; }

@@ -753,10 +753,25 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     }
   }
   const float* actor_wpack = nullptr;
+  // the actor's first layer sees [h | one-hot z]: its z columns are a gathered sum of W0^T rows (indices from the prior
+  // sampler; step 0's z is a dense vector: its non-zeros are found by ballot), the MFMA product runs over h only
+  float *actor_w0t = nullptr, *actor_add0 = nullptr;
   if (dm_mlp_chain_ok(M, F, Hm, L, AO, feats, F, actor) && !dm_panel_ok(M, Hm)) {
     float* wpk = ar.take(dm_mlp_chain_pack_floats(F, L));
     if (ar.ok) {
-      DM_TRY(dm_mlp_chain_pack_launch(F, L, actor, wpk, st));
+      int k0 = 0;
+      if (C != 0 && pidx && dm_mlp_chain_sparse_ok(F, Z) && dm_z_embed_ok(Hm)) {
+        const size_t mark = ar.off;
+        float* wt = ar.take((size_t)F * Hm);
+        float* ad = ar.take((size_t)M * Hm);
+        if (ar.ok) {
+          actor_w0t = wt; actor_add0 = ad; k0 = D;
+          DM_TRY(transpose(st, actor->w[0], actor_w0t, Hm, F));
+        } else {
+          ar.off = mark; ar.ok = true;
+        }
+      }
+      DM_TRY(dm_mlp_chain_pack_launch(F, L, actor, wpk, st, k0));
       actor_wpack = wpk;
     }
   }
@@ -771,9 +786,16 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     // with actor_acts the activations of all H steps are kept (rows i*M..) so ActorCritic's policy-gradient backward
     // reuses them instead of recomputing forward_actor(features[:-1]) (the reference's own TODO, a2c.py:119)
     float* logits = actor_acts ? actor_logits + (size_t)i * M * AO : logits_ws;
+    if (actor_add0) {
+      if (i == 0) DM_TRY(dm_sparse_rows_launch(M, Hm, Z, cur + D, F, actor_w0t + (size_t)D * Hm, actor_add0, Hm, st));
+      else DM_TRY(dm_z_embed_launch(M, Hm, S, C, pidx, nullptr, actor_w0t + (size_t)D * Hm, nullptr, nullptr, 0, nullptr, nullptr,
+                                    actor_add0, Hm, nullptr, nullptr, nullptr, 0.f, nullptr, 0, st));
+    }
+    const int asp = actor_add0 ? Z : 0;
     if (actor_acts)
-      DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st, actor_wpack));
-    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack));
+      DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st, actor_wpack, asp,
+                               actor_add0));
+    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack, asp, actor_add0));
     int32_t* ai = act_idx ? act_idx + (size_t)i * M : aidx;       // the sampled action's index (scratch if the caller wants none)
     if (adist == 0)
       DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A, ai, nullptr, nullptr, st));

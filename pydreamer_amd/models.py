@@ -928,8 +928,9 @@ class WorldModel(_Params):
         if I > 1:                                  # targets expanded over I (decoders.py:270,305: insert_dim)
             reward_t = reward_t.repeat_interleave(I, dim=1).contiguous()
             terminal_t = terminal_t.repeat_interleave(I, dim=1).contiguous()
-        mu, r_acts = dec.reward.model.fwd(feat, F_, N, ws)
-        tl, t_acts = dec.terminal.model.fwd(feat, F_, N, ws)
+        sp = 0 if c.stoch_discrete == 0 else c.stoch_dim * c.stoch_discrete      # the one-hot latent columns of a feature row
+        mu, r_acts = dec.reward.model.fwd(feat, F_, N, ws, sparse_cols=sp)
+        tl, t_acts = dec.terminal.model.fwd(feat, F_, N, ws, sparse_cols=sp)
         loss_reward, dmu, reward_rec = (torch.empty(N, device=dev) for _ in range(3))
         loss_terminal, dtl, terminal_rec = (torch.empty(N, device=dev) for _ in range(3))
         # -Normal(mu, std).log_prob(y) * std^2 = 0.5 (mu-y)^2 + std^2 (log std + log sqrt(2 pi))   (decoders.py:296-304)

@@ -107,12 +107,14 @@ def test_mlp_head_panel_fwd_bwd(hip, rows, in_dim, out_dim):
         assert _rel_l2(g, p[key].grad) < 1e-4, name
 
 
-@pytest.mark.parametrize('rows,dense,S,C,out_dim', [(16400, 72, 8, 8, 6), (20000, 600, 32, 32, 1)])
+@pytest.mark.parametrize('rows,dense,S,C,out_dim', [(16400, 72, 8, 8, 6), (20000, 600, 32, 32, 1), (2500, 600, 32, 32, 18),
+                                                    (1100, 64, 8, 8, 6)])
 def test_mlp_head_sparse_trailing_columns(hip, rows, dense, S, C, out_dim):
     """dm_mlp_head_fwd_sparse (layer 0 = dense columns on the matrix pipe + the one-hot latent columns as a sum of weight
     rows) equals dm_mlp_head_fwd on feature rows [h | one-hot z] - output, saved pre-activations and statistics, so the
     unchanged dm_mlp_head_bwd gives the same gradients - and stays EXACT for arbitrary (dense, scaled, all-zero) trailing
-    columns; fp64 reference; bf16 operands too."""
+    columns; fp64 reference; bf16 operands too.  Rows >= 16 384: the row-panel kernels; 1 024 <= rows < 16 384: the whole-MLP
+    kernel (weights packed for the dense columns only, the addend joins the layer-0 pre-activation before the LayerNorm)."""
     from pydreamer_amd.models import MLP
     torch.manual_seed(11)
     Z = S * C
