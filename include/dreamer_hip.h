@@ -100,9 +100,9 @@ int dm_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
 int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
                   float* C, int ldc, uint16_t* C_h, const float* bias, int flags, void* ws, size_t ws_bytes, void* stream);
 /* Calls with DM_FLAG_BF16 keep bf16 twins of their activations / per-call weight copies and feed them to dm_gemm_bf16h's
- * kernel (activation arenas of such calls are larger: the *_acts_floats functions account for it; acts handed to a backward
- * entry point must come from a forward call with the same flags).  1 / 0 switches that path on / off, -1 queries; returns
- * the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
+ * kernel (activation arenas of such calls are larger: the *_acts_floats functions account for it; a backward entry point uses
+ * the arena twins only if the forward call that filled that `acts` buffer wrote them - the library keeps a host-side note per
+ * buffer).  1 / 0 switches that path on / off, -1 queries; returns the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
 int dm_bf16_twins_enable(int on);
 /* EXPERIMENTAL, off by default (slower than the launch schedule as measured): the posterior T loop
  * (rssm.py:38-58) as ONE persistent kernel confined to one XCD when the shape qualifies (plain GRU, LayerNorm, 32-class

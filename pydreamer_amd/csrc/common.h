@@ -75,6 +75,10 @@ bool dm_twins_on();                       // a scope is active on this thread
 void dm_twin_add(const float* base, size_t n, unsigned short* twin, bool valid);
 void dm_twin_mark(const float* p);        // the range holding p now has a complete twin
 unsigned short* dm_twin_of(const float* p, bool need_valid);      // twin address of element p, or nullptr
+// A forward entry point notes whether it wrote the arena twins of `acts`; the matching backward asks before trusting them
+// (dm_bf16_twins_enable may have been flipped in between, or the forward ran without DM_FLAG_BF16): host-side table.
+void dm_twin_arena_note(const void* acts, bool written);
+bool dm_twin_arena_valid(const void* acts);
 // dst[i] = bf16(src[i]) for up to 8 segments in one launch (weights of a call, small activations)
 struct DmCvtSeg { const float* src; unsigned short* dst; size_t n; };
 int dm_to_bf16_multi_launch(const DmCvtSeg* segs, int count, hipStream_t st);

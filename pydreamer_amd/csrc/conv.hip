@@ -514,7 +514,8 @@ extern "C" int dm_conv_encoder_fwd_rows(const dm_shape* shp, int n0, int n, int 
   enc_carve(g, acts, (size_t)1 << 60, &a);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "conv_encoder_fwd: workspace too small");
   DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
-  enc_register_twins(g, a, false, !prepare);
+  enc_register_twins(g, a, false, !prepare && dm_twin_arena_valid(acts));
+  dm_twin_arena_note(acts, dm_twins_on());
   if (prepare) {
     for (int l = 1; l < 4; ++l) {
       DM_TRY(conv_tables_launch(g.N, g.hb[l], g.hb[l], g.cin[l], 4, a.rowoff[l], a.koff[l], st));
@@ -622,7 +623,8 @@ extern "C" int dm_conv_encoder_bwd(const dm_shape* shp, const float* image, cons
   unsigned short* wcat_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wcmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_encoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
-  enc_register_twins(g, a, true, true);
+  const bool arena_tw = dm_twin_arena_valid(acts);      // the forward that filled `acts` wrote its twins
+  enc_register_twins(g, a, arena_tw, arena_tw);
   dm_twin_add(ga, gmax, ga_h, false);
   dm_twin_add(gb, g.rows[1] * g.cout[1], gb_h, false);
 
@@ -806,7 +808,8 @@ extern "C" int dm_conv_decoder_mse_fwd_rows(const dm_shape* shp, int n0, int n, 
   dec_carve(g, acts, (size_t)1 << 60, &a);
   DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
   const bool tw_on = dm_twins_on();
-  dec_register_twins(g, a, false, !prepare);
+  dec_register_twins(g, a, false, !prepare && dm_twin_arena_valid(acts));
+  dm_twin_arena_note(acts, tw_on);
   if (prepare) {
     for (int l = 1; l <= 4; ++l)
       DM_TRY(dm_permute4_launch(p->w[l], a.wr[l], g.cin[l], g.cout[l], g.k[l], g.k[l], 0, 2, 3, 1, st));
@@ -991,7 +994,8 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
   unsigned short* wpad_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wpadmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
-  dec_register_twins(g, a, true, true);
+  const bool arena_tw = dm_twin_arena_valid(acts);      // the forward that filled `acts` wrote its twins
+  dec_register_twins(g, a, arena_tw, arena_tw);
   dm_twin_add(ga, gmax, ga_h, false);
   dm_twin_add(gb, gmax, gb_h, false);
   dm_twin_add(wpad, wpadmax, wpad_h, false);

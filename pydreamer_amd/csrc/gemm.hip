@@ -1224,6 +1224,21 @@ unsigned short* dm_twin_of(const float* p, bool need_valid) {
   return r->twin + (p - r->base);
 }
 
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_arena_mu;
+static std::unordered_map<const void*, bool> g_arena_twins;
+void dm_twin_arena_note(const void* acts, bool written) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  if (g_arena_twins.size() > 4096) g_arena_twins.clear();       // stale keys of freed buffers: forgetting only disables the twin path once
+  g_arena_twins[acts] = written;
+}
+bool dm_twin_arena_valid(const void* acts) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  auto it = g_arena_twins.find(acts);
+  return it != g_arena_twins.end() && it->second;
+}
+
 static thread_local int tl_precision = 0;
 int dm_cur_precision() { return tl_precision; }
 DmPrecisionScope::DmPrecisionScope(int p) : prev(tl_precision) { tl_precision = p ? 1 : 0; }

@@ -337,7 +337,7 @@ def test_conv_decoder_mse_fwd_bwd(hip):
         assert _rel_l2(gb[i], p[f'wm.decoder.image.model.{idx}.bias'].grad) < 2e-4, f'dec layer {i} db'
 
 
-def _conv_stack_bf16(model, T, B, twins, seed=5):
+def _conv_stack_bf16(model, T, B, twins, seed=5, flip_before_backward=False):
     """Encoder fwd+bwd and decoder fwd+bwd through the C-ABI with DM_FLAG_BF16, the bf16-storage operand path on / off."""
     import ctypes
     from pydreamer_amd import hip as H
@@ -359,8 +359,12 @@ def _conv_stack_bf16(model, T, B, twins, seed=5):
                H.ptr(ws), ws.numel(), H.stream())
         eg = [torch.empty_like(m.weight) for m in enc.convs()], [torch.empty_like(m.bias) for m in enc.convs()]
         enc_g = H.conv_struct(eg[0], eg[1], cls=H.dm_conv_grads)
+        if flip_before_backward:
+            acts[int(H.lib().dm_conv_encoder_acts_floats(ctypes.byref(model.wm.shape(T, B, 1)))):].fill_(float('nan'))   # the (unwritten) twin region
+            H.lib().dm_bf16_twins_enable(0 if twins else 1)
         H.call('dm_conv_encoder_bwd', ctypes.byref(shp), H.fptr(image), ctypes.byref(enc_p), H.fptr(acts), H.fptr(dembed),
                ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
+        H.lib().dm_bf16_twins_enable(1 if twins else 0)
         dl = model.wm.decoder.image.layers()
         dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
         dacts = torch.empty(int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(shp))), device=DEV)
@@ -371,6 +375,9 @@ def _conv_stack_bf16(model, T, B, twins, seed=5):
                H.fptr(dacts), H.fptr(loss), H.fptr(rec), H.ptr(ws), ws.numel(), H.stream())
         dg = [torch.empty_like(m.weight) for m in dl], [torch.empty_like(m.bias) for m in dl]
         dec_g = H.conv_struct(dg[0], dg[1], cls=H.dm_conv_grads)
+        if flip_before_backward:
+            dacts[int(H.lib().dm_conv_decoder_acts_floats(ctypes.byref(model.wm.shape(T, B, 1)))):].fill_(float('nan'))
+            H.lib().dm_bf16_twins_enable(0 if twins else 1)
         dfeat = torch.zeros(N, F_, device=DEV)
         H.call('dm_conv_decoder_mse_bwd', ctypes.byref(shp), H.fptr(feat), F_, H.fptr(target), ctypes.byref(dec_p),
                H.fptr(dacts), 1.0 / N, ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws), ws.numel(), H.stream())
@@ -397,6 +404,10 @@ def test_conv_bf16_storage_twins_match_fp32_storage(hip, depth, T, B):
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert _rel_l2(a[k], b[k]) < 2e-5, (k, _rel_l2(a[k], b[k]))
+    # the switch flipped BETWEEN forward and backward: the backward must not trust twins that were never written
+    c = _conv_stack_bf16(model, T, B, twins=False, flip_before_backward=True)
+    for k in a:
+        assert _rel_l2(c[k], b[k]) < 2e-5, (k, 'switch flipped between forward and backward')
 
 
 def test_dream_rollout_bf16_storage_twins_match_fp32_storage(hip):
