@@ -243,13 +243,13 @@ def main():
     # DM_BENCH_ONE_DEVICE=1 (smoke test of the N > 1 code path on a 1-GPU box, tests/test_gpu_dist.py): every rank uses
     # cuda:0 and the ranks talk over gloo; the line is marked invalid as a metric
     one_device = bool(os.environ.get('DM_BENCH_ONE_DEVICE')) and world > 1
+    if one_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)                   # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
-    if one_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
 
     from pydreamer_amd import config, hip
     from pydreamer_amd import dist as DP
