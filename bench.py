@@ -216,7 +216,7 @@ def main():
     ap.add_argument('--ring', type=int, default=8)
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--pmc-json', default=os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'),
+    ap.add_argument('--pmc-json', default='',
                     help='per-kernel HBM traffic from two rocprofv3 PMC passes of THIS command (scripts/pmc_traffic.py); it carries a '
                          'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
     ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
@@ -232,6 +232,8 @@ def main():
     ap.add_argument('--h2d-steps', type=int, default=20)
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
+    if not args.pmc_json:       # the committed counter summary of the same command (fp32 / bf16 step), if its fingerprint matches the tree
+        args.pmc_json = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r03_pmc_traffic.json')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -420,7 +422,8 @@ def main():
         for k in range(23):
             cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
-                kname = (f"gemm_f32_kernel<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>" if k < 20 else
+                # (bf16 mode: the same tile / layout runs as gemm_pipe_kernel, or gemm_h_kernel when both operands have bf16 twins)
+                kname = (f"{'gemm_pipe_kernel' if args.dtype == 'bf16' else 'gemm_f32_kernel'}<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>" if k < 20 else
                          ('panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2' if k == 21 else 'mlp_chain_fwd_kernel'))
                 kinds.append(dict(kernel=kname,
                                   layout=names[k & 3] if k < 20 else ('row panel fwd' if k == 20 else 'row panel bwd' if k == 21 else 'whole-MLP forward, 16-row blocks'), launches_per_step=cnt / args.prof_steps,
@@ -443,7 +446,8 @@ def main():
             else:
                 pmc = pj['kernels']
                 key = dom['kernel'].replace('>', '') + ','        # "gemm_f32_kernel<64,64,0,0" + remaining template args
-                hits = [v for k, v in pmc.items() if k.replace(' ', '').startswith(key.replace(' ', ''))]
+                keys = [key.replace(' ', '')] + ([key.replace(' ', '').replace('gemm_pipe_kernel', 'gemm_h_kernel')] if args.dtype == 'bf16' else [])
+                hits = [v for k, v in pmc.items() if any(k.replace(' ', '').startswith(kk) for kk in keys)]
                 if hits:
                     n_pmc = sum(h['launches'] for h in hits)
                     traffic = sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_pmc, 1)

@@ -25,13 +25,14 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/prof_WRITE_SIZE -name "*counter_collection.csv" | head -1) 3 $SHA > $OUT/${TAG}_pmc_traffic.json
 cd $REPO
-python bench.py --pmc-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # where bench.py looks by default (on this box; copy gpurun_out/<tag>/ into profiles/ afterwards)
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
 for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
 DM_FP32_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg > $OUT/${TAG}_bench_fp32_split.json 2>/dev/null
-python bench.py --dtype bf16 --no-cpu-baseline --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes_bf16.txt > $OUT/${TAG}_bench_bf16.json 2>/dev/null
+bash scripts/collect_pmc_bf16.sh $TAG > $OUT/collect_bf16.log 2>&1      # bf16 step: its own counter passes, then the bf16 bench line
 DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
 # per-CU operand load ceilings (coalesced vs MFMA-fragment gather), see scripts/microbench/l2_stream.hip
