@@ -229,3 +229,14 @@ def test_graft_entry_build_passes():
     """The driver's build check (make is a no-op on an up-to-date tree; the ABI assertion and symbol walk are what is tested)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_runtime_switch_defaults():
+    """Library-wide switches that change WHICH kernels run (never what they compute): the bf16-storage operand path is on, the
+    experimental persistent posterior chain and the chain graphs are off unless the environment says otherwise."""
+    lib = hip.lib()
+    if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_PERSIST', 'DM_CHAIN_GRAPH')):
+        assert lib.dm_bf16_twins_enable(-1) == 1
+        assert lib.dm_rssm_persist_enable(-1) == 0
+        assert lib.dm_chain_graph_enable(-1) == 0
+    assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
