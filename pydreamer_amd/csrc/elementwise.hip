@@ -884,6 +884,48 @@ int dm_sparse_rows_launch(int rows, int n, int Zc, const float* z, int ldz, cons
 }
 
 bool dm_z_embed_ok(int n) { return n <= 1024 && (n & 3) == 0; }
+// The same sums for the <= 64-row steps of the posterior chain when only x is wanted (the LayerNorm rides in the consuming
+// product's prologue there): ONE ROW PER WORKGROUP, its 4 waves split the columns (one float4 per lane for n <= 1024) and all S <= 32
+// gathers of a lane are in flight at once - the one-wave-per-row form walks them in 4 dependent batches of 8, four global round
+// trips on a kernel that is nothing but latency.  Per column the additions run in the same order, so x is bit-identical.
+__global__ void __launch_bounds__(256) z_embed_wide_kernel(int n, int S, int C, const int32_t* __restrict__ idx,
+                                                           const uint8_t* __restrict__ row_zero, const float* __restrict__ Wt,
+                                                           const float* __restrict__ bias, const float* __restrict__ add, int ldadd,
+                                                           const int32_t* __restrict__ idx2, const float* __restrict__ Wt2,
+                                                           float* __restrict__ x, int ldx, float* __restrict__ x_frag) {
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = threadIdx.x * 4;                       // this thread's 4 columns
+  const bool in = c < n;
+  const int off = in ? c : 0;
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (add) {
+    const float4 a = *reinterpret_cast<const float4*>(add + (size_t)row * ldadd + off);
+    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  }
+  if (idx2) {
+    const float4 a = *reinterpret_cast<const float4*>(Wt2 + (size_t)idx2[row] * n + off);
+    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  }
+  if (!(row_zero && row_zero[row])) {
+    const int mine = idx[(size_t)row * S + min(lane, S - 1)];      // S <= 32 (host-checked): every wave holds the row's indices
+    float4 w[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int sc = s < S ? s : S - 1;                  // past S: re-read the last row (not added)
+      w[s] = *reinterpret_cast<const float4*>(Wt + ((size_t)sc * C + __shfl(mine, sc, 64)) * n + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+      if (s < S) { acc.x += w[s].x; acc.y += w[s].y; acc.z += w[s].z; acc.w += w[s].w; }
+  }
+  if (in) {
+    if (x) *reinterpret_cast<float4*>(x + (size_t)row * ldx + c) = acc;
+    if (x_frag) *reinterpret_cast<float4*>(x_frag + dm_frag_off(row, c)) = acc;
+  }
+}
+
 int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
                       const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
                       float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st) {
@@ -893,6 +935,13 @@ int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const u
   DM_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0, DM_E_SHAPE, "z_embed: leading dims must be multiples of 4");
   DM_REQUIRE(!x_frag || rows <= 64, DM_E_SHAPE, "z_embed: the fragment-major copy needs rows <= 64");
   DM_REQUIRE(!y || (gamma != nullptr) == (beta != nullptr), DM_E_NULL, "z_embed: LayerNorm gain without its bias");
+  static const int no_wide = getenv("DM_Z_EMBED_NO_WIDE") ? 1 : 0;      // A/B switch
+  if (!y && x && rows <= 64 && S <= 32 && !no_wide) {      // the chain's steps: latency only, one workgroup per row
+    hipLaunchKernelGGL(z_embed_wide_kernel, dim3(rows), dim3(256), 0, st, n, S, C, idx, row_zero, Wt, bias, add, ldadd, idx2, Wt2, x,
+                       ldx, x_frag);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   unsigned short* y_h = (y && gamma) ? dm_twin_of(y, false) : nullptr;      // bf16 mode: the LayerNorm+ELU output's twin
   if (y_h) dm_twin_mark(y);
   hipLaunchKernelGGL(z_embed_kernel, dim3(dm_cdiv(rows, 4)), dim3(256), 0, st, rows, n, S, C, idx, row_zero, Wt, bias, add,
