@@ -17,8 +17,13 @@ Here the same batches are produced as what the HIP path consumes directly:
   * `DeviceRing`              - a background thread fills pinned host buffers and issues the H2D copies on its own HIP
     stream into a ring of device-resident batches; `next()` hands out a batch whose copy the consumer's stream waits on.
 
-parity: the reference's data.py imports mlflow at module scope, which is absent here, so this reader is pinned by its
-own property tests (tests/test_replay_cpu.py), not against the reference implementation - "parity unpinned" for this file.
+parity: pinned against the reference's own DataSequential + Preprocessor run in the build container
+(oracle/gen_replay_golden.py -> tests/golden/replay_reader.npz; tests/test_replay_cpu.py replays it: same episode files,
+same arguments, same seed of numpy's legacy random stream => identical batches, byte for byte, for 7 reader configurations).
+The limits of that pin, as the generator's header states them: data.py imports mlflow at module scope and mlflow is absent,
+so the import statements were satisfied with empty placeholder modules (nothing in them is called), and the episode source
+was a local subclass of the reference's abstract EpisodeRepository instead of MlflowEpisodeRepository.  `DeviceRing` has no
+reference counterpart (the reference uses a DataLoader + `.to(device)`) and is covered by its own tests.
 """
 import os
 import queue
