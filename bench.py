@@ -328,6 +328,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_model = float(metrics['loss_model'])
+    # What the host needs to ENQUEUE a step when nothing holds it back: three more steps right after the synchronise (empty
+    # queues).  `host_enqueue_ms_per_step` above is taken over the timed region, where the runtime's queue back-pressure
+    # makes the launching threads wait for the GPU once they are a few steps ahead - it tracks the GPU, not the host's cost.
+    th = time.perf_counter()
+    for i in range(3):
+        step(args.warmup + args.steps + i)
+    host_free_ms = 1e3 * (time.perf_counter() - th) / 3
+    torch.cuda.synchronize()
     dist_info = None
     if world > 1:
         # per-rank numbers (before the MAX) and the stand-alone cost of the step's all-reduces on this fabric
@@ -487,6 +495,7 @@ def main():
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
                     loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
+                    host_enqueue_unthrottled_ms_per_step=host_free_ms,
                     fp32_products=('split-bf16 x3 pieces / 6 MFMA products, fp32 accumulate (DM_FP32_SPLIT=1)' if hip.lib().dm_fp32_mode() else 'fp32 MFMA'),
                     chain_graphs=hip.chain_graph_stats(),
                     step_tflops=alg_tflop / (ms * 1e-3), step_frac_of_fp32_peak=alg_tflop / (ms * 1e-3) / 157.3,

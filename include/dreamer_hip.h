@@ -70,9 +70,10 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 6 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 7 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
-                                         v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58) */
+                                         v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
+                                         v7: dm_wgrad_side_arm / _join - additions only) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -80,6 +81,20 @@ size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call 
  * posterior loop's latency chain with it (no reference counterpart: torch exposes no CU masks). */
 int dm_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int dm_stream_destroy(void* stream);
+/* Weight gradients off the critical chain.  In the world-model backward (train.py:189 loss_model.backward()) only the DATA
+ * gradients are a chain - image decoder -> BPTT loop -> encoder; every weight / bias / LayerNorm gradient is a leaf that
+ * nothing waits for until the gradient clip.  dm_wgrad_side_arm(1) arms the CALLING THREAD: while armed,
+ * dm_conv_decoder_mse_bwd*() and dm_rssm_sequence_bwd() enqueue their parameter-gradient kernels on a library-owned
+ * low-priority stream that waits (events) for the gradient rows they read, so they run beside the BPTT loop - a B-row
+ * latency chain that leaves most CUs idle - instead of in front of / behind it (dm_rssm_sequence_bwd cuts its batched weight
+ * gradients into up to four time chunks for this, armed or not: the sums are the same either way).
+ * Contract while armed: the `ws` handed to such a call must not be reused by any other call before the join (the deferred
+ * kernels read their gradient buffers, tables and split-K scratch there), and the parameter gradients are complete on
+ * `stream` only after dm_wgrad_side_join(stream), which makes `stream` wait for the side stream and disarms the thread.
+ * Unarmed (the default for every direct caller) everything is enqueued on the caller's stream.  Results are bit-identical
+ * either way (same kernels, same arguments).  No reference counterpart (autograd orders these itself). */
+int dm_wgrad_side_arm(int on);
+int dm_wgrad_side_join(void* stream);
 
 /* ---------------------------------------------------------------- primitives ------------------- */
 /* C[m,n] (ldc) = epi( sum_k A(m,k) * B(n,k) ), fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -43,6 +43,14 @@ struct DmArena {
   }
 };
 
+// ---- weight-gradient side stream (lib.hip; include/dreamer_hip.h dm_wgrad_side_arm / _join) -------
+// dm_wgrad_side_stream(st): the library's low-priority side stream if the calling thread is armed, else `st` itself.
+// dm_wgrad_side_fork(st, sw): sw waits for everything enqueued on st so far (no-op when sw == st).
+// dm_wgrad_side_mark(sw, st): records the "deferred work enqueued so far" event the join waits for (no-op when sw == st).
+hipStream_t dm_wgrad_side_stream(hipStream_t st);
+int dm_wgrad_side_fork(hipStream_t st, hipStream_t sw);
+int dm_wgrad_side_mark(hipStream_t sw, hipStream_t st);
+
 // ---- operand precision of the call in progress ---------------------------------------------------
 // Every C-ABI entry point that runs contractions takes its precision from ITS OWN arguments (dm_shape.flags bit
 // DM_FLAG_BF16, dm_mlp_params.precision, the DM_GEMM_BF16 flag of dm_gemm_f32) and holds it in a thread-local for the

@@ -974,34 +974,42 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     if (co4[l] != g.cout[l] && w > wpadmax) wpadmax = w;
   }
   if ((size_t)g.N * g.cin[1] > gmax) gmax = (size_t)g.N * g.cin[1];
-  float* ga = ar.take(gmax);
-  float* gb = ar.take(gmax);
+  // One gradient buffer per layer (together smaller than a ping-pong pair of the largest) and one gather table pair per layer:
+  // a layer's weight / bias gradient only reads G[l], its tables and the saved activations, so those launches can sit on
+  // the weight-gradient side stream (common.h, dm_wgrad_side_*) and run beside whatever follows the DATA-gradient chain on
+  // `st` - the BPTT loop - instead of in front of it.  Not armed: sw == st and the order below is simply "as enqueued".
+  float* Gl[5];
+  unsigned short* Gl_h[5];
+  size_t gsz[5];
+  gsz[0] = (size_t)g.N * g.cin[1];
+  for (int l = 1; l <= 4; ++l) gsz[l] = g.rows_b[l] * co4[l];
+  for (int l = 0; l <= 4; ++l) Gl[l] = ar.take(gsz[l]);
+  (void)gmax;
   float* dwr = ar.take(wmax);
   float* wpad = ar.take(wpadmax);
   float* bsum = ar.take(64);
-  size_t romax = 0, komax = 0;
+  int* rowoff_l[5];
+  int* koff_l[5];
   for (int l = 1; l <= 4; ++l) {
-    if (g.rows_s[l] > romax) romax = g.rows_s[l];
-    if ((size_t)g.k[l] * g.k[l] * co4[l] > komax) komax = (size_t)g.k[l] * g.k[l] * co4[l];
+    rowoff_l[l] = (int*)ar.take(g.rows_s[l]);
+    koff_l[l] = (int*)ar.take((size_t)g.k[l] * g.k[l] * co4[l]);
   }
-  int* rowoff = (int*)ar.take(romax);
-  int* koff = (int*)ar.take(komax);
-  // bf16 mode: twins of the two gradient ping-pong buffers and of the padded image-layer weights
+  float* splitk_w = ar.take(DM_SPLITK_FLOATS);          // the side stream's own split-K scratch
+  // bf16 mode: twins of the gradient buffers and of the padded image-layer weights
   DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
   const bool tw_on = dm_twins_on();
-  unsigned short* ga_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(gmax) : 0);
-  unsigned short* gb_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(gmax) : 0);
+  for (int l = 0; l <= 4; ++l) Gl_h[l] = (unsigned short*)ar.take(tw_on ? dm_half_floats(gsz[l]) : 0);
   unsigned short* wpad_h = (unsigned short*)ar.take(tw_on ? dm_half_floats(wpadmax) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "conv_decoder_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   const bool arena_tw = dm_twin_arena_valid(acts);      // the forward that filled `acts` wrote its twins
   dec_register_twins(g, a, arena_tw, arena_tw);
-  dm_twin_add(ga, gmax, ga_h, false);
-  dm_twin_add(gb, gmax, gb_h, false);
+  for (int l = 0; l <= 4; ++l) dm_twin_add(Gl[l], gsz[l], Gl_h[l], false);
   dm_twin_add(wpad, wpadmax, wpad_h, false);
+  hipStream_t sw = dm_wgrad_side_stream(st);
 
   // G4 = scale * (pred - target), NHWC with co4[4] channels per pixel
-  float* G = ga;
+  float* G = Gl[4];
   DM_TRY(mse_launch(shape_u8(shp), g.N, g.hbg[4] * g.hbg[4], g.ch, a.x[4], (const void*)target, shp->I > 0 ? shp->I : 1, scale,
                     row_scale, nullptr, G, co4[4], nullptr, st));
   for (int l = 4; l >= 1; --l) {
@@ -1010,10 +1018,13 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     const bool padded = co != g.cout[l];
     const int ncol = kk * co;
     const int rows_s = (int)g.rows_s[l];
+    int* rowoff = rowoff_l[l];
+    int* koff = koff_l[l];
+    // patches of the output gradient, gathered implicitly (16-byte gathers: co is a multiple of 4)
+    DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], co, g.k[l], rowoff, koff, st));
+    DM_TRY(dm_wgrad_side_fork(st, sw));                  // G[l] and its tables are enqueued: the side stream may read them
+    // ---- data gradient (the chain the BPTT loop waits for), on st
     if (padded) {
-      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, bsum, splitk, skb, st));
-      hipError_t e = hipMemcpyAsync(gr->b[l], bsum, (size_t)g.cout[l] * sizeof(float), hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_decoder_bwd: %s", hipGetErrorString(e));
       hipLaunchKernelGGL(convt_pad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * ncol)), dim3(256), 0, st, g.cin[l], g.cout[l], co,
                          g.k[l], p->w[l], wpad);
       DM_LAUNCH_CHECK();
@@ -1022,11 +1033,27 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
         DM_TRY(dm_to_bf16_multi_launch(&sg, 1, st));
         dm_twin_mark(wpad);
       }
-    } else {
-      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, gr->b[l], splitk, skb, st));
     }
-    // patches of the output gradient, gathered implicitly (16-byte gathers: co is a multiple of 4)
-    DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], co, g.k[l], rowoff, koff, st));
+    float* Gn = Gl[l - 1];
+    {
+      DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
+      d.a_layout = 0; d.b_layout = 0;
+      d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
+      d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1;
+      d.a_tab_vec8 = (co & 7) == 0 || (co == 4 && (g.k[l] & 1) == 0);
+      d.B = padded ? wpad : a.wr[l]; d.ldb = ncol;
+      d.C = Gn; d.ldc = g.cin[l];
+      if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }
+      DM_TRY(dm_gemm_launch(d, splitk, skb, st));
+    }
+    // ---- bias and weight gradient, on sw
+    if (padded) {
+      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, bsum, splitk_w, skb, sw));
+      hipError_t e = hipMemcpyAsync(gr->b[l], bsum, (size_t)g.cout[l] * sizeof(float), hipMemcpyDeviceToDevice, sw);
+      if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_decoder_bwd: %s", hipGetErrorString(e));
+    } else {
+      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, gr->b[l], splitk_w, skb, sw));
+    }
     DmGemm q;   // dWr[i][(ky,kx,o)] = sum_rows X[row][i] * dYcol[row][(ky,kx,o)]
     q.a_layout = 1; q.b_layout = 1;
     q.M = g.cin[l]; q.N = ncol; q.K = rows_s;
@@ -1034,38 +1061,19 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     q.B = G; q.b_maj = rowoff; q.b_min = koff; q.b_tab_vec = 1;
     q.b_tab_vec8 = (co & 7) == 0 || (co == 4 && (g.k[l] & 1) == 0);      // 8 minors = 8 channels, or 2 pixels x 4 channels of an even-width window
     q.C = dwr; q.ldc = ncol;
-    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
+    DM_TRY(dm_gemm_launch(q, splitk_w, skb, sw));
     if (padded) {
-      hipLaunchKernelGGL(convt_unpad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * kk * g.cout[l])), dim3(256), 0, st, g.cin[l],
+      hipLaunchKernelGGL(convt_unpad_cout_kernel, dim3(grid_for((size_t)g.cin[l] * kk * g.cout[l])), dim3(256), 0, sw, g.cin[l],
                          g.cout[l], co, g.k[l], dwr, gr->w[l]);
       DM_LAUNCH_CHECK();
     } else {
-      DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, st));
+      DM_TRY(dm_permute4_launch(dwr, gr->w[l], g.cin[l], g.k[l], g.k[l], g.cout[l], 0, 3, 1, 2, sw));
     }
-    float* Gn = (G == ga) ? gb : ga;
-    DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
-    d.a_layout = 0; d.b_layout = 0;
-    d.M = rows_s; d.N = g.cin[l]; d.K = ncol;
-    d.A = G; d.a_maj = rowoff; d.a_min = koff; d.a_tab_vec = 1;
-    d.a_tab_vec8 = (co & 7) == 0 || (co == 4 && (g.k[l] & 1) == 0);
-    d.B = padded ? wpad : a.wr[l]; d.ldb = ncol;
-    d.C = Gn; d.ldc = g.cin[l];
-    if (l - 1 >= 1) { d.mulref = a.x[l - 1]; d.ldmul = g.cin[l]; }
-    DM_TRY(dm_gemm_launch(d, splitk, skb, st));
     G = Gn;
   }
   // fc: x0 = feat W^T + b
   const int O = g.cin[1];
-  DM_TRY(dm_colsum_launch(g.N, O, G, O, gr->b[0], splitk, skb, st));
-  {
-    DmGemm q;   // dW[o][f] = sum_n G[n][o] feat[n][f]
-    q.a_layout = 1; q.b_layout = 1;
-    q.M = O; q.N = g.F; q.K = g.N;
-    q.A = G; q.lda = O;
-    q.B = feat; q.ldb = ldf;
-    q.C = gr->w[0]; q.ldc = g.F;
-    DM_TRY(dm_gemm_launch(q, splitk, skb, st));
-  }
+  DM_TRY(dm_wgrad_side_fork(st, sw));
   if (dfeat) {
     DmGemm d;   // dfeat[n][f] += sum_o G[n][o] W[o][f]
     d.a_layout = 0; d.b_layout = 1;
@@ -1076,5 +1084,16 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     d.flags = DM_GEMM_ACCUM;
     DM_TRY(dm_gemm_launch(d, splitk, skb, st));
   }
+  DM_TRY(dm_colsum_launch(g.N, O, G, O, gr->b[0], splitk_w, skb, sw));
+  {
+    DmGemm q;   // dW[o][f] = sum_n G[n][o] feat[n][f]
+    q.a_layout = 1; q.b_layout = 1;
+    q.M = O; q.N = g.F; q.K = g.N;
+    q.A = G; q.lda = O;
+    q.B = feat; q.ldb = ldf;
+    q.C = gr->w[0]; q.ldc = g.F;
+    DM_TRY(dm_gemm_launch(q, splitk_w, skb, sw));
+  }
+  DM_TRY(dm_wgrad_side_mark(sw, st));
   return DM_OK;
 }

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -14,7 +16,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 6; }
+extern "C" int dm_version(void) { return 7; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -42,6 +44,74 @@ extern "C" int dm_stream_destroy(void* stream) {
   if (!stream) return DM_OK;
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+// ---- weight-gradient side stream (see include/dreamer_hip.h) ---------------------------------------------------------
+// One stream + two events per process (one process drives one GPU); the armed flag is per host thread, because the
+// world-model backward is enqueued by one thread while others enqueue the rollout / actor-critic passes.
+static std::mutex g_side_mu;
+static hipStream_t g_side_stream = nullptr;
+static hipEvent_t g_side_fork_ev[8] = {nullptr}, g_side_done_ev = nullptr;      // fork events rotate: one per fork point in flight
+static unsigned g_side_fork_i = 0;
+static int g_side_dev = -1;
+static bool g_side_pending = false;
+static thread_local bool tl_side_armed = false;
+
+static int side_init_locked() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return dm_fail(DM_E_DEVICE, "wgrad_side: hipGetDevice failed");
+  if (g_side_stream && dev == g_side_dev) return DM_OK;
+  if (g_side_stream) return dm_fail(DM_E_DEVICE, "wgrad_side: created on device %d, called on device %d", g_side_dev, dev);
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const char* pe = getenv("DM_WGRAD_SIDE_PRIO");
+  const int prio = pe ? atoi(pe) : least;               // lowest priority: the chains' small kernels dispatch first
+  hipError_t e = hipStreamCreateWithPriority(&g_side_stream, hipStreamNonBlocking, prio);
+  for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&g_side_fork_ev[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g_side_done_ev, hipEventDisableTiming);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side: %s", hipGetErrorString(e));
+  g_side_dev = dev;
+  return DM_OK;
+}
+
+extern "C" int dm_wgrad_side_arm(int on) {
+  if (on) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    DM_TRY(side_init_locked());
+  }
+  tl_side_armed = on != 0;
+  return DM_OK;
+}
+
+hipStream_t dm_wgrad_side_stream(hipStream_t st) { return tl_side_armed && g_side_stream ? g_side_stream : st; }
+
+int dm_wgrad_side_fork(hipStream_t st, hipStream_t sw) {
+  if (sw == st) return DM_OK;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  hipEvent_t ev = g_side_fork_ev[g_side_fork_i++ & 7];
+  hipError_t e = hipEventRecord(ev, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(sw, ev, 0);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side fork: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_wgrad_side_mark(hipStream_t sw, hipStream_t st) {
+  if (sw == st) return DM_OK;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  hipError_t e = hipEventRecord(g_side_done_ev, sw);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side mark: %s", hipGetErrorString(e));
+  g_side_pending = true;
+  return DM_OK;
+}
+
+extern "C" int dm_wgrad_side_join(void* stream) {
+  tl_side_armed = false;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (!g_side_pending) return DM_OK;
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, g_side_done_ev, 0);
+  if (e != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side join: %s", hipGetErrorString(e));
+  g_side_pending = false;
   return DM_OK;
 }
 
@@ -90,9 +160,19 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t dec_fwd = SK + pad64(col) + pad64(gpad) + 3 * pad64(gtab) + pad64(9 * 1024) + pad64(4 * 2 * d * 9 * 2 * d) +
                          pad64(144 * d) + 1024 +      // + the direct layer-4 kernel's class-ordered weights
                          tw * pad64(2 * 2 * d * 9 * 2 * d + 1);
-  const size_t dec_bwd = SK + 2 * pad64(gmax) + 2 * pad64(wmax + 36 * 4 * d) + pad64(N * 900) + pad64(100 * d + 36 * 4 + 36 * ch) + 1024 +   // + gather tables, padded image-layer weights
-                         tw * (2 * pad64(gmax / 2 + 1) + pad64((wmax + 36 * 4 * d) / 2 + 1));
-  const size_t rssm_bwd = SK + 6 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
+  // decoder backward: one gradient buffer per layer, one gather-table pair per layer, two split-K scratches (the weight
+  // gradients may run on the side stream, conv.hip conv_decoder_mse_bwd_impl)
+  const size_t r4 = (size_t)((ch + 3) / 4 * 4), q4 = 4;
+  auto up4 = [&](size_t v) { return (v + q4 - 1) / q4 * q4; };
+  const size_t g_l[5] = {N * 32 * d, N * 25 * up4(4 * d), N * 169 * up4(2 * d), N * 900 * up4(d), N * 4096 * r4};
+  size_t g_sum = 0, g_tw = 0;
+  for (int l = 0; l < 5; ++l) { g_sum += pad64(g_l[l]); g_tw += pad64(g_l[l] / 2 + 1); }
+  const size_t dec_tabs = pad64(N) + pad64(N * 25) + pad64(N * 169) + pad64(N * 900) + pad64(25 * up4(4 * d)) + pad64(25 * up4(2 * d)) +
+                          pad64(36 * up4(d)) + pad64(36 * r4);
+  (void)gmax;
+  const size_t dec_bwd = 2 * SK + g_sum + 2 * pad64(wmax + 36 * 4 * d) + dec_tabs + 1024 +
+                         tw * (g_tw + pad64((wmax + 36 * 4 * d) / 2 + 1));
+  const size_t rssm_bwd = 2 * SK + 8 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg
                           2 * pad64((3 * D + 15) / 16 * 1024) + 2 * pad64((Hd + 15) / 16 * 1024);   // + fragment-major dgi / dgh / dpin / dza
   const size_t rows = (H + 1) * N;

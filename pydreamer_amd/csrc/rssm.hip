@@ -124,13 +124,14 @@ static int linear(hipStream_t st, void* sk, size_t skb, int rows, int nout, int 
 }
 // dW[o][i] = sum_r dy[r][o] x[r][i]
 static int wgrad(hipStream_t st, void* sk, size_t skb, int rows, int nout, int kin, const float* dy, int lddy,
-                 const float* x, int ldx, float* dW) {
+                 const float* x, int ldx, float* dW, int accum = 0) {
   DmGemm q;
   q.a_layout = 1; q.b_layout = 1;
   q.M = nout; q.N = kin; q.K = rows;
   q.A = dy; q.lda = lddy;
   q.B = x; q.ldb = ldx;
   q.C = dW; q.ldc = kin;
+  q.flags = accum ? DM_GEMM_ACCUM : 0;
   return dm_gemm_launch(q, sk, skb, st);
 }
 // dx[r][i] (+)= mask_r * sum_o dy[r][o] W[o][i]
@@ -450,6 +451,11 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   float* dgl = ar.take(kind ? (size_t)N * 3 * D : 0);       // LayerNorm GRU cells: gradients w.r.t. the LayerNorm outputs
   float* lnpg = ar.take(kind ? (size_t)3 * D : 0);
   float* lnpb = ar.take(kind ? (size_t)3 * D : 0);
+  // the weight-gradient side stream's own split-K scratch and its own dx2 / dx1 (fused schedule: the LayerNorm backward of a
+  // chunk of rows is redone there instead of being shared with the chain)
+  float* sk_w = ar.take(DM_SPLITK_FLOATS);
+  float* dx2_w = ar.take((size_t)N * Hd);
+  float* dx1_w = ar.take((size_t)N * Hd);
   const float* lng[3] = {p[DM_RSSM_GRU_LN_G0], p[DM_RSSM_GRU_LN_G1], p[DM_RSSM_GRU_LN_G2]};
   const float* lnb[3] = {p[DM_RSSM_GRU_LN_B0], p[DM_RSSM_GRU_LN_B1], p[DM_RSSM_GRU_LN_B2]};
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
@@ -461,17 +467,26 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DmChainGraph cg("rssm_sequence_bwd", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();
+  // Parameter gradients are leaves of this pass: nothing reads them before the gradient clip.  They go to `sw` - the
+  // library's weight-gradient side stream when the calling thread is armed (include/dreamer_hip.h dm_wgrad_side_arm), else
+  // `st` itself - and the big ones are cut into up to four time chunks that are launched as soon as the BPTT loop has finished
+  // their rows, so they run BESIDE the loop (a B-row latency chain that leaves most CUs idle) instead of behind it.  The chunk
+  // boundaries, and with them every sum, are the same whether or not a side stream is used.
+  hipStream_t const st_main = st;
+  hipStream_t sw = st == (hipStream_t)stream ? dm_wgrad_side_stream(st) : st;      // (no side stream inside a chain-graph capture)
 
-  // ---- prior branch, batched over all rows
-  DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dprior, ZP, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
-  DM_TRY(dm_colsum_launch(N, ZP, dprior, ZP, g[DM_RSSM_PRIOR_OB], sk, skb, st));
+  // ---- prior branch, batched over all rows: the data gradient on st ...
   DM_TRY(dgrad(st, sk, skb, N, ZP, Hd, dprior, ZP, p[DM_RSSM_PRIOR_W], dprin, Hd, 0, nullptr));
   DM_TRY(norm_elu_bwd_dx(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, p[DM_RSSM_PRIOR_G], dprin, Hd, dx3, Hd, st));
-  DM_TRY(norm_elu_bwd_params(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
-                                     g[DM_RSSM_PRIOR_B], sk, skb, st));
-  DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
-  DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk, skb, st));
   DM_TRY(dgrad(st, sk, skb, N, Hd, D, dx3, Hd, p[DM_RSSM_PRIOR_H_W], dfeat, F, 1, nullptr));
+  // ... its parameter gradients on sw
+  DM_TRY(dm_wgrad_side_fork(st, sw));
+  DM_TRY(wgrad(sw, sk_w, skb, N, ZP, Hd, dprior, ZP, a.prin, Hd, g[DM_RSSM_PRIOR_W]));
+  DM_TRY(dm_colsum_launch(N, ZP, dprior, ZP, g[DM_RSSM_PRIOR_OB], sk_w, skb, sw));
+  DM_TRY(norm_elu_bwd_params(N, Hd, a.x3, Hd, a.prin, Hd, a.st3, dprin, Hd, g[DM_RSSM_PRIOR_G],
+                                     g[DM_RSSM_PRIOR_B], sk_w, skb, sw));
+  DM_TRY(wgrad(sw, sk_w, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
+  DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk_w, skb, sw));
 
   // ---- BPTT.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
   // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
@@ -499,6 +514,34 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   float* dpinf = dgif ? ar.take(dm_frag_floats(Hd)) : nullptr;      // ... and of dpin, dza (written by the epilogue of the
   float* dzaf = dgif ? ar.take(dm_frag_floats(Hd)) : nullptr;       // product that makes them)
   if (!ar.ok) { dgif = nullptr; dghf = nullptr; dpinf = nullptr; dzaf = nullptr; }
+  // time chunks of the batched weight gradients (single-layer cells): chunk c = steps [T*c/nchunk, T*(c+1)/nchunk); the loop
+  // runs t downwards, so the LAST chunk completes first - it overwrites the gradient, the others accumulate
+  const int nchunk = (stacked || B < 16) ? 1 : (T >= 16 ? 4 : T >= 8 ? 2 : 1);      // (a few-column shard: the chunks' extra launches cost more than they hide)
+  int next_chunk = nchunk - 1;
+  const float* dx2s = fuse_b ? dx2_w : dx2;
+  const float* dx1s = fuse_b ? dx1_w : dx1;
+  auto side_chunk = [&](int t) -> int {
+    if (stacked || next_chunk < 0 || t != (int)((long long)T * next_chunk / nchunk)) return DM_OK;
+    const int c = next_chunk--;
+    const int t0 = (int)((long long)T * c / nchunk), t1 = (int)((long long)T * (c + 1) / nchunk);
+    const size_t c0 = (size_t)t0 * B;
+    const int rows = (t1 - t0) * B, acc = c != nchunk - 1;
+    DM_TRY(dm_wgrad_side_fork(st, sw));            // rows [c0, c0 + rows) of dpost, dpin, dgi, dgh, dza (dx2, dx1) are final
+    if (fuse_b) {
+      DM_TRY(norm_elu_bwd_dx(rows, Hd, a.x2 + c0 * Hd, Hd, a.pin + c0 * Hd, Hd, a.st2 + c0 * 2, p[DM_RSSM_POST_G], dpin + c0 * Hd, Hd,
+                             dx2_w + c0 * Hd, Hd, sw));
+      DM_TRY(norm_elu_bwd_dx(rows, Hd, a.x1 + c0 * Hd, Hd, a.za + c0 * Hd, Hd, a.st1 + c0 * 2, p[DM_RSSM_IN_G], dza + c0 * Hd, Hd,
+                             dx1_w + c0 * Hd, Hd, sw));
+    }
+    DM_TRY(wgrad(sw, sk_w, skb, rows, ZP, Hd, dpost + c0 * ZP, ZP, a.pin + c0 * Hd, Hd, g[DM_RSSM_POST_W], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, D, dx2s + c0 * Hd, Hd, feat + c0 * F, F, g[DM_RSSM_POST_H_W], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, E, dx2s + c0 * Hd, Hd, embed + c0 * E, E, g[DM_RSSM_POST_E_W], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, 3 * D, Hd, dgi + c0 * 3 * D, 3 * D, a.za + c0 * Hd, Hd, g[DM_RSSM_GRU_WIH], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, 3 * D, D, dgh + c0 * 3 * D, 3 * D, a.hin + c0 * D, D, g[DM_RSSM_GRU_WHH], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, Z, dx1s + c0 * Hd, Hd, a.zin + c0 * Z, Z, g[DM_RSSM_Z_W], acc));
+    DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, A, dx1s + c0 * Hd, Hd, action + c0 * A, A, g[DM_RSSM_A_W], acc));
+    return DM_OK;
+  };
   for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
@@ -545,6 +588,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
         qz.lnb_stats = a.st1 + r0 * 2; qz.A_frag = dzaf;
         DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));
       }
+      DM_TRY(side_chunk(t));
       continue;
     }
     DM_TRY(norm_elu_bwd_dx(B, Hd, a.x2 + r0 * Hd, Hd, a.pin + r0 * Hd, Hd, a.st2 + r0 * 2, p[DM_RSSM_POST_G],
@@ -595,21 +639,25 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       qz.C = dprev + D; qz.ldc = F; qz.flags = DM_GEMM_ACCUM; qz.row_zero = rz;
       DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));
     }
+    DM_TRY(side_chunk(t));
   }
 
-  if (fuse_b) {    // dx2 / dx1 of every row for the batched weight gradients below
-    DM_TRY(norm_elu_bwd_dx(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, p[DM_RSSM_POST_G], dpin, Hd, dx2, Hd, st));
-    DM_TRY(norm_elu_bwd_dx(N, Hd, a.x1, Hd, a.za, Hd, a.st1, p[DM_RSSM_IN_G], dza, Hd, dx1, Hd, st));
-  }
-  // ---- weight / bias / LayerNorm gradients, batched over all rows
-  DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dpost, ZP, a.pin, Hd, g[DM_RSSM_POST_W]));
+  // ---- the one data gradient left: dembed, for the encoder backward that follows on st
+  if (fuse_b) DM_TRY(norm_elu_bwd_dx(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, p[DM_RSSM_POST_G], dpin, Hd, dx2, Hd, st));
+  if (dembed) DM_TRY(dgrad(st, sk, skb, N, Hd, E, dx2, Hd, p[DM_RSSM_POST_E_W], dembed, E, 0, nullptr));
+  // ---- bias / LayerNorm gradients (column passes over all rows) and, for cell stacks, the weight gradients: on sw
+  st = sw;
+  sk = sk_w;
+  if (stacked) DM_TRY(dm_wgrad_side_fork(st_main, sw));      // (single-layer cells forked at their last chunk)
   DM_TRY(dm_colsum_launch(N, ZP, dpost, ZP, g[DM_RSSM_POST_OB], sk, skb, st));
   DM_TRY(norm_elu_bwd_params(N, Hd, a.x2, Hd, a.pin, Hd, a.st2, dpin, Hd, g[DM_RSSM_POST_G], g[DM_RSSM_POST_B],
                                      sk, skb, st));
-  DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx2, Hd, feat, F, g[DM_RSSM_POST_H_W]));
-  DM_TRY(dm_colsum_launch(N, Hd, dx2, Hd, g[DM_RSSM_POST_H_B], sk, skb, st));
-  DM_TRY(wgrad(st, sk, skb, N, Hd, E, dx2, Hd, embed, E, g[DM_RSSM_POST_E_W]));
-  if (dembed) DM_TRY(dgrad(st, sk, skb, N, Hd, E, dx2, Hd, p[DM_RSSM_POST_E_W], dembed, E, 0, nullptr));
+  DM_TRY(dm_colsum_launch(N, Hd, dx2s, Hd, g[DM_RSSM_POST_H_B], sk, skb, st));
+  if (stacked) {
+    DM_TRY(wgrad(st, sk, skb, N, ZP, Hd, dpost, ZP, a.pin, Hd, g[DM_RSSM_POST_W]));
+    DM_TRY(wgrad(st, sk, skb, N, Hd, D, dx2, Hd, feat, F, g[DM_RSSM_POST_H_W]));
+    DM_TRY(wgrad(st, sk, skb, N, Hd, E, dx2, Hd, embed, E, g[DM_RSSM_POST_E_W]));
+  }
   if (stacked) {
     const int ls = gk.ls;
     for (int i = 0; i < gk.L; ++i) {
@@ -631,9 +679,6 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
             return dm_fail(DM_E_HIP, "rssm_sequence_bwd: gradient copy failed");
       }
     }
-  } else {
-    DM_TRY(wgrad(st, sk, skb, N, 3 * D, Hd, dgi, 3 * D, a.za, Hd, g[DM_RSSM_GRU_WIH]));
-    DM_TRY(wgrad(st, sk, skb, N, 3 * D, D, dgh, 3 * D, a.hin, D, g[DM_RSSM_GRU_WHH]));
   }
   if (stacked) {
   } else if (kind == 0) {
@@ -654,9 +699,12 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   }
   DM_TRY(norm_elu_bwd_params(N, Hd, a.x1, Hd, a.za, Hd, a.st1, dza, Hd, g[DM_RSSM_IN_G], g[DM_RSSM_IN_B], sk, skb,
                                      st));
-  DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
-  DM_TRY(dm_colsum_launch(N, Hd, dx1, Hd, g[DM_RSSM_Z_B], sk, skb, st));
-  DM_TRY(wgrad(st, sk, skb, N, Hd, A, dx1, Hd, action, A, g[DM_RSSM_A_W]));
+  DM_TRY(dm_colsum_launch(N, Hd, dx1s, Hd, g[DM_RSSM_Z_B], sk, skb, st));
+  if (stacked) {
+    DM_TRY(wgrad(st, sk, skb, N, Hd, Z, dx1, Hd, a.zin, Z, g[DM_RSSM_Z_W]));
+    DM_TRY(wgrad(st, sk, skb, N, Hd, A, dx1, Hd, action, A, g[DM_RSSM_A_W]));
+  }
+  DM_TRY(dm_wgrad_side_mark(sw, st_main));
   return cg.finish();
 }
 

@@ -189,10 +189,12 @@ _SIGNATURES = {
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_rssm_persist_enable': (c_int, [c_int]),
     'dm_rssm_persist_prof': (c_int, [_P, c_int]),
+    'dm_wgrad_side_arm': (c_int, [c_int]),
+    'dm_wgrad_side_join': (c_int, [_P]),
 }
 
 _lib = None
-DM_ABI_VERSION = 6      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 7      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

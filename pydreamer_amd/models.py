@@ -444,6 +444,9 @@ def _prelaunched(owner, fn):
     return out
 
 
+_WGRAD_SIDE = os.environ.get('DM_WGRAD_SIDE', '1') != '0'      # A/B switch: 0 keeps every weight gradient on the caller's stream
+
+
 class _Overlap:
     """Side streams for the backward passes.  Everything the three backward passes consume is fixed once the matching
     forward has run (dreamer.py:149-157 detaches the features the actor-critic trains on), so training_step() launches
@@ -679,6 +682,8 @@ class WorldModel(_Params):
         self._ws = None
         self._pipe = None
         self._arena = _StepArena()
+        self._ws_dec = None                # own workspaces of the decoder / encoder backward while weight gradients are deferred
+        self._ws_enc = None
         # Forward time-chunk pipeline over 3 streams (encoder chunk i+1 | posterior steps of chunk i | decoder chunk i-1).
         # OFF by default: measured on MI355X / ROCm 7.2 it LOSES (61.9 vs 47.7 ms per step at B=50, 33.1 vs 16.5 ms at
         # B=7): the loop's 1024-thread workgroups starve behind the conv GEMMs of the other streams and every cross-stream
@@ -1040,7 +1045,7 @@ class WorldModel(_Params):
     def _param_order(self):
         return list(self.parameters())
 
-    def _backward(self, pk, ws, scratch=False):
+    def _backward(self, pk, ws, scratch=False, defer_wgrad=False):
         c = self.conf
         shp, T, B, I = pk['shp'], pk['T'], pk['B'], pk.get('I', 1)
         NE, N = T * B, T * B * I
@@ -1075,47 +1080,68 @@ class WorldModel(_Params):
         dl = dec.image.layers()
         dec_p = H.conv_struct([m.weight for m in dl], [m.bias for m in dl])
         dec_g = H.conv_struct([gof[id(m.weight)] for m in dl], [gof[id(m.bias)] for m in dl], cls=H.dm_conv_grads)
-        H.call('dm_conv_decoder_mse_bwd_rows', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
-               H.fptr(pk['dec_acts']), gw * dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_, H.ptr(ws),
-               ws.numel(), H.stream())
-        # KL (dreamer.py:334-343)
-        dpost = ar.get('dpost', (N, Z), device=dev)
-        dprior = ar.get('dprior', (N, Z), device=dev)
-        if iw is not None and not c.stoch_discrete:      # sampled Normal KL: explicit parameter gradients + the path through z
-            D_ = c.deter_dim
-            H.call('dm_kl_sampled_gauss_bwd', N, c.stoch_dim, H.fptr(pk['post']), H.fptr(pk['prior']),
-                   ctypes.c_void_p(feat.data_ptr() + 4 * D_), F_, gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost),
-                   H.fptr(dprior), ctypes.c_void_p(dfeat.data_ptr() + 4 * D_), F_, H.stream())
-        elif iw is not None:         # sampled KL of the IWAE bound
-            H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
-                   H.ptr(pk['idx']), gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
-        else:
-            if self.kl_balance is None:
-                sp = sq = gw * self.kl_weight / N
+        # Parameter gradients are leaves: nothing waits for them before the gradient clip, while the DATA gradients are the
+        # chain decoder -> BPTT -> encoder.  Armed, the library enqueues the decoder's and the RSSM's parameter gradients on its
+        # low-priority side stream, where they run beside the BPTT loop (a 50-row latency chain that leaves most CUs idle); they
+        # read gradient buffers in the workspace of THEIR call, so each call gets its own (include/dreamer_hip.h
+        # dm_wgrad_side_arm).  The encoder backward is not deferred (it is the tail: there is nothing left to hide behind).
+        side = defer_wgrad and _WGRAD_SIDE and B * I >= 16 and not torch.cuda.is_current_stream_capturing()      # (measured: no gain on a 7-column shard)
+        ws_dec = ws_enc = ws
+        if side:
+            need = H.workspace_bytes(shp)
+            if self._ws_dec is None or self._ws_dec.numel() < need or self._ws_dec.device != dev:
+                self._ws_dec = torch.empty(need, dtype=torch.uint8, device=dev)
+                self._ws_enc = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws_dec, ws_enc = self._ws_dec, self._ws_enc       # decoder / BPTT (`ws`) / encoder: one workspace each until the join
+            H.call('dm_wgrad_side_arm', 1)
+        try:
+            H.call('dm_conv_decoder_mse_bwd_rows', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(pk['image']), ctypes.byref(dec_p),
+                   H.fptr(pk['dec_acts']), gw * dec.image_weight / NE, H.fptr(iw), ctypes.byref(dec_g), H.fptr(dfeat), F_,
+                   H.ptr(ws_dec), ws_dec.numel(), H.stream())
+            # KL (dreamer.py:334-343)
+            dpost = ar.get('dpost', (N, Z), device=dev)
+            dprior = ar.get('dprior', (N, Z), device=dev)
+            if iw is not None and not c.stoch_discrete:      # sampled Normal KL: explicit parameter gradients + the path through z
+                D_ = c.deter_dim
+                H.call('dm_kl_sampled_gauss_bwd', N, c.stoch_dim, H.fptr(pk['post']), H.fptr(pk['prior']),
+                       ctypes.c_void_p(feat.data_ptr() + 4 * D_), F_, gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost),
+                       H.fptr(dprior), ctypes.c_void_p(dfeat.data_ptr() + 4 * D_), F_, H.stream())
+            elif iw is not None:         # sampled KL of the IWAE bound
+                H.call('dm_kl_sampled_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']),
+                       H.ptr(pk['idx']), gw * self.kl_weight / NE, H.fptr(iw), H.fptr(dpost), H.fptr(dprior), H.stream())
             else:
-                sp, sq = gw * self.kl_weight * (1 - self.kl_balance) / N, gw * self.kl_weight * self.kl_balance / N
-            H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
-                   H.fptr(dpost), H.fptr(dprior), H.stream())
-        # RSSM BPTT
-        cell = self.core.cell
-        rssm_p = H.rssm_struct(cell.ordered())
-        rssm_g = H.rssm_struct([None if p is None else gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
-        dembed = ar.get('dembed', (N, E), device=dev)
-        H.call('dm_rssm_sequence_bwd', ctypes.byref(pk['shp_r']), H.fptr(pk['embed_x']), H.fptr(pk['action_x']),
-               H.ptr(pk['reset_x']), ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']),
-               H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(),
-               H.stream())
-        if I > 1:                  # the I samples of a (t,b) share one embedding row: their gradients add up
-            dsum = torch.empty(NE, E, device=dev)
-            H.call('dm_reduce_i', NE, I, E, H.fptr(dembed), 2, H.fptr(dsum), None, H.stream())
-            dembed = dsum
-        # encoder
-        enc = self.encoder.encoder_image
-        enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
-        enc_g = H.conv_struct([gof[id(m.weight)] for m in enc.convs()], [gof[id(m.bias)] for m in enc.convs()],
-                              cls=H.dm_conv_grads)
-        H.call('dm_conv_encoder_bwd', ctypes.byref(pk['shp_e']), H.ptr(pk['image']), ctypes.byref(enc_p),
-               H.fptr(pk['enc_acts']), H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws), ws.numel(), H.stream())
+                if self.kl_balance is None:
+                    sp = sq = gw * self.kl_weight / N
+                else:
+                    sp, sq = gw * self.kl_weight * (1 - self.kl_balance) / N, gw * self.kl_weight * self.kl_balance / N
+                H.call('dm_kl_balance_bwd', N, c.stoch_dim, c.stoch_discrete, H.fptr(pk['post']), H.fptr(pk['prior']), sp, sq,
+                       H.fptr(dpost), H.fptr(dprior), H.stream())
+            # RSSM BPTT
+            cell = self.core.cell
+            rssm_p = H.rssm_struct(cell.ordered())
+            rssm_g = H.rssm_struct([None if p is None else gof[id(p)] for p in cell.ordered()], cls=H.dm_rssm_grads)
+            dembed = ar.get('dembed', (N, E), device=dev)
+            H.call('dm_rssm_sequence_bwd', ctypes.byref(pk['shp_r']), H.fptr(pk['embed_x']), H.fptr(pk['action_x']),
+                   H.ptr(pk['reset_x']), ctypes.byref(rssm_p), H.fptr(pk['rssm_acts']), H.fptr(feat), H.fptr(pk['post']),
+                   H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(rssm_g), H.fptr(dembed), H.ptr(ws), ws.numel(),
+                   H.stream())
+            if I > 1:                  # the I samples of a (t,b) share one embedding row: their gradients add up
+                dsum = torch.empty(NE, E, device=dev)
+                H.call('dm_reduce_i', NE, I, E, H.fptr(dembed), 2, H.fptr(dsum), None, H.stream())
+                dembed = dsum
+            # encoder
+            enc = self.encoder.encoder_image
+            enc_p = H.conv_struct([m.weight for m in enc.convs()], [m.bias for m in enc.convs()])
+            enc_g = H.conv_struct([gof[id(m.weight)] for m in enc.convs()], [gof[id(m.bias)] for m in enc.convs()],
+                                  cls=H.dm_conv_grads)
+            H.call('dm_conv_encoder_bwd', ctypes.byref(pk['shp_e']), H.ptr(pk['image']), ctypes.byref(enc_p),
+                   H.fptr(pk['enc_acts']), H.fptr(dembed), ctypes.byref(enc_g), H.ptr(ws_enc), ws_enc.numel(), H.stream())
+        except BaseException:
+            if side:
+                H.lib().dm_wgrad_side_join(H.stream())      # disarm this thread; the error propagates
+            raise
+        if side:
+            H.call('dm_wgrad_side_join', H.stream())    # every gradient of this pass is complete on this stream from here on
         return views, flat, direct
 
     def _image_pred(self, pk, obs, u_pred):
@@ -1537,7 +1563,7 @@ class Dreamer(nn.Module):
                 ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
             ov.ev_wm_fwd.record(torch.cuda.current_stream())
             pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: _prelaunched(self.wm, lambda: self.wm._backward(
-                pk, ov.ws_wm, scratch=gens.get(id(self.wm), True))))
+                pk, ov.ws_wm, scratch=gens.get(id(self.wm), True), defer_wgrad=True)))
         metrics, tensors = dict(metrics), tensors.copy()          # LazyTensors.copy(): image_rec stays a thunk
         loss_probe, metrics_probe, tensors_probe = self.probe_model.training_step(features.detach(), obs)
         metrics.update(**metrics_probe)

@@ -996,6 +996,48 @@ def test_graphed_step_is_bit_identical_to_eager(hip, overlap):
         assert e['steps'] == g['steps'] == s + 1
 
 
+@pytest.mark.parametrize('amp', [False, True])
+def test_deferred_weight_gradients_are_bit_identical(hip, amp):
+    """dm_wgrad_side_arm / _join (the decoder's weight and bias gradients on the library's side stream, beside the BPTT loop):
+    same kernels, same arguments, other stream - losses, every gradient and the updated parameters are bit-identical to the
+    single-stream order over three trainer iterations, fp32 and bf16 (twins of the per-layer gradient buffers)."""
+    from pydreamer_amd import models as M
+    oconf = O.tiny_conf(amp=amp) if amp else O.tiny_conf()
+    params = O.make_params(oconf, seed=5)
+    runs = []
+    keep = M._WGRAD_SIDE
+    try:
+        for side in (False, True):
+            M._WGRAD_SIDE = side
+            model = _build(oconf, params)
+            assert model.overlap_backward
+            opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+            st = model.init_state(oconf.batch_size)
+            hist = []
+            for s in range(3):
+                obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=60 + s, first=(s == 0)), oconf))
+                noise = _to_dev(O.make_noise(oconf, seed=70 + s))
+                losses, st2, _, _, _ = model.training_step(obs, st, noise=noise)
+                for opt in opts:
+                    opt.zero_grad()
+                for loss in losses:
+                    loss.backward()
+                model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+                grads = torch.cat([o.flat_grad for o in opts]).clone()
+                for opt in opts:
+                    opt.step()
+                st = tuple(x.clone() for x in st2)
+                hist.append((([float(x) for x in losses]), grads.cpu(), torch.cat([o.flat_param for o in opts]).cpu()))
+            runs.append(hist)
+    finally:
+        M._WGRAD_SIDE = keep
+    for s, (a, b) in enumerate(zip(*runs)):
+        assert a[0] == b[0], (s, a[0], b[0])
+        assert torch.equal(a[1], b[1]), f'step {s}: gradients differ'
+        assert torch.equal(a[2], b[2]), f'step {s}: parameters differ'
+    assert float(runs[0][0][1].abs().sum()) > 0
+
+
 def test_training_step_matches_reference_at_atari_literal(hip):
     """BASELINE.json configs[1] at FULL size against the slim golden written by the real reference
     (tests/golden/atari_literal.npz; inputs regenerated from the same seeds and fingerprinted).
