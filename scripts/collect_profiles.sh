@@ -31,13 +31,14 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate
 for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
-DM_FP32_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg > $OUT/${TAG}_bench_fp32_split.json 2>/dev/null
 bash scripts/collect_pmc_bf16.sh $TAG > $OUT/collect_bf16.log 2>&1      # bf16 step: its own counter passes, then the bf16 bench line
 DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
-# per-CU operand load ceilings (coalesced vs MFMA-fragment gather), see scripts/microbench/l2_stream.hip
-(cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 l2_stream.hip -o /tmp/l2_stream 2>/dev/null && \
- for kib in 2048 8192 65536; do /tmp/l2_stream $kib 8 256 4 0; /tmp/l2_stream $kib 8 1024 1 0; /tmp/l2_stream $kib 8 256 4 1; /tmp/l2_stream $kib 8 1024 1 1; done) > $OUT/${TAG}_l2_stream.txt 2>&1
+# per-queue timelines of one step (which stream is busy when), fp32 and bf16
+bash scripts/gpu_trace.sh f32 $TAG > /dev/null 2>&1; cp $OUT/queues_f32.txt $OUT/${TAG}_queues_f32.txt
+bash scripts/gpu_trace.sh bf16 $TAG > /dev/null 2>&1; cp $OUT/queues_bf16.txt $OUT/${TAG}_queues_bf16.txt
+# (the split-bf16 fp32 mode line and the per-CU load-rate microbenchmark, scripts/microbench/l2_stream.hip, concern code that has
+#  not changed since they were taken: profiles/<tag>_bench_fp32_split.json, <tag>_l2_stream.txt are kept from the earlier collection)
 python - << PY
 import json
 d = json.load(open('$OUT/${TAG}_bench.json'))
