@@ -1085,7 +1085,11 @@ class WorldModel(_Params):
         # low-priority side stream, where they run beside the BPTT loop (a 50-row latency chain that leaves most CUs idle); they
         # read gradient buffers in the workspace of THEIR call, so each call gets its own (include/dreamer_hip.h
         # dm_wgrad_side_arm).  The encoder backward is not deferred (it is the tail: there is nothing left to hide behind).
-        side = defer_wgrad and _WGRAD_SIDE and B * I >= 16 and not torch.cuda.is_current_stream_capturing()      # (measured: no gain on a 7-column shard)
+        # (measured: no gain on a 7-column shard.  Not under data parallelism: ROCm multiplexes streams onto 4 hardware queues by
+        #  default, a rank already runs caller + two backward streams + the communication stream + RCCL's own, and a parked
+        #  stream stalls whatever shares its queue - see replay.DeviceRing._produce; unmeasured there, so left as it was)
+        dp_on = getattr(getattr(self, '_fused', None), 'dp', None) is not None
+        side = defer_wgrad and _WGRAD_SIDE and B * I >= 16 and not dp_on and not torch.cuda.is_current_stream_capturing()
         ws_dec = ws_enc = ws
         if side:
             need = H.workspace_bytes(shp)

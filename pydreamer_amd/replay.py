@@ -258,8 +258,12 @@ class DeviceRing:
                     ev.synchronize()
                     for k, v in batch.items():
                         host[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
-                    if done[0] is not None:         # the steps that read this slot's previous batch must have finished on the GPU
-                        self.stream.wait_event(done[0])
+                    if done[0] is not None:         # the steps that read this slot's previous batch must have finished on the GPU.
+                        # HOST wait (this is the producer thread, it has nothing else to do), not stream.wait_event: a copy
+                        # stream parked behind an event that fires two steps later blocks every other stream the runtime
+                        # maps onto the same hardware queue (ROCm multiplexes streams onto 4 by default; measured: the
+                        # H2D-included step went 38 -> 53 ms when the library's side stream became the fifth)
+                        done[0].synchronize()
                     with torch.cuda.stream(self.stream):
                         for k in host:
                             dev[k].copy_(host[k], non_blocking=True)
