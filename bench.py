@@ -14,8 +14,8 @@ Other workloads (diagnostic lines, marked as such): --workload atari-native = py
 deter 1024: what the reference's README measured), --workload dmc = BASELINE configs[4] at one GPU (defaults+dmc, B=T=50).
 
 The JSON line also carries
-  h2d_included : the same step fed from HOST memory through pydreamer_amd.replay.DeviceRing (pinned uint8 frames, copy
-                 stream) - SURVEY 8(d) asks for it next to `value`, which keeps the replay resident in HBM.
+  h2d_included : the same step fed from HOST memory through pydreamer_amd.replay.DeviceRing (pinned uint8 frames, copies
+                 prefetched behind the forward) - SURVEY 8(d) asks for it next to `value`, which keeps the replay resident in HBM.
   roofline     : the GEMM kernel family (every dense contraction of the step runs on it), algorithmic 2MNK flops per
                  launch / HIP-event launch durations recorded on the launch stream in a profiled pass of the same steps
                  that directly follows the timed region (events are kept out of the timed region so `value` is unperturbed);
@@ -229,7 +229,7 @@ def main():
                     help="atari-literal = BASELINE configs[1] (the metric); atari-native = pydreamer's own defaults+atari (B=32, T=48, deter 1024; "
                          "README.md:90-97); dmc = configs[4] at one GPU (defaults+dmc, actor_grad=reinforce, action_dim 6, B=T=50); the last two are diagnostic lines")
     ap.add_argument('--no-h2d-leg', action='store_true', help='skip the H2D-included leg (DeviceRing from host memory)')
-    ap.add_argument('--h2d-steps', type=int, default=20)
+    ap.add_argument('--h2d-steps', type=int, default=40)
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
     if not args.pmc_json:       # the committed counter summary of the same command (fp32 / bf16 step), if its fingerprint matches the tree
@@ -365,7 +365,7 @@ def main():
                          note='all-reduce of each optimizer group\'s flat fp32 gradient buffer, timed alone (in the step the world-model '
                               'group\'s is overlapped with the actor / critic backward)')
 
-    # H2D-included leg: the same step fed from host memory through the DeviceRing (pinned uint8 frames, own copy stream)
+    # H2D-included leg: the same step fed from host memory through the DeviceRing (pinned uint8 frames, copies prefetched behind the forward)
     h2d = None
     if world == 1 and not args.no_h2d_leg and args.emulate_world <= 1 and not args.graph:
         from pydreamer_amd.replay import DeviceRing
@@ -378,6 +378,7 @@ def main():
             nonlocal hstate
             obs = dring.next()
             losses, hstate, *_ = model.training_step(obs, hstate, noise=noise.draw())
+            dring.prefetch()       # the next batch's H2D copies, behind this step's forward on the caller's stream (idle from here on)
             for opt in opts:
                 opt.zero_grad()
             for loss in losses:
@@ -385,7 +386,7 @@ def main():
             model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
             for opt in opts:
                 opt.step()
-        for _ in range(3):
+        for _ in range(8):                     # (the ring's pinned slots are allocated and first filled during these)
             hstep()
         torch.cuda.synchronize()
         th = time.perf_counter()

@@ -14,8 +14,8 @@ Here the same batches are produced as what the HIP path consumes directly:
   * `preprocess_batch`        - the hot-path subset of Preprocessor.apply: one-hot float32 actions, float32 reward with
     `clip_rewards`, float32 terminal, bool reset - and the image is LEFT AS uint8 (T,B,H,W,C): x/255-0.5 and HWC->CHW
     happen inside the first conv's patch loader on the GPU (N1), so a batch crosses PCIe at 1 byte per pixel value;
-  * `DeviceRing`              - a background thread fills pinned host buffers and issues the H2D copies on its own HIP
-    stream into a ring of device-resident batches; `next()` hands out a batch whose copy the consumer's stream waits on.
+  * `DeviceRing`              - a background thread fills pinned host buffers; the consumer enqueues the H2D copies on its
+    own stream at a point where that stream is idle (`prefetch()` after `training_step()`), into a ring of device batches.
 
 parity: pinned against the reference's own DataSequential + Preprocessor run in the build container
 (oracle/gen_replay_golden.py -> tests/golden/replay_reader.npz; tests/test_replay_cpu.py replays it: same episode files,
@@ -213,90 +213,97 @@ def preprocess_batch(batch, action_dim, clip_rewards=None, image_key='image'):
 
 
 class DeviceRing:
-    """Pinned staging + asynchronous H2D into a ring of device-resident batches.
+    """Pinned staging + asynchronous H2D into a ring of device-resident batches, WITHOUT a stream of its own.
 
-    A producer thread pulls numpy batches from `source` (an iterator of preprocess_batch outputs), copies them into one of
-    `depth` pinned host slots and enqueues the H2D copies on a dedicated copy stream; `next()` returns the device batch of
-    the oldest filled slot after making the CURRENT stream wait for that slot's copy event.  A slot is recycled when the
-    consumer asks for the batch after next (so the previous batch stays valid while the current step runs)."""
+    A producer thread pulls numpy batches from `source` (an iterator of preprocess_batch outputs) into one of `depth` pinned
+    host slots - host work only.  The H2D copies are enqueued by the CONSUMER, on whatever stream is current, in one of two
+    places: `prefetch()` stages the next batch (call it right after `training_step()` returned: the caller's stream has
+    nothing left to do then while the backward passes run on their own streams, so the ~31 MB transfer is hidden), and
+    `next()` returns the staged batch, staging it first if nobody prefetched (the copy then sits in front of the step).
+    Ordering needs no events on the device side: a device slot is overwritten by a copy on the caller's stream `depth`
+    batches after it was handed out, and everything that read it (the step's kernels, the side-stream backward passes that
+    `loss.backward()` joins) is ordered before that on the same stream.  A pinned slot is rewritten by the producer only
+    after a host-side wait for the event recorded behind its copy.
+
+    Why no copy stream (rounds 1-2 had one): ROCm multiplexes HIP streams onto four hardware queues by default, and the
+    step already uses the caller's stream, two backward streams and the library's weight-gradient side stream.  A copy
+    stream is the fifth; when it lands on the queue of a stream that is parked behind an event for most of a step (the
+    actor-critic backward stream is), the transfer for step n+2 completes a step late - measured as a bimodal H2D-included
+    step, 37.3 or 44-47 ms depending on the process."""
 
     def __init__(self, source, device, depth=4):
-        # depth >= 3: next() keeps the current and the previous batch and frees the one before (a ring of 2 would deadlock:
-        # the third next() waits for a filled slot while the producer waits for a free one)
         self.source, self.device, self.depth = iter(source), torch.device(device), max(3, depth)
-        self.stream = torch.cuda.Stream(self.device)
-        self.free = queue.Queue()
-        self.ready = queue.Queue(maxsize=self.depth)
-        self.slots = None
-        self.held = []
+        self.free = queue.Queue()               # pinned slots the producer may fill
+        self.filled = queue.Queue()             # pinned slots holding a batch, in source order (None: exhausted / failed)
+        self.host = None                        # per pinned slot: {key: pinned tensor}
+        self.copied = [None] * self.depth       # per pinned slot: event behind its last H2D copy
+        self.dev = None                         # per device slot: {key: device tensor}
+        self.next_dev = 0
+        self.staged = None
         self.error = None
+        self.done = False
         for i in range(self.depth):
             self.free.put(i)
         self.thread = threading.Thread(target=self._produce, daemon=True, name='dm-replay')
         self.thread.start()
 
-    def _alloc(self, batch):
-        self.slots = []
-        for _ in range(self.depth):
-            host = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().pin_memory() for k, v in batch.items()}
-            dev = {k: torch.empty_like(h, device=self.device) for k, h in host.items()}
-            self.slots.append((host, dev, torch.cuda.Event(), [None]))        # [3]: event after the consumer's last use
-
     def _produce(self):
         try:
-            with torch.cuda.device(self.device):
-                for batch in self.source:
-                    if self.slots is None:
-                        self._alloc(batch)
-                    i = self.free.get()
-                    if i is None:
-                        return
-                    host, dev, ev, done = self.slots[i]
-                    # HOST-side wait for this slot's previous H2D copy: the copy stream may still be parked behind
-                    # wait_event(done) (the step path never syncs, so the host runs ahead), and rewriting the pinned
-                    # buffer under a pending asynchronous copy would hand the model a half-overwritten batch
-                    ev.synchronize()
+            for batch in self.source:
+                i = self.free.get()
+                if i is None:
+                    return
+                if self.host is None:
+                    self.host = [None] * self.depth
+                if self.host[i] is None:
+                    self.host[i] = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().pin_memory() for k, v in batch.items()}
+                else:
+                    ev = self.copied[i]
+                    if ev is not None:          # the pinned buffer is still the source of an asynchronous copy until this fires
+                        ev.synchronize()
                     for k, v in batch.items():
-                        host[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
-                    if done[0] is not None:         # the steps that read this slot's previous batch must have finished on the GPU.
-                        # HOST wait (this is the producer thread, it has nothing else to do), not stream.wait_event: a copy
-                        # stream parked behind an event that fires two steps later blocks every other stream the runtime
-                        # maps onto the same hardware queue (ROCm multiplexes streams onto 4 by default; measured: the
-                        # H2D-included step went 38 -> 53 ms when the library's side stream became the fifth)
-                        done[0].synchronize()
-                    with torch.cuda.stream(self.stream):
-                        for k in host:
-                            dev[k].copy_(host[k], non_blocking=True)
-                        ev.record(self.stream)
-                    self.ready.put(i)
-            self.ready.put(None)        # source exhausted: next() raises StopIteration after the last batch
-        except Exception as e:          # surfaced by next()
+                        self.host[i][k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+                self.filled.put(i)
+            self.filled.put(None)               # source exhausted: next() raises StopIteration after the last batch
+        except Exception as e:                  # surfaced by next()
             self.error = e
-            self.ready.put(None)
+            self.filled.put(None)
 
     def __iter__(self):
         return self
 
     __next__ = lambda self: self.next()
 
-    def next(self):
-        i = self.ready.get()
+    def prefetch(self):
+        """Stage the next batch: enqueue its H2D copies on the current stream (no-op if one is staged already)."""
+        if self.staged is not None or self.done:
+            return
+        i = self.filled.get()
         if i is None:
-            self.ready.put(None)        # stay exhausted / failed for later calls
+            self.done = True
+            return
+        host = self.host[i]
+        with torch.cuda.device(self.device):
+            if self.dev is None:
+                self.dev = [{k: torch.empty_like(h, device=self.device) for k, h in host.items()} for _ in range(self.depth)]
+            d = self.dev[self.next_dev]
+            self.next_dev = (self.next_dev + 1) % self.depth
+            for k in host:
+                d[k].copy_(host[k], non_blocking=True)
+            ev = self.copied[i] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.copied[i] = ev
+        self.free.put(i)                        # the producer waits for `ev` before touching the pinned buffers again
+        self.staged = d
+
+    def next(self):
+        self.prefetch()
+        if self.staged is None:
             if self.error is not None:
                 raise RuntimeError('replay producer failed') from self.error
             raise StopIteration
-        host, dev, ev, done = self.slots[i]
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_event(ev)
-        self.held.append(i)
-        if len(self.held) > 2:          # the batch before the previous one: everything that reads it is already enqueued
-            j = self.held.pop(0)
-            e = torch.cuda.Event()
-            e.record(cur)
-            self.slots[j][3][0] = e
-            self.free.put(j)
-        return dev
+        d, self.staged = self.staged, None
+        return d
 
     def close(self):
         self.free.put(None)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# H2D-included leg with / without the weight-gradient side stream (diagnostic)
+# H2D-included leg, repeated in fresh processes (diagnostic: it was bimodal with a copy stream of its own)
 export PYTHONPATH=$PWD
-for v in 1 0; do
-  DM_WGRAD_SIDE=$v timeout 300 python bench.py --no-cpu-baseline --steps 20 --prof-steps 0 --pmc-json /nonexistent 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('side=$v', round(d['ms_per_step'],3), 'h2d', round(d['h2d_included']['ms_per_step'],3))"
-done
+p() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['ms_per_step'],3), 'h2d', round(d['h2d_included']['ms_per_step'],3))"; }
+python -m pytest tests/test_gpu_replay.py -q -m gpu 2>&1 | tail -1
+for i in 1 2 3 4; do timeout 300 python bench.py --no-cpu-baseline --prof-steps 0 --steps 20 2>/dev/null | p run$i; done

@@ -1,6 +1,7 @@
 """GPU: replay reader -> device ring -> training_step.
 
-The ring (pinned staging, its own copy stream, slot recycling behind events) must hand the step exactly the bytes the
+The ring (pinned staging, copies on the consumer's stream - staged by next() or ahead of time by prefetch() -, slot recycling)
+must hand the step exactly the bytes the
 reader produced: several optimizer steps fed by `DeviceRing` are bit-identical to the same steps fed by plain
 synchronous `.to(device)` copies of an identically seeded reader - with more steps than ring slots, so slots recycle
 while earlier steps may still be running."""
@@ -31,7 +32,7 @@ def _source(repo, oconf, seed):
         yield R.preprocess_batch(b, oconf.action_dim, clip_rewards='tanh')
 
 
-def _train(model, conf, batches, noises, nsteps):
+def _train(model, conf, batches, noises, nsteps, after_step=None):
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
     state = model.init_state(conf.batch_size)
     out = []
@@ -39,6 +40,8 @@ def _train(model, conf, batches, noises, nsteps):
         obs = batches()
         assert obs['image'].dtype == torch.uint8 and obs['image'].is_cuda
         losses, state, metrics, tensors, _ = model.training_step(obs, state, noise=noises[s])
+        if after_step is not None:
+            after_step()
         for opt in opts:
             opt.zero_grad()
         for loss in losses:
@@ -61,6 +64,11 @@ def test_device_ring_feeds_training_step(hip, tmp_path):
     ring = R.DeviceRing(_source(repo, oconf, seed=7), DEV, depth=3)
     a = _train(_build(oconf, O.make_params(oconf, seed=2)), conf, ring.next, noises, nsteps)
     ring.close()
+    # the trainer's order: the next batch is staged right after training_step() returned, while the backward passes run
+    ring = R.DeviceRing(_source(repo, oconf, seed=7), DEV, depth=3)
+    c = _train(_build(oconf, O.make_params(oconf, seed=2)), conf, ring.next, noises, nsteps, after_step=ring.prefetch)
+    ring.close()
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
     it = _source(repo, oconf, seed=7)
     b = _train(_build(oconf, O.make_params(oconf, seed=2)), conf,
