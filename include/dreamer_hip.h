@@ -73,7 +73,7 @@ typedef struct dm_shape {
 int dm_version(void);                 /* ABI version, currently 7 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
-                                         v7: dm_wgrad_side_arm / _join - additions only) */
+                                         v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -232,6 +232,14 @@ int dm_mlp_head_fwd(int rows, int in_dim, int hidden, int layers, int out_dim,
 int dm_mlp_head_fwd_sparse(int rows, int in_dim, int sparse_cols, int hidden, int layers, int out_dim,
                            const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
                            void* ws, size_t ws_bytes, void* stream);
+/* Rows [row0, row0 + rows) of dm_mlp_head_fwd(_sparse) over rows_total rows; x, out and acts are the FULL arrays (acts
+ * carved for rows_total rows, or NULL).  A row's result does not depend on the window, so a forward over 40 000 imagined
+ * states can be issued in pieces as the rollout produces them (host mirror: the heads of the first horizon steps run on an
+ * idle stream while the rollout finishes; dreamer.py:212-213, a2c.py:85,113 apply the heads to the stacked features). */
+int dm_mlp_head_fwd_rows(int rows_total, int row0, int rows, int in_dim, int sparse_cols, int hidden, int layers, int out_dim,
+                         const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* dout (rows,out_dim); grads overwritten; dx (rows,in_dim; ld lddx) written if non-null (accumulated if dx_accum). */
 int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim,
                     const float* x, int ldx, const dm_mlp_params* p, const float* acts, const float* dout,
@@ -325,6 +333,13 @@ int dm_rssm_sequence_bwd(const dm_shape* shp, const float* embed, const float* a
                          const dm_rssm_params* p, const float* acts, const float* feat, const float* post,
                          float* dfeat, float* dpost, float* dprior,
                          const dm_rssm_grads* g, float* dembed, void* ws, size_t ws_bytes, void* stream);
+
+/* Progress marks for the NEXT dm_dream_rollout call of the calling thread (n <= 4; cleared by that call): events[i] - a
+ * hipEvent_t owned by the caller - is recorded on the rollout's stream when horizon step steps[i] (0-based) has been
+ * enqueued, i.e. when feature rows [0, (steps[i] + 2) * M) are final; marks that cannot be placed inside the loop (step out
+ * of range, chain-graph replay) are recorded behind the call.  Lets the caller start per-row work on the first horizon
+ * steps on another stream while the rollout continues.  No reference counterpart. */
+int dm_dream_rollout_marks(int n, const int* steps, void* const* events);
 
 /* Imagination rollout (dreamer.py:188-216, rssm.py:155-184, a2c.py:43-55), no autograd graph (actor_grad=reinforce).
  * start (M,F) = [h|z] rows; feats (H+1,M,F); actions (H,M,A) one-hot (or continuous); act_idx (H,M) (onehot only);

@@ -208,6 +208,19 @@ extern "C" int dm_mlp_head_fwd_sparse(int rows, int in_dim, int sparse_cols, int
                            (hipStream_t)stream, nullptr, sparse_cols);
 }
 
+// Rows [row0, row0 + rows) of an MLP forward over rows_total rows: x, out and acts are the FULL arrays (acts carved for
+// rows_total rows; may be NULL).  Row results do not depend on the window (no cross-row reduction in the forward).
+extern "C" int dm_mlp_head_fwd_rows(int rows_total, int row0, int rows, int in_dim, int sparse_cols, int hidden, int layers,
+                                    int out_dim, const float* x, int ldx, const dm_mlp_params* p, float* acts, float* out,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(x && p && out && ws, DM_E_NULL, "mlp_head_fwd_rows: null pointer");
+  DM_REQUIRE(row0 >= 0 && rows >= 1 && row0 + rows <= rows_total, DM_E_SHAPE, "mlp_head_fwd_rows: window [%d, %d) of %d rows", row0,
+             row0 + rows, rows_total);
+  DmPrecisionScope prec(p->precision);
+  return dm_mlp_fwd_launch(rows, in_dim, hidden, layers, out_dim, x + (size_t)row0 * ldx, ldx, p, acts, rows_total, row0,
+                           out + (size_t)row0 * out_dim, out_dim, ws, ws_bytes, (hipStream_t)stream, nullptr, sparse_cols);
+}
+
 extern "C" int dm_mlp_head_bwd(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                                const dm_mlp_params* p, const float* acts, const float* dout, const dm_mlp_grads* g,
                                float* dx, int lddx, int dx_accum, void* ws, size_t ws_bytes, void* stream) {

@@ -709,6 +709,39 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
 }
 
 // ---------------------------------------------------------------- imagination -------------------
+// Progress marks of the NEXT dm_dream_rollout call of this thread (include/dreamer_hip.h): events[i] is recorded on the
+// rollout's stream once horizon step steps[i] has been enqueued, i.e. when feature rows [0, (steps[i] + 2) * M) are final.
+static thread_local int tl_marks_n = 0;
+static thread_local int tl_mark_step[4];
+static thread_local hipEvent_t tl_mark_ev[4];
+extern "C" int dm_dream_rollout_marks(int n, const int* steps, void* const* events) {
+  DM_REQUIRE(n >= 0 && n <= 4 && (n == 0 || (steps && events)), DM_E_SHAPE, "dream_rollout_marks: n=%d (0..4)", n);
+  for (int i = 0; i < n; ++i) {
+    DM_REQUIRE(events[i], DM_E_NULL, "dream_rollout_marks: null event %d", i);
+    tl_mark_step[i] = steps[i];
+    tl_mark_ev[i] = (hipEvent_t)events[i];
+  }
+  tl_marks_n = n;
+  return DM_OK;
+}
+// every mark not recorded inside the loop (step out of range, or the chain ran as a captured / replayed graph) is recorded
+// behind the whole call, so a waiter is never left with a stale event
+struct DmRolloutMarks {
+  int n;
+  bool done[4] = {false, false, false, false};
+  hipStream_t caller;
+  explicit DmRolloutMarks(hipStream_t st) : n(tl_marks_n), caller(st) { tl_marks_n = 0; }
+  void at_step(int i, hipStream_t st, bool eager) {
+    if (!eager) return;
+    for (int k = 0; k < n; ++k)
+      if (!done[k] && tl_mark_step[k] == i) { (void)hipEventRecord(tl_mark_ev[k], st); done[k] = true; }
+  }
+  ~DmRolloutMarks() {
+    for (int k = 0; k < n; ++k)
+      if (!done[k]) (void)hipEventRecord(tl_mark_ev[k], caller);
+  }
+};
+
 extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, const dm_rssm_params* P,
                                 const dm_mlp_params* actor, const float* u_act, const float* u_prior, float* feats,
                                 float* actions, int32_t* act_idx, float* actor_acts, float* actor_logits, void* ws,
@@ -763,9 +796,11 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
       .add(feats).add(actions).add(act_idx).add(actor_acts).add(actor_logits).add(ws).add((long long)ws_bytes)
       .add((long long)dm_cur_precision()).add((long long)dm_mlp_chain_min_rows(0))       // + the one mutable dispatch threshold
       .add((long long)tw_on);
+  DmRolloutMarks marks(st);          // (declared before the graph object: its destructor runs after the graph was launched)
   DmChainGraph cg("dream_rollout", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();
+  const bool marks_eager = st == (hipStream_t)stream;
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
   GruStack gk;
   DM_TRY(gru_stack(s, p, nullptr, &gk));
@@ -874,6 +909,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
     DM_TRY(linear(st, sk, skb, M, ZP, Hd, za, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0, prior, ZP));
     DM_TRY(dm_sample_onehot_launch(M, S, C, prior, ZP, u_prior + (size_t)i * M * S, nullptr, nxt + D, F, pidx, nullptr,
                                    nullptr, st));
+    marks.at_step(i, st, marks_eager);
   }
   return cg.finish();
 }

@@ -191,6 +191,9 @@ _SIGNATURES = {
     'dm_rssm_persist_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),
     'dm_wgrad_side_join': (c_int, [_P]),
+    'dm_dream_rollout_marks': (c_int, [c_int, POINTER(c_int), POINTER(c_void_p)]),
+    'dm_mlp_head_fwd_rows': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P,
+                                     c_size_t, _P]),
 }
 
 _lib = None

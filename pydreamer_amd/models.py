@@ -129,17 +129,27 @@ class MLP(_Params):
     def acts_floats(self, rows):
         return int(H.lib().dm_mlp_acts_floats(rows, self.hidden_dim, self.hidden_layers))
 
-    def fwd(self, x2d, ldx, rows, ws, acts=None, save_acts=True, sparse_cols=0):
+    def fwd(self, x2d, ldx, rows, ws, acts=None, save_acts=True, sparse_cols=0, window=None, out=None):
         """x2d: device tensor whose rows (leading dim ldx floats) hold in_dim features. Returns (out, acts).
         save_acts=False (heads nobody differentiates: critic_target, the dream's reward / terminal heads, inference):
         no activation buffer is allocated or written; the library ping-pongs through the workspace.
         sparse_cols: the last sparse_cols input columns are mostly zero (the one-hot latent part of a feature row); same
-        result for any input, cheaper first layer on large batches (dm_mlp_head_fwd_sparse)."""
-        if acts is None and save_acts:
-            acts = torch.empty(self.acts_floats(rows), device=x2d.device)
+        result for any input, cheaper first layer on large batches (dm_mlp_head_fwd_sparse).
+        window=(rows_total, row0): x2d, `out` and `acts` are the FULL arrays of rows_total rows (given by the caller) and
+        only rows [row0, row0 + rows) are computed (dm_mlp_head_fwd_rows); a row's result does not depend on the window."""
         need = 4 * int(H.lib().dm_mlp_ws_floats(rows, self.hidden_dim, self.hidden_layers))
         if ws.numel() < need:
             raise H.DreamerHipError(f'MLP.fwd: workspace of {ws.numel()} bytes, need {need} for {rows} rows')
+        if window is not None:
+            rows_total, row0 = window
+            assert out is not None and out.shape[0] == rows_total and (acts is not None or not save_acts)
+            st = self.struct()
+            H.call('dm_mlp_head_fwd_rows', rows_total, row0, rows, self.in_dim, sparse_cols if 0 < sparse_cols < self.in_dim else 0,
+                   self.hidden_dim, self.hidden_layers, self.out_dim, H.fptr(x2d), ldx, ctypes.byref(st),
+                   H.fptr(acts) if save_acts else None, H.fptr(out), H.ptr(ws), ws.numel(), H.stream())
+            return out, acts
+        if acts is None and save_acts:
+            acts = torch.empty(self.acts_floats(rows), device=x2d.device)
         out = torch.empty(rows, self.out_dim, device=x2d.device)
         st = self.struct()
         if 0 < sparse_cols < self.in_dim:
@@ -444,6 +454,7 @@ def _prelaunched(owner, fn):
     return out
 
 
+_HEADS_EARLY = os.environ.get('DM_HEADS_EARLY', '1') != '0'    # A/B switch: 0 runs the heads over the imagined states behind the rollout only
 _WGRAD_SIDE = os.environ.get('DM_WGRAD_SIDE', '1') != '0'      # A/B switch: 0 keeps every weight gradient on the caller's stream
 
 
@@ -465,6 +476,11 @@ class _Overlap:
         self.s_ac = torch.cuda.Stream(device, priority=int(os.environ.get('DM_AC_PRIO', '0')))
         self.ev_wm_fwd = torch.cuda.Event()
         self.ev_fwd = torch.cuda.Event()
+        # the rollout's progress mark (recorded by the library, dm_dream_rollout_marks) and the early head window's completion
+        self.ev_mark, self.ev_heads = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.device(device):
+            self.ev_mark.record()          # (torch creates the HIP event at the first record; the library needs its handle)
+            self.ev_heads.record()
         self.ws_wm = None
         self.ws_ac = None
         # The HIP runtime needs ~6 us of host time per kernel launch and a step is ~1800 launches; at small per-GPU
@@ -1290,16 +1306,38 @@ class ActorCritic(_Params):
             for dst, src in zip(self.critic_target.parameters(), self.critic.parameters()):
                 H.call('dm_copy_params', H.fptr(dst), H.fptr(src), dst.numel(), H.stream())
 
-    def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None,
-                      actor_acts=None, actor_logits=None, overlap=None, mbuf=None):
-        """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149.
-        actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
-        features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
-        _require_cuda(features, 'features')
+    def begin_step(self, log_only=False):
+        """The head of training_step (a2c.py:76-79): refresh the target network every target_interval steps, count the step."""
         if not log_only and not self.defer_target_update:
             if self.train_steps % self.target_interval == 0:
                 self.update_critic_target()
             self.train_steps += 1
+
+    @staticmethod
+    def split_steps(J):
+        """The heads over the (J, M) imagined states run as two row windows, steps [0, split) and [split, J): the first one can
+        start while the rollout is still producing the last steps (Dreamer._heads_forward).  Always the same split, so every
+        execution order computes the same numbers.  Short horizons: one window."""
+        return (J * 5) // 8 if J >= 9 else J
+
+    def value_buffers(self, rows, device):
+        return dict(value_t=torch.empty(rows, 1, device=device), value=torch.empty(rows, 1, device=device),
+                    c_acts=torch.empty(self.critic.acts_floats(rows), device=device))
+
+    def forward_values(self, feats, F_, rows_total, row0, rows, ws, bufs):
+        """critic_target and critic over rows [row0, row0 + rows) of the feature matrix (a2c.py:85,113)."""
+        sp = self.sparse_cols        # the one-hot latent columns at the end of a feature row (0: unknown)
+        self.critic_target.fwd(feats, F_, rows, ws, save_acts=False, sparse_cols=sp, window=(rows_total, row0), out=bufs['value_t'])
+        self.critic.fwd(feats, F_, rows, ws, acts=bufs['c_acts'], sparse_cols=sp, window=(rows_total, row0), out=bufs['value'])
+
+    def training_step(self, features, actions, rewards, terminals, log_only=False, act_idx=None, ws=None,
+                      actor_acts=None, actor_logits=None, overlap=None, mbuf=None, values=None, _begun=False):
+        """features (J,M,F), actions (H,M,A) one-hot, rewards/terminals (J,M). a2c.py:61-149.
+        actor_acts / actor_logits: forward_actor(features[:-1]) as already computed by the dream rollout on the same
+        features and weights (bit-identical to recomputing it, which is what the reference does, a2c.py:119)."""
+        _require_cuda(features, 'features')
+        if not _begun:
+            self.begin_step(log_only)
         J, M, F_ = features.shape
         Hh, A, dev = J - 1, self.out_actions, features.device
         feats = features.contiguous().view(J * M, F_)
@@ -1312,8 +1350,13 @@ class ActorCritic(_Params):
             raise H.DreamerHipError('ActorCritic.training_step needs the model workspace (called through Dreamer.training_step)')
 
         sp = self.sparse_cols        # the one-hot latent columns at the end of a feature row (0: unknown)
-        value_t, _ = self.critic_target.fwd(feats, F_, J * M, ws, save_acts=False, sparse_cols=sp)
-        value, c_acts = self.critic.fwd(feats, F_, J * M, ws, sparse_cols=sp)
+        if values is None:           # (Dreamer.training_step hands them over: computed next to the reward / terminal heads)
+            values = self.value_buffers(J * M, dev)
+            r0 = self.split_steps(J) * M
+            for a, b in ((0, r0), (r0, J * M)):
+                if b > a:
+                    self.forward_values(feats, F_, J * M, a, b - a, ws, values)
+        value_t, value, c_acts = values['value_t'], values['value'], values['c_acts']
         if actor_acts is not None:
             logits, a_acts = actor_logits, actor_acts
         else:
@@ -1459,7 +1502,7 @@ class Dreamer(nn.Module):
         start = torch.cat((h, z), -1).contiguous()           # to_feature (rssm.py:83-84)
         return self._dream_from_features(start, Hh, u_act, u_prior, _pack)
 
-    def _dream_from_features(self, start, Hh, u_act=None, u_prior=None, _pack=None, _start_in_arena=False):
+    def _dream_from_features(self, start, Hh, u_act=None, u_prior=None, _pack=None, _start_in_arena=False, early=None):
         """start: (M,F) rows [h|z] (the world model's feature matrix is passed as is, no concat copy)."""
         c = self.conf
         M, dev = start.shape[0], start.device
@@ -1507,18 +1550,49 @@ class Dreamer(nn.Module):
         if _pack is not None:          # training: keep the actor activations of all H steps for the policy-gradient backward
             a_acts = ar.get('dream_actor_acts', (self.ac.actor.acts_floats(Hh * M),), device=dev)
             a_logits = ar.get('dream_actor_logits', (Hh * M, self.ac.actor.out_dim), device=dev)
+        # The heads over the imagined states (reward, terminal: dreamer.py:212-213; critic_target, critic: a2c.py:85,113) are
+        # per-row work on 40 000 rows, 4 ms behind a rollout whose last steps leave the chip half idle (profiles/r03_queues_*):
+        # they run as two row windows - steps [0, split) and [split, H] - and with `early` (the training step's side streams)
+        # the first window runs on the idle actor-critic stream as soon as the library reports those rows final, while the
+        # rollout finishes on this one.  Same windows, same kernels either way: bit-identical to the single-stream order.
+        rows = (Hh + 1) * M
+        r_split = self.ac.split_steps(Hh + 1) * M
+        # (not under conf.amp: there the world-model backward chain on the other side stream is the step's critical path and the
+        #  early window only takes CUs from it - measured 23.5 vs 23.2 ms; fp32: 37.1 vs 37.3 ms, 7-column shard 11.36 vs 11.50)
+        use_early = (early is not None and _pack is not None and not ar.on and r_split < rows and _HEADS_EARLY
+                     and not getattr(c, 'amp', False))
+        if use_early:
+            H.call('dm_dream_rollout_marks', 1, (ctypes.c_int * 1)(r_split // M - 2),
+                   (ctypes.c_void_p * 1)(int(early.ev_mark.cuda_event)))
         H.call('dm_dream_rollout', ctypes.byref(shp), M, H.fptr(start), ctypes.byref(cell_p), ctypes.byref(actor_p),
                H.fptr(u_act), H.fptr(u_prior), H.fptr(feats), H.fptr(actions), H.ptr(act_idx),
                H.fptr(a_acts), H.fptr(a_logits), H.ptr(ws), ws.numel(), H.stream())
-        rows = (Hh + 1) * M
         f2 = feats.view(rows, F_)
         Zc = c.stoch_dim * c.stoch_discrete            # the sampled one-hot latent columns of a feature row
-        mu, _ = self.wm.decoder.reward.model.fwd(f2, F_, rows, ws, save_acts=False, sparse_cols=Zc)
-        tl, _ = self.wm.decoder.terminal.model.fwd(f2, F_, rows, ws, save_acts=False, sparse_cols=Zc)
+        mu, tl = torch.empty(rows, 1, device=dev), torch.empty(rows, 1, device=dev)
+        values = self.ac.value_buffers(rows, dev) if _pack is not None else None
+
+        def heads(a, b, wsx):
+            if b <= a:
+                return
+            self.wm.decoder.reward.model.fwd(f2, F_, b - a, wsx, save_acts=False, sparse_cols=Zc, window=(rows, a), out=mu)
+            self.wm.decoder.terminal.model.fwd(f2, F_, b - a, wsx, save_acts=False, sparse_cols=Zc, window=(rows, a), out=tl)
+            if values is not None:
+                self.ac.forward_values(f2, F_, rows, a, b - a, wsx, values)
+        if use_early:
+            early.s_ac.wait_event(early.ev_mark)
+            with torch.cuda.stream(early.s_ac):
+                heads(0, r_split, early.ws_ac)
+                early.ev_heads.record(early.s_ac)
+            heads(r_split, rows, ws)
+            torch.cuda.current_stream().wait_event(early.ev_heads)
+        else:
+            heads(0, r_split, ws)
+            heads(r_split, rows, ws)
         term = torch.empty(rows, device=dev)
         H.call('dm_head_loss', 1, rows, H.fptr(tl), None, 0.0, 0.0, None, None, H.fptr(term), H.stream())
         if _pack is not None:
-            _pack.update(act_idx=act_idx, ws=ws, actor_acts=a_acts, actor_logits=a_logits)
+            _pack.update(act_idx=act_idx, ws=ws, actor_acts=a_acts, actor_logits=a_logits, values=values)
         return feats, actions, _Mean(mu.view(Hh + 1, M)), _Mean(term.view(Hh + 1, M))
 
     # ---- training step (dreamer.py:113-186)
@@ -1575,18 +1649,20 @@ class Dreamer(nn.Module):
 
         # (T,B,I) => (TBI): the feature matrix [h|z] of all posterior states, detached (dreamer.py:149)
         dpk = {}
-        features_dream, actions_dream, rewards_dream, terminals_dream = \
-            self._dream_from_features(pk['feat'], imag_horizon,
-                                      noise.get('u_act') if self.ac.dist_kind == 0 else noise.get('eps_act'),
-                                      noise.get('u_prior'), _pack=dpk, _start_in_arena=True)
-        (loss_actor, loss_critic), metrics_ac, tensors_ac = \
-            self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
-                                  act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
-                                  actor_logits=dpk['actor_logits'], overlap=ov, mbuf=mbuf)
         if ov is not None:
             need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B * I, MLP_HIDDEN, 4))
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
+        self.ac.begin_step()             # the target-network refresh comes before the first use of critic_target (a2c.py:76-79)
+        features_dream, actions_dream, rewards_dream, terminals_dream = \
+            self._dream_from_features(pk['feat'], imag_horizon,
+                                      noise.get('u_act') if self.ac.dist_kind == 0 else noise.get('eps_act'),
+                                      noise.get('u_prior'), _pack=dpk, _start_in_arena=True, early=ov)
+        (loss_actor, loss_critic), metrics_ac, tensors_ac = \
+            self.ac.training_step(features_dream, actions_dream, rewards_dream.mean, terminals_dream.mean,
+                                  act_idx=dpk['act_idx'], ws=dpk['ws'], actor_acts=dpk['actor_acts'],
+                                  actor_logits=dpk['actor_logits'], overlap=ov, mbuf=mbuf, values=dpk['values'], _begun=True)
+        if ov is not None:
             ov.ev_fwd.record(torch.cuda.current_stream())
             for mlp, hp in zip((self.ac.actor, self.ac.critic), self.ac._last_packs):
                 hp['pre'] = ov.submit(ov.s_ac, ov.ev_fwd, lambda mlp=mlp, hp=hp: _prelaunched(mlp, lambda: mlp.bwd(
@@ -1622,7 +1698,7 @@ class Dreamer(nn.Module):
                        ctypes.byref(dec_p), H.fptr(acts), None, H.fptr(image_dream), H.ptr(ws), ws.numel(), H.stream())
                 _, _, t_ac2 = self.ac.training_step(f2, a2, r2.mean, t2.mean, log_only=True, act_idx=dpk2['act_idx'],
                                                     ws=dpk2['ws'], actor_acts=dpk2['actor_acts'],
-                                                    actor_logits=dpk2['actor_logits'])
+                                                    actor_logits=dpk2['actor_logits'], values=dpk2['values'])
                 dream_tensors = dict(action_pred=torch.cat([obs['action'][:1].float(), a2]), reward_pred=r2.mean,
                                      terminal_pred=t2.mean, image_pred=image_dream.view(T, B, *image_dream.shape[-3:]),
                                      **t_ac2)

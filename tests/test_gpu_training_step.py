@@ -1038,6 +1038,50 @@ def test_deferred_weight_gradients_are_bit_identical(hip, amp):
     assert float(runs[0][0][1].abs().sum()) > 0
 
 
+def test_early_head_window_is_bit_identical(hip):
+    """The heads over the imagined states run as two row windows (ActorCritic.split_steps); in the training step the first
+    one is issued on the actor-critic stream behind a progress mark of the rollout (dm_dream_rollout_marks) while the
+    rollout finishes.  Same windows and kernels on another stream: losses, gradients and updated parameters are
+    bit-identical to issuing both windows behind the rollout (DM_HEADS_EARLY=0) and to the plain single-stream order
+    (overlap_backward=False).  imag_horizon = 9: 10 imagined steps, windows [0, 6) and [6, 10)."""
+    from pydreamer_amd import models as M
+    oconf = O.tiny_conf(imag_horizon=9)
+    assert M.ActorCritic.split_steps(10) == 6
+    params = O.make_params(oconf, seed=6)
+    runs = []
+    keep = M._HEADS_EARLY
+    try:
+        for early, overlap in ((True, True), (False, True), (False, False)):
+            M._HEADS_EARLY = early
+            model = _build(oconf, params)
+            model.overlap_backward = overlap
+            opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+            st = model.init_state(oconf.batch_size)
+            hist = []
+            for s in range(3):
+                obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=80 + s, first=(s == 0)), oconf))
+                noise = _to_dev(O.make_noise(oconf, seed=85 + s))
+                losses, st2, _, _, _ = model.training_step(obs, st, noise=noise)
+                for opt in opts:
+                    opt.zero_grad()
+                for loss in losses:
+                    loss.backward()
+                model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+                grads = torch.cat([o.flat_grad for o in opts]).clone()
+                for opt in opts:
+                    opt.step()
+                st = tuple(x.clone() for x in st2)
+                hist.append(([float(x) for x in losses], grads.cpu(), torch.cat([o.flat_param for o in opts]).cpu()))
+            runs.append(hist)
+    finally:
+        M._HEADS_EARLY = keep
+    for other in runs[1:]:
+        for s, (a, b) in enumerate(zip(runs[0], other)):
+            assert a[0] == b[0], (s, a[0], b[0])
+            assert torch.equal(a[1], b[1]), f'step {s}: gradients differ'
+            assert torch.equal(a[2], b[2]), f'step {s}: parameters differ'
+
+
 def test_training_step_matches_reference_at_atari_literal(hip):
     """BASELINE.json configs[1] at FULL size against the slim golden written by the real reference
     (tests/golden/atari_literal.npz; inputs regenerated from the same seeds and fingerprinted).
