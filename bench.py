@@ -378,7 +378,8 @@ def main():
             nonlocal hstate
             obs = dring.next()
             losses, hstate, *_ = model.training_step(obs, hstate, noise=noise.draw())
-            dring.prefetch()       # the next batch's H2D copies, behind this step's forward on the caller's stream (idle from here on)
+            if not os.environ.get('DM_RING_NO_PREFETCH'):      # (A/B switch: the copies then sit in front of the next step)
+                dring.prefetch()   # the next batch's H2D copies, behind this step's forward on the caller's stream (idle from here on)
             for opt in opts:
                 opt.zero_grad()
             for loss in losses:
