@@ -240,3 +240,23 @@ def test_runtime_switch_defaults():
         assert lib.dm_rssm_persist_enable(-1) == 0
         assert lib.dm_chain_graph_enable(-1) == 0
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
+
+
+def test_scheduling_switches_and_windows():
+    """Host-side scheduling decisions that never change what is computed: parameter gradients on the library's side stream and
+    the early head window are on by default; the head windows are the same in every execution order (ActorCritic.split_steps);
+    joining / disarming the side stream with nothing deferred is a no-op that needs no device; rollout marks are validated."""
+    import ctypes
+    from pydreamer_amd import models as M
+    if not any(os.environ.get(k) for k in ('DM_WGRAD_SIDE', 'DM_HEADS_EARLY')):
+        assert M._WGRAD_SIDE and M._HEADS_EARLY
+    S = M.ActorCritic.split_steps
+    assert [S(j) for j in (2, 6, 8, 9, 10, 16, 50)] == [2, 6, 8, 5, 6, 10, 31]      # J < 9: one window; else 5/8 of the steps first
+    assert all(0 < S(j) <= j for j in range(1, 200))
+    lib = hip.lib()
+    assert lib.dm_wgrad_side_arm(0) == 0
+    assert lib.dm_wgrad_side_join(None) == 0
+    assert lib.dm_dream_rollout_marks(0, None, None) == 0
+    assert lib.dm_dream_rollout_marks(5, (ctypes.c_int * 5)(), (ctypes.c_void_p * 5)()) != 0       # at most four marks
+    assert b'marks' in lib.dm_last_error()
+    assert lib.dm_dream_rollout_marks(1, (ctypes.c_int * 1)(3), (ctypes.c_void_p * 1)(None)) != 0   # null event
