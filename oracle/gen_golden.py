@@ -446,6 +446,16 @@ if __name__ == '__main__':
         run('tiny_gru_layernorm_layers2', ['defaults', 'atari'],
             dict(base, stoch_discrete=t.stoch_discrete, gru_type='gru_layernorm', gru_layers=2), steps=1,
             full_grads=('wm.core.cell.gru.layers.1.ln_update.weight',))
+    if 'variants2' in which:
+        # SURVEY 8(a) variants inside the same functions: the normal_tanh actor (functions.py:59-66, a2c.py:43-55; continuous
+        # actions with actor_grad=reinforce) and the plain-KL branch kl_balance = 0.5 (dreamer.py:241,334-335)
+        t = O.tiny_conf()
+        base = dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                    cnn_depth=t.cnn_depth, batch_length=t.batch_length, batch_size=t.batch_size, imag_horizon=t.imag_horizon)
+        run('tiny_normal_tanh', ['defaults', 'dmc'], dict(base, action_dim=4, actor_grad='reinforce', actor_dist='normal_tanh'),
+            steps=2, full_grads=('ac.actor.model.12.weight', 'ac.actor.model.12.bias', 'ac.critic.model.12.weight'))
+        run('tiny_kl_plain', ['defaults', 'atari'], dict(base, action_dim=t.action_dim, kl_balance=0.5), steps=2,
+            full_grads=('wm.core.cell.post_mlp.weight', 'wm.core.cell.prior_mlp.weight', 'wm.core.cell.prior_mlp.bias'))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

@@ -629,10 +629,12 @@ def test_training_step_matches_reference_goldens(hip):
     the LayerNorm GRU cells of rnn.py:95-138: tiny_gru_layernorm.npz, tiny_gru_layernorm_dv2.npz, and the auxiliary critic
     of dreamer.py:267-279,347-358: tiny_aux_critic.npz, and the 3-layer GRUCellStack of rnn.py:40-67: tiny_gru_layers3.npz -
     SURVEY 8(f) N4; layer_norm=False, common.py:68-74 NoNorm: tiny_no_layernorm.npz; Gaussian latents, stoch_discrete=0,
-    rssm.py:195-203: tiny_gaussian_latents.npz; a 2-layer stack of NormGRUCells: tiny_gru_layernorm_layers2.npz)."""
+    rssm.py:195-203: tiny_gaussian_latents.npz; a 2-layer stack of NormGRUCells: tiny_gru_layernorm_layers2.npz; the
+    normal_tanh actor of functions.py:59-66: tiny_normal_tanh.npz; the plain-KL branch kl_balance = 0.5 of dreamer.py:241,334-335:
+    tiny_kl_plain.npz)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
                         ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2),
-                        ('tiny_gaussian_latents', 2), ('tiny_gru_layernorm_layers2', 1)):
+                        ('tiny_gaussian_latents', 2), ('tiny_gru_layernorm_layers2', 1), ('tiny_normal_tanh', 2), ('tiny_kl_plain', 2)):
         g = np.load(os.path.join(GOLD, f'{name}.npz'))
         oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
         params = O.make_params(oconf, seed=0)

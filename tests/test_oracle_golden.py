@@ -161,6 +161,24 @@ def test_oracle_matches_reference_gaussian_latents():
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_normal_tanh_actor():
+    """SURVEY 8(a) variant: actor_dist = normal_tanh (functions.py:59-66: Independent(Normal(tanh(mean_), sigmoid(std_) + 0.01)),
+    no transform on the sample), continuous actions under actor_grad = reinforce, two training steps incl. gradients."""
+    g, conf, results = _replay('tiny_normal_tanh', 2)
+    assert conf.actor_dist == 'normal_tanh' and conf.actor_grad == 'reinforce'
+    for res in results:
+        _check_step(g, conf, res)
+
+
+def test_oracle_matches_reference_plain_kl():
+    """SURVEY 8(a) variant: kl_balance = 0.5 selects the un-balanced KL (dreamer.py:241: `None if kl_balance == 0.5`,
+    dreamer.py:334-335), two training steps incl. gradients of the prior / posterior heads."""
+    g, conf, results = _replay('tiny_kl_plain', 2)
+    assert conf.kl_balance == 0.5
+    for res in results:
+        _check_step(g, conf, res)
+
+
 @pytest.mark.parametrize('name', ['tiny_gaussian_iwae', 'tiny_gru_layernorm_layers2'])
 def test_oracle_matches_reference_corners_ahead_of_the_product(name):
     """Two corners the HIP path still refuses, pinned in the oracle ahead of it: Gaussian latents with
