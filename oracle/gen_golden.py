@@ -456,6 +456,18 @@ if __name__ == '__main__':
             steps=2, full_grads=('ac.actor.model.12.weight', 'ac.actor.model.12.bias', 'ac.critic.model.12.weight'))
         run('tiny_kl_plain', ['defaults', 'atari'], dict(base, action_dim=t.action_dim, kl_balance=0.5), steps=2,
             full_grads=('wm.core.cell.post_mlp.weight', 'wm.core.cell.prior_mlp.weight', 'wm.core.cell.prior_mlp.bias'))
+    if 'scalars' in which:
+        # every scalar hyper-parameter of the path away from its default at once (defaults.yaml:38-53,94-97): loss weights, KL
+        # weight and balance, discount, GAE lambda, entropy weight, learning rates, Adam eps, clip thresholds that BIND
+        # (grad_clip 100 / grad_clip_ac 0.2 are below the tiny model's gradient norms), target refresh every step; 3 steps
+        t = O.tiny_conf()
+        run('tiny_scalars', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, kl_weight=0.3, kl_balance=0.65, image_weight=0.7, reward_weight=2.0,
+                 terminal_weight=0.5, gamma=0.95, lambda_gae=0.8, entropy=0.01, target_interval=1, adam_lr=1.0e-3,
+                 adam_lr_actor=3.0e-4, adam_lr_critic=2.0e-4, adam_eps=1.0e-6, grad_clip=100, grad_clip_ac=0.2), steps=3,
+            full_grads=SMALL_GRADS)
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

@@ -170,6 +170,17 @@ def test_oracle_matches_reference_normal_tanh_actor():
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_off_default_scalars():
+    """Every scalar hyper-parameter of the path away from its default at once (loss weights, KL weight / balance, discount,
+    GAE lambda, entropy weight, learning rates, Adam eps, target refresh every step) with gradient clips that BIND
+    (grad_clip 100, grad_clip_ac 0.2), three consecutive training steps."""
+    g, conf, results = _replay('tiny_scalars', 3)
+    assert (conf.kl_weight, conf.kl_balance, conf.reward_weight, conf.grad_clip_ac, conf.target_interval) == (0.3, 0.65, 2.0, 0.2, 1)
+    assert float(g['s0_metric_grad_norm']) > conf.grad_clip and float(g['s0_metric_grad_norm_actor']) > conf.grad_clip_ac
+    for res in results:
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_plain_kl():
     """SURVEY 8(a) variant: kl_balance = 0.5 selects the un-balanced KL (dreamer.py:241: `None if kl_balance == 0.5`,
     dreamer.py:334-335), two training steps incl. gradients of the prior / posterior heads."""
