@@ -468,6 +468,18 @@ if __name__ == '__main__':
                  terminal_weight=0.5, gamma=0.95, lambda_gae=0.8, entropy=0.01, target_interval=1, adam_lr=1.0e-3,
                  adam_lr_actor=3.0e-4, adam_lr_critic=2.0e-4, adam_eps=1.0e-6, grad_clip=100, grad_clip_ac=0.2), steps=3,
             full_grads=SMALL_GRADS)
+    if 'combo' in which:
+        # the structural variants of SURVEY 8(a) TOGETHER: Gaussian latents, a 2-layer stack of late-reset LayerNorm GRU cells,
+        # NoNorm MLPs, the auxiliary critic and a tanh_normal actor on continuous actions - the corners were pinned one by one,
+        # this pins their interaction
+        t = O.tiny_conf()
+        run('tiny_combo', ['defaults', 'dmc'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=0, cnn_depth=t.cnn_depth,
+                 action_dim=4, batch_length=t.batch_length, batch_size=t.batch_size, imag_horizon=t.imag_horizon,
+                 actor_grad='reinforce', actor_dist='tanh_normal', gru_type='gru_layernorm_dv2', gru_layers=2, layer_norm=False,
+                 aux_critic=True), steps=2,
+            full_grads=('wm.core.cell.gru.layers.1.weight_hh.weight', 'wm.core.cell.post_mlp.weight', 'ac.actor.model.12.weight',
+                        'wm.ac_aux.critic.model.12.weight'))
     if 'aux' in which:
         # aux_critic (dreamer.py:267-279,347-358): a critic on the REAL trajectory inside the world model
         t = O.tiny_conf()

@@ -636,44 +636,56 @@ def test_training_step_matches_reference_goldens(hip):
                         ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2),
                         ('tiny_gaussian_latents', 2), ('tiny_gru_layernorm_layers2', 1), ('tiny_normal_tanh', 2), ('tiny_kl_plain', 2),
                         ('tiny_scalars', 3)):
-        g = np.load(os.path.join(GOLD, f'{name}.npz'))
-        oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
-        params = O.make_params(oconf, seed=0)
-        model = _build(oconf, params)
-        opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
-        state = model.init_state(oconf.batch_size)
-        T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
-        for s in range(steps):
-            pre = f's{s}_'
-            raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
-            obs = _to_dev(O.preprocess(raw, oconf))
-            noise = {k: torch.from_numpy(g[pre + 'in_' + k]).to(DEV) for k in ('u_post', 'u_act', 'u_prior', 'eps_act')
-                     if pre + 'in_' + k in g.files}
-            losses, state, metrics, tensors, _ = model.training_step(obs, state, noise=noise)
-            for opt in opts:
-                opt.zero_grad()
-            for loss in losses:
-                loss.backward()
-            gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
-            for opt in opts:
-                opt.step()
-            assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_post']), name
-            if oconf.actor_dist == 'onehot':
-                assert np.array_equal(model.last_extras['act_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_act']), name
-            for i, l in enumerate(losses):
-                ref = g[pre + 'losses'][i]
-                assert _rel(l, ref) < 2e-5 or abs(float(l) - ref) < 2e-6, (name, s, i, float(l), ref)
-            assert abs(float(losses[0]) - g[pre + 'losses'][0]) < 1e-3
-            for k, v in {**metrics, **gm}.items():
-                ref = float(g[pre + 'metric_' + k])
-                assert _rel(v, ref) < 1e-4 or abs(float(v) - ref) < 5e-6, (name, s, k, float(v), ref)
-            names = [str(n) for n in g[pre + 'grad_names']]
-            named = dict(model.named_parameters())
-            for n, ref in zip(names, g[pre + 'grad_norms']):
-                got = float(named[n].grad.double().norm())     # (after the clip, like the fixture's: it binds in tiny_scalars only)
-                assert abs(got - ref) <= 2e-3 * ref + 1e-7, (name, s, n, got, ref)
-            sums = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()])
-            np.testing.assert_allclose(sums, g[pre + 'param_abs_sums'], rtol=2e-6)
+        _check_reference_golden(name, steps)
+
+
+def test_combined_variants_match_reference_golden(hip):
+    """tests/golden/tiny_combo.npz: the structural variants TOGETHER (Gaussian latents, a 2-layer stack of late-reset LayerNorm GRU
+    cells, NoNorm MLPs, the auxiliary critic, a tanh_normal actor on continuous actions) - their interaction, not each alone."""
+    _check_reference_golden('tiny_combo', 2)
+
+
+def _check_reference_golden(name, steps):
+    """One fixture written by the real reference (oracle/gen_golden.py) replayed through the HIP path: sampled indices bit-exact,
+    losses / metrics / gradient norms (after the clip, like the fixture's) / post-AdamW parameter checksums at the bars below."""
+    g = np.load(os.path.join(GOLD, f'{name}.npz'))
+    oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
+    params = O.make_params(oconf, seed=0)
+    model = _build(oconf, params)
+    opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+    state = model.init_state(oconf.batch_size)
+    T, B, S = oconf.batch_length, oconf.batch_size, oconf.stoch_dim
+    for s in range(steps):
+        pre = f's{s}_'
+        raw = {k: g[pre + 'in_' + k] for k in ('image_u8', 'action_idx', 'reward', 'terminal', 'reset')}
+        obs = _to_dev(O.preprocess(raw, oconf))
+        noise = {k: torch.from_numpy(g[pre + 'in_' + k]).to(DEV) for k in ('u_post', 'u_act', 'u_prior', 'eps_act')
+                 if pre + 'in_' + k in g.files}
+        losses, state, metrics, tensors, _ = model.training_step(obs, state, noise=noise)
+        for opt in opts:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
+        gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+        for opt in opts:
+            opt.step()
+        assert np.array_equal(model.last_extras['post_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_post']), name
+        if oconf.actor_dist == 'onehot':
+            assert np.array_equal(model.last_extras['act_idx'].cpu().numpy().astype(np.uint8), g[pre + 'idx_act']), name
+        for i, l in enumerate(losses):
+            ref = g[pre + 'losses'][i]
+            assert _rel(l, ref) < 2e-5 or abs(float(l) - ref) < 2e-6, (name, s, i, float(l), ref)
+        assert abs(float(losses[0]) - g[pre + 'losses'][0]) < 1e-3
+        for k, v in {**metrics, **gm}.items():
+            ref = float(g[pre + 'metric_' + k])
+            assert _rel(v, ref) < 1e-4 or abs(float(v) - ref) < 5e-6, (name, s, k, float(v), ref)
+        names = [str(n) for n in g[pre + 'grad_names']]
+        named = dict(model.named_parameters())
+        for n, ref in zip(names, g[pre + 'grad_norms']):
+            got = float(named[n].grad.double().norm())     # (after the clip, like the fixture's: it binds in tiny_scalars only)
+            assert abs(got - ref) <= 2e-3 * ref + 1e-7, (name, s, n, got, ref)
+        sums = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()])
+        np.testing.assert_allclose(sums, g[pre + 'param_abs_sums'], rtol=2e-6)
 
 
 def test_gaussian_latents_iwae_matches_reference_golden(hip):

@@ -181,6 +181,16 @@ def test_oracle_matches_reference_off_default_scalars():
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_combined_variants():
+    """The structural variants of SURVEY 8(a) TOGETHER: Gaussian latents, a 2-layer stack of late-reset LayerNorm GRU cells,
+    NoNorm MLPs, the auxiliary critic and a tanh_normal actor on continuous actions; two training steps incl. gradients."""
+    g, conf, results = _replay('tiny_combo', 2)
+    assert (conf.stoch_discrete, conf.gru_type, conf.gru_layers, conf.layer_norm, conf.aux_critic, conf.actor_dist) == \
+        (0, 'gru_layernorm_dv2', 2, False, True, 'tanh_normal')
+    for res in results:
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_plain_kl():
     """SURVEY 8(a) variant: kl_balance = 0.5 selects the un-balanced KL (dreamer.py:241: `None if kl_balance == 0.5`,
     dreamer.py:334-335), two training steps incl. gradients of the prior / posterior heads."""
