@@ -122,6 +122,10 @@ def main():
     probe = ['ep000012_000014-r35-0421.npz', 'x/y/ep000007-r-3-0099.npz', '20210101T000000-0500.npz', 'ep000003_000004-2-r7-0100.npz'] + names
     out['name_probe'] = np.array(probe)
     out['name_probe_parsed'] = np.array([repo.parse(p) for p in probe], np.int64)
+    # ... and the builder (data.py:97-101), with and without the generator's chunk sequence number
+    build_args = [(3, 4, 7.4, 100, None), (3, 4, 7.6, 100, 2), (0, 0, -3.0, 9, None), (12, 14, 35.49, 421, 0), (123456, 123457, 0.0, 12345, None)]
+    out['name_build_args'] = np.array([[a, b, r, n, -1 if c is None else c] for a, b, r, n, c in build_args], np.float64)
+    out['name_build'] = np.array([repo.build(a, b, r, n, chunk_seq=c) for a, b, r, n, c in build_args])
 
     case_names = []
     for (cname, kw, seed, nb, clip) in CASES:

@@ -72,11 +72,18 @@ class LocalEpisodeRepository:
                     files.append(FileInfo(os.path.join(d, name), a, b, steps))
         return files
 
-    def save_data(self, data, episode_from, episode_to):
+    @staticmethod
+    def build_episode_name(episode_from, episode, reward, steps, chunk_seq=None):
+        """data.py:97-101 (chunk_seq: the generator's sequence number of a partial episode file)."""
+        if chunk_seq is None:
+            return f'ep{episode_from:06}_{episode:06}-r{reward:.0f}-{steps:04}.npz'
+        return f'ep{episode_from:06}_{episode:06}-{chunk_seq}-r{reward:.0f}-{steps:04}.npz'
+
+    def save_data(self, data, episode_from, episode_to, chunk_seq=None):
         """data.py:62-69 naming; written with np.savez_compressed like tools.py:200-207."""
         n_episodes = int(data['reset'].sum())
         steps = len(data['reset']) - n_episodes
-        name = f"ep{episode_from:06}_{episode_to:06}-r{float(data['reward'].sum()):.0f}-{steps:04}.npz"
+        name = self.build_episode_name(episode_from, episode_to, float(data['reward'].sum()), steps, chunk_seq)
         path = os.path.join(self.dirs[0], name)
         np.savez_compressed(path, **data)
         return path
