@@ -72,6 +72,11 @@ class LocalEpisodeRepository:
                     files.append(FileInfo(os.path.join(d, name), a, b, steps))
         return files
 
+    def count_steps(self):
+        """data.py:90-94: (files, steps, episodes) of the repository."""
+        files = self.list_files()
+        return len(files), sum(f.steps for f in files), (max(f.episode_to for f in files) + 1) if files else 0
+
     @staticmethod
     def build_episode_name(episode_from, episode, reward, steps, chunk_seq=None):
         """data.py:97-101 (chunk_seq: the generator's sequence number of a partial episode file)."""
