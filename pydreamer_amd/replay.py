@@ -9,7 +9,7 @@ Here the same batches are produced as what the HIP path consumes directly:
     data.py:53-122; the file-name grammar `ep{from}_{to}-r{reward}-{steps}.npz` is the same);
   * `SequentialReplay`        - DataSequential's algorithm: per-column sequential iteration (`iter_single`), random start
     in the first file (`skip_first`), partial-window carry (`allow_mid_reset`), `randomize_resets`, `buffer_size`
-    filtering, `image_t` HWCT -> THWC (data.py:237-239), `reset[0] = True` / `reward[0] = 0` per file (data.py:256-260);
+    filtering, periodic re-listing (`reload_interval`), `image_t` HWCT -> THWC (data.py:237-239), `reset[0] = True` / `reward[0] = 0` per file (data.py:256-260);
     the random stream is an explicit `numpy.random.RandomState` (the reference uses the global one);
   * `preprocess_batch`        - the hot-path subset of Preprocessor.apply: one-hot float32 actions, float32 reward with
     `clip_rewards`, float32 terminal, bool reset - and the image is LEFT AS uint8 (T,B,H,W,C): x/255-0.5 and HWC->CHW
@@ -28,6 +28,7 @@ reference counterpart (the reference uses a DataLoader + `.to(device)`) and is c
 import os
 import queue
 import threading
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -101,11 +102,12 @@ def _lenb(batch):
 class SequentialReplay:
     """DataSequential (data.py:128-304) as a plain iterator of time-major numpy batches {key: (T, B, ...)}."""
 
-    def __init__(self, repository, batch_length, batch_size, skip_first=True, buffer_size=0, reset_interval=0,
+    def __init__(self, repository, batch_length, batch_size, skip_first=True, reload_interval=0, buffer_size=0, reset_interval=0,
                  allow_mid_reset=False, seed=0, check_nonempty=True):
         self.repository = repository
         self.batch_length, self.batch_size = batch_length, batch_size
         self.skip_first, self.buffer_size = skip_first, buffer_size
+        self.reload_interval = reload_interval                       # seconds between re-listings of the repository (online training)
         self.reset_interval, self.allow_mid_reset = reset_interval, allow_mid_reset
         self.rs = np.random.RandomState(seed)
         self.reload_files()
@@ -121,6 +123,11 @@ class SequentialReplay:
             if total < self.buffer_size or not self.buffer_size:
                 files.append(f)
         self.files, self.stats_steps = files, total
+        self.last_reload = time.time()
+
+    def should_reload_files(self):
+        """data.py:186-187."""
+        return bool(self.reload_interval) and (time.time() - self.last_reload > self.reload_interval)
 
     def __iter__(self):
         iters = [self.iter_single(ix) for ix in range(self.batch_size)]
@@ -131,7 +138,9 @@ class SequentialReplay:
         skip_random = self.skip_first
         last_partial = None
         while True:
-            file = self.files[self.rs.randint(len(self.files))]                          # iter_shuffled_files
+            if self.should_reload_files():                                               # iter_shuffled_files (data.py:273-278)
+                self.reload_files()
+            file = self.files[self.rs.randint(len(self.files))]
             first_shorter = self.batch_length - _lenb(last_partial) if last_partial else None
             it = self.iter_file(file, skip_random, first_shorter)
             if last_partial is not None:
