@@ -506,6 +506,10 @@ if __name__ == '__main__':
         # actor_grad=reinforce, action_dim 6, B=50, T=50, H=15; slim fixture (several minutes per step on 8 vCPU)
         run('dmc_native', ['defaults', 'dmc'],
             dict(batch_size=50, batch_length=50, imag_horizon=15, action_dim=6, actor_grad='reinforce'), steps=1, slim=True)
+    if 'atari_native' in which:
+        # pydreamer's OWN Atari configuration (defaults+atari as shipped: B=32, T=48, deter_dim 1024, H=15; what the reference's
+        # README measured and what `bench.py --workload atari-native` runs), action_dim 18; slim fixture
+        run('atari_native', ['defaults', 'atari'], dict(action_dim=18), steps=1, slim=True)
     if 'atari_amp' in which:
         # BASELINE.json configs[2]: Atari-literal forward under torch.autocast('cpu', bfloat16) and in fp32 (slim: scalars +
         # posterior indices)

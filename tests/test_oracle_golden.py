@@ -239,10 +239,10 @@ def test_sampler_rule_edges():
     assert O.sample_inverse_cdf(p, torch.tensor([0.999, 0.999999, 0.999])).tolist() == [2, 3, 2]
 
 
-def test_oracle_matches_reference_at_atari_literal():
-    """BASELINE.json configs[1] at full size (B=50,T=50,H=15, deter 600): the oracle against the slim golden written by the
-    real reference.  Inputs are regenerated from the same seeds and fingerprinted."""
-    g = _load('atari_literal')
+def _check_full_size_step(name):
+    """A full-size training step of the oracle against a slim golden written by the real reference; inputs are regenerated
+    from the same seeds and fingerprinted."""
+    g = _load(name)
     conf = _conf_from(g)
     raw = O.synthetic_batch(conf, seed=1234, first=True)
     noise = O.make_noise(conf, seed=777)
@@ -279,6 +279,20 @@ def test_oracle_matches_reference_at_atari_literal():
                 continue
             got = O.grad_probe(grads[n], i)
             assert max(abs(got[0] - pr[0]), abs(got[1] - pr[1])) <= 1e-4 * r + 1e-9, (n, got, pr, r)
+
+
+def test_oracle_matches_reference_at_atari_literal():
+    """BASELINE.json configs[1] at full size (B=50,T=50,H=15, deter 600)."""
+    _check_full_size_step('atari_literal')
+
+
+def test_oracle_matches_reference_at_atari_native():
+    """pydreamer's OWN Atari configuration as shipped (defaults+atari: B=32, T=48, deter_dim 1024, H=15, action_dim 18 - what the
+    reference's README measured and `bench.py --workload atari-native` runs), full step incl. gradient directions."""
+    g = _load('atari_native')
+    conf = _conf_from(g)
+    assert (conf.batch_size, conf.batch_length, conf.deter_dim, conf.imag_horizon) == (32, 48, 1024, 15)
+    _check_full_size_step('atari_native')
 
 
 def test_oracle_matches_reference_at_dmc_native():
