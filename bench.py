@@ -399,7 +399,7 @@ def main():
         nbytes = sum(v.nbytes for v in host_ring[0].values())
         h2d = dict(value=args.h2d_steps / th, unit='grad-steps/s', ms_per_step=1e3 * th / args.h2d_steps, steps=args.h2d_steps,
                    host_bytes_per_step=nbytes, note='uint8 (T,B,64,64,3) frames + actions / rewards / flags from pinned host memory through '
-                   'pydreamer_amd.replay.DeviceRing (depth 4, own copy stream); x/255-0.5 and HWC->CHW happen inside the first conv\'s loader')
+                   'pydreamer_amd.replay.DeviceRing (depth 4; copies prefetched on the caller\'s stream behind the forward, no copy stream); x/255-0.5 and HWC->CHW happen inside the first conv\'s loader')
 
     # profiled pass: HIP events around every GEMM launch on the launch stream (same steps, right after the timed region)
     roof = None

@@ -223,7 +223,11 @@ def run_amp(name, sections, overrides):
         with MultinomialPatch() as mp:
             mp.queue = [noise['u_post'][t] for t in range(T)]
             for i in range(H):
-                mp.queue += [noise['u_act'][i], noise['u_prior'][i]]
+                if rconf.actor_dist == 'onehot':
+                    mp.queue.append(noise['u_act'][i])
+                else:      # continuous actors draw through torch.normal (Normal.sample), as in run()
+                    mp.eps_queue.append(noise['eps_act'][i])
+                mp.queue.append(noise['u_prior'][i])
             with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16, enabled=amp):
                 losses, _, metrics, _, _ = model.training_step(obs, model.init_state(B))
             post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
@@ -515,6 +519,11 @@ if __name__ == '__main__':
         # posterior indices)
         run_amp('atari_literal_amp', ['defaults', 'atari'],
                 dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18))
+    if 'dmc_amp' in which:
+        # BASELINE.json configs[4] as named: DMC continuous actions (defaults+dmc, deter_dim 2048, tanh_normal, action_dim 6,
+        # actor_grad=reinforce) at B=50, T=50, H=15 forward under torch.autocast('cpu', bfloat16) and in fp32
+        run_amp('dmc_native_amp', ['defaults', 'dmc'],
+                dict(batch_size=50, batch_length=50, imag_horizon=15, action_dim=6, actor_grad='reinforce'))
     if 'debug' in which:
         # BASELINE.json configs[0]: defaults+atari+debug on CPU, B=4,T=10,H=5, discrete(6)
         run('debug_literal', ['defaults', 'atari', 'debug'],

@@ -139,6 +139,11 @@ int DmChainGraph::finish() {
   if (mode_ == 0) return DM_OK;
   if (mode_ == 1) {
     mode_ = 0;
+    // launched under the cache lock: another host thread's finish() may evict (and destroy) this exec otherwise
+    std::lock_guard<std::mutex> lk(g_mu);
+    bool alive = false;
+    for (auto& e : g_cache) alive = alive || e.exec == exec_;
+    if (!alive) return dm_fail(DM_E_HIP, "chain graph %s: the cached graph was evicted between lookup and launch", tag_);
     if (hipGraphLaunch(exec_, st_) != hipSuccess) return dm_fail(DM_E_HIP, "chain graph %s: hipGraphLaunch: %s", tag_, hipGetErrorString(hipGetLastError()));
     return DM_OK;
   }

@@ -220,7 +220,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DmChainKey ck;
   ck.add(s).add((long long)t0).add((long long)t1).add(embed).add(action).add(reset).add(h0).add(z0).add(u).add(forced_idx)
       .add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(prior).add(idx).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision());
+      .add((long long)dm_cur_precision()).add((long long)dm_twins_on());      // + every run-time switch that changes the launch sequence
   DmChainGraph cg("rssm_sequence_fwd", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();

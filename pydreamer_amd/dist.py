@@ -38,17 +38,25 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None):
         model.wm.grad_weight = w
         model.ac.grad_weight = w
         folded = {id(model._opt[k]) for k in ('wm', 'actor', 'critic')}
+    global _attached
     for opt in optimizers:
         opt.dp = (group, w)
         opt.dp_folded = id(opt) in folded
+    _attached = True
 
 
 _inflight = []      # futures of launcher-thread jobs that may issue collectives (models._Overlap.submit)
+_attached = False   # set by attach(): only then can a launcher job issue a collective, and only then does drain() ever run
 
 
 def track(fut):
-    if dist.is_available() and dist.is_initialized():
-        _inflight.append(fut)
+    """Remember a launcher-thread job that may issue a collective.  Nothing is kept unless a data-parallel group is attached
+    (an initialised process group of world size 1 never reaches drain(), so its futures - each pinning the job's result -
+    would pile up for the life of the process); jobs that have already finished are dropped on the way."""
+    if not _attached:
+        return
+    _inflight[:] = [f for f in _inflight if not f.done()]
+    _inflight.append(fut)
 
 
 def drain():
@@ -60,7 +68,7 @@ def drain():
         fut = _inflight.pop(0)
         try:
             fut.result()
-        except Exception:      # surfaced by the backward() that owns the future
+        except Exception:      # re-raised, with its traceback, by the loss.backward() that owns the future (models._Overlap)
             pass
 
 

@@ -1612,7 +1612,17 @@ class Dreamer(nn.Module):
             u_post = u_post.reshape(T, B * I, -1)
 
         if self._overlap is not None:
-            # pre-launched backward passes of a step whose losses were never backpropagated may still be reading the arena
+            # pre-launched backward passes of a step whose losses were never backpropagated may still be reading the arena -
+            # and their launcher jobs may still be ENQUEUING: a stream wait only orders what is already in the stream, so the
+            # jobs are awaited first (their exceptions belong to the backward() that owns them, not to this step)
+            stale = [getattr(self.wm, '_last_pack', None)] + list(getattr(self.ac, '_last_packs', None) or ())
+            for old_pk in stale:
+                fut = old_pk.get('pre') if isinstance(old_pk, dict) else None
+                if fut is not None:
+                    try:
+                        fut.result()
+                    except Exception:
+                        pass
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._overlap.s_wm)
             cur.wait_stream(self._overlap.s_ac)

@@ -277,7 +277,9 @@ class DeviceRing:
                 if self.host is None:
                     self.host = [None] * self.depth
                 if self.host[i] is None:
-                    self.host[i] = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().pin_memory() for k, v in batch.items()}
+                    # a new thread's current device is 0: pin under THIS ring's device, or every rank creates a context on GPU 0
+                    with torch.cuda.device(self.device):
+                        self.host[i] = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().pin_memory() for k, v in batch.items()}
                 else:
                     ev = self.copied[i]
                     if ev is not None:          # the pinned buffer is still the source of an asynchronous copy until this fires
