@@ -70,10 +70,11 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 7 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 8 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
-                                         v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only) */
+                                         v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
+                                         v8: dm_rssm_lds_* replace dm_rssm_persist_*) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -119,13 +120,17 @@ int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_
  * the arena twins only if the forward call that filled that `acts` buffer wrote them - the library keeps a host-side note per
  * buffer).  1 / 0 switches that path on / off, -1 queries; returns the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
 int dm_bf16_twins_enable(int on);
-/* EXPERIMENTAL, off by default (slower than the launch schedule as measured): the posterior T loop
- * (rssm.py:38-58) as ONE persistent kernel confined to one XCD when the shape qualifies (plain GRU, LayerNorm, 32-class
- * latents, B <= 64): five phases per step separated by a flag barrier in that XCD's L2 instead of five dependent launches;
- * results are bit-identical to the launch schedule.  1 / 0 switches it on / off, -1 queries; returns the state.
- * dm_rssm_persist_prof: per-phase clock ticks of its workgroup 0 (diagnostic). */
-int dm_rssm_persist_enable(int on);
-int dm_rssm_persist_prof(unsigned long long* out12, int reset);
+/* The posterior T loop (rssm.py:38-58, cell rssm.py:125-153, nn.GRUCell rnn.py:40-67) runs, when the shape qualifies (plain
+ * single-layer GRU, LayerNorm, categorical latents, B <= 64, the layer slices fit one CU's LDS), as ONE persistent kernel with
+ * one workgroup per compute unit that keeps its 4-column slice of every layer's weights in LDS for all T steps and exchanges
+ * the small activation rows through poison-filled per-step buffers (csrc/rssm_lds.hip) - instead of five
+ * dependent launches per step that re-stream the weights.  Same arithmetic up to fp32 summation order, same sampler rule.
+ * dm_rssm_lds_enable: 1 / 0 switches it on / off, -1 queries; returns the state (default on; DM_RSSM_LDS=0 in the environment).
+ * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (bounded polls; later calls are refused).
+ * dm_rssm_lds_prof: clock ticks (100 MHz) of its workgroup 0 summed per phase since the last reset (diagnostic). */
+int dm_rssm_lds_enable(int on);
+int dm_rssm_lds_status(void);
+int dm_rssm_lds_prof(unsigned long long* out8, int reset);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
 int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,

@@ -147,19 +147,21 @@ int dm_frag_pack_launch(int rows, int K, const float* X, int ldx, float* Xf, hip
 // x = bias + add + sum_s Wt[s*C + idx[r][s]] (+ Wt2[idx2[r]])  (z_mlp of a one-hot latent as a gather-sum; Wt = W^T, (S*C, n)
 // row-major; idx2 / Wt2 optional: one more gathered row per output row, a_mlp of a one-hot action);
 // y (optional) = ELU(LayerNorm(x)); x (optional when y is given); x_frag (optional, rows <= 64): fragment-major copy of x
-// The posterior chain's steps [t_begin, t_end) as ONE persistent kernel on one XCD (gemm_skinny.hip rssm_persist_kernel); all
-// activation pointers are the bases of the full (T*B)-row buffers, the *f ones the fragment-major ping-pong copies.
-struct DmRssmPersist {
-  int B, D, Hd, S, Z, ZP, F, t_begin, t_end;
-  int32_t* idx; const uint8_t* reset; const float* wzt; const float* zb; const float* ea; float* x1; float* x1f;
-  const float *wih, *bih, *whh, *bhh, *wph, *bph, *wpo, *bpo, *in_g, *in_b, *post_g, *post_b, *ee;
-  float *gi, *gh, *hin, *feat, *hf, *hinf, *x2, *x2f, *post, *zin, *zinf;
-  const float* u; const int32_t* forced;
-  float* sync;      // dm_rssm_persist_sync_floats() floats of scratch
+// The posterior chain's steps [t_begin, t_end) as ONE persistent kernel whose workgroups (one per CU, all XCDs) keep their
+// column slices of the cell's weights in LDS (rssm_lds.hip); all activation pointers are the bases of the full (T*B)-row
+// buffers; step t_begin - 1 has been run by the launch schedule (its h in `feat`, its indices in `idx`, the masked inputs of
+// step t_begin in `hin`).
+struct DmRssmLds {
+  int B, D, Hd, S, C, F, t_begin, t_end;
+  const float *wzt, *zb, *wih, *bih, *whh, *bhh, *wph, *bph, *wpo, *bpo, *in_g, *in_b, *post_g, *post_b, *ea, *ee;
+  const uint8_t* reset; const float* u; const int32_t* forced;
+  float *x1, *gi, *gh, *hin, *zin, *feat, *x2, *post; int32_t* idx;
+  float* ws; size_t ws_floats;      // dm_rssm_lds_ws_floats(...) floats: the per-step exchange buffers
 };
-bool dm_rssm_persist_ok(int B, int D, int Hd, int S, int C, int ZP, int F);
-size_t dm_rssm_persist_sync_floats();
-int dm_rssm_persist_launch(const DmRssmPersist& q, hipStream_t st);
+bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C);
+size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps);
+int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st);
+extern "C" int dm_rssm_lds_enable(int on);
 bool dm_z_embed_ok(int n);
 // x[r][:] = sum over the non-zero e of z[r][e] * Wt[e][:]   (Wt: (Zc, n) row-major, n <= 1024, n % 4 == 0): exact for any z,
 // cheap for rows of concatenated one-hot groups

@@ -546,286 +546,3 @@ int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t strea
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
-
-// ================================================================================================================
-// The posterior T loop as ONE persistent kernel on ONE XCD (rssm.py:38-58; the 5-launch fused schedule of rssm.hip).
-//
-// A dependent launch costs the chain ~8-15 us whatever it computes, a software grid barrier across the 8 XCDs 7-13 us
-// (scripts/microbench/grid_barrier.hip), an agent-scope acquire fence ~1 us PER WORKGROUP (the L1/L2 invalidate serialises:
-// scripts/microbench/xcd_barrier.hip).  What is cheap: a flag barrier among workgroups that share ONE L2 - every workgroup
-// publishes its epoch with a relaxed agent-scope store, one wave polls all flags with relaxed agent-scope loads, nobody
-// fences: 1.1 us for 32 workgroups, and 32 CUs of one XCD still stream the step's 23 MB of weights at 1.1 TB/s
-// (~20 us).  So: 32 workgroups of 1024 threads, all on the XCD whose XCC_ID they read from the hardware register
-// (workgroups that land elsewhere exit; the first 32 to claim a slot are by construction resident), one workgroup per CU
-// (LDS), and the five phases of a posterior step separated by that barrier:
-//   1. x1 = z_mlp(z) + a_mlp(a) as the gather-sum over z_mlp^T rows (z_embed)          one wave per row
-//   2. gi = ELU(in_norm(x1)) W_ih^T + b ; gh = h_in W_hh^T + b                          16-column strips, skinny_strip
-//   3. GRU gates -> h (into the feature matrix), the next step's masked h_in            one element per thread
-//   4. x2 = h W_post_h^T + b + post_mlp_e(embed)                                        16-column strips
-//   5. post = ELU(post_norm(x2)) W_post^T + b ; z ~ straight-through categorical        one 32-logit group per workgroup
-// with exactly the device code of the stand-alone kernels (skinny_strip and its LayerNorm prologue / sampler epilogue), so
-// the arithmetic of every element is the stand-alone schedule's.  Data written by one workgroup and read by another inside
-// the launch is read with L1-bypassing loads (COH); the L1 is write-through, so a store that has retired (s_waitcnt) is in
-// the shared L2.  Every spin loop has a bail-out that raises a sticky error word instead of hanging the GPU.
-struct RssmPersistArgs {
-  int B, D, Hd, S, Z, ZP, F, t_begin, t_end;       // steps [t_begin, t_end) of a range that ends at t_end
-  const int32_t* idx_in; const uint8_t* reset; const float* wzt; const float* zb; const float* ea;
-  float* x1; float* x1f;
-  const float *wih, *bih, *whh, *bhh, *wph, *bph, *wpo, *bpo, *in_g, *in_b, *post_g, *post_b, *ee;
-  float *gi, *gh, *hin, *feat, *hf, *hinf, *x2, *x2f, *post, *zin, *zinf;
-  const float* u; const int32_t* forced; int32_t* idx_out;
-  unsigned* sync;          // [0..63] barrier flags, [64] error (sticky), [65] slot claims; zeroed by the host before the launch
-  unsigned target_xcc, G;
-};
-constexpr unsigned RP_SPIN_LIMIT = 1u << 22;
-
-__device__ __forceinline__ unsigned rp_xcc_id() {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 0xFu;
-}
-__device__ __forceinline__ void rp_barrier(unsigned* sync, unsigned& epoch, unsigned G, unsigned me) {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have retired into the XCD's L2
-  __syncthreads();
-  epoch += 1;
-  if (threadIdx.x < 64) {
-    if (threadIdx.x == 0) __hip_atomic_store(sync + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned lane = threadIdx.x;
-    bool ok = lane >= G;
-    unsigned spins = 0;
-    while (true) {
-      if (!ok) ok = __hip_atomic_load(sync + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-      if (__all(ok)) break;
-      if (++spins > RP_SPIN_LIMIT || __hip_atomic_load(sync + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(sync + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void rp_fill(SkinnyArgs& a, int M, int N, int K, const float* A, int lda, const float* Af, const float* B,
-                                        int ldb, float* C, int ldc, float* Cf, const float* bias, const float* add, int ldadd,
-                                        const float* ln_g, const float* ln_b) {
-  a.A = A; a.B = B; a.C = C; a.bias = bias; a.add = add; a.row_zero = nullptr;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldadd = ldadd; a.flags = 0;
-  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-3f;
-  a.u = nullptr; a.forced = nullptr; a.onehot = nullptr; a.ldo = 0; a.idx = nullptr; a.z_next = nullptr; a.next_reset = nullptr;
-  a.lnb_x = nullptr; a.lnb_ldx = 0; a.lnb_stats = nullptr;
-  a.gb_gi = nullptr; a.gb_gh = nullptr; a.gb_hin = nullptr; a.gb_ldh = 0; a.gb_D = 0; a.gb_dgi = nullptr; a.gb_dgh = nullptr;
-  a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr; a.gb_dgif = nullptr; a.gb_dghf = nullptr;
-  a.Af = Af; a.Cf = Cf; a.znf = nullptr;
-}
-
-// phase timing (diagnostic): s_memtime ticks (100 MHz) of workgroup 0 summed per phase: z_embed, b1, gates products, b2, gates, b3,
-// post_h, b4, post+sample, b5
-__device__ unsigned long long rp_prof[12];
-#define RP_TICK(k_)                                                          \
-  do {                                                                       \
-    if (me == 0 && tid == 0) {                                               \
-      const unsigned long long now_ = __builtin_readcyclecounter();          \
-      rp_prof[k_] += now_ - tick_;                                           \
-      tick_ = now_;                                                          \
-    }                                                                        \
-  } while (0)
-extern "C" int dm_rssm_persist_prof(unsigned long long* out12, int reset) {
-  if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(rp_prof), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[12] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-template <int NRB>
-__global__ void __launch_bounds__(SK_WAVES * 64) rssm_persist_kernel(const RssmPersistArgs p) {
-  __shared__ float part[SK_WAVES * 64 * 32];
-  __shared__ SkinnyShared sh;
-  __shared__ float tile[64 * 33];
-  __shared__ unsigned my_slot;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) {
-    unsigned m = 0xFFFFFFFFu;
-    if (rp_xcc_id() == p.target_xcc) m = __hip_atomic_fetch_add(p.sync + 65, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    my_slot = m;
-  }
-  __syncthreads();
-  const unsigned me = my_slot, G = p.G;
-  if (me >= G) return;
-  unsigned epoch = 0;
-  const int B = p.B, D = p.D, Hd = p.Hd, S = p.S, Z = p.Z, ZP = p.ZP, F = p.F;
-  constexpr int C = 32;
-  unsigned long long tick_ = __builtin_readcyclecounter();
-  for (int t = p.t_begin; t < p.t_end; ++t) {
-    const size_t r0 = (size_t)t * B;
-    const bool more = t + 1 < p.t_end;
-    // ---- 1. x1 = bias + a_mlp(a) + sum_s z_mlp^T[s*C + idx[r][s]]   (reset rows: no latent term)      rssm.py:138-139
-    for (int row = (int)me + (int)G * wave; row < B; row += (int)G * SK_WAVES) {
-      float4 acc[4];
-      int off[4];
-      bool in[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (lane + 64 * j) * 4;
-        in[j] = c < Hd;
-        off[j] = in[j] ? c : 0;
-        acc[j] = *reinterpret_cast<const float4*>(p.zb + off[j]);
-        const float4 a = *reinterpret_cast<const float4*>(p.ea + (r0 + row) * Hd + off[j]);
-        acc[j].x += a.x; acc[j].y += a.y; acc[j].z += a.z; acc[j].w += a.w;
-      }
-      if (!p.reset[r0 + row]) {
-        const int32_t* ir = p.idx_in + (r0 - B + row) * S;
-        const int mine = sk_ldi_coh(ir + (lane < S ? lane : S - 1));      // S <= 64 (host-checked)
-        int tq = 0;
-        for (; tq + 4 <= S; tq += 4) {
-          float4 w[4][4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float* wr = p.wzt + ((size_t)(tq + u) * C + __shfl(mine, tq + u, 64)) * Hd;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[u][j] = *reinterpret_cast<const float4*>(wr + off[j]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              acc[j].x += w[u][j].x; acc[j].y += w[u][j].y; acc[j].z += w[u][j].z; acc[j].w += w[u][j].w;
-            }
-        }
-        for (; tq < S; ++tq) {
-          const float* wr = p.wzt + ((size_t)tq * C + __shfl(mine, tq, 64)) * Hd;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + off[j]);
-            acc[j].x += w.x; acc[j].y += w.y; acc[j].z += w.z; acc[j].w += w.w;
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (in[j]) {
-          const int c = (lane + 64 * j) * 4;
-          *reinterpret_cast<float4*>(p.x1 + (r0 + row) * Hd + c) = acc[j];
-          *reinterpret_cast<float4*>(p.x1f + dm_frag_off(row, c)) = acc[j];
-        }
-    }
-    RP_TICK(0);
-    rp_barrier(p.sync, epoch, G, me);
-    RP_TICK(1);
-    // ---- 2. gi = ELU(in_norm(x1)) W_ih^T + b_ih ; gh = h_in W_hh^T + b_hh                              rssm.py:140-141
-    {
-      SkinnyArgs a;
-      const int nsi = (3 * D + 15) / 16;
-      rp_fill(a, B, 3 * D, Hd, p.x1 + r0 * Hd, Hd, p.x1f, p.wih, Hd, p.gi + r0 * 3 * D, 3 * D, nullptr, p.bih, nullptr, 0, p.in_g,
-              p.in_b);
-      bool first = true;
-      for (int s = (int)me; s < nsi; s += (int)G) {
-        skinny_strip<0, NRB, 1, 1, 0, 4, true>(a, s, 0, part, &sh, nullptr, !first);
-        first = false;
-        __syncthreads();
-      }
-      rp_fill(a, B, 3 * D, D, p.hin + r0 * D, D, p.hinf, p.whh, D, p.gh + r0 * 3 * D, 3 * D, nullptr, p.bhh, nullptr, 0, nullptr,
-              nullptr);
-      for (int s = (int)((me + G / 2) % G); s < nsi; s += (int)G) {      // (offset: the workgroups with an extra gi strip get no extra gh strip)
-        skinny_strip<0, NRB, 1, 0, 0, 4, true>(a, s, 0, part, &sh, nullptr);
-        __syncthreads();
-      }
-    }
-    RP_TICK(2);
-    rp_barrier(p.sync, epoch, G, me);
-    RP_TICK(3);
-    // ---- 3. GRU gates (torch GRUCell, rnn.py:48-49): h into the feature matrix, the next step's masked h_in
-    for (int i = (int)me * (SK_WAVES * 64) + tid; i < B * D; i += (int)G * SK_WAVES * 64) {
-      const int r = i / D, d = i - r * D;
-      const float* gir = p.gi + (r0 + r) * 3 * D;
-      const float* ghr = p.gh + (r0 + r) * 3 * D;
-      const float rg = 1.0f / (1.0f + expf(-(sk_ld1_coh(gir + d) + sk_ld1_coh(ghr + d))));
-      const float ug = 1.0f / (1.0f + expf(-(sk_ld1_coh(gir + D + d) + sk_ld1_coh(ghr + D + d))));
-      const float ng = tanhf(sk_ld1_coh(gir + 2 * D + d) + rg * sk_ld1_coh(ghr + 2 * D + d));
-      const float h = sk_ld1_coh(p.hin + (r0 + r) * D + d);
-      const float ho = (h - ng) * ug + ng;
-      p.feat[(r0 + r) * F + d] = ho;
-      p.hf[dm_frag_off(r, d)] = ho;
-      if (more) {
-        const float hn = p.reset[r0 + B + r] ? 0.f : ho;
-        p.hin[(r0 + B + r) * D + d] = hn;
-        p.hinf[dm_frag_off(r, d)] = hn;
-      }
-    }
-    RP_TICK(4);
-    rp_barrier(p.sync, epoch, G, me);
-    RP_TICK(5);
-    // ---- 4. x2 = h W_post_h^T + b + post_mlp_e(embed)                                                  rssm.py:143-144
-    {
-      SkinnyArgs a;
-      rp_fill(a, B, Hd, D, p.feat + r0 * F, F, p.hf, p.wph, D, p.x2 + r0 * Hd, Hd, p.x2f, p.bph, p.ee + r0 * Hd, Hd, nullptr, nullptr);
-      const int ns = (Hd + 15) / 16;
-      for (int s = (int)me; s < ns; s += (int)G) {
-        skinny_strip<0, NRB, 1, 0, 0, 4, true>(a, s, 0, part, &sh, nullptr);
-        __syncthreads();
-      }
-    }
-    RP_TICK(6);
-    rp_barrier(p.sync, epoch, G, me);
-    RP_TICK(7);
-    // ---- 5. post = ELU(post_norm(x2)) W_post^T + b ; z ~ OneHotCategoricalStraightThrough(post)        rssm.py:145-148
-    {
-      SkinnyArgs a;
-      rp_fill(a, B, ZP, Hd, p.x2 + r0 * Hd, Hd, p.x2f, p.wpo, Hd, p.post + r0 * ZP, ZP, nullptr, p.bpo, nullptr, 0, p.post_g, p.post_b);
-      a.u = p.u ? p.u + r0 * S : nullptr;
-      a.forced = p.forced ? p.forced + r0 * S : nullptr;
-      a.onehot = p.feat + r0 * F + D; a.ldo = F;
-      a.idx = p.idx_out + r0 * S;
-      a.z_next = more ? p.zin + (r0 + B) * Z : nullptr;
-      a.next_reset = more ? p.reset + r0 + B : nullptr;
-      a.znf = more ? p.zinf : nullptr;
-      bool first = true;
-      for (int s = (int)me; s < ZP / 32; s += (int)G) {
-        skinny_strip<0, NRB, 2, 1, 1, 2, true>(a, s, 0, part, &sh, tile, !first);
-        first = false;
-        __syncthreads();
-      }
-    }
-    RP_TICK(8);
-    if (more) rp_barrier(p.sync, epoch, G, me);
-    RP_TICK(9);
-  }
-}
-
-// OFF by default - measured (profiles/r03_rssm_persist.txt): the barrier is as cheap as planned (1.4-3.3 us) but a strip product is
-// LATENCY-bound (~11-15 us: LayerNorm statistics, operand round trip, LDS reduction, epilogue round trip), and a workgroup
-// that runs its ~7 strips of the gate products one after the other takes 108 us where 226 concurrent workgroups take 21:
-// T = 50, B = 50: 9.9 ms vs 3.7 ms for the launch schedule (B = 7: 4.3 vs 2.0).  Kept (bit-identical, tested) as the
-// starting point of a version whose waves own whole strips with all of a phase's loads in flight at once.
-static int g_rssm_persist = getenv("DM_RSSM_PERSIST") ? atoi(getenv("DM_RSSM_PERSIST")) : 0;
-// 1 / 0: run the posterior chain's steps as the single-XCD persistent kernel when the shape qualifies / always as launches;
-// -1: query.  Returns the state.
-extern "C" int dm_rssm_persist_enable(int on) {
-  if (on >= 0) g_rssm_persist = on ? 1 : 0;
-  return g_rssm_persist;
-}
-bool dm_rssm_persist_ok(int B, int D, int Hd, int S, int C, int ZP, int F) {
-  return g_rssm_persist && !g_skinny_disabled && !g_skinny_nofuse && B >= 1 && B <= 64 && C == 32 && S >= 1 && S <= 64 && ZP == S * C &&
-         (Hd & 3) == 0 && Hd <= SK_LN_MAXK && (D & 3) == 0 && (F & 3) == 0 && dm_skinny_ln_ok(B, 3 * D, Hd) && dm_skinny_ln_ok(B, ZP, Hd);
-}
-size_t dm_rssm_persist_sync_floats() { return 128; }
-int dm_rssm_persist_launch(const DmRssmPersist& q, hipStream_t st) {
-  RssmPersistArgs a;
-  a.B = q.B; a.D = q.D; a.Hd = q.Hd; a.S = q.S; a.Z = q.Z; a.ZP = q.ZP; a.F = q.F; a.t_begin = q.t_begin; a.t_end = q.t_end;
-  a.idx_in = q.idx; a.reset = q.reset; a.wzt = q.wzt; a.zb = q.zb; a.ea = q.ea; a.x1 = q.x1; a.x1f = q.x1f;
-  a.wih = q.wih; a.bih = q.bih; a.whh = q.whh; a.bhh = q.bhh; a.wph = q.wph; a.bph = q.bph; a.wpo = q.wpo; a.bpo = q.bpo;
-  a.in_g = q.in_g; a.in_b = q.in_b; a.post_g = q.post_g; a.post_b = q.post_b; a.ee = q.ee;
-  a.gi = q.gi; a.gh = q.gh; a.hin = q.hin; a.feat = q.feat; a.hf = q.hf; a.hinf = q.hinf; a.x2 = q.x2; a.x2f = q.x2f;
-  a.post = q.post; a.zin = q.zin; a.zinf = q.zinf; a.u = q.u; a.forced = q.forced; a.idx_out = q.idx;
-  a.sync = reinterpret_cast<unsigned*>(q.sync);
-  a.target_xcc = 0; a.G = 32;
-  if (hipMemsetAsync(q.sync, 0, 128 * sizeof(float), st) != hipSuccess) return dm_fail(DM_E_HIP, "rssm_persist: memset failed");
-  // 8 XCDs x (32 participants + 4 spares): workgroups are dealt round-robin over the XCDs, the ones on other XCDs exit at once
-  const dim3 grid(8 * 36), blk(SK_WAVES * 64);
-  if (q.B <= 16) hipLaunchKernelGGL((rssm_persist_kernel<1>), grid, blk, 0, st, a);
-  else if (q.B <= 32) hipLaunchKernelGGL((rssm_persist_kernel<2>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((rssm_persist_kernel<4>), grid, blk, 0, st, a);
-  DM_LAUNCH_CHECK();
-  return DM_OK;
-}

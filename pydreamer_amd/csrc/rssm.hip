@@ -220,7 +220,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   DmChainKey ck;
   ck.add(s).add((long long)t0).add((long long)t1).add(embed).add(action).add(reset).add(h0).add(z0).add(u).add(forced_idx)
       .add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(prior).add(idx).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision()).add((long long)dm_twins_on());      // + every run-time switch that changes the launch sequence
+      .add((long long)dm_cur_precision()).add((long long)dm_twins_on()).add((long long)dm_rssm_lds_enable(-1));      // + every run-time switch that changes the launch sequence
   DmChainGraph cg("rssm_sequence_fwd", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();
@@ -276,12 +276,14 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     float* f3 = ar.take(dm_frag_floats(D)); float* f4 = ar.take(dm_frag_floats(Hd));
     if (ar.ok) { zinf = f0; x1f = f1; hinf = f2; hf = f3; x2f = f4; }
   }
-  // The fused schedule's steps after the first of a range as ONE persistent kernel on one XCD (gemm_skinny.hip
-  // rssm_persist_kernel): the first step runs as launches (its z is a dense vector from the caller) and leaves the masked
-  // inputs, fragment-major copies and indices the kernel's first step needs.
+  // The fused schedule's steps after the first of a range as ONE persistent kernel with the cell's weights stationary in
+  // LDS (rssm_lds.hip): the first step runs as launches (its z is a dense vector from the caller) and leaves h, the masked
+  // inputs and the indices the kernel's first step continues from.
   float* psync = nullptr;
-  if (fuse_sample && zinf && wzt && idx && t1 - t0 >= 3 && dm_rssm_persist_ok(B, D, Hd, S, C, ZP, F)) {
-    float* sy = ar.take(dm_rssm_persist_sync_floats());
+  size_t psync_floats = 0;
+  if (fuse_sample && wzt && idx && kind == 0 && t1 - t0 >= 3 && dm_rssm_lds_ok(B, D, Hd, S, C)) {
+    psync_floats = dm_rssm_lds_ws_floats(B, D, Hd, S, C, t1 - t0 - 1);
+    float* sy = ar.take(psync_floats);
     if (ar.ok) psync = sy;
     else ar.ok = true;
   }
@@ -380,15 +382,16 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
                                    idx ? idx + r0 * S : nullptr, zin_next, reset_next, st));
   }
   if (psync) {
-    DmRssmPersist pq;
-    pq.B = B; pq.D = D; pq.Hd = Hd; pq.S = S; pq.Z = Z; pq.ZP = ZP; pq.F = F; pq.t_begin = t0 + 1; pq.t_end = t1;
-    pq.idx = idx; pq.reset = reset; pq.wzt = wzt; pq.zb = p[DM_RSSM_Z_B]; pq.ea = a.ea; pq.x1 = a.x1; pq.x1f = x1f;
+    DmRssmLds pq;
+    pq.B = B; pq.D = D; pq.Hd = Hd; pq.S = S; pq.C = C; pq.F = F; pq.t_begin = t0 + 1; pq.t_end = t1;
+    pq.wzt = wzt; pq.zb = p[DM_RSSM_Z_B];
     pq.wih = p[DM_RSSM_GRU_WIH]; pq.bih = p[DM_RSSM_GRU_BIH]; pq.whh = p[DM_RSSM_GRU_WHH]; pq.bhh = p[DM_RSSM_GRU_BHH];
     pq.wph = p[DM_RSSM_POST_H_W]; pq.bph = p[DM_RSSM_POST_H_B]; pq.wpo = p[DM_RSSM_POST_W]; pq.bpo = p[DM_RSSM_POST_OB];
     pq.in_g = p[DM_RSSM_IN_G]; pq.in_b = p[DM_RSSM_IN_B]; pq.post_g = p[DM_RSSM_POST_G]; pq.post_b = p[DM_RSSM_POST_B];
-    pq.ee = a.ee; pq.gi = a.gi; pq.gh = a.gh; pq.hin = a.hin; pq.feat = feat; pq.hf = hf; pq.hinf = hinf; pq.x2 = a.x2;
-    pq.x2f = x2f; pq.post = post; pq.zin = a.zin; pq.zinf = zinf; pq.u = u; pq.forced = forced_idx; pq.sync = psync;
-    DM_TRY(dm_rssm_persist_launch(pq, st));
+    pq.ea = a.ea; pq.ee = a.ee; pq.reset = reset; pq.u = u; pq.forced = forced_idx;
+    pq.x1 = a.x1; pq.gi = a.gi; pq.gh = a.gh; pq.hin = a.hin; pq.zin = a.zin; pq.feat = feat; pq.x2 = a.x2; pq.post = post;
+    pq.idx = idx; pq.ws = psync; pq.ws_floats = psync_floats;
+    DM_TRY(dm_rssm_lds_launch(pq, st));
   }
   if (fuse_ln) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
     DM_TRY(norm_elu_fwd(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,

@@ -187,8 +187,9 @@ _SIGNATURES = {
     'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_fp32_mode': (c_int, []),
     'dm_bf16_twins_enable': (c_int, [c_int]),
-    'dm_rssm_persist_enable': (c_int, [c_int]),
-    'dm_rssm_persist_prof': (c_int, [_P, c_int]),
+    'dm_rssm_lds_enable': (c_int, [c_int]),
+    'dm_rssm_lds_status': (c_int, []),
+    'dm_rssm_lds_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),
     'dm_wgrad_side_join': (c_int, [_P]),
     'dm_dream_rollout_marks': (c_int, [c_int, POINTER(c_int), POINTER(c_void_p)]),
@@ -197,7 +198,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 7      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 8      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

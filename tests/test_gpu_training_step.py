@@ -454,11 +454,16 @@ def test_dream_rollout_bf16_storage_twins_match_fp32_storage(hip):
     _close(f1[:, zsame], f0[:, zsame], 0, 2e-5, 'dream features, twins on vs off')
 
 
-@pytest.mark.parametrize('B', [7, 50])
-def test_rssm_persistent_chain_matches_launch_schedule(hip, B):
-    """The posterior T loop as one persistent kernel on one XCD (five phases per step behind an L2 flag barrier) against the
-    five-launch fused schedule it replaces, at the Atari-literal cell width, T = 12: same device code per phase, so sampled
-    indices, logits, states and saved activations are bit-identical."""
+@pytest.mark.parametrize('B', [6, 7, 13, 25, 50, 64])
+def test_rssm_lds_chain_matches_launch_schedule(hip, B):
+    """The posterior T loop as ONE persistent kernel whose workgroups keep the cell's weight slices in LDS (csrc/rssm_lds.hip:
+    one workgroup per CU on all XCDs, activation rows exchanged through poison-filled per-step buffers) against the
+    five-launch fused schedule it replaces, at the Atari-literal cell width, T = 12, for the row counts of a 1 / 2 / 4 / 8-way
+    batch shard (50, 25, 13, 7 / 6; one lane group layout each: 64, 32, 16, 8 rows per k-group) and a full 64.  Same
+    arithmetic up to fp32 summation order (K is split over waves and k-groups differently), same sampler rule: sampled
+    indices equal (a uniform within an ulp of a CDF edge excepted: >= 99.9 %), logits / states / saved activations within
+    2e-5 + 1e-5 relative of the launch schedule on the rows whose history of indices is identical; the kernel never gave up
+    in a spin loop.  (Parity with the reference itself: test_rssm_sequence_fwd_bwd_vs_oracle runs this kernel too.)"""
     import ctypes
     from pydreamer_amd import hip as H
     T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
@@ -477,22 +482,44 @@ def test_rssm_persistent_chain_matches_launch_schedule(hip, B):
     ws = model.wm.workspace(shp, torch.device(DEV, 0))
     P = H.rssm_struct(cell.ordered())
     outs = []
+    assert H.lib().dm_rssm_lds_status() == 0
     try:
         for on in (1, 0):
-            H.lib().dm_rssm_persist_enable(on)
+            H.lib().dm_rssm_lds_enable(on)
             acts = torch.zeros(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
             feat, post, prior = torch.zeros(T * B, F_, device=DEV), torch.zeros(T * B, Z, device=DEV), torch.zeros(T * B, Z, device=DEV)
             idx = torch.zeros(T * B, S, dtype=torch.int32, device=DEV)
-            H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
-                   H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
-                   H.ptr(ws), ws.numel(), H.stream())
-            torch.cuda.synchronize()
+            for rep in range(2):      # twice: the second call runs with L1 / L2 warm on the same exchange addresses
+                H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
+                       H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
+                       H.ptr(ws), ws.numel(), H.stream())
+                torch.cuda.synchronize()
             outs.append((feat, post, prior, idx, acts))
     finally:
-        H.lib().dm_rssm_persist_enable(1)
-    for a, b, what in zip(outs[0], outs[1], ('feat', 'post', 'prior', 'idx', 'acts')):
-        assert torch.isfinite(a.float()).all(), what
-        assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
+        H.lib().dm_rssm_lds_enable(1)
+    assert H.lib().dm_rssm_lds_status() == 0, 'the persistent kernel gave up in a spin loop'
+    same = (outs[0][3] == outs[1][3]).view(T, B, S)
+    print(f'B={B}: indices equal {float(same.float().mean()):.6f}')
+    assert float(same.float().mean()) >= 0.999
+    # rows whose indices agree at every step so far carry the same state; a flipped draw legitimately changes what follows
+    ok_rows = same.all(dim=2).cummin(dim=0).values.reshape(T * B)
+    assert float(ok_rows.float().mean()) >= 0.97
+    for a, b, what in zip(outs[0][:3], outs[1][:3], ('feat', 'post', 'prior')):
+        assert torch.isfinite(a).all(), what
+        err = (a[ok_rows] - b[ok_rows]).abs()
+        assert float((err - 1e-5 * b[ok_rows].abs()).max()) <= 2e-5, (what, float(err.max()))
+    # saved activations (what the backward pass reads): the whole arena, rows with an identical history
+    RA, N = outs[0][4], T * B
+    RB = outs[1][4]
+    assert torch.isfinite(RA).all()
+    off = 0
+    for name, width in (('ea', Hd), ('ee', Hd), ('hin', D_), ('zin', Z), ('x1', Hd), ('st1', 2), ('za', Hd), ('gi', 3 * D_), ('gh', 3 * D_),
+                        ('x2', Hd), ('st2', 2), ('pin', Hd)):
+        a = RA[off:off + N * width].view(N, width)[ok_rows]
+        b = RB[off:off + N * width].view(N, width)[ok_rows]
+        err = (a - b).abs()
+        assert float((err - 2e-5 * b.abs()).max()) <= 5e-5, (name, float(err.max()))
+        off += (N * width + 63) // 64 * 64      # the arena is carved in 64-float granules (csrc/common.h DmArena)
 
 
 # ------------------------------------------------------------------------------------------- end to end
@@ -810,19 +837,20 @@ def test_dream_rollout_vs_oracle(hip):
     _close(th.mean, to, 1e-4, 1e-5, 'dream terminals')
 
 
-@pytest.mark.parametrize('B', [6, 7, 50])
-def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B):
+@pytest.mark.parametrize('B,T', [(6, 4), (7, 4), (50, 4), (50, 10)])
+def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T):
     """dm_rssm_sequence_fwd / dm_rssm_sequence_bwd stand-alone through the C-ABI at the Atari-literal cell width (deter 600,
     hidden 1000, stoch 32x32) for a 7-column data-parallel shard and the full 50 columns: at these sizes the T loop runs its
-    FUSED schedule (LayerNorm+ELU in the prologue of the consuming <= 64-row product, sampler in the epilogue of the
-    posterior-logits product).  Oracle = rssm.py:21-78,125-153,186-193 restated in fp64 (oracle.cell_forward /
+    FUSED schedule: the first step as launches (LayerNorm+ELU in the prologue of the consuming <= 64-row product, sampler in
+    the epilogue of the posterior-logits product), the following steps as the LDS-weight-stationary persistent kernel
+    (csrc/rssm_lds.hip; B = 6 is the shard of ranks 2-7 of an 8-way split of 50 columns).  Oracle = rssm.py:21-78,125-153,186-193 restated in fp64 (oracle.cell_forward /
     prior_head) with autograd; the loss is a random projection of (features, post, prior).
     Bars: indices identical (a uniform within 1e-6 of a CDF edge excepted), states / logits 2e-5, every parameter
     gradient and dembed within 2e-4 relative L2 (posterior indices forced to the HIP draw in the oracle)."""
     import ctypes
     from pydreamer_amd import config, hip as H
     from pydreamer_amd.models import Dreamer
-    T, D_, Hd, S, C, A, depth = 4, 600, 1000, 32, 32, 18, 8
+    D_, Hd, S, C, A, depth = 600, 1000, 32, 32, 18, 8
     oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
                         batch_size=B, batch_length=T)
     params = O.make_params(oconf, seed=4)
@@ -848,9 +876,13 @@ def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B):
     idx = torch.empty(N, S, dtype=torch.int32, device=DEV)
     e_d, a_d, r_d, u_d = dev(embed.view(N, E)), dev(action.view(N, A)), dev(reset.view(N).to(torch.uint8)), dev(u.view(N, S))
     P = H.rssm_struct(cell.ordered())
-    H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), H.fptr(dev(h0)), H.fptr(dev(z0)),
+    # (the initial state stays referenced: a pointer taken from a temporary tensor is handed back to the caching allocator at
+    # once, and the next temporary may land on it - round 4 found this test flaky for exactly that reason)
+    h0_d, z0_d = dev(h0), dev(z0)
+    H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), H.fptr(h0_d), H.fptr(z0_d),
            H.fptr(u_d), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(ws),
            ws.numel(), H.stream())
+    assert H.lib().dm_rssm_lds_status() == 0
     # oracle, fp64, posterior indices forced to the HIP draw (compared separately below)
     pd = {k: v.double().requires_grad_(True) for k, v in params.items() if k.startswith('wm.core.')}
     emb64 = embed.double().requires_grad_(True)
@@ -868,6 +900,8 @@ def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B):
     priors = O.prior_head(pd, hs)
     feat_o = torch.cat((hs, zs), -1).reshape(N, F_)
     same = torch.stack(idx_o).reshape(N, S) == idx.cpu().long()
+    print('index agreement with the oracle per step:', same.view(T, B, S).float().mean(dim=(1, 2)).tolist(),
+          'per row:', same.view(T, B, S).float().mean(dim=(0, 2)).tolist())
     assert same.float().mean() > 0.999, float(same.float().mean())
     _close(feat, feat_o, 0, 2e-5, 'rssm features')
     _close(post, posts.reshape(N, Z), 1e-5, 2e-5, 'rssm post logits')

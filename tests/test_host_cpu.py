@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
     lib = hip.lib()
-    assert lib.dm_version() == hip.DM_ABI_VERSION == 7
+    assert lib.dm_version() == hip.DM_ABI_VERSION == 8
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
@@ -233,12 +233,14 @@ def test_graft_entry_build_passes():
 
 def test_runtime_switch_defaults():
     """Library-wide switches that change WHICH kernels run (never what they compute): the bf16-storage operand path is on, the
-    experimental persistent posterior chain and the chain graphs are off unless the environment says otherwise."""
+    LDS-weight-stationary persistent posterior chain is on (where the shape qualifies) and the chain graphs are off unless the
+    environment says otherwise."""
     lib = hip.lib()
-    if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_PERSIST', 'DM_CHAIN_GRAPH')):
+    if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_LDS', 'DM_CHAIN_GRAPH')):
         assert lib.dm_bf16_twins_enable(-1) == 1
-        assert lib.dm_rssm_persist_enable(-1) == 0
+        assert lib.dm_rssm_lds_enable(-1) == 1
         assert lib.dm_chain_graph_enable(-1) == 0
+    assert lib.dm_rssm_lds_status() == 0
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
 
 
