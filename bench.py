@@ -37,30 +37,35 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = 'grad-steps/sec (world-model+AC) at B=50,T=50,H=15, 64×64 obs, 1/2/4/8 GPU'
-ORACLE_VS_REF = 'r03_oracle_vs_reference.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_oracle_vs_reference.json')) else 'r02_oracle_vs_reference.json'
+ORACLE_VS_REF = next((f for f in ('r04_oracle_vs_reference.json', 'r03_oracle_vs_reference.json', 'r02_oracle_vs_reference.json')
+                      if os.path.exists(os.path.join(ROOT, 'profiles', f))), 'r04_oracle_vs_reference.json')
 
 
-def make_ring(conf, b_local, n_batches, device, seed):
-    """Offline synthetic replay: uint8 frames -> x/255-0.5 CHW float, one-hot actions, tanh rewards."""
+def make_ring(conf, b_global, lo, hi, n_batches, device, seed):
+    """Offline synthetic replay: uint8 frames -> x/255-0.5 CHW float, one-hot actions, tanh rewards.
+    Every rank draws the GLOBAL batch (b_global columns) from the same seed and keeps its columns [lo, hi) - like the sampler
+    uniforms (GlobalNoise) - so an N-rank job steps on exactly the batch the 1-rank job steps on (sharded ==
+    unsharded); only one batch of the global layout is alive at a time."""
     g = torch.Generator(device=device).manual_seed(seed)
     T, A = conf.batch_length, conf.action_dim
     ring = []
     for i in range(n_batches):
-        u8 = torch.randint(0, 256, (T, b_local, conf.image_size, conf.image_size, conf.image_channels), generator=g,
+        u8 = torch.randint(0, 256, (T, b_global, conf.image_size, conf.image_size, conf.image_channels), generator=g,
                            device=device, dtype=torch.uint8)
-        image = u8.float().div_(255.0).sub_(0.5).permute(0, 1, 4, 2, 3).contiguous()
+        image = u8[:, lo:hi].float().div_(255.0).sub_(0.5).permute(0, 1, 4, 2, 3).contiguous()
+        del u8
         if conf.actor_dist == 'onehot':
-            act = torch.randint(0, A, (T, b_local), generator=g, device=device)
-            action = torch.nn.functional.one_hot(act, A).float()
+            act = torch.randint(0, A, (T, b_global), generator=g, device=device)
+            action = torch.nn.functional.one_hot(act[:, lo:hi], A).float()
         else:                                          # continuous control (DMC): U(-1, 1) actions (SURVEY 8(d))
-            action = torch.rand(T, b_local, A, generator=g, device=device) * 2 - 1
-        reward = torch.tanh(torch.randn(T, b_local, generator=g, device=device))
-        terminal = (torch.rand(T, b_local, generator=g, device=device) < 0.005).float()
-        reset = torch.zeros(T, b_local, dtype=torch.bool, device=device)
-        reset[0] = torch.rand(b_local, generator=g, device=device) < (1.0 / 200)
+            action = (torch.rand(T, b_global, A, generator=g, device=device) * 2 - 1)[:, lo:hi].contiguous()
+        reward = torch.tanh(torch.randn(T, b_global, generator=g, device=device))[:, lo:hi].contiguous()
+        terminal = (torch.rand(T, b_global, generator=g, device=device) < 0.005).float()[:, lo:hi].contiguous()
+        reset = torch.zeros(T, b_global, dtype=torch.bool, device=device)
+        reset[0] = torch.rand(b_global, generator=g, device=device) < (1.0 / 200)
         if i == 0:
             reset[0, 0] = True
-        ring.append(dict(image=image, action=action, reward=reward, terminal=terminal, reset=reset))
+        ring.append(dict(image=image, action=action, reward=reward, terminal=terminal, reset=reset[:, lo:hi].contiguous()))
     return ring
 
 
@@ -124,7 +129,7 @@ def _effective_cores():
 
 def cpu_baseline_worker(sample_batch, threads):
     """Runs in a subprocess (see cpu_baseline): oracle grad steps on the FULL workload (all 50 batch columns, T=50, H=15),
-    one warm-up step excluded, >= 3 timed steps or ~25 s of CPU work, whichever comes first."""
+    one warm-up step excluded, >= 5 timed steps (about 30 s of CPU work on 16 cores; at most 8 steps / 75 s)."""
     from oracle import dreamer_oracle as O
     torch.set_num_threads(threads)
     full = O.atari_literal_conf()
@@ -147,9 +152,9 @@ def cpu_baseline_worker(sample_batch, threads):
         state = one(state)
         n += 1
         el = time.perf_counter() - t0
-        if n >= 3 and (el >= 15.0 or n >= 8):
+        if n >= 5 and (el >= 25.0 or n >= 8):       # >= 5 timed steps (three was thin), about 30 s of CPU work
             break
-        if el >= 40.0:
+        if el >= 75.0:
             break
     frac = sample_batch / full.batch_size
     print(json.dumps(dict(value=(n / el) * frac, unit='grad-steps/s', cores=threads, kind='port',
@@ -159,7 +164,7 @@ def cpu_baseline_worker(sample_batch, threads):
                                  ('' if frac == 1.0 else f'; scaled by {sample_batch}/{full.batch_size} to full-batch grad-steps/s'))))
 
 
-def cpu_baseline(sample_batch=50, threads_cap=32, timeout_s=200):
+def cpu_baseline(sample_batch=50, threads_cap=32, timeout_s=260):
     """Oracle (test infrastructure, kind "port") as the CPU baseline, in a subprocess with a hard timeout so a pathological
     host (thread oversubscription cost 889 s for one step in the first run of round 1) can never stall the bench; returns a
     dict with value=None and the reason if it does not finish."""
@@ -180,6 +185,8 @@ def cpu_baseline(sample_batch=50, threads_cap=32, timeout_s=200):
                 m = json.load(f)
             res['oracle_over_reference_time'] = m['oracle_over_reference_time']
             res['representative'] = bool(abs(m['oracle_over_reference_time'] - 1.0) <= 0.10)      # within +-10 %
+            # what the reference's own Python loop would score on these cores: the port's rate x (port time / reference time)
+            res['reference_equivalent'] = res['value'] * m['oracle_over_reference_time'] if res.get('value') else None
             res['oracle_over_reference_source'] = (f"profiles/{ORACLE_VS_REF}: oracle {m['oracle_s_per_step']:.2f} s vs reference "
                                                    f"{m['reference_s_per_step']:.2f} s per step, {m['batch_columns']} columns, {m['threads']} threads, "
                                                    f"build container")
@@ -233,7 +240,7 @@ def main():
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
     if not args.pmc_json:       # the committed counter summary of the same command (fp32 / bf16 step), if its fingerprint matches the tree
-        args.pmc_json = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r03_pmc_traffic.json')
+        args.pmc_json = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r04_pmc_traffic.json')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -277,7 +284,7 @@ def main():
     model.overlap_backward = not args.no_overlap
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
     DP.attach(opts, hi - lo, B, model=model)           # the B_r/B weight rides in the backward kernels' scale arguments
-    ring = make_ring(conf, hi - lo, args.ring, dev, 1234 + rank)
+    ring = make_ring(conf, B, lo, hi, args.ring, dev, 1234)      # the global batch, this rank's columns
     noise = GlobalNoise(conf, B, lo, hi, dev, 777)     # global-layout sampler uniforms, the rank's columns sliced out
     state = {'s': model.init_state(hi - lo)}
 
@@ -360,7 +367,19 @@ def main():
             rccl = '.'.join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             rccl = None
+        # replicas: every rank must hold bit-identical parameters after the same steps (fp64 checksum of each group's flat
+        # parameter buffer, gathered); and the loss of the GLOBAL batch = sum_r (B_r / B) loss_r, comparable with a 1-rank run
+        chk = torch.tensor([float(o.flat_param.double().sum()) for o in opts] +
+                           [float(o.flat_param.double().abs().sum()) for o in opts], device=dev, dtype=torch.float64)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        replicas_identical = all(bool(torch.equal(c, allc[0])) for c in allc)
+        gl = torch.tensor([loss_model * (hi - lo) / B], device=dev, dtype=torch.float64)
+        dist.all_reduce(gl)
+        shard_sizes = [DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]
         dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), rccl_version=rccl,
+                         shard_columns=shard_sizes, replicas_identical=replicas_identical,
+                         param_checksum_rank0=[float(x) for x in allc[0].tolist()], loss_model_global=float(gl.item()),
                          ms_per_step_per_rank=rank_ms, host_enqueue_ms_per_rank=host_ms, allreduce_standalone=ar_ms,
                          note='all-reduce of each optimizer group\'s flat fp32 gradient buffer, timed alone (in the step the world-model '
                               'group\'s is overlapped with the actor / critic backward)')
@@ -468,6 +487,8 @@ def main():
             traffic_note = f'no PMC file ({type(e).__name__})' 
         roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=traffic,
                     traffic_unit=traffic_note,
+                    # not observed by THIS run: read back from the committed counter passes of the same command (fingerprint-checked)
+                    traffic_source=('committed profile ' + os.path.relpath(args.pmc_json, ROOT)) if traffic is not None else None,
                     algorithmic_bytes_per_launch=dom.get('alg_bytes_per_launch'),
                     kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
@@ -496,7 +517,9 @@ def main():
                                 algorithmic_tflop_per_step=alg_tflop),
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
                     **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
-                    loss_model_last=loss_model, host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
+                    loss_model_last=loss_model,
+                    param_checksum=[float(o.flat_param.double().sum()) for o in opts] + [float(o.flat_param.double().abs().sum()) for o in opts],
+                    host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     host_enqueue_unthrottled_ms_per_step=host_free_ms,
                     fp32_products=('split-bf16 x3 pieces / 6 MFMA products, fp32 accumulate (DM_FP32_SPLIT=1)' if hip.lib().dm_fp32_mode() else 'fp32 MFMA'),
                     chain_graphs=hip.chain_graph_stats(),

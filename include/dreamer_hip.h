@@ -127,10 +127,10 @@ int dm_bf16_twins_enable(int on);
  * dependent launches per step that re-stream the weights.  Same arithmetic up to fp32 summation order, same sampler rule.
  * dm_rssm_lds_enable: 1 / 0 switches it on / off, -1 queries; returns the state (default on; DM_RSSM_LDS=0 in the environment).
  * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (bounded polls; later calls are refused).
- * dm_rssm_lds_prof: clock ticks (100 MHz) of its workgroup 0 summed per phase since the last reset (diagnostic). */
+ * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */
 int dm_rssm_lds_enable(int on);
 int dm_rssm_lds_status(void);
-int dm_rssm_lds_prof(unsigned long long* out8, int reset);
+int dm_rssm_lds_prof(unsigned long long* out16, int reset);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
 int dm_ln_elu_fwd(int rows, int n, const float* x, int ldx, const float* gamma, const float* beta, float eps,

@@ -32,18 +32,11 @@ def main():
     noise = O.make_noise(oconf)
     params = O.make_params(oconf, seed=0)
 
-    # oracle
+    # both models are built first and their steps INTERLEAVED (oracle, reference, oracle, ...), so that slow drifts of the
+    # container (other tenants, clocks) hit both alike; per step the forward / backward / clip+optimizer parts are timed too
     model = O.OracleDreamer(oconf, params)
     model.init_optimizers()
     state = model.init_state(cols)
-    t_or = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        losses, state, *_ = model.training_step(obs, state, noise)
-        model.backward_clip_step(losses)
-        t_or.append(time.perf_counter() - t0)
-
-    # reference (its own modules; torch.multinomial / torch.normal unpatched: it draws its own samples)
     sys.path.insert(0, G.REF)
     from pydreamer.models import Dreamer
     import torch.distributions as D
@@ -52,24 +45,41 @@ def main():
     ref.load_state_dict(params, strict=True)
     opts = ref.init_optimizers(rconf.adam_lr, rconf.adam_lr_actor, rconf.adam_lr_critic, rconf.adam_eps)
     rstate = ref.init_state(cols)
-    t_ref = []
+    t_or, t_ref, ph_or, ph_ref = [], [], [], []
     for i in range(steps + 1):
         t0 = time.perf_counter()
+        losses, state, *_ = model.training_step(obs, state, noise)
+        t1 = time.perf_counter()
+        model.backward_clip_step(losses)
+        t2 = time.perf_counter()
+        t_or.append(t2 - t0); ph_or.append((t1 - t0, t2 - t1))
+
+        t0 = time.perf_counter()
         losses, rstate, metrics, tensors, _ = ref.training_step(obs, rstate)
+        t1 = time.perf_counter()
         for opt in opts:
             opt.zero_grad()
         for loss in losses:
             loss.backward()
+        t2 = time.perf_counter()
         ref.grad_clip(rconf.grad_clip, rconf.grad_clip_ac)
         for opt in opts:
             opt.step()
-        t_ref.append(time.perf_counter() - t0)
+        t3 = time.perf_counter()
+        t_ref.append(t3 - t0); ph_ref.append((t1 - t0, t3 - t1))
+        print(f'step {i}: oracle {t_or[-1]:.2f} s (fwd {ph_or[-1][0]:.2f}, bwd+opt {ph_or[-1][1]:.2f}) | reference {t_ref[-1]:.2f} s '
+              f'(fwd {ph_ref[-1][0]:.2f}, bwd+opt {ph_ref[-1][1]:.2f})', flush=True)
     o, r = sum(t_or[1:]) / steps, sum(t_ref[1:]) / steps
-    out = dict(oracle_s_per_step=o, reference_s_per_step=r, oracle_over_reference_time=o / r, batch_columns=cols, steps=steps,
-               threads=threads, host='build container (no GPU)', warmup_steps_excluded=1,
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    out = dict(oracle_s_per_step=o, reference_s_per_step=r, oracle_over_reference_time=o / r,
+               oracle_over_reference_median=med(t_or[1:]) / med(t_ref[1:]),
+               oracle_fwd_s=sum(p[0] for p in ph_or[1:]) / steps, oracle_bwd_opt_s=sum(p[1] for p in ph_or[1:]) / steps,
+               reference_fwd_s=sum(p[0] for p in ph_ref[1:]) / steps, reference_bwd_opt_s=sum(p[1] for p in ph_ref[1:]) / steps,
+               per_step_oracle_s=t_or[1:], per_step_reference_s=t_ref[1:], interleaved=True,
+               batch_columns=cols, steps=steps, threads=threads, host='build container (no GPU)', warmup_steps_excluded=1,
                note='reference = /root/reference pydreamer.models.Dreamer driven by the train.py:165-198 section; same batch, '
                     'same weights, same torch build; within +-10 % means the oracle is a representative CPU baseline (SURVEY 8(d))')
-    path = os.path.join(ROOT, 'profiles', sys.argv[3] if len(sys.argv) > 3 else 'r03_oracle_vs_reference.json')
+    path = os.path.join(ROOT, 'profiles', sys.argv[3] if len(sys.argv) > 3 else 'r04_oracle_vs_reference.json')
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))

@@ -56,7 +56,7 @@ struct RlArgs {
   unsigned step_bytes, off_h, off_c, off_d, off_i;
   unsigned* err;                // [0] sticky give-up flag of this launch (device), polled inside the spin loops
   unsigned* host_err;           // host-visible sticky flag (mapped pinned memory)
-  unsigned long long* prof;     // optional: 8 phase tick sums of workgroup 0
+  unsigned long long* prof;     // optional: 16 phase tick sums of workgroup 0
   // LDS carve, in floats
   int l_wz, l_wg, l_wh, l_wc, l_wd, l_gb1, l_gb2, l_red, l_gh, l_hown, l_stage, l_flag;
 };
@@ -211,6 +211,36 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
   f32x4 odd[NCS];
 #pragma unroll
   for (int cs = 0; cs < NCS; ++cs) odd[cs] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (KG == 1 && NCS == 3) {
+    // 64 rows, 12 columns: every 4-lane block multiplies the SAME k, so lane l < 12 holds column l (one ds_read_b128 per
+    // granule instead of three) and the instruction's A-broadcast (cbsz 4: block `abid` feeds all 16 blocks) selects the
+    // column set - verified by scripts/microbench/allgather_xcd.hip (layout modes 1 / 2)
+    const f32x4* wl = reinterpret_cast<const f32x4*>(w) + wave * 12 + ((lane & 15) < 12 ? (lane & 15) : 11);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (FULL || j < nj) {
+        const f32x4 ww = wl[j * RL_WAVES * 12];
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[1], 4, 1, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[2], 4, 2, 0);
+        odd[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.y, v[j].y, odd[0], 4, 0, 0);
+        odd[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.y, v[j].y, odd[1], 4, 1, 0);
+        odd[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.y, v[j].y, odd[2], 4, 2, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.z, v[j].z, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.z, v[j].z, acc[1], 4, 1, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.z, v[j].z, acc[2], 4, 2, 0);
+        odd[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.w, v[j].w, odd[0], 4, 0, 0);
+        odd[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.w, v[j].w, odd[1], 4, 1, 0);
+        odd[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.w, v[j].w, odd[2], 4, 2, 0);
+      }
+      if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      acc[cs].x += odd[cs].x; acc[cs].y += odd[cs].y; acc[cs].z += odd[cs].z; acc[cs].w += odd[cs].w;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     if (FULL || j < nj) {                         // (uniform) granules past the operand are zeros: skip their instructions
@@ -293,6 +323,14 @@ __device__ __forceinline__ void rl_fill(float* dst, const float* W, int K, int P
   }
 }
 
+// Sub-phase ticks (slots 8-14) sit between the LayerNorm and the product it feeds: they stop the compiler from interleaving
+// the two, and at 64 rows per wave the split code spills 420 registers (5.2 vs 2.9 ms per T=50 call) - so they are compiled in
+// only with -DRL_FINE_PROF; they are valid as measurements for <= 32 rows.
+#ifdef RL_FINE_PROF
+#define RL_FINE_TICK(k_) RL_TICK(k_)
+#else
+#define RL_FINE_TICK(k_) do { } while (0)
+#endif
 #define RL_TICK(k_)                                                  \
   do {                                                               \
     if (a.prof && me == 0 && tid == 0) {                             \
@@ -435,9 +473,12 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
       if (!rl_sweep<RL>(a, ra, xo, xjs, true, v)) lflag[0] = 1u;
       RL_TICK(1);
       rl_ln_elu<RL>(v, a.nA, row, kg, wave, gb1, 1e-3f, red);
+      RL_FINE_TICK(8);
       f32x4 acc[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
       rl_dot<RL, 3, true>(acc, v, a.nA, kg, wave, lane, wg);
+      RL_FINE_TICK(9);
       rl_reduce_store<RL, 3>(acc, row, kg, wave, red);
+      RL_FINE_TICK(10);
       if (tid < RL * 4) {
         const int r = tid % RL, un = tid / RL, d = 4 * me + un;
         const float gir = rl_red_sum<RL, 3>(red, r, un) + a.bih[d];
@@ -489,6 +530,7 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
         __builtin_amdgcn_raw_buffer_store_b128(rl_asu(o), rs, a.off_c + (unsigned)me * blk + (unsigned)tid * 16u, 0, 16);
         *reinterpret_cast<f32x4*>(a.x2 + (r0 + tid) * Hd + 4 * me) = o;
       }
+      RL_FINE_TICK(14);
       if (roleB && more) {
         const float keep = a.reset[r0 + B + rowc] ? 0.f : 1.f;
 #pragma unroll
@@ -513,9 +555,12 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
       if (!rl_sweep<RL>(a, rc, xo, xjs, true, v)) lflag[0] = 1u;
       RL_TICK(5);
       rl_ln_elu<RL>(v, a.nC, row, kg, wave, gb2, 1e-3f, red);
+      RL_FINE_TICK(11);
       f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
       rl_dot<RL, 1, true>(acc1, v, a.nC, kg, wave, lane, wd);
+      RL_FINE_TICK(12);
       rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
+      RL_FINE_TICK(13);
       if (tid < RL && tid < B) {
         f32x4 o = *reinterpret_cast<const f32x4*>(a.bpo + 4 * me);
         o.x += rl_red_sum<RL, 1>(red, tid, 0); o.y += rl_red_sum<RL, 1>(red, tid, 1);
@@ -529,7 +574,78 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
     // ---- L. z ~ OneHotCategoricalStraightThrough(post) for one latent group                             rssm.py:147-148,195-201
     // The rule's sums (softmax denominator, total, cdf) are sequential fp32 chains per row like sample_onehot_kernel
     // (bit-identical draws for identical logits); max, exp and the divisions are elementwise and spread over the workgroup.
-    if (leader) {
+    if (leader && cpg <= 8) {
+      // C <= 32: 8 lanes per row (lane c holds the 4 logits of block c), 8 rows per wave, all 8 waves: exp and the divisions
+      // run across lanes, the rule's three fp32 sums stay SEQUENTIAL in k - a carry handed from lane c to lane c + 1 by a
+      // shuffle, (((0 + x0) + x1) + ...) exactly like sample_onehot_kernel - so the draw is bit-identical for identical
+      // logits.  (One lane per row took 3.6 us of serial expf / divide code per step; the LDS version before it 7 us.)
+      const int g = me / cpg;
+      const int c = lane & 7, srow = wave * 8 + (lane >> 3), gl = lane & ~7;
+      __amdgpu_buffer_rsrc_t rs = rl_rsrc(xs, a.step_bytes);
+      const bool rowok = srow < B, mine = rowok && c < cpg;
+      f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (mine) {
+        const unsigned off = a.off_d + (unsigned)(me + c) * blk + (unsigned)srow * 16u;
+        u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        unsigned spins = 0;
+        while (!rl_valid(raw)) {
+          if (++spins > RL_SPIN_LIMIT || ((spins & 63u) == 0 && rl_dead(a))) { rl_give_up(a); lflag[0] = 1u; break; }
+          __builtin_amdgcn_s_sleep(1);
+          raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        }
+        x = rl_asf(raw);
+      }
+      float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      if (!rowok) mx = 0.f;
+      f32x4 e = {0.f, 0.f, 0.f, 0.f};
+      if (mine) { e.x = expf(x.x - mx); e.y = expf(x.y - mx); e.z = expf(x.z - mx); e.w = expf(x.w - mx); }
+      float carry = 0.f, held = 0.f;
+      for (int q = 0; q < cpg; ++q) {                        // sum = sequential over k
+        if (c == q) { float t = carry; t += e.x; t += e.y; t += e.z; t += e.w; held = t; }
+        carry = __shfl(held, gl + q, 64);
+      }
+      const float sum = carry;
+      f32x4 pr = {0.f, 0.f, 0.f, 0.f};
+      if (mine) { pr.x = e.x / sum; pr.y = e.y / sum; pr.z = e.z / sum; pr.w = e.w / sum; }
+      carry = 0.f; held = 0.f;
+      for (int q = 0; q < cpg; ++q) {                        // total = sequential over k
+        if (c == q) { float t = carry; t += pr.x; t += pr.y; t += pr.z; t += pr.w; held = t; }
+        carry = __shfl(held, gl + q, 64);
+      }
+      const float target = (rowok && !a.forced ? a.u[(r0 + srow) * S + g] : 0.f) * carry;
+      carry = 0.f; held = 0.f;
+      int cnt = 0;
+      for (int q = 0; q < cpg; ++q) {                        // cdf = sequential over k; idx = #{k : cdf_k <= target}
+        if (c == q) {
+          float t = carry;
+          t += pr.x; cnt += (t <= target) ? 1 : 0;
+          t += pr.y; cnt += (t <= target) ? 1 : 0;
+          t += pr.z; cnt += (t <= target) ? 1 : 0;
+          t += pr.w; cnt += (t <= target) ? 1 : 0;
+          held = t;
+        }
+        carry = __shfl(held, gl + q, 64);
+      }
+      if (!mine) cnt = 0;
+      cnt += __shfl_xor(cnt, 1, 64); cnt += __shfl_xor(cnt, 2, 64); cnt += __shfl_xor(cnt, 4, 64);
+      int ix = cnt > C - 1 ? C - 1 : cnt;
+      if (rowok && a.forced) ix = a.forced[(r0 + srow) * S + g];
+      if (mine) {
+        if (c == 0) {
+          __hip_atomic_store(reinterpret_cast<unsigned*>(xs + a.off_i) + srow * S + g, (unsigned)ix, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          a.idx[(r0 + srow) * S + g] = ix;
+        }
+        const int k4 = 4 * c;
+        const f32x4 o = {ix == k4 ? 1.f : 0.f, ix == k4 + 1 ? 1.f : 0.f, ix == k4 + 2 ? 1.f : 0.f, ix == k4 + 3 ? 1.f : 0.f};
+        *reinterpret_cast<f32x4*>(a.feat + (r0 + srow) * F + D + g * C + k4) = o;
+        if (more) {
+          const bool rz = a.reset[r0 + B + srow];
+          *reinterpret_cast<f32x4*>(a.zin + (r0 + B + srow) * Z + g * C + k4) = rz ? f32x4{0.f, 0.f, 0.f, 0.f} : o;
+        }
+      }
+    } else if (leader) {
       const int g = me / cpg, ldl = C + 1;                   // row stride C + 1: conflict-free column walks
       float* lg = red;                                       // (RL, C + 1) logits -> exp -> probabilities
       float* rowv = red + RL * ldl;                          // (RL) row max, then row sum
@@ -710,14 +826,14 @@ size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
   return ((size_t)p.step_bytes * (size_t)steps + 256) / 4 + 64;
 }
 
-static unsigned long long* g_rl_prof = nullptr;      // device, 8 words; allocated on first dm_rssm_lds_prof call
-extern "C" int dm_rssm_lds_prof(unsigned long long* out8, int reset) {
+static unsigned long long* g_rl_prof = nullptr;      // device, 16 words; allocated on first dm_rssm_lds_prof call
+extern "C" int dm_rssm_lds_prof(unsigned long long* out16, int reset) {
   if (!g_rl_prof) {
-    if (hipMalloc(reinterpret_cast<void**>(&g_rl_prof), 64) != hipSuccess) return -1;
-    (void)hipMemset(g_rl_prof, 0, 64);
+    if (hipMalloc(reinterpret_cast<void**>(&g_rl_prof), 128) != hipSuccess) return -1;
+    (void)hipMemset(g_rl_prof, 0, 128);
   }
-  if (out8 && hipMemcpy(out8, g_rl_prof, 64, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (reset && hipMemset(g_rl_prof, 0, 64) != hipSuccess) return -1;
+  if (out16 && hipMemcpy(out16, g_rl_prof, 128, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset && hipMemset(g_rl_prof, 0, 128) != hipSuccess) return -1;
   return 0;
 }
 

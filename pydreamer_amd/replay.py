@@ -7,10 +7,13 @@ Here the same batches are produced as what the HIP path consumes directly:
 
   * `LocalEpisodeRepository`  - episode `.npz` files in local directories (the reference lists mlflow artifacts,
     data.py:53-122; the file-name grammar `ep{from}_{to}-r{reward}-{steps}.npz` is the same);
-  * `SequentialReplay`        - DataSequential's algorithm: per-column sequential iteration (`iter_single`), random start
-    in the first file (`skip_first`), partial-window carry (`allow_mid_reset`), `randomize_resets`, `buffer_size`
-    filtering, periodic re-listing (`reload_interval`), `image_t` HWCT -> THWC (data.py:237-239), `reset[0] = True` / `reward[0] = 0` per file (data.py:256-260);
-    the random stream is an explicit `numpy.random.RandomState` (the reference uses the global one);
+  * `SequentialReplay`        - a window planner: per batch column a cursor (episode, row) that cuts consecutive
+    `batch_length`-row windows, planned as (episode, start, stop) pieces and copied once, straight into the (T, B, ...) arrays
+    the caller hands it (the pinned slot of the device ring).  Same batches as DataSequential for the same files, arguments and
+    seed (random start in a column's first file, tails carried into the next file with `allow_mid_reset`, artificial resets
+    every `reset_interval`, `buffer_size` / `reload_interval` file selection); the random stream is an explicit
+    `numpy.random.RandomState` (the reference uses the global one);
+  * `ReplayFeed`              - planner + preprocessing writing IN PLACE into a ring slot;
   * `preprocess_batch`        - the hot-path subset of Preprocessor.apply: one-hot float32 actions, float32 reward with
     `clip_rewards`, float32 terminal, bool reset - and the image is LEFT AS uint8 (T,B,H,W,C): x/255-0.5 and HWC->CHW
     happen inside the first conv's patch loader on the GPU (N1), so a batch crosses PCIe at 1 byte per pixel value;
@@ -95,115 +98,159 @@ class LocalEpisodeRepository:
         return path
 
 
-def _lenb(batch):
-    return batch['reward'].shape[0]
+class _Episode:
+    """One episode file, prepared once: frames as (T,H,W,C) (the generator may store them time-last, data.py:237-239), the
+    action that FOLLOWS each step, and the two per-file fix-ups of data.py:256-260 (a file starts with a reset and carries no
+    reward on its first row).  `marks` flags the rows where a window gets an artificial reset (scatter_resets)."""
+    __slots__ = ('fields', 'rows', 'marks')
+
+    def __init__(self, arrays):
+        if 'image' not in arrays and 'image_t' in arrays:
+            arrays['image'] = arrays.pop('image_t').transpose(3, 0, 1, 2)
+        arrays['action_next'] = np.concatenate([arrays['action'][1:], np.zeros_like(arrays['action'][:1])])
+        self.rows = arrays['reward'].shape[0]
+        reset = arrays['reset'].copy() if 'reset' in arrays else np.zeros(self.rows, bool)
+        reward = arrays['reward'].copy()
+        reset[0], reward[0] = True, 0.0
+        arrays['reset'], arrays['reward'] = reset, reward
+        self.fields = arrays
+        self.marks = None
+
+
+class _Column:
+    """Cursor of one batch column: where in which episode its next window starts, how long that window is (a window that
+    completes a carried tail is shorter), and the tail of the previous episode waiting to be completed."""
+    __slots__ = ('episode', 'pos', 'want', 'tail', 'random_start')
+
+    def __init__(self, random_start):
+        self.episode, self.pos, self.want, self.tail, self.random_start = None, 0, 0, None, random_start
 
 
 class SequentialReplay:
-    """DataSequential (data.py:128-304) as a plain iterator of time-major numpy batches {key: (T, B, ...)}."""
+    """Truncated-BPTT window planner over episode files: every batch column walks its own random sequence of episodes and
+    cuts consecutive windows of `batch_length` rows out of them, so the recurrent state a trainer carries from batch to batch
+    (train.py:168-178) stays aligned with the data.  The batches are those of the reference's DataSequential (data.py:128-304)
+    BYTE FOR BYTE for the same files, arguments and seed of numpy's legacy random stream - it draws in the same order: file
+    choice, random start inside a column's first file, reset scatter of the file - which tests/test_replay_cpu.py checks
+    against batches written by the reference itself.
+
+    What is different is where the rows go.  A window is planned as one or two (episode, start, stop) pieces and copied ONCE,
+    straight into the (T, B, ...) arrays the caller hands to `fill()` - for the training loop the pinned slot of the device
+    ring (`ReplayFeed`), from where the frames cross PCIe as uint8 - instead of slice dicts -> np.concatenate -> np.stack ->
+    another copy.  `__iter__` (tests, small tools) allocates fresh arrays per batch and fills those."""
 
     def __init__(self, repository, batch_length, batch_size, skip_first=True, reload_interval=0, buffer_size=0, reset_interval=0,
                  allow_mid_reset=False, seed=0, check_nonempty=True):
         self.repository = repository
-        self.batch_length, self.batch_size = batch_length, batch_size
-        self.skip_first, self.buffer_size = skip_first, buffer_size
-        self.reload_interval = reload_interval                       # seconds between re-listings of the repository (online training)
+        self.batch_length, self.batch_size = int(batch_length), int(batch_size)
+        self.buffer_size = buffer_size                       # keep the newest files whose step counts fit (0: all)
+        self.reload_interval = reload_interval               # seconds between re-listings of the repository (online training)
         self.reset_interval, self.allow_mid_reset = reset_interval, allow_mid_reset
         self.rs = np.random.RandomState(seed)
-        self.reload_files()
-        if check_nonempty:
-            assert len(self.files) > 0, 'No data found'
+        self.columns = [_Column(bool(skip_first)) for _ in range(self.batch_size)]
+        self.relist()
+        if check_nonempty and not self.files:
+            raise ValueError(f'no episode files in {getattr(repository, "dirs", repository)}')
 
-    def reload_files(self):
-        files_all = self.repository.list_files()
-        files_all.sort(key=lambda e: -e.episode_to)                  # newest first (data.py:164)
-        files, total = [], 0
-        for f in files_all:
-            total += f.steps
-            if total < self.buffer_size or not self.buffer_size:
-                files.append(f)
-        self.files, self.stats_steps = files, total
-        self.last_reload = time.time()
+    # ---- which files are in play
+    def relist(self):
+        listed = sorted(self.repository.list_files(), key=lambda f: -f.episode_to)      # newest first (data.py:164)
+        kept, steps = [], 0
+        for f in listed:
+            steps += f.steps
+            if not self.buffer_size or steps < self.buffer_size:
+                kept.append(f)
+        self.files, self.listed_steps, self.listed_at = kept, steps, time.time()
 
-    def should_reload_files(self):
-        """data.py:186-187."""
-        return bool(self.reload_interval) and (time.time() - self.last_reload > self.reload_interval)
+    def relist_due(self):
+        return bool(self.reload_interval) and time.time() - self.listed_at > self.reload_interval
+
+    # ---- artificial resets: a long episode is cut into 1..steps/interval+1 backprop spans at random window-aligned rows
+    def scatter_resets(self, resets, reset_interval, batch_length):
+        """Same draws, same result as data.py:280-300."""
+        if not resets[0]:
+            raise ValueError('an episode file must start with a reset')
+        starts = np.flatnonzero(resets).tolist() + [len(resets)]
+        marks = np.zeros_like(resets)
+        for a, b in zip(starts[:-1], starts[1:]):
+            spans = self.rs.randint(1, (b - a) // reset_interval + 2)
+            if spans > 1:
+                gaps = np.sort(self.rs.choice(b - a - batch_length * spans, spans - 1))
+                marks[a + gaps + np.arange(1, spans) * batch_length] = True
+        return marks
+
+    # ---- one column, one window
+    def _open(self, col):
+        """Next episode of a column: a random file; unreadable ones and ones shorter than a window are passed over (they cost
+        the draw that chose them, nothing else)."""
+        if self.relist_due():
+            self.relist()
+        info = self.files[self.rs.randint(len(self.files))]
+        random_start, col.random_start = col.random_start, False
+        try:
+            ep = _Episode(info.load_data())
+        except Exception as e:
+            print('replay: skipping unreadable episode file', info.path, e)
+            return
+        L = self.batch_length
+        if ep.rows < L:
+            return
+        col.pos = self.rs.randint(ep.rows - L + 1) if random_start else 0
+        col.want = L - (col.tail[2] - col.tail[1]) if col.tail is not None else L
+        ep.marks = self.scatter_resets(ep.fields['reset'], self.reset_interval, L) if self.reset_interval else None
+        col.episode = ep
+
+    def _plan(self, col):
+        """The pieces [(episode, start, stop), ...] of the column's next window (their lengths add up to batch_length)."""
+        while True:
+            if col.episode is None:
+                self._open(col)
+                continue
+            ep = col.episode
+            if col.pos >= ep.rows:                           # the file ended on a window boundary
+                col.episode = None
+                continue
+            stop = min(col.pos + col.want, ep.rows)
+            piece = (ep, col.pos, stop)
+            if stop - col.pos < col.want:                    # the file's last rows do not fill the window
+                if col.tail is not None:
+                    raise ValueError('an episode file is too short to complete the window carried over from the previous one')
+                col.tail = piece if self.allow_mid_reset else None
+                col.episode = None
+                continue
+            pieces = [piece] if col.tail is None else [col.tail, piece]
+            col.tail, col.pos, col.want = None, stop, self.batch_length
+            return pieces
+
+    def _copy(self, pieces, out, b):
+        t = 0
+        for ep, a, z in pieces:
+            n = z - a
+            for k, dst in out.items():
+                dst[t:t + n, b] = ep.fields[k][a:z]
+            if ep.marks is not None and ep.marks[a:z].any():
+                if ep.fields['reset'][a:z].any():
+                    raise ValueError('an artificial reset fell into a window that holds a real one')
+                out['reset'][t, b] = True                     # at the piece's first row: the longest backprop span
+            t += n
+
+    # ---- batches
+    def fill(self, out=None):
+        """Write the next batch into `out` ({key: (T, B, ...) array}; only the keys present are written - all of the files' keys
+        when out is None or empty, in freshly allocated arrays).  Returns out."""
+        plans = [self._plan(col) for col in self.columns]
+        if not out:
+            first = plans[0][0][0].fields
+            out = {} if out is None else out
+            for k, v in first.items():
+                out[k] = np.empty((self.batch_length, self.batch_size) + v.shape[1:], v.dtype)
+        for b, pieces in enumerate(plans):
+            self._copy(pieces, out, b)
+        return out
 
     def __iter__(self):
-        iters = [self.iter_single(ix) for ix in range(self.batch_size)]
-        for batches in zip(*iters):
-            yield {k: np.stack([b[k] for b in batches], axis=1) for k in batches[0]}      # (T, B, ...)
-
-    def iter_single(self, ix):
-        skip_random = self.skip_first
-        last_partial = None
         while True:
-            if self.should_reload_files():                                               # iter_shuffled_files (data.py:273-278)
-                self.reload_files()
-            file = self.files[self.rs.randint(len(self.files))]
-            first_shorter = self.batch_length - _lenb(last_partial) if last_partial else None
-            it = self.iter_file(file, skip_random, first_shorter)
-            if last_partial is not None:
-                for batch, partial in it:
-                    assert not partial, 'First batch must be full. Is episode_length < batch_size?'
-                    batch = {k: np.concatenate([last_partial[k], batch[k]]) for k in batch}
-                    assert _lenb(batch) == self.batch_length
-                    last_partial = None
-                    yield batch
-                    break
-            for batch, partial in it:
-                if partial:
-                    last_partial = batch if self.allow_mid_reset else None
-                    break
-                yield batch
-            skip_random = False
-
-    def iter_file(self, file, skip_random=False, first_shorter_length=None):
-        try:
-            data = file.load_data()
-        except Exception as e:                                       # data.py:229-233: skip unreadable files
-            print('Error reading file - skipping', file.path, e)
-            return
-        if 'image' not in data and 'image_t' in data:
-            data['image'] = data['image_t'].transpose(3, 0, 1, 2)    # HWCT => THWC
-            del data['image_t']
-        data['action_next'] = np.concatenate([data['action'][1:], np.zeros_like(data['action'][:1])])
-        n = _lenb(data)
-        if n < self.batch_length:
-            return
-        if 'reset' not in data:
-            data['reset'] = np.zeros(n, bool)
-        data['reset'] = data['reset'].copy()
-        data['reward'] = data['reward'].copy()
-        data['reset'][0] = True                                      # a file starts with a reset ...
-        data['reward'][0] = 0.0                                      # ... and no reward
-        i = 0 if not skip_random else self.rs.randint(n - self.batch_length + 1)
-        l = first_shorter_length or self.batch_length
-        random_resets = (self.randomize_resets(data['reset'], self.reset_interval, self.batch_length)
-                         if self.reset_interval else np.zeros_like(data['reset']))
-        while i < n:
-            batch = {k: data[k][i:i + l] for k in data}
-            if np.any(random_resets[i:i + l]):
-                assert not np.any(batch['reset']), 'randomize_resets should not coincide with actual resets'
-                batch['reset'] = batch['reset'].copy()
-                batch['reset'][0] = True                             # always at the start of a window: longer backprop
-            partial = _lenb(batch) < l
-            i += l
-            l = self.batch_length
-            yield batch, partial
-
-    def randomize_resets(self, resets, reset_interval, batch_length):
-        """data.py:280-300."""
-        assert resets[0]
-        bounds = np.where(resets)[0].tolist() + [len(resets)]
-        out = np.zeros_like(resets)
-        for a, b in zip(bounds[:-1], bounds[1:]):
-            steps = b - a
-            n_int = self.rs.randint(1, steps // reset_interval + 2)
-            if n_int > 1:
-                cuts = np.sort(self.rs.choice(steps - batch_length * n_int, n_int - 1))
-                out[a + cuts + np.arange(1, n_int) * batch_length] = True
-        return out
+            yield self.fill()
 
 
 def preprocess_batch(batch, action_dim, clip_rewards=None, image_key='image'):
@@ -233,6 +280,59 @@ def preprocess_batch(batch, action_dim, clip_rewards=None, image_key='image'):
     return out
 
 
+class ReplayFeed:
+    """Planner + hot-path preprocessing writing IN PLACE into a slot of host arrays (DeviceRing hands it the numpy views of a
+    pinned slot): the uint8 frame windows and the reset flags go from the episode arrays straight into the slot - one copy
+    between the file and PCIe - and the small per-step fields (actions, reward, terminal) through a reused scratch batch.
+    Field for field what `preprocess_batch(next(iter(replay)), ...)` returns (tests/test_replay_cpu.py compares the two)."""
+
+    def __init__(self, replay, action_dim, clip_rewards=None, image_key='image'):
+        if clip_rewards not in (None, '', False, 'tanh', 'log1p'):
+            raise ValueError(clip_rewards)
+        self.replay, self.action_dim, self.clip_rewards, self.image_key = replay, int(action_dim), clip_rewards, image_key
+        probe = _Episode(replay.files[0].load_data()).fields      # shapes only; draws nothing from the random stream
+        T, B = replay.batch_length, replay.batch_size
+        self._has_terminal = 'terminal' in probe
+        self._small = {k: np.empty((T, B) + probe[k].shape[1:], probe[k].dtype)
+                       for k in ('action', 'action_next', 'reward', 'terminal') if k in probe}
+        img = probe[image_key]
+        if img.dtype != np.uint8 or img.ndim != 4:
+            raise ValueError(f'expected uint8 (T,H,W,C) frames in the episode files, got {img.dtype} {img.shape}')
+        self._spec = {'image': ((T, B) + img.shape[1:], np.uint8), 'action': ((T, B, self.action_dim), np.float32),
+                      'action_next': ((T, B, self.action_dim), np.float32), 'terminal': ((T, B), np.float32),
+                      'reward': ((T, B), np.float32), 'reset': ((T, B), np.bool_)}
+
+    def spec(self):
+        """{field: (shape, dtype)} of a slot."""
+        return dict(self._spec)
+
+    def _actions(self, src, dst):
+        if src.ndim == 2:                                     # integer actions -> one-hot rows
+            dst[...] = 0.0
+            np.put_along_axis(dst, src[..., None].astype(np.int64), 1.0, axis=2)
+        else:
+            dst[...] = src
+
+    def fill(self, slot):
+        raw = dict(self._small)
+        raw[self.image_key] = slot['image']
+        raw['reset'] = slot['reset']
+        self.replay.fill(raw)
+        self._actions(raw['action'], slot['action'])
+        self._actions(raw['action_next'], slot['action_next'])
+        if self._has_terminal:
+            slot['terminal'][...] = raw['terminal']
+        else:
+            slot['terminal'][...] = 0.0
+        r = raw['reward'].astype(np.float32)
+        if self.clip_rewards == 'tanh':
+            r = np.tanh(r)
+        elif self.clip_rewards == 'log1p':
+            r = np.log1p(r)
+        slot['reward'][...] = r
+        return slot
+
+
 class DeviceRing:
     """Pinned staging + asynchronous H2D into a ring of device-resident batches, WITHOUT a stream of its own.
 
@@ -253,7 +353,11 @@ class DeviceRing:
     step, 37.3 or 44-47 ms depending on the process."""
 
     def __init__(self, source, device, depth=4):
-        self.source, self.device, self.depth = iter(source), torch.device(device), max(3, depth)
+        # source: an iterator of {key: numpy array} batches (copied into the pinned slot), or a feed with spec() / fill(slot)
+        # (ReplayFeed) that writes the batch INTO the pinned slot
+        self.feed = source if hasattr(source, 'fill') and hasattr(source, 'spec') else None
+        self.source = None if self.feed is not None else iter(source)
+        self.device, self.depth = torch.device(device), max(3, depth)
         self.free = queue.Queue()               # pinned slots the producer may fill
         self.filled = queue.Queue()             # pinned slots holding a batch, in source order (None: exhausted / failed)
         self.host = None                        # per pinned slot: {key: pinned tensor}
@@ -268,8 +372,26 @@ class DeviceRing:
         self.thread = threading.Thread(target=self._produce, daemon=True, name='dm-replay')
         self.thread.start()
 
+    def _produce_feed(self):
+        spec = self.feed.spec()
+        self.host = [None] * self.depth
+        while True:
+            i = self.free.get()
+            if i is None:
+                return
+            if self.host[i] is None:
+                with torch.cuda.device(self.device):        # (a new thread's current device is 0)
+                    self.host[i] = {k: torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dt)).dtype).pin_memory()
+                                    for k, (shape, dt) in spec.items()}
+            elif self.copied[i] is not None:                 # the pinned buffer is the source of an asynchronous copy until this fires
+                self.copied[i].synchronize()
+            self.feed.fill({k: t.numpy() for k, t in self.host[i].items()})
+            self.filled.put(i)
+
     def _produce(self):
         try:
+            if self.feed is not None:
+                return self._produce_feed()
             for batch in self.source:
                 i = self.free.get()
                 if i is None:

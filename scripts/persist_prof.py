@@ -40,7 +40,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
         for _ in range(2):
             run()
         torch.cuda.synchronize()
-        out = (ctypes.c_ulonglong * 8)()
+        out = (ctypes.c_ulonglong * 16)()
         lib.dm_rssm_lds_prof(out, 1)
         reps = 7
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
@@ -54,9 +54,13 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
         total_us = per[reps // 2]
         print(f'B={B} lds={on}: median {total_us:.0f} us per sequence call (T={T}; min {per[0]:.0f}, max {per[-1]:.0f}), status {lib.dm_rssm_lds_status()}')
         if on:
-            names = ['A x1 gather+publish', 'B wait x1', 'B LN+gi+gates', 'C wait h', 'C x2 (+gh next)', 'D wait x2', 'D LN+logits', 'L sample']
-            print('   per step, us (workgroup 0): ' + ', '.join(f'{n} {out[i] * 0.01 / (reps * (T - 1)):.2f}' for i, n in enumerate(names))
-                  + f'; sum {sum(out) * 0.01 / (reps * (T - 1)):.2f}')
+            # slot k holds the ticks between the previous tick of the step and tick k (csrc/rssm_lds.hip RL_TICK)
+            order = [(0, 'A idx poll+gather+publish'), (1, 'B sweep x1'), (8, 'B LN+ELU'), (9, 'B gi MFMA'), (10, 'B reduce'),
+                     (2, 'B gates+publish'), (3, 'C sweep h'), (14, 'C x2 MFMA+reduce+publish'), (4, 'C gh(t+1)'), (5, 'D sweep x2'),
+                     (11, 'D LN+ELU'), (12, 'D logits MFMA'), (13, 'D reduce'), (6, 'D publish'), (7, 'L poll+sample+publish')]
+            den = reps * (T - 1)
+            print('   per step, us (workgroup 0): ' + ', '.join(f'{n} {out[k] * 0.01 / den:.2f}' for k, n in order)
+                  + f'; sum {sum(out) * 0.01 / den:.2f}')
             keep = idx.clone()
         else:
             print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')

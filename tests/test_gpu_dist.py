@@ -145,3 +145,45 @@ def test_bench_multi_rank_code_path_smoke(hip):
     assert dd['world_size'] == 2 and len(dd['ms_per_step_per_rank']) == 2 and set(dd['allreduce_standalone']) == {'wm', 'probe', 'actor', 'critic'}
     assert dd['allreduce_standalone']['wm']['bytes'] > 80e6 and dd['allreduce_standalone']['wm']['ms'] > 0
     assert np.isfinite(d['loss_model_last']) and d['roofline'] is not None and d['roofline']['frac'] > 0
+
+
+def _run_bench(world, extra_env, *flags):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    if world > 1:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(world)]
+    else:
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1']
+    out = subprocess.run(cmd + list(flags), env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
+    """BASELINE configs[3] as far as one GPU can show it: bench.py --gpus 8 at the FULL Atari-literal dimensions, one process
+    per rank as the driver launches it.  On a box with < 8 GPUs all ranks share cuda:0 and talk over gloo
+    (DM_BENCH_ONE_DEVICE=1; same FusedAdamW / early all-reduce / B_r/B-folded backward code as over RCCL).  Checks
+    (SURVEY 8(e)): the 50 columns are dealt 7/7/6/6/6/6/6/6 (the 6-column shard shape of ranks 2-7 executes here at full
+    width), every rank holds BIT-IDENTICAL parameters after 2 steps, the loss of the global batch (sum_r B_r/B loss_r) and the
+    parameters equal the 1-rank run on the same global batch (the replay ring and the sampler uniforms are drawn in the global
+    layout and sliced) up to fp32 summation order."""
+    flags = ('--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
+    ndev = torch.cuda.device_count()
+    d8 = _run_bench(8, {'DM_BENCH_ONE_DEVICE': '1'} if ndev < 8 else {}, *flags)
+    d1 = _run_bench(1, {}, *flags)
+    dd = d8['distributed']
+    assert d8['n_gpus'] == 8 and dd['world_size'] == 8
+    assert dd['shard_columns'] == [7, 7, 6, 6, 6, 6, 6, 6]
+    assert dd['backend'] == ('nccl' if ndev >= 8 else 'gloo')
+    assert dd['replicas_identical'] is True
+    l8, l1 = dd['loss_model_global'], d1['loss_model_last']
+    print('loss_model of the global batch: 8 ranks', l8, '1 rank', l1)
+    assert abs(l8 - l1) <= 1e-4 * abs(l1), (l8, l1)
+    for a, b in zip(dd['param_checksum_rank0'], d1['param_checksum']):
+        assert abs(a - b) <= 2e-6 * max(abs(b), 1.0), (dd['param_checksum_rank0'], d1['param_checksum'])

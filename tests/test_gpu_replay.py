@@ -70,6 +70,14 @@ def test_device_ring_feeds_training_step(hip, tmp_path):
     ring.close()
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
+    # the in-place path: the planner writes the frame windows straight into the ring's pinned slots (ReplayFeed)
+    feed = R.ReplayFeed(R.SequentialReplay(repo, oconf.batch_length, oconf.batch_size, allow_mid_reset=True, seed=7), oconf.action_dim,
+                        clip_rewards='tanh')
+    ring = R.DeviceRing(feed, DEV, depth=3)
+    d = _train(_build(oconf, O.make_params(oconf, seed=2)), conf, ring.next, noises, nsteps, after_step=ring.prefetch)
+    ring.close()
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+
     it = _source(repo, oconf, seed=7)
     b = _train(_build(oconf, O.make_params(oconf, seed=2)), conf,
                lambda: {k: torch.from_numpy(v).to(DEV) for k, v in next(it).items()}, noises, nsteps)
