@@ -129,6 +129,9 @@ int dm_bf16_twins_enable(int on);
  * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (bounded polls; later calls are refused).
  * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */
 int dm_rssm_lds_enable(int on);
+int dm_rssm_lds_bwd_enable(int on);     /* the BPTT loop of dm_rssm_sequence_bwd as a second persistent kernel of the same kind: 1.6x faster alone, slower
+                                            inside the multi-stream training step (it needs every CU at once) - OFF by default, DM_RSSM_LDS_BWD=1;
+                                            needs dm_rssm_lds_enable too */
 int dm_rssm_lds_status(void);
 int dm_rssm_lds_prof(unsigned long long* out16, int reset);
 

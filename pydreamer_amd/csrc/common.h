@@ -162,6 +162,20 @@ bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C);
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps);
 int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st);
 extern "C" int dm_rssm_lds_enable(int on);
+// The BPTT loop of the same chain (all T steps) as one persistent kernel (rssm_lds.hip rssm_lds_bwd_kernel): saved forward
+// activations and the external gradients in, dpost (final) / dpin / dgi / dgh / dza out; xw2 = x2 W_post_h and xwz = x1 W_z are
+// batched products over all rows made by the caller before the launch.
+struct DmRssmLdsBwd {
+  int B, D, Hd, S, C, F, T;
+  const float *w_post, *w_post_h, *w_ih, *w_hh, *w_z, *g_post, *g_in;
+  const uint8_t* reset;
+  const float *post, *pin, *x2, *st2, *za, *x1, *st1, *gi, *gh, *hin, *xw2, *xwz, *dfeat;
+  float *dpost, *dpin, *dgi, *dgh, *dza;
+  float* ws; size_t ws_floats;
+};
+bool dm_rssm_lds_bwd_ok(int B, int D, int Hd, int S, int C);
+size_t dm_rssm_lds_bwd_ws_floats(int B, int D, int Hd, int S, int C, int steps);
+int dm_rssm_lds_bwd_launch(const DmRssmLdsBwd& q, hipStream_t st);
 bool dm_z_embed_ok(int n);
 // x[r][:] = sum over the non-zero e of z[r][e] * Wt[e][:]   (Wt: (Zc, n) row-major, n <= 1024, n % 4 == 0): exact for any z,
 // cheap for rows of concatenated one-hot groups

@@ -466,7 +466,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
 
   DmChainKey ck;
   ck.add(s).add(embed).add(action).add(reset).add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(dfeat).add(dpost)
-      .add(dprior).add_words(G, sizeof(*G)).add(dembed).add(ws).add((long long)ws_bytes).add((long long)dm_cur_precision());
+      .add(dprior).add_words(G, sizeof(*G)).add(dembed).add(ws).add((long long)ws_bytes).add((long long)dm_cur_precision())
+      .add((long long)dm_rssm_lds_bwd_ok(B, D, Hd, S, C));
   DmChainGraph cg("rssm_sequence_bwd", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();
@@ -491,18 +492,48 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(wgrad(sw, sk_w, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk_w, skb, sw));
 
-  // ---- BPTT.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
+  // ---- BPTT as ONE persistent kernel with the (untransposed) weight slices stationary in LDS (rssm_lds.hip), when the shape
+  // qualifies: plain single-layer GRU, LayerNorm, categorical latents with <= 32 classes, B <= 64.  The two LayerNorm backward
+  // stages are folded into the products that follow them (rssm_lds.hip header), which needs x2 W_post_h and x1 W_z for all rows:
+  // two batched products here, before the loop.
+  bool lds_bwd = p[DM_RSSM_IN_G] != nullptr && rssm_gru_layers(s) == 1 && !gauss && kind == 0 && (F & 3) == 0 && T >= 2 &&
+                 dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) &&      // (= the fused launch schedule's conditions: dx2 / dx1 are re-made in batch after the loop)
+                 dm_rssm_lds_bwd_ok(B, D, Hd, S, C);
+  float *xw2 = nullptr, *xwz = nullptr, *xws = nullptr;
+  size_t xfl = 0;
+  if (lds_bwd) {
+    const size_t mark = ar.off;
+    xw2 = ar.take((size_t)N * D);
+    xwz = ar.take((size_t)N * Z);
+    xfl = dm_rssm_lds_bwd_ws_floats(B, D, Hd, S, C, T);
+    xws = ar.take(xfl);
+    if (!ar.ok) { ar.off = mark; ar.ok = true; lds_bwd = false; }      // a small caller workspace keeps the launch schedule
+  }
+  if (lds_bwd) {
+    DM_TRY(dgrad(st, sk, skb, N, Hd, D, a.x2, Hd, p[DM_RSSM_POST_H_W], xw2, D, 0, nullptr));      // x2 W_post_h
+    DM_TRY(dgrad(st, sk, skb, N, Hd, Z, a.x1, Hd, p[DM_RSSM_Z_W], xwz, Z, 0, nullptr));           // x1 W_z
+    DmRssmLdsBwd q;
+    q.B = B; q.D = D; q.Hd = Hd; q.S = S; q.C = C; q.F = F; q.T = T;
+    q.w_post = p[DM_RSSM_POST_W]; q.w_post_h = p[DM_RSSM_POST_H_W]; q.w_ih = p[DM_RSSM_GRU_WIH]; q.w_hh = p[DM_RSSM_GRU_WHH];
+    q.w_z = p[DM_RSSM_Z_W]; q.g_post = p[DM_RSSM_POST_G]; q.g_in = p[DM_RSSM_IN_G];
+    q.reset = reset; q.post = post; q.pin = a.pin; q.x2 = a.x2; q.st2 = a.st2; q.za = a.za; q.x1 = a.x1; q.st1 = a.st1;
+    q.gi = a.gi; q.gh = a.gh; q.hin = a.hin; q.xw2 = xw2; q.xwz = xwz; q.dfeat = dfeat;
+    q.dpost = dpost; q.dpin = dpin; q.dgi = dgi; q.dgh = dgh; q.dza = dza;
+    q.ws = xws; q.ws_floats = xfl;
+    DM_TRY(dm_rssm_lds_bwd_launch(q, st));
+  }
+  // ---- BPTT as launches.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
   // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
-  DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, ZP, Hd));
-  DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
+  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, ZP, Hd));
+  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
   GruStack gk;
   DM_TRY(gru_stack(s, p, g, &gk));
   const bool stacked = gk.L > 1;
-  if (!stacked) {
+  if (!stacked && !lds_bwd) {
     DM_TRY(transpose(st, p[DM_RSSM_GRU_WIH], wt_ih, 3 * D, Hd));
     DM_TRY(transpose(st, p[DM_RSSM_GRU_WHH], wt_hh, 3 * D, D));
   }
-  DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
+  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
   // Fused schedule (5 launches per step instead of 8), mirror of the forward T loop: both LayerNorm+ELU BACKWARD stages
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
@@ -519,7 +550,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   if (!ar.ok) { dgif = nullptr; dghf = nullptr; dpinf = nullptr; dzaf = nullptr; }
   // time chunks of the batched weight gradients (single-layer cells): chunk c = steps [T*c/nchunk, T*(c+1)/nchunk); the loop
   // runs t downwards, so the LAST chunk completes first - it overwrites the gradient, the others accumulate
-  const int nchunk = (stacked || B < 16) ? 1 : (T >= 16 ? 4 : T >= 8 ? 2 : 1);      // (a few-column shard: the chunks' extra launches cost more than they hide)
+  const int nchunk = (stacked || B < 16 || lds_bwd) ? 1 : (T >= 16 ? 4 : T >= 8 ? 2 : 1);      // (a few-column shard: the chunks' extra launches cost more than they hide; the persistent kernel finishes all rows at once)
   int next_chunk = nchunk - 1;
   const float* dx2s = fuse_b ? dx2_w : dx2;
   const float* dx1s = fuse_b ? dx1_w : dx1;
@@ -545,7 +576,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, A, dx1s + c0 * Hd, Hd, action + c0 * A, A, g[DM_RSSM_A_W], acc));
     return DM_OK;
   };
-  for (int t = T - 1; t >= 0; --t) {
+  if (lds_bwd) DM_TRY(side_chunk(0));      // all rows are final: the batched weight gradients (one chunk) on the side stream
+  for (int t = lds_bwd ? -1 : T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
     float* dpt = dpost + r0 * ZP;

@@ -188,6 +188,7 @@ _SIGNATURES = {
     'dm_fp32_mode': (c_int, []),
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
+    'dm_rssm_lds_bwd_enable': (c_int, [c_int]),
     'dm_rssm_lds_status': (c_int, []),
     'dm_rssm_lds_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),

@@ -64,4 +64,31 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
             keep = idx.clone()
         else:
             print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')
+    # ---- the BPTT loop (dm_rssm_sequence_bwd: prior branch, loop, batched weight gradients) with the persistent kernel on / off
+    lib.dm_rssm_lds_enable(1)
+    run(); torch.cuda.synchronize()
+    Gf, Gp, Gq = (torch.randn(T * B, n, generator=g).cuda() / (T * B) for n in (F_, Z, Z))
+    grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
+    Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
+    dembed = torch.zeros(T * B, E, device='cuda')
+    keep_g = None
+    for on in (1, 0):
+        lib.dm_rssm_lds_bwd_enable(on)
+        per = []
+        for rep in range(6):
+            dfeat, dpost, dprior = Gf.clone(), Gp.clone(), Gq.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), ctypes.byref(P), H.fptr(acts),
+                   H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
+                   H.ptr(ws), ws.numel(), H.stream())
+            e1.record(); torch.cuda.synchronize()
+            if rep:
+                per.append(e0.elapsed_time(e1) * 1e3)
+        per.sort()
+        flat = torch.cat([x.flatten() for x in grads if x is not None])
+        print(f'B={B} bwd lds={on}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}), status {lib.dm_rssm_lds_status()}'
+              + ('' if keep_g is None else f'; gradients vs the persistent kernel: rel-L2 {float((flat - keep_g).norm() / keep_g.norm()):.2e}'))
+        keep_g = flat.clone() if keep_g is None else keep_g
+    lib.dm_rssm_lds_bwd_enable(1)
 lib.dm_rssm_lds_enable(1)

@@ -522,6 +522,70 @@ def test_rssm_lds_chain_matches_launch_schedule(hip, B):
         off += (N * width + 63) // 64 * 64      # the arena is carved in 64-float granules (csrc/common.h DmArena)
 
 
+@pytest.mark.parametrize('B', [6, 7, 13, 25, 50, 64])
+def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
+    """The BPTT loop of dm_rssm_sequence_bwd as ONE persistent kernel (csrc/rssm_lds.hip rssm_lds_bwd_kernel: untransposed
+    weight slices resident in LDS, the two LayerNorm backward stages folded into the products that follow them) against the
+    ~6-launches-per-step schedule it replaces, on the same forward pass: Atari-literal cell width, T = 12, every row-count
+    layout (8 / 16 / 32 / 64 rows per k-group).  Every parameter gradient and dembed within 2e-4 relative L2 (fp32
+    summation order differs: K split over waves / k-groups, the expanded LayerNorm backward); the kernel never gave up.
+    (Against the fp64 oracle: test_rssm_sequence_fwd_bwd_vs_oracle runs this kernel too.)"""
+    import ctypes
+    from pydreamer_amd import hip as H
+    T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
+    oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
+                        batch_size=B, batch_length=T)
+    model = _build(oconf, O.make_params(oconf, seed=4))
+    cell = model.wm.core.cell
+    E, Z, F_, N = 32 * depth, S * C, D_ + S * C, T * B
+    g = torch.Generator().manual_seed(13)
+    embed = torch.randn(N, E, generator=g).to(DEV)
+    action = F.one_hot(torch.randint(0, A, (N,), generator=g), A).float().to(DEV)
+    reset = (torch.rand(N, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    h0, z0 = torch.tanh(torch.randn(B, D_, generator=g)).to(DEV), torch.zeros(B, Z).to(DEV)
+    u = torch.rand(N, S, generator=g).to(DEV)
+    Gf, Gp, Gq = (torch.randn(N, n, generator=g).to(DEV) / N for n in (F_, Z, Z))
+    shp = model.wm.shape(T, B, 1)
+    ws = model.wm.workspace(shp, torch.device(DEV, 0))
+    P = H.rssm_struct(cell.ordered())
+    acts = torch.zeros(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
+    feat, post, prior = torch.zeros(N, F_, device=DEV), torch.zeros(N, Z, device=DEV), torch.zeros(N, Z, device=DEV)
+    idx = torch.zeros(N, S, dtype=torch.int32, device=DEV)
+    H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
+           H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
+           H.ptr(ws), ws.numel(), H.stream())
+    outs = []
+    was = H.lib().dm_rssm_lds_bwd_enable(-1)
+    try:
+        for on in (1, 0):
+            H.lib().dm_rssm_lds_bwd_enable(on)
+            for rep in range(2):      # twice: the second call reuses the exchange addresses with caches warm
+                grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
+                Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
+                dembed = torch.zeros(N, E, device=DEV)
+                dfeat, dpost, dprior = Gf.clone(), Gp.clone(), Gq.clone()
+                H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), ctypes.byref(P),
+                       H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs),
+                       H.fptr(dembed), H.ptr(ws), ws.numel(), H.stream())
+                torch.cuda.synchronize()
+            outs.append((grads, dembed, dpost))
+    finally:
+        H.lib().dm_rssm_lds_bwd_enable(was)
+    assert H.lib().dm_rssm_lds_status() == 0, 'the persistent kernel gave up in a spin loop'
+    names = H.rssm_param_names('gru')
+    worst = 0.0
+    for name, a, b in zip(names, outs[0][0], outs[1][0]):
+        if name is None or a is None:
+            continue
+        assert torch.isfinite(a).all(), name
+        e = _rel_l2(a, b)
+        worst = max(worst, e)
+        assert e < 2e-4, (name, e)
+    assert _rel_l2(outs[0][1], outs[1][1]) < 2e-4, 'dembed'
+    assert _rel_l2(outs[0][2], outs[1][2]) < 2e-4, 'dpost (final, with the straight-through part)'
+    print(f'B={B}: worst parameter-gradient rel-L2 vs the launch schedule {worst:.2e}')
+
+
 # ------------------------------------------------------------------------------------------- end to end
 def _run_pair(oconf, steps, forced=False, seed=0):
     """One or more full trainer iterations (train.py:165-198) on the oracle (CPU) and the HIP model (GPU)."""
@@ -837,8 +901,8 @@ def test_dream_rollout_vs_oracle(hip):
     _close(th.mean, to, 1e-4, 1e-5, 'dream terminals')
 
 
-@pytest.mark.parametrize('B,T', [(6, 4), (7, 4), (50, 4), (50, 10)])
-def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T):
+@pytest.mark.parametrize('B,T,lds_bwd', [(6, 4, 0), (7, 4, 0), (50, 4, 0), (50, 10, 0), (7, 10, 1), (50, 10, 1)])
+def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T, lds_bwd):
     """dm_rssm_sequence_fwd / dm_rssm_sequence_bwd stand-alone through the C-ABI at the Atari-literal cell width (deter 600,
     hidden 1000, stoch 32x32) for a 7-column data-parallel shard and the full 50 columns: at these sizes the T loop runs its
     FUSED schedule: the first step as launches (LayerNorm+ELU in the prologue of the consuming <= 64-row product, sampler in
@@ -912,9 +976,16 @@ def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T):
     Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
     dembed = torch.empty(N, E, device=DEV)
     dfeat, dpost, dprior = dev(Gf), dev(Gp), dev(Gq)
-    H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), ctypes.byref(P), H.fptr(acts),
-           H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
-           H.ptr(ws), ws.numel(), H.stream())
+    was = H.lib().dm_rssm_lds_bwd_enable(-1)
+    H.lib().dm_rssm_lds_bwd_enable(lds_bwd)          # 1: the BPTT loop as the persistent kernel (off by default)
+    try:
+        H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), ctypes.byref(P), H.fptr(acts),
+               H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
+               H.ptr(ws), ws.numel(), H.stream())
+        torch.cuda.synchronize()
+    finally:
+        H.lib().dm_rssm_lds_bwd_enable(was)
+    assert H.lib().dm_rssm_lds_status() == 0
     for name, gh in zip(H.rssm_param_names('gru'), grads):
         if name is not None:
             assert _rel_l2(gh, pd['wm.core.cell.' + name].grad) < 2e-4, name

@@ -239,6 +239,7 @@ def test_runtime_switch_defaults():
     if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_LDS', 'DM_CHAIN_GRAPH')):
         assert lib.dm_bf16_twins_enable(-1) == 1
         assert lib.dm_rssm_lds_enable(-1) == 1
+        assert lib.dm_rssm_lds_bwd_enable(-1) == 0 or os.environ.get('DM_RSSM_LDS_BWD')      # (slower inside the multi-stream step)
         assert lib.dm_chain_graph_enable(-1) == 0
     assert lib.dm_rssm_lds_status() == 0
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
