@@ -65,6 +65,7 @@ struct RlArgs {
 // fp32 rounding of the O(1) activation itself - at 5 VALU operations instead of expm1f's ~30; every CU applies it to the
 // WHOLE (rows x K) operand of its product, so with expm1f it was the longest phase of a step (8.5 of 21 us, measured).
 __device__ __forceinline__ float rl_elu(float v) {
+  // (max(v, 0) + min(e, 0) is no cheaper: gfx950 has packed mul / add / fma but no packed max / min or select)
   const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.0f;
   return v > 0.f ? v : e;
 }
@@ -218,10 +219,12 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
     // granule instead of three) and the instruction's A-broadcast (cbsz 4: block `abid` feeds all 16 blocks) selects the
     // column set - verified by scripts/microbench/allgather_xcd.hip (layout modes 1 / 2)
     const f32x4* wl = reinterpret_cast<const f32x4*>(w) + wave * 12 + ((lane & 15) < 12 ? (lane & 15) : 11);
+    f32x4 wnext = wl[0];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       if (FULL || j < nj) {
-        const f32x4 ww = wl[j * RL_WAVES * 12];
+        const f32x4 ww = wnext;
+        if (j + 1 < MAXJ) wnext = wl[(j + 1) * RL_WAVES * 12];      // the next granule's weights are in flight under this one's 12 MFMAs
         acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[0], 4, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[1], 4, 1, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[2], 4, 2, 0);
@@ -235,7 +238,7 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
         odd[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.w, v[j].w, odd[1], 4, 1, 0);
         odd[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.w, v[j].w, odd[2], 4, 2, 0);
       }
-      if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
