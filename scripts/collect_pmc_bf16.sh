@@ -2,7 +2,7 @@
 # HBM traffic of the bf16 step (two rocprofv3 PMC passes, as collect_profiles.sh does for fp32) -> <tag>_pmc_traffic_bf16.json,
 # then the bf16 bench line reading it.  Run on the GPU box from the repo root: bash scripts/collect_pmc_bf16.sh r03
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

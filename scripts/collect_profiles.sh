@@ -6,7 +6,7 @@
 #   3. the bench line itself, reading the fresh PMC file -> <tag>_bench.json
 # Everything lands in gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -31,6 +31,8 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate
 for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --dtype bf16 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50_bf16.json 2>/dev/null
+python scripts/persist_prof.py 50 25 13 7 2>/dev/null | grep -v Warning > $OUT/${TAG}_rssm_lds.txt
 bash scripts/collect_pmc_bf16.sh $TAG > $OUT/collect_bf16.log 2>&1      # bf16 step: its own counter passes, then the bf16 bench line
 DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
