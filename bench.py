@@ -232,6 +232,8 @@ def main():
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
+    ap.add_argument('--no-pipeline', action='store_true', help='actor / critic clip + AdamW on the caller\'s stream (A/B switch; default: on the '
+                    'actor-critic stream behind their backward pass, Dreamer.pipeline_ac_optimizer, so the next step\'s forward does not wait for it)')
     ap.add_argument('--workload', choices=('atari-literal', 'atari-native', 'dmc'), default='atari-literal',
                     help="atari-literal = BASELINE configs[1] (the metric); atari-native = pydreamer's own defaults+atari (B=32, T=48, deter 1024; "
                          "README.md:90-97); dmc = configs[4] at one GPU (defaults+dmc, actor_grad=reinforce, action_dim 6, B=T=50); the last two are diagnostic lines")
@@ -282,6 +284,7 @@ def main():
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
     model.overlap_backward = not args.no_overlap
+    model.pipeline_ac_optimizer = not (args.no_pipeline or args.no_overlap or args.graph)
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
     DP.attach(opts, hi - lo, B, model=model)           # the B_r/B weight rides in the backward kernels' scale arguments
     ring = make_ring(conf, B, lo, hi, args.ring, dev, 1234)      # the global batch, this rank's columns

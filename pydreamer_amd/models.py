@@ -437,6 +437,9 @@ def _finish_backward(owner, grads, flat, direct, grad_loss):
             raise RuntimeError('the gradients pre-computed by this training_step() were overwritten by a later training_step() '
                                'before backward() was called; call backward() after each training_step(), or set '
                                'model.overlap_backward = False to compute gradients inside backward()')
+        fused.order_after_current()          # (pipelined mode: `gl` was made on this stream, the hand-over runs on the group's)
+        if fused.home is not None:
+            gl.record_stream(fused.home)
         fused.adopt_scratch(gl)              # buffer swap ('=' semantics) or accumulation; see FusedAdamW.adopt_scratch
         return tuple(None for _ in grads)
     H.call('dm_scale_inplace', H.fptr(flat), flat.numel(), H.fptr(gl), H.stream())
@@ -1270,7 +1273,15 @@ class _HeadLoss(torch.autograd.Function):
         ov = pk.get('overlap')
         if 'pre' in pk:                                   # launched on s_ac inside training_step()
             grads, flat, direct = pk.pop('pre').result()
-            torch.cuda.current_stream().wait_stream(ov.s_ac)
+            fused = getattr(mlp, '_fused', None)
+            if fused is None or fused.home is not ov.s_ac or flat is not fused.scratch:
+                torch.cuda.current_stream().wait_stream(ov.s_ac)
+            else:      # what the backward pass reads was allocated on the caller's stream and is released below: not before s_ac is done with it
+                for t in (pk.get('x'), pk.get('acts'), pk.get('dout')):
+                    if torch.is_tensor(t):
+                        t.record_stream(ov.s_ac)
+            # else (Dreamer.pipeline_ac_optimizer): the hand-over, the clip and the AdamW step of this group are enqueued on
+            # s_ac behind the backward pass; the caller's stream goes on to the next step's forward without waiting for it
         else:
             grads, flat, direct = mlp.bwd(pk['x'], pk['ldx'], pk['rows'], pk['acts'], pk['dout'], pk['ws'])
         pk.pop('acts', None)
@@ -1458,11 +1469,59 @@ class Dreamer(nn.Module):
         mb = getattr(self, 'metric_buffer', None)
         if mb is not None and mb.device != o['wm'].flat_grad.device:
             mb = None
+        if mb is not None and o['actor'].home is not None:
+            mb.record_stream(o['actor'].home)      # (pipelined mode: two of its slots are written on the actor-critic stream)
         out = lambda name: None if mb is None else mb[METRIC_SLOTS[name]:METRIC_SLOTS[name] + 2]   # [norm, clip coefficient]
         return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip, out('grad_norm')),
                     grad_norm_probe=o['probe'].clip_grad_norm(grad_clip, out('grad_norm_probe')),
                     grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_actor')),
                     grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_critic')))
+
+    # ---- pipelined actor / critic optimizer (round 4) --------------------------------------------------------------------
+    # The four optimizer groups are independent (dreamer.py:60-71).  With `pipeline_ac_optimizer = True` the gradient hand-over,
+    # clip and AdamW step of the ACTOR and CRITIC groups are enqueued on the actor-critic stream, behind their backward pass,
+    # instead of on the caller's stream - which therefore no longer waits for the actor-critic backward before the next
+    # step's encoder and posterior loop: the tail of step n (actor-critic backward, ~2.5 ms after the world-model backward has
+    # finished, profiles/r04_queues_f32.txt) overlaps the head of step n+1.  Same kernels, same per-stream order: bit-identical
+    # parameters (test_pipelined_ac_optimizer_is_bit_identical).  The caller's stream waits for those AdamW steps where it
+    # first reads actor / critic parameters (the rollout), in inference() and state_dict(), and in packed_metrics() for the two
+    # gradient norms.  OFF by default: a trainer that touches actor / critic `.grad`s or reads `grad_norm_actor / _critic` on its
+    # own stream between backward() and step() (GradScaler.unscale_ with amp; `.item()` on grad_clip()'s dict) must leave it off
+    # or call join_optimizers() first.  bench.py switches it on (its loop reads no per-step scalars).
+    pipeline_ac_optimizer = False
+
+    def _set_ac_home(self, ov):
+        o = getattr(self, '_opt', None)
+        if o is None:
+            return
+        on = bool(self.pipeline_ac_optimizer) and ov is not None and all(o[k].dp is None for k in ('actor', 'critic')) \
+            and not torch.cuda.is_current_stream_capturing() and not self.wm._arena.on      # (the step arena re-uses buffers)
+        for k in ('actor', 'critic'):
+            if o[k].home is not None and not on:
+                o[k].join()
+            o[k].home = ov.s_ac if on else None
+
+    def _ac_pipelined(self):
+        o = getattr(self, '_opt', None)
+        return o is not None and o['actor'].home is not None
+
+    def _await_ac_optimizers(self):
+        """Before the caller's stream first touches what the actor-critic stream may still be using - actor / critic parameters
+        (AdamW), the imagined trajectory and the heads' activations of the previous step (its backward pass) - it waits for
+        that stream.  By now it holds nothing but the previous step's tail."""
+        if self._ac_pipelined():
+            self.join_optimizers()
+
+    def join_optimizers(self):
+        """The current stream waits for everything the pipelined optimizer groups have enqueued on their own stream."""
+        o = getattr(self, '_opt', None)
+        if o is not None:
+            for k in ('actor', 'critic'):
+                o[k].join()
+
+    def state_dict(self, *args, **kwargs):
+        self.join_optimizers()
+        return super().state_dict(*args, **kwargs)
 
     def packed_metrics(self):
         """(names, buffer, idx): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
@@ -1470,6 +1529,7 @@ class Dreamer(nn.Module):
         `vals = buffer.tolist(); dict(zip(names, (vals[i] for i in idx)))` replaces the trainer's ~20 `.item()` syncs per
         logged step (train.py:204-214) with a single device-to-host copy.  No kernel runs here: the kernels of the step
         wrote their results straight into this buffer."""
+        self.join_optimizers()      # (pipelined mode: the actor / critic gradient norms were written on the actor-critic stream)
         names = list(METRIC_SLOTS)
         return names, self.metric_buffer, [METRIC_SLOTS[n] for n in names]
 
@@ -1482,6 +1542,7 @@ class Dreamer(nn.Module):
         assert 'action' in obs, 'Observation should contain previous action'
         act_shape = obs['action'].shape
         assert len(act_shape) == 3 and act_shape[0] == 1, f'Expected shape (1,B,A), got {act_shape}'
+        self.join_optimizers()
         features, out_state = self.wm.forward(obs, in_state, None if noise is None else noise['u_post'])
         B = act_shape[1]
         feat = features.reshape(B, -1)
@@ -1625,7 +1686,8 @@ class Dreamer(nn.Module):
                         pass
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._overlap.s_wm)
-            cur.wait_stream(self._overlap.s_ac)
+            if not self._ac_pipelined():          # (pipelined mode waits for the actor-critic stream where the rollout starts:
+                cur.wait_stream(self._overlap.s_ac)      # nothing the world-model forward writes is read by that stream)
         # every loss / metric scalar of this step lands in ONE device buffer (METRIC_SLOTS)
         mbuf = torch.zeros(METRIC_BUF_FLOATS, device=obs['action'].device)
         self.metric_buffer = mbuf
@@ -1635,12 +1697,15 @@ class Dreamer(nn.Module):
                                   imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf, _internal=True)
         pk = self.wm._last_pack
         ov = None
+        if not (self.overlap_backward and torch.is_grad_enabled()):
+            self._set_ac_home(None)
         if self.overlap_backward and torch.is_grad_enabled():
             dev = pk['feat'].device
             if self._overlap is None or self._overlap.s_wm.device != dev:
                 self._overlap = _Overlap(dev)
             ov = self._overlap
             pk['overlap'] = ov
+            self._set_ac_home(ov)
             gens = {}
             for owner in (self.wm, self.ac.actor, self.ac.critic):      # main thread: zero_grad() - or a backward() on
                 if getattr(owner, '_fused', None) is not None:          # an OLDER step's losses - may come before the
@@ -1663,6 +1728,7 @@ class Dreamer(nn.Module):
             need = 4 * int(H.lib().dm_mlp_ws_floats((imag_horizon + 1) * T * B * I, MLP_HIDDEN, 4))
             if ov.ws_ac is None or ov.ws_ac.numel() < need:
                 ov.ws_ac = torch.empty(need, dtype=torch.uint8, device=pk['feat'].device)
+        self._await_ac_optimizers()      # (pipelined mode: the previous step's actor / critic AdamW ran on the actor-critic stream)
         self.ac.begin_step()             # the target-network refresh comes before the first use of critic_target (a2c.py:76-79)
         features_dream, actions_dream, rewards_dream, terminals_dream = \
             self._dream_from_features(pk['feat'], imag_horizon,

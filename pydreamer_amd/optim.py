@@ -7,6 +7,7 @@ buffer, so that
   * the norm, the in-place clip and the AdamW update are three streaming kernels per group instead of ~100 small ones;
   * data-parallel training all-reduces one buffer per group over RCCL (see pydreamer_amd/dist.py).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -51,6 +52,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._pending = False                             # a pre-launched backward result sits in `scratch`, not yet handed over
         self.early_reduce = None                          # (work handle) all-reduce of `scratch` already in flight (dist.py)
         self._reduced = False                             # flat_grad already holds the all-reduced gradient of this step
+        # Pipelined mode (models.Dreamer.pipeline_ac_optimizer): the stream this group's backward pass ran on.  The gradient
+        # hand-over, the clip and the AdamW step of the group are then enqueued THERE instead of on the caller's stream, so the
+        # caller's stream does not wait for that backward pass before the next step's forward; `done` is recorded behind
+        # step() and awaited by whoever reads the parameters next on another stream.
+        self.home = None
+        self.done = None
+        self._gl_event = None
         self._ids = {id(p) for p in params}
         fz = {id(p) for p in frozen} | {id(p) for p in params if not p.requires_grad}
         self._frozen_idx = {i for i, p in enumerate(params) if id(p) in fz}
@@ -73,6 +81,23 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.data = self.flat_param[off:off + k].view(p.shape)
         self._grad_views = {}                             # buffer data_ptr -> per-parameter views of that buffer
         self._point_grads(self.flat_grad)
+
+    def _on_home(self):
+        return torch.cuda.stream(self.home) if self.home is not None else contextlib.nullcontext()
+
+    def order_after_current(self):
+        """Pipelined mode: what the caller's stream has enqueued so far (e.g. the incoming scalar gradient of backward())
+        happens before what this group enqueues next on its home stream."""
+        if self.home is not None:
+            if self._gl_event is None:
+                self._gl_event = torch.cuda.Event()
+            self._gl_event.record(torch.cuda.current_stream())
+            self.home.wait_event(self._gl_event)
+
+    def join(self):
+        """The current stream waits for everything this group has enqueued on its home stream (no-op outside pipelined mode)."""
+        if self.home is not None:
+            torch.cuda.current_stream().wait_stream(self.home)
 
     def _views_of(self, buf):
         v = self._grad_views.get(buf.data_ptr())
@@ -131,7 +156,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._pending and not torch.cuda.is_current_stream_capturing():
             self._lazy_zero = True
         else:
-            self.flat_grad.zero_()
+            with self._on_home():
+                self.flat_grad.zero_()
             self._lazy_zero = False
         self.fresh = True
         self._reduced = False
@@ -163,6 +189,10 @@ class FusedAdamW(torch.optim.Optimizer):
         last write) the two buffers swap roles - no copy; otherwise (gradient accumulation) it is added.  `gl` is the
         incoming scalar gradient as a 1-element device tensor (1.0 unless a GradScaler is active): the in-place scale
         kernel returns at once when it is exactly 1."""
+        with self._on_home():
+            self._adopt_scratch(gl)
+
+    def _adopt_scratch(self, gl):
         self._pending = False
         work, self.early_reduce = self.early_reduce, None
         if work is not None:
@@ -199,6 +229,10 @@ class FusedAdamW(torch.optim.Optimizer):
     def clip_grad_norm(self, max_norm, out=None):
         """clip_grad_norm_ on the flat buffer: returns the pre-clip total norm as a 0-d device tensor (no host sync).
         out: optional 2-float device slice receiving [norm, clip coefficient] (the step's metric buffer)."""
+        with self._on_home():
+            return self._clip_grad_norm(max_norm, out)
+
+    def _clip_grad_norm(self, max_norm, out):
         if not self._grads_are_views():
             self._regather()
         self._ensure_zeroed()
@@ -216,6 +250,14 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError('closures are not used by the trainer section (train.py:193-198)')
+        with self._on_home():
+            self._step()
+            if self.home is not None:
+                if self.done is None:
+                    self.done = torch.cuda.Event()
+                self.done.record(self.home)
+
+    def _step(self):
         self._check_params_are_views()
         if not self._grads_are_views():
             self._regather()

@@ -1165,6 +1165,54 @@ def test_deferred_weight_gradients_are_bit_identical(hip, amp):
     assert float(runs[0][0][1].abs().sum()) > 0
 
 
+@pytest.mark.parametrize('cfg', ['tiny', 'shard'])
+def test_pipelined_ac_optimizer_is_bit_identical(hip, cfg):
+    """Dreamer.pipeline_ac_optimizer: the gradient hand-over, clip and AdamW step of the actor and critic groups enqueued on the
+    actor-critic stream behind their backward pass, so that the caller's stream starts the next step's forward without waiting
+    for it (the four optimizer groups are independent, dreamer.py:60-71).  Same kernels, same per-stream order: losses and all
+    parameters after every one of 5 trainer iterations are BIT-IDENTICAL to the serial order - the loop reads nothing between
+    steps, so the next forward really is enqueued while the previous actor-critic backward is still running; the metric
+    buffer (gradient norms written on the other stream) read through packed_metrics() agrees too."""
+    if cfg == 'tiny':
+        oconf = O.tiny_conf()
+    else:      # a 7-column shard at the Atari-literal cell width: long enough streams for the overlap to be real
+        oconf = O.make_conf(deter_dim=600, hidden_dim=1000, stoch_dim=32, stoch_discrete=32, cnn_depth=8, action_dim=18,
+                            batch_size=7, batch_length=12, imag_horizon=5)
+    params = O.make_params(oconf, seed=6)
+    runs = []
+    for pipelined in (False, True):
+        model = _build(oconf, params)
+        model.pipeline_ac_optimizer = pipelined
+        opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+        st = model.init_state(oconf.batch_size)
+        batches = [(_to_dev(O.preprocess(O.synthetic_batch(oconf, seed=80 + s, first=(s == 0)), oconf)),
+                    _to_dev(O.make_noise(oconf, seed=90 + s))) for s in range(5)]
+        hist, keep = [], []
+        for s in range(5):
+            obs, noise = batches[s]
+            losses, st, _, _, _ = model.training_step(obs, st, noise=noise)
+            for opt in opts:
+                opt.zero_grad()
+            for loss in losses:
+                loss.backward()
+            model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+            for opt in opts:
+                opt.step()
+            keep.append((torch.stack([l.detach() for l in losses]), model.metric_buffer))      # no host read inside the loop
+        assert (model._opt['actor'].home is not None) == pipelined
+        names, buf, idx = model.packed_metrics()
+        vals = buf.tolist()
+        torch.cuda.synchronize()
+        runs.append(([k[0].cpu() for k in keep], torch.cat([o.flat_param for o in opts]).cpu(),
+                     {n: vals[i] for n, i in zip(names, idx)}))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1]), 'parameters after 5 steps differ'
+    assert runs[0][2] == runs[1][2], 'last step metrics (incl. the gradient norms written on the other stream) differ'
+    sd = model.state_dict()
+    assert torch.isfinite(sd['ac.actor.model.0.weight']).all()
+
+
 def test_early_head_window_is_bit_identical(hip):
     """The heads over the imagined states run as two row windows (ActorCritic.split_steps); in the training step the first
     one is issued on the actor-critic stream behind a progress mark of the rollout (dm_dream_rollout_marks) while the
