@@ -1198,7 +1198,7 @@ def test_pipelined_ac_optimizer_is_bit_identical(hip, cfg):
             model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
             for opt in opts:
                 opt.step()
-            keep.append((torch.stack([l.detach() for l in losses]), model.metric_buffer))      # no host read inside the loop
+            keep.append((torch.stack([l.detach().reshape(()) for l in losses]), model.metric_buffer))      # no host read inside the loop
         assert (model._opt['actor'].home is not None) == pipelined
         names, buf, idx = model.packed_metrics()
         vals = buf.tolist()
