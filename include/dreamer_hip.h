@@ -125,7 +125,8 @@ int dm_bf16_twins_enable(int on);
  * one workgroup per compute unit that keeps its 4-column slice of every layer's weights in LDS for all T steps and exchanges
  * the small activation rows through poison-filled per-step buffers (csrc/rssm_lds.hip) - instead of five
  * dependent launches per step that re-stream the weights.  Same arithmetic up to fp32 summation order, same sampler rule.
- * dm_rssm_lds_enable: 1 / 0 switches it on / off, -1 queries; returns the state (default on; DM_RSSM_LDS=0 in the environment).
+ * dm_rssm_lds_enable: 1 / 0 switches it on / off, 2 = on also for small models (slices under half a CU's LDS: tests), -1 queries;
+ * returns the state (default 1; DM_RSSM_LDS=0 / 2 in the environment).
  * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (bounded polls; later calls are refused).
  * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */
 int dm_rssm_lds_enable(int on);

@@ -281,7 +281,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   // inputs and the indices the kernel's first step continues from.
   float* psync = nullptr;
   size_t psync_floats = 0;
-  if (fuse_sample && wzt && idx && kind == 0 && t1 - t0 >= 3 && dm_rssm_lds_ok(B, D, Hd, S, C)) {
+  if (normed && !stacked && !gauss && kind == 0 && wzt && idx && (F & 3) == 0 && t1 - t0 >= 3 && dm_rssm_lds_ok(B, D, Hd, S, C)) {
     psync_floats = dm_rssm_lds_ws_floats(B, D, Hd, S, C, t1 - t0 - 1);
     float* sy = ar.take(psync_floats);
     if (ar.ok) psync = sy;
@@ -393,7 +393,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     pq.idx = idx; pq.ws = psync; pq.ws_floats = psync_floats;
     DM_TRY(dm_rssm_lds_launch(pq, st));
   }
-  if (fuse_ln) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
+  if (fuse_ln || psync) {     // what only the backward pass reads: post-LayerNorm activations + statistics of every row of the range
     DM_TRY(norm_elu_fwd(N, Hd, a.x1 + q0 * Hd, Hd, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f, a.za + q0 * Hd, Hd,
                                 a.st1 + q0 * 2, st));
     DM_TRY(norm_elu_fwd(N, Hd, a.x2 + q0 * Hd, Hd, p[DM_RSSM_POST_G], p[DM_RSSM_POST_B], 1e-3f, a.pin + q0 * Hd, Hd,
@@ -497,8 +497,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // stages are folded into the products that follow them (rssm_lds.hip header), which needs x2 W_post_h and x1 W_z for all rows:
   // two batched products here, before the loop.
   bool lds_bwd = p[DM_RSSM_IN_G] != nullptr && rssm_gru_layers(s) == 1 && !gauss && kind == 0 && (F & 3) == 0 && T >= 2 &&
-                 dm_skinny_ln_ok(B, D, Hd) && dm_skinny_ln_ok(B, Z, Hd) &&      // (= the fused launch schedule's conditions: dx2 / dx1 are re-made in batch after the loop)
-                 dm_rssm_lds_bwd_ok(B, D, Hd, S, C);
+                 dm_rssm_lds_bwd_ok(B, D, Hd, S, C);      // (dx2 / dx1 are re-made in batch after the loop, like the fused launch schedule)
   float *xw2 = nullptr, *xwz = nullptr, *xws = nullptr;
   size_t xfl = 0;
   if (lds_bwd) {
@@ -538,8 +537,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
-                      dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
+  const bool fuse_b = lds_bwd || (p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
+                                  dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0);
   // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
   // backward epilogue, read by the two products that follow it
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;

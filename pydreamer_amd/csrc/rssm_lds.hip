@@ -185,8 +185,10 @@ __device__ __forceinline__ void rl_ln_elu(f32x4 (&v)[32 / (64 / RL)], int P, int
   // gamma / beta images are padded with zeros to the granule grid: a granule past P becomes ELU(0 * .. + 0) = 0 again
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gb) + (wave * KG + kg);
   const f32x4* b4 = g4 + rl_pad_blocks<RL>(P);
+  const int njp = rl_pad_blocks<RL>(P) / (RL_WAVES * KG);     // granules per lane the padded images cover (= MAXJ at production sizes)
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
+    if (njp < MAXJ && j >= njp) continue;         // small models: past the images (the granule holds zeros and stays zero)
     const f32x4 g = g4[j * RL_WAVES * KG], b = b4[j * RL_WAVES * KG];
     // x a + (b - mean a), a = rstd gamma: written without (x - mean) so that the compiler does not keep the variance pass's 128
     // differences alive for reuse here (it did: 444 spilled registers)
@@ -211,6 +213,7 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
   // (the image is zero-padded to the granule grid: no clamp; the address is base + a compile-time offset per (j, cs))
   const f32x4* w4 = reinterpret_cast<const f32x4*>(w) + ((wave * KG + kg) * NCS) * 4 + (lane & 3);
   const int nj = (P + RL_WAVES * KG - 1) / (RL_WAVES * KG);
+  const bool full = FULL && nj == MAXJ;      // (small models: the padded LDS image ends before the granule grid does)
   f32x4 odd[NCS];
 #pragma unroll
   for (int cs = 0; cs < NCS; ++cs) odd[cs] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -222,7 +225,7 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
     f32x4 wnext = wl[0];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
-      if (FULL || j < nj) {
+      if (full || j < nj) {
         const f32x4 ww = wnext;
         if (j + 1 < MAXJ) wnext = wl[(j + 1) * RL_WAVES * 12];      // the next granule's weights are in flight under this one's 12 MFMAs
         acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ww.x, v[j].x, acc[0], 4, 0, 0);
@@ -248,7 +251,7 @@ __device__ __forceinline__ void rl_dot(f32x4 (&acc)[NCS], const f32x4 (&v)[32 / 
   }
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    if (FULL || j < nj) {                         // (uniform) granules past the operand are zeros: skip their instructions
+    if (full || j < nj) {                         // (uniform) granules past the operand are zeros: skip their instructions
       f32x4 ww[NCS];
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs) ww[cs] = w4[(j * RL_WAVES * KG * NCS + cs) * 4];
@@ -1205,7 +1208,10 @@ bool rl_device_ok(int G, size_t lds_bytes) {
     }
   }
   // one workgroup per CU, all resident at once: more than half of a CU's LDS each, and no more workgroups than CUs
-  return g_host_err_dev && G <= g_cus && lds_bytes <= (size_t)g_lds_max && lds_bytes > 80 * 1024;
+  // All workgroups must be resident at once: never more workgroups than CUs.  Production sizes need more than half of a CU's LDS
+  // each (so exactly one sits on every CU); smaller models are left to the launch chain, whose few small launches they do not
+  // outweigh - except at switch level 2 (tests: the tiny reference goldens through these kernels).
+  return g_host_err_dev && G <= g_cus && lds_bytes <= (size_t)g_lds_max && (lds_bytes > 80 * 1024 || g_rssm_lds >= 2);
 }
 
 }  // namespace
@@ -1213,7 +1219,7 @@ bool rl_device_ok(int G, size_t lds_bytes) {
 // 1 / 0: run the posterior chain's steps as the LDS-weight-stationary persistent kernel when the shape qualifies / always
 // as launches; -1: query.  Returns the state.
 extern "C" int dm_rssm_lds_enable(int on) {
-  if (on >= 0) g_rssm_lds = on ? 1 : 0;
+  if (on >= 0) g_rssm_lds = on > 2 ? 2 : on;      // 2: also for models whose slices need less than half a CU's LDS (tests)
   return g_rssm_lds;
 }
 // Sticky: non-zero once a persistent kernel of this process has given up inside a spin loop (its outputs are garbage).

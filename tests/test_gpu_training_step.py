@@ -786,6 +786,33 @@ def _check_reference_golden(name, steps):
         np.testing.assert_allclose(sums, g[pre + 'param_abs_sums'], rtol=2e-6)
 
 
+@pytest.mark.parametrize('name,steps', [('tiny', 2), ('tiny_aux_critic', 2), ('tiny_scalars', 3), ('tiny_kl_plain', 2)])
+def test_reference_goldens_through_the_persistent_chain_kernels(hip, name, steps):
+    """The fixtures written by the real reference replayed with BOTH persistent chain kernels forced on (csrc/rssm_lds.hip: the
+    posterior T loop and its BPTT loop; switch level 2 admits models whose weight slices need less than half a CU's LDS, which
+    the default leaves to the launch chain): sampled indices bit-exact, losses / metrics / gradient norms / post-AdamW parameter
+    checksums at the same bars as the launch schedule - incl. two consecutive steps with the carried state, binding gradient
+    clips and off-default loss weights (tiny_scalars), the un-balanced KL, the auxiliary critic.  (debug_literal and the two full-size
+    fixtures have deter_dim 1024 / 600: the first does not fit a CU's LDS and stays on the launch chain, the second runs the
+    posterior kernel by default in test_training_step_matches_reference_at_atari_literal.)"""
+    from pydreamer_amd import hip as H
+    lib = H.lib()
+    was, was_b = lib.dm_rssm_lds_enable(-1), lib.dm_rssm_lds_bwd_enable(-1)
+    lib.dm_rssm_lds_enable(2)
+    lib.dm_rssm_lds_bwd_enable(1)
+    try:
+        out = (ctypes_ull16 := (__import__('ctypes').c_ulonglong * 16)())
+        lib.dm_rssm_lds_prof(out, 1)                  # (allocates and zeroes the phase clocks: non-zero afterwards = the kernel ran)
+        _check_reference_golden(name, steps)
+        torch.cuda.synchronize()
+        lib.dm_rssm_lds_prof(ctypes_ull16, 0)
+        assert sum(ctypes_ull16) > 0, 'the persistent posterior kernel did not run'
+        assert lib.dm_rssm_lds_status() == 0
+    finally:
+        lib.dm_rssm_lds_enable(was)
+        lib.dm_rssm_lds_bwd_enable(was_b)
+
+
 def test_gaussian_latents_iwae_matches_reference_golden(hip):
     """stoch_discrete = 0 WITH iwae_samples = 2 (dreamer.py:340-343 with rssm.py:202-203: the sampled KL is a difference of
     Normal log-densities of the reparameterised sample, through which a gradient flows) against
