@@ -59,6 +59,7 @@ struct RlArgs {
   unsigned long long* prof;     // optional: 16 phase tick sums of workgroup 0
   // LDS carve, in floats
   int l_wz, l_wg, l_wh, l_wc, l_wd, l_gb1, l_gb2, l_red, l_gh, l_hown, l_stage, l_flag;
+  int wz_global;                // 1: the z_mlp^T slice does not fit beside the others (deter 1024): its 32 rows per batch row are gathered from L2
 };
 
 // ELU through the hardware exponential: x > 0 ? x : 2^(x log2 e) - 1.  Absolute error <= ~2 ulp(1) = 2.4e-7 - the size of one
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
   unsigned long long tick_ = wall_clock64();
 
   // ---- weights into LDS, once
-  if (roleA) {
+  if (roleA && !a.wz_global) {
     f32x4* d4 = reinterpret_cast<f32x4*>(wz);
     for (int e = tid; e < Z; e += RL_THREADS) d4[e] = *reinterpret_cast<const f32x4*>(a.wzt + (size_t)e * Hd + 4 * me);
   }
@@ -451,7 +452,8 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (q0 + q < ng) {
-              const f32x4 w = reinterpret_cast<const f32x4*>(wz)[(part * gpp + q0 + q) * C + (int)ix[q]];
+              const int e = (part * gpp + q0 + q) * C + (int)ix[q];
+              const f32x4 w = a.wz_global ? *reinterpret_cast<const f32x4*>(a.wzt + (size_t)e * Hd + 4 * me) : reinterpret_cast<const f32x4*>(wz)[e];
               acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
             }
         }
@@ -522,15 +524,17 @@ __global__ void __launch_bounds__(RL_THREADS) rssm_lds_fwd_kernel(const RlArgs a
     }
     RL_TICK(2);
     // ---- C. x2 = h W_post_h^T + b + post_mlp_e(embed); then gh of step t+1 from the same h                rssm.py:143-144
-    if (roleC) {
+    if (roleC || (roleB && more)) {      // (unit owners past the last hidden block - deter_dim > hidden_dim - still need h for their gh)
       __amdgpu_buffer_rsrc_t rs = rl_rsrc(xs, a.step_bytes);
       __amdgpu_buffer_rsrc_t rh = rl_rsrc(xs + a.off_h, (unsigned)a.nB * blk);      // the h blocks
       if (!rl_sweep<RL>(a, rh, xo, xjs, true, v)) lflag[0] = 1u;
       RL_TICK(3);
       f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      rl_dot<RL, 1, false>(acc1, v, a.nB, kg, wave, lane, wc);
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL && tid < B) {
+      if (roleC) {
+        rl_dot<RL, 1, false>(acc1, v, a.nB, kg, wave, lane, wc);
+        rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
+      }
+      if (roleC && tid < RL && tid < B) {
         f32x4 o = *reinterpret_cast<const f32x4*>(a.bph + 4 * me);
         const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.ee + (r0 + tid) * Hd + 4 * me);
         o.x += e4.x + rl_red_sum<RL, 1>(red, tid, 0); o.y += e4.y + rl_red_sum<RL, 1>(red, tid, 1);
@@ -751,6 +755,7 @@ struct RlPlan {
   size_t lds_bytes;
   unsigned step_bytes, off_h, off_c, off_d, off_i;
   int l_wz, l_wg, l_wh, l_wc, l_wd, l_gb1, l_gb2, l_red, l_gh, l_hown, l_stage, l_flag;
+  int wz_global;
 };
 
 int g_rssm_lds = getenv("DM_RSSM_LDS") ? atoi(getenv("DM_RSSM_LDS")) : 1;
@@ -759,7 +764,7 @@ unsigned* g_host_err = nullptr;      // mapped pinned word
 unsigned* g_host_err_dev = nullptr;
 std::mutex g_mu;
 
-bool rl_plan(int B, int D, int Hd, int S, int C, RlPlan* pl) {
+bool rl_plan_one(int B, int D, int Hd, int S, int C, int wz_global, RlPlan* pl) {
   if (B < 1 || B > 64 || C < 4 || (C & 3) || S < 1 || (D & 3) || (Hd & 3)) return false;
   RlPlan p;
   p.rl = B <= 8 ? 8 : (B <= 16 ? 16 : (B <= 32 ? 32 : 64));
@@ -772,7 +777,8 @@ bool rl_plan(int B, int D, int Hd, int S, int C, RlPlan* pl) {
   auto take = [&](int floats) { const int o = off; off += (floats + 3) & ~3; return o; };
   const int grid = RL_WAVES * (64 / p.rl);
   const int PH = (Hd / 4 + grid - 1) / grid * grid, PD = (D / 4 + grid - 1) / grid * grid;      // = rl_pad_blocks<rl>
-  p.l_wz = take(Z * 4); p.l_wg = take(PH * 48); p.l_wh = take(PD * 48); p.l_wc = take(PD * 16); p.l_wd = take(PH * 16);
+  p.wz_global = wz_global;
+  p.l_wz = take(wz_global ? 4 : Z * 4); p.l_wg = take(PH * 48); p.l_wh = take(PD * 48); p.l_wc = take(PD * 16); p.l_wd = take(PH * 16);
   p.l_gb1 = take(8 * PH); p.l_gb2 = take(8 * PH);
   int red = RL_RED_WAVES * p.rl * 12;                           // wave partials of a 12-column product (two rounds)
   if (red < RL_WAVES * p.rl * 4) red = RL_WAVES * p.rl * 4;     // ... of a 4-column product; LayerNorm statistics
@@ -1189,6 +1195,13 @@ bool rb_plan(int B, int D, int Hd, int S, int C, RbPlan* pl) {
   return true;
 }
 
+bool rl_plan(int B, int D, int Hd, int S, int C, RlPlan* pl) {
+  // everything in LDS if it fits 160 KB; else z_mlp^T stays in L2 (16 KB less: pydreamer's shipped Atari configuration, deter 1024, B <= 32)
+  if (!rl_plan_one(B, D, Hd, S, C, 0, pl)) return false;
+  if (pl->lds_bytes > 160 * 1024) return rl_plan_one(B, D, Hd, S, C, 1, pl);
+  return true;
+}
+
 bool rl_device_ok(int G, size_t lds_bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_cus < 0) {
@@ -1267,6 +1280,7 @@ int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st) {
   a.step_bytes = p.step_bytes; a.off_h = p.off_h; a.off_c = p.off_c; a.off_d = p.off_d; a.off_i = p.off_i;
   a.host_err = g_host_err_dev;
   a.prof = g_rl_prof;
+  a.wz_global = p.wz_global;
   a.l_wz = p.l_wz; a.l_wg = p.l_wg; a.l_wh = p.l_wh; a.l_wc = p.l_wc; a.l_wd = p.l_wd; a.l_gb1 = p.l_gb1; a.l_gb2 = p.l_gb2;
   a.l_red = p.l_red; a.l_gh = p.l_gh;
   a.l_hown = p.l_hown; a.l_stage = p.l_stage; a.l_flag = p.l_flag;

@@ -9,7 +9,7 @@ from oracle import dreamer_oracle as O
 from pydreamer_amd import config, hip as H
 from pydreamer_amd.models import Dreamer
 
-T, D_, Hd, S, C, A, depth = 50, 600, 1000, 32, 32, 18, 8
+T, D_, Hd, S, C, A, depth = 50, int(os.environ.get('DETER', 600)), 1000, 32, 32, 18, 8      # DETER=1024: pydreamer's shipped Atari cell
 lib = H.lib()
 for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
     oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A, batch_size=B, batch_length=T)

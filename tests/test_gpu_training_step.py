@@ -454,8 +454,8 @@ def test_dream_rollout_bf16_storage_twins_match_fp32_storage(hip):
     _close(f1[:, zsame], f0[:, zsame], 0, 2e-5, 'dream features, twins on vs off')
 
 
-@pytest.mark.parametrize('B', [6, 7, 13, 25, 50, 64])
-def test_rssm_lds_chain_matches_launch_schedule(hip, B):
+@pytest.mark.parametrize('B,D_', [(6, 600), (7, 600), (13, 600), (25, 600), (50, 600), (64, 600), (32, 1024)])
+def test_rssm_lds_chain_matches_launch_schedule(hip, B, D_):
     """The posterior T loop as ONE persistent kernel whose workgroups keep the cell's weight slices in LDS (csrc/rssm_lds.hip:
     one workgroup per CU on all XCDs, activation rows exchanged through poison-filled per-step buffers) against the
     five-launch fused schedule it replaces, at the Atari-literal cell width, T = 12, for the row counts of a 1 / 2 / 4 / 8-way
@@ -463,10 +463,12 @@ def test_rssm_lds_chain_matches_launch_schedule(hip, B):
     arithmetic up to fp32 summation order (K is split over waves and k-groups differently), same sampler rule: sampled
     indices equal (a uniform within an ulp of a CDF edge excepted: >= 99.9 %), logits / states / saved activations within
     2e-5 + 1e-5 relative of the launch schedule on the rows whose history of indices is identical; the kernel never gave up
-    in a spin loop.  (Parity with the reference itself: test_rssm_sequence_fwd_bwd_vs_oracle runs this kernel too.)"""
+    in a spin loop.  (32, 1024) is pydreamer's own shipped Atari cell (defaults+atari: B = 32, deter_dim 1024): its slices fill a
+    CU's LDS only with z_mlp^T left in L2 (`wz_global`).  (Parity with the reference itself: test_rssm_sequence_fwd_bwd_vs_oracle
+    and both full-size golden replays run this kernel too.)"""
     import ctypes
     from pydreamer_amd import hip as H
-    T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
+    T, Hd, S, C, A, depth = 12, 1000, 32, 32, 18, 8
     oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
                         batch_size=B, batch_length=T)
     model = _build(oconf, O.make_params(oconf, seed=4))
