@@ -1227,6 +1227,55 @@ bool rl_device_ok(int G, size_t lds_bytes) {
   return g_host_err_dev && G <= g_cus && lds_bytes <= (size_t)g_lds_max && (lds_bytes > 80 * 1024 || g_rssm_lds >= 2);
 }
 
+// Two kernels that each need every CU at once must never be in flight together (each would hold some CUs and spin for the rest):
+// within a process, a launch waits for the previous persistent launch of ANY stream and records itself behind it.  (Other
+// processes' kernels are time-sliced against ours by the driver, not co-scheduled.)
+hipEvent_t g_chip_lease = nullptr;
+std::mutex g_lease_mu;
+int rl_launch_exclusive(const void* fn, unsigned grid, void** args, size_t lds_bytes, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_lease_mu);
+  if (!g_chip_lease && hipEventCreateWithFlags(&g_chip_lease, hipEventDisableTiming) != hipSuccess) {
+    g_chip_lease = nullptr;
+    return dm_fail(DM_E_HIP, "rssm_lds: cannot create the chip-lease event");
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (!capturing && hipStreamWaitEvent(st, g_chip_lease, 0) != hipSuccess) (void)hipGetLastError();      // (never recorded yet: no-op)
+  if (hipLaunchKernel(fn, dim3(grid), dim3(RL_THREADS), args, lds_bytes, st) != hipSuccess)
+    return dm_fail(DM_E_HIP, "rssm_lds: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!capturing && hipEventRecord(g_chip_lease, st) != hipSuccess) (void)hipGetLastError();
+  return DM_OK;
+}
+
+// The kernels need more dynamic LDS than the 64 KB default: raised once per variant; a driver that refuses leaves the launch chain in charge.
+template <class FN>
+bool rl_raise_lds(FN fn, int slot) {
+  static int state[16] = {0};      // 0 untried, 1 ok, -1 refused
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (state[slot] == 0) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_max);
+    if (e != hipSuccess) (void)hipGetLastError();
+    state[slot] = e == hipSuccess ? 1 : -1;
+  }
+  return state[slot] == 1;
+}
+bool rl_fwd_ready(int rl) {
+  switch (rl) {
+    case 8: return rl_raise_lds(rssm_lds_fwd_kernel<8>, 0);
+    case 16: return rl_raise_lds(rssm_lds_fwd_kernel<16>, 1);
+    case 32: return rl_raise_lds(rssm_lds_fwd_kernel<32>, 2);
+    default: return rl_raise_lds(rssm_lds_fwd_kernel<64>, 3);
+  }
+}
+bool rl_bwd_ready(int rl) {
+  switch (rl) {
+    case 8: return rl_raise_lds(rssm_lds_bwd_kernel<8>, 4);
+    case 16: return rl_raise_lds(rssm_lds_bwd_kernel<16>, 5);
+    case 32: return rl_raise_lds(rssm_lds_bwd_kernel<32>, 6);
+    default: return rl_raise_lds(rssm_lds_bwd_kernel<64>, 7);
+  }
+}
+
 }  // namespace
 
 // 1 / 0: run the posterior chain's steps as the LDS-weight-stationary persistent kernel when the shape qualifies / always
@@ -1240,7 +1289,7 @@ extern "C" int dm_rssm_lds_status(void) { return g_host_err ? (int)*(volatile un
 
 bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C) {
   RlPlan p;
-  return g_rssm_lds && rl_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes);
+  return g_rssm_lds && rl_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes) && rl_fwd_ready(p.rl);
 }
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
   RlPlan p;
@@ -1296,16 +1345,9 @@ int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st) {
     case 32: fn = reinterpret_cast<const void*>(rssm_lds_fwd_kernel<32>); break;
     default: fn = reinterpret_cast<const void*>(rssm_lds_fwd_kernel<64>); break;
   }
-  static std::mutex attr_mu;
-  {
-    std::lock_guard<std::mutex> lk(attr_mu);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes) != hipSuccess)
-      return dm_fail(DM_E_HIP, "rssm_lds: cannot raise the dynamic LDS limit to %zu bytes: %s", p.lds_bytes,
-                     hipGetErrorString(hipGetLastError()));
-  }
+  if (!rl_fwd_ready(p.rl)) return dm_fail(DM_E_HIP, "rssm_lds: the driver refused %zu bytes of dynamic LDS", p.lds_bytes);
   void* args[] = {&a};
-  if (hipLaunchKernel(fn, dim3((unsigned)p.G), dim3(RL_THREADS), args, p.lds_bytes, st) != hipSuccess)
-    return dm_fail(DM_E_HIP, "rssm_lds: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  DM_TRY(rl_launch_exclusive(fn, (unsigned)p.G, args, p.lds_bytes, st));
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -1325,7 +1367,7 @@ extern "C" int dm_rssm_lds_bwd_enable(int on) {
 }
 bool dm_rssm_lds_bwd_ok(int B, int D, int Hd, int S, int C) {
   RbPlan p;
-  return g_rssm_lds && g_rssm_lds_bwd && rb_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes);
+  return g_rssm_lds && g_rssm_lds_bwd && rb_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes) && rl_bwd_ready(p.rl);
 }
 size_t dm_rssm_lds_bwd_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
   RbPlan p;
@@ -1364,16 +1406,9 @@ int dm_rssm_lds_bwd_launch(const DmRssmLdsBwd& q, hipStream_t st) {
     case 32: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<32>); break;
     default: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<64>); break;
   }
-  static std::mutex attr_mu;
-  {
-    std::lock_guard<std::mutex> lk(attr_mu);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes) != hipSuccess)
-      return dm_fail(DM_E_HIP, "rssm_lds_bwd: cannot raise the dynamic LDS limit to %zu bytes: %s", p.lds_bytes,
-                     hipGetErrorString(hipGetLastError()));
-  }
+  if (!rl_bwd_ready(p.rl)) return dm_fail(DM_E_HIP, "rssm_lds_bwd: the driver refused %zu bytes of dynamic LDS", p.lds_bytes);
   void* args[] = {&a};
-  if (hipLaunchKernel(fn, dim3((unsigned)p.G), dim3(RL_THREADS), args, p.lds_bytes, st) != hipSuccess)
-    return dm_fail(DM_E_HIP, "rssm_lds_bwd: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  DM_TRY(rl_launch_exclusive(fn, (unsigned)p.G, args, p.lds_bytes, st));
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
