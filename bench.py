@@ -472,7 +472,9 @@ def main():
         try:
             with open(args.pmc_json) as f:
                 pj = json.load(f)
-            if pj.get('csrc_sha') != csrc_sha():
+            if args.workload != 'atari-literal':
+                traffic_note = f"{os.path.relpath(args.pmc_json, ROOT)} was collected on the atari-literal workload, not on '{args.workload}': not applied"
+            elif pj.get('csrc_sha') != csrc_sha():
                 traffic_note = (f"{os.path.relpath(args.pmc_json, ROOT)} was collected for kernel sources {pj.get('csrc_sha')}, the tree is "
                                 f"{csrc_sha()}: stale, refused")
             else:
