@@ -70,11 +70,12 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 8 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 9 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
-                                         v8: dm_rssm_lds_* replace dm_rssm_persist_*) */
+                                         v8: dm_rssm_lds_* replace dm_rssm_persist_*;
+                                         v9: dm_bptt_fold_enable added, dm_fp32_mode (split-bf16 fp32 products) removed) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -133,6 +134,9 @@ int dm_rssm_lds_enable(int on);
 int dm_rssm_lds_bwd_enable(int on);     /* the BPTT loop of dm_rssm_sequence_bwd as a second persistent kernel of the same kind: 1.6x faster alone, slower
                                             inside the multi-stream training step (it needs every CU at once) - OFF by default, DM_RSSM_LDS_BWD=1;
                                             needs dm_rssm_lds_enable too */
+int dm_bptt_fold_enable(int on);        /* launch schedule of the BPTT loop: the two LayerNorm+ELU backward stages of a step folded into the products
+                                            that consume them, dx W = rstd (g W - mean(g) colsum(W) - mean(g xhat) xhat W), so those products start
+                                            with their operand loads instead of a row reduction.  ON by default (DM_BPTT_FOLD=0); -1 queries. */
 int dm_rssm_lds_status(void);
 int dm_rssm_lds_prof(unsigned long long* out16, int reset);
 

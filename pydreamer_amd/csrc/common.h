@@ -121,6 +121,18 @@ struct DmGemm {
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-3f;
   // LayerNorm+ELU BACKWARD prologue on A (A holds dy; the product uses dx): lnb_x = pre-activations, lnb_stats = (mean, rstd)
   const float* lnb_x = nullptr; int lnb_ldx = 0; const float* lnb_stats = nullptr;
+  // The same backward in FOLDED form, split over the product that MAKES dy and the one that consumes dx (the BPTT launch schedule,
+  // rssm.hip): dx B^T = rstd (g B^T - mean(g) cs - mean(g xhat) xhat B^T), g = dy ELU'(pre) gamma, xhat B^T = rstd (x B^T - mean cs).
+  //   producer (C = dy): eg_x / eg_ldx pre-activations, eg_stats (mean, rstd), eg_gamma / eg_beta; its epilogue also writes
+  //     g (eg_G row-major, leading dim eg_ldg, and / or eg_Gf fragment-major) and, per 16-column strip, the row sums of g and
+  //     g xhat (eg_ps[strip][64][2]) - the transform is done ONCE, by the workgroup that owns the element;
+  //   consumer (A = g, a plain product): lnf_ps / lnf_nps those partial sums, lnf_stats, lnf_xw = x B^T for these rows
+  //     (leading dim lnf_ldxw), lnf_cs[n] = sum_k B(n,k); the correction enters in its epilogue.
+  // <= 64-row skinny products only.
+  const float* eg_x = nullptr; int eg_ldx = 0; const float* eg_stats = nullptr; const float* eg_gamma = nullptr; const float* eg_beta = nullptr;
+  float* eg_G = nullptr; int eg_ldg = 0; float* eg_Gf = nullptr; float* eg_ps = nullptr;
+  const float* lnf_ps = nullptr; int lnf_nps = 0; const float* lnf_stats = nullptr;
+  const float* lnf_xw = nullptr; int lnf_ldxw = 0; const float* lnf_cs = nullptr;
   const struct DmGatesBwd* gates = nullptr;       // GRU gates backward in the epilogue (C = dh', N = D), skinny products only
   // Fragment-major copies of <= 64-row chain operands (dm_frag_off): A_frag mirrors A (the skinny kernel then loads its
   // MFMA fragments as contiguous KiB instead of 16 rows x 64 B per instruction); C_frag receives such a copy of C for

@@ -33,6 +33,12 @@ struct SkinnyArgs {
   //   dx = rstd * (g - mean_row(g) - xhat * mean_row(g xhat)),  g = dy * ELU'(pre) * gamma,  pre = xhat * gamma + beta
   // with x (pre-activations, leading dim ldx2) and the saved statistics (mean, rstd per row)
   const float* lnb_x; int lnb_ldx; const float* lnb_stats;
+  // the same backward FOLDED and split over two products (common.h DmGemm::eg_x / lnf_ps): the producer's epilogue turns its
+  // dy into g = dy ELU'(pre) gamma and leaves the strip's row sums of g and g xhat; the consumer is a PLAIN product on g whose
+  // epilogue applies  rstd (P - mean(g) cs - mean(g xhat) rstd (x B^T - mean cs))
+  const float* eg_x; int eg_ldx; const float* eg_stats; const float* eg_gamma; const float* eg_beta;
+  float* eg_G; int eg_ldg; float* eg_Gf; float* eg_ps;
+  const float* lnf_ps; int lnf_nps; const float* lnf_stats; const float* lnf_xw; int lnf_ldxw; const float* lnf_cs;
   // EPI 2 (GRU gates backward in the epilogue; the strip holds 16 hidden units of dh' = C): see skinny_gates_bwd
   const float* gb_gi; const float* gb_gh; const float* gb_hin; int gb_ldh, gb_D;
   float* gb_dgi; float* gb_dgh; float* gb_dprev; int gb_ldp; const uint8_t* gb_rz;
@@ -104,6 +110,7 @@ struct __attribute__((aligned(16))) SkinnyShared {
   float lnstat[64][4];      // mean, rstd (+ MODE 2: mean(g), mean(g xhat))
   float lng[SK_LN_MAXK];
   float lnb[SK_LN_MAXK];
+  float psum[8][64][2];      // folded LayerNorm backward, consumer side: eight interleaved sub-sums of the producer's strip sums
 };
 
 // One (16*NRB) x (16*NCB) output strip; NRB = populated 16-row blocks (M <= 16*NRB): a 7-row data-parallel shard reads
@@ -131,6 +138,14 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (g.lnf_ps) {
+    // thread (part, which, row) adds every 8th strip's sum: one round of independent loads per wave, combined (fixed order) in
+    // the epilogue behind the barrier that already separates it from the main loop
+    const int r = tid & 63, wq = (tid >> 6) & 1, pt = tid >> 7;
+    float sacc = 0.f;
+    for (int i = pt; i < g.lnf_nps; i += 8) sacc += g.lnf_ps[((size_t)i * 64 + r) * 2 + wq];
+    sh->psum[pt][r][wq] = sacc;
+  }
   if (LNA && !reuse_prologue) {
     // row statistics of this strip's A rows (two-pass, the row cached in registers: K <= 1024), gamma / beta staged in LDS
     for (int e = tid; e < g.K; e += SK_WAVES * 64) { sh->lng[e] = g.ln_g[e]; sh->lnb[e] = g.ln_b[e]; }
@@ -289,9 +304,20 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
     const int lr = e / PW, lc = e % PW;
     const int row = m0 + lr, col = n0 + lc;
     float v = 0.f;
-    if (row < g.M && col < g.N) {
+    const bool valid = row < g.M && col < g.N;
+    if (valid) {
 #pragma unroll
       for (int w = 0; w < SK_WAVES; ++w) v += part[(size_t)w * (64 * PW) + e];
+      if (g.lnf_ps) {
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) { p0 += sh->psum[pt][lr][0]; p1 += sh->psum[pt][lr][1]; }
+        const float mg = p0 / (float)g.K, mgx = p1 / (float)g.K;
+        const float mean = g.lnf_stats[2 * (size_t)row], rstd = g.lnf_stats[2 * (size_t)row + 1];
+        const float cs = g.lnf_cs[col];
+        const float xhw = rstd * (g.lnf_xw[(size_t)row * g.lnf_ldxw + col] - mean * cs);
+        v = rstd * (v - mg * cs - mgx * xhw);
+      }
       if (g.row_zero && g.row_zero[row]) v = 0.f;
       if (g.bias) v += g.bias[col];
       if (g.add) v += g.add[(size_t)row * g.ldadd + col];
@@ -328,6 +354,23 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
           g.gb_dprev[(size_t)row * g.gb_ldp + col] += dv;
         }
       }
+    }
+    if (PW == 16 && g.eg_x) {      // (workgroup-uniform) v = dy[row][col], complete
+      float gg = 0.f, gx = 0.f;
+      if (valid) {
+        const float mean = g.eg_stats[2 * (size_t)row], rstd = g.eg_stats[2 * (size_t)row + 1];
+        const float ga = g.eg_gamma[col];
+        const float xh = (g.eg_x[(size_t)row * g.eg_ldx + col] - mean) * rstd;
+        const float pre = xh * ga + g.eg_beta[col];
+        gg = v * (pre > 0.f ? 1.f : __expf(pre)) * ga;
+        gx = gg * xh;
+        if (g.eg_G) g.eg_G[(size_t)row * g.eg_ldg + col] = gg;
+        if (g.eg_Gf) g.eg_Gf[dm_frag_off(row, col)] = gg;
+      }
+      // the 16 columns of a row sit in 16 consecutive lanes (e = lr * 16 + lc): the strip's row sums, in a fixed order
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { gg += __shfl_xor(gg, o); gx += __shfl_xor(gx, o); }
+      if (lc == 0) { g.eg_ps[((size_t)strip * 64 + lr) * 2] = gg; g.eg_ps[((size_t)strip * 64 + lr) * 2 + 1] = gx; }
     }
     if (SAMPLE) tile[lr * 33 + lc] = v;
   }
@@ -438,6 +481,9 @@ static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ldadd = q.ldadd; a.flags = q.flags;
   a.ln_g = q.ln_g; a.ln_b = q.ln_b; a.ln_eps = q.ln_eps;
   a.lnb_x = q.lnb_x; a.lnb_ldx = q.lnb_ldx; a.lnb_stats = q.lnb_stats;
+  a.eg_x = q.eg_x; a.eg_ldx = q.eg_ldx; a.eg_stats = q.eg_stats; a.eg_gamma = q.eg_gamma; a.eg_beta = q.eg_beta;
+  a.eg_G = q.eg_G; a.eg_ldg = q.eg_ldg; a.eg_Gf = q.M <= 64 ? q.eg_Gf : nullptr; a.eg_ps = q.eg_ps;
+  a.lnf_ps = q.lnf_ps; a.lnf_nps = q.lnf_nps; a.lnf_stats = q.lnf_stats; a.lnf_xw = q.lnf_xw; a.lnf_ldxw = q.lnf_ldxw; a.lnf_cs = q.lnf_cs;
   a.gb_gi = nullptr; a.gb_gh = nullptr; a.gb_hin = nullptr; a.gb_ldh = 0; a.gb_D = 0; a.gb_dgi = nullptr; a.gb_dgh = nullptr;
   a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr; a.gb_dgif = nullptr; a.gb_dghf = nullptr;
   if (q.gates) {
@@ -461,6 +507,15 @@ bool dm_skinny_ln_ok(int M, int N, int K) {
 
 // Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
 int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
+  const bool folded = q.eg_x || q.lnf_ps;      // folded LayerNorm backward (producer / consumer side): skinny-only epilogues
+  if (folded) {
+    if (g_skinny_disabled || !skinny_ok(q, 64) || q.b_layout != 0 || q.ln_g || q.lnb_x)
+      return dm_fail(DM_E_SHAPE, "skinny gemm: the folded LayerNorm backward is built for plain <= 64-row skinny products (M=%d N=%d K=%d)", q.M, q.N, q.K);
+    if (q.eg_x && (!q.eg_stats || !q.eg_gamma || !q.eg_beta || !q.eg_ps || (!q.eg_G && !q.eg_Gf)))
+      return dm_fail(DM_E_SHAPE, "skinny gemm: folded LayerNorm backward, producer side: statistics, gamma, beta, an output for g and the strip sums are required");
+    if (q.lnf_ps && (!q.lnf_stats || !q.lnf_xw || !q.lnf_cs || q.lnf_nps < 1))
+      return dm_fail(DM_E_SHAPE, "skinny gemm: folded LayerNorm backward, consumer side: statistics, x B^T and the weights' k-sums are required");
+  }
   if (g_skinny_disabled || !skinny_ok(q, g_skinny_max_m)) return 0;
   if (q.C_frag && q.M > 64) return 0;      // the tiled path reports the misuse
   // beyond one chunk it pays only for short reductions over small weight matrices (measured at M = 350: 1000x1024
@@ -469,7 +524,7 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   const bool lnb = q.lnb_x != nullptr, ln = q.ln_g != nullptr && !lnb;
   if ((ln || lnb) && (q.K > SK_LN_MAXK || q.b_layout != 0 || !q.ln_b || !q.ln_g || q.M > 64)) return 0;
   if (lnb && (!q.lnb_stats || (q.lnb_ldx & 3) || ((uintptr_t)q.lnb_x & 15))) return 0;
-  if (q.gates && (!lnb || q.N != q.gates->D)) return 0;
+  if (q.gates && ((!lnb && !q.lnf_ps) || q.N != q.gates->D || q.b_layout != 0)) return 0;
   SkinnyArgs a;
   skinny_fill(q, a);
   const dim3 grid((unsigned)dm_cdiv(q.N, 16), (unsigned)dm_cdiv(q.M, 64));
@@ -480,7 +535,8 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
     else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 2, MODE_, EPI_>), grid, blk, 0, stream, a);         \
     else hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 4, MODE_, EPI_>), grid, blk, 0, stream, a);                        \
   } while (0)
-  if (lnb && q.gates) SK_LAUNCH(0, 2, 2);
+  if (!lnb && q.gates) SK_LAUNCH(0, 0, 2);      // (consumer side of the folded LayerNorm backward)
+  else if (lnb && q.gates) SK_LAUNCH(0, 2, 2);
   else if (lnb) SK_LAUNCH(0, 2, 0);
   else if (ln) SK_LAUNCH(0, 1, 0);
   else if (q.b_layout == 0) SK_LAUNCH(0, 0, 0);
@@ -495,6 +551,8 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
 // dm_skinny_ln_ok first).
 int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_bytes, hipStream_t stream) {
   const bool ln0 = q0.ln_g != nullptr && !q0.lnb_x, lnb1 = q1.lnb_x != nullptr;
+  DM_REQUIRE(!q0.eg_x && !q1.eg_x && !q0.lnf_ps && (!q1.lnf_ps || (q1.lnf_stats && q1.lnf_xw && q1.lnf_cs && q1.lnf_nps >= 1 && !q1.lnb_x && !q1.ln_g)),
+             DM_E_SHAPE, "gemm pair: the folded LayerNorm backward is built for the consumer side on the second product");
   DM_REQUIRE(!q0.lnb_x && !(q1.ln_g && !q1.lnb_x) && !q0.gates && !q1.gates, DM_E_SHAPE,
              "gemm pair: built for a forward LayerNorm prologue on the first product or a backward one on the second");
   const bool fused = ln0 || lnb1;
@@ -521,7 +579,7 @@ int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
-  DM_REQUIRE(!fused, DM_E_SHAPE, "gemm pair: LayerNorm prologue requested but the one-launch skinny path does not apply");
+  DM_REQUIRE(!fused && !q1.lnf_ps, DM_E_SHAPE, "gemm pair: LayerNorm prologue / folded backward requested but the one-launch skinny path does not apply");
   DM_TRY(dm_gemm_launch(q0, ws, ws_bytes, stream));
   return dm_gemm_launch(q1, ws, ws_bytes, stream);
 }

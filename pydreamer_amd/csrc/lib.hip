@@ -16,7 +16,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 8; }
+extern "C" int dm_version(void) { return 9; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -179,7 +179,7 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t Zw = (size_t)s->S * (s->C ? s->C : 1);
   const size_t lds_fwd = SK + pad64(Zw * Hd) + 5 * pad64((Zw + 15) / 16 * 1024) +
                          (s->C ? pad64(dm_rssm_lds_ws_floats(s->B, s->D, s->Hd, s->S, s->C, s->T)) : 0) + 1024;
-  const size_t rssm_bwd_lds = rssm_bwd + pad64(N * D) + pad64(N * Zw) +
+  const size_t rssm_bwd_lds = rssm_bwd + pad64(N * D) + pad64(N * Zw) + pad64(D) + pad64(Zw) + 2 * pad64((Hd + 15) / 16 * 128) +      // (+ the folded launch schedule's column sums and strip sums)
                               (s->C ? pad64(dm_rssm_lds_bwd_ws_floats(s->B, s->D, s->Hd, s->S, s->C, s->T)) : 0);
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials

@@ -417,6 +417,13 @@ extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const
                                     idx, ws, ws_bytes, stream);
 }
 
+// A/B switch of the BPTT launch schedule's folded LayerNorm backward (include/dreamer_hip.h dm_bptt_fold_enable; DM_BPTT_FOLD=0 in the environment)
+static int g_bptt_fold = getenv("DM_BPTT_FOLD") ? (atoi(getenv("DM_BPTT_FOLD")) ? 1 : 0) : 1;
+extern "C" int dm_bptt_fold_enable(int on) {
+  const int was = g_bptt_fold;
+  if (on >= 0) g_bptt_fold = on ? 1 : 0;
+  return was;
+}
 extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
                                     const dm_rssm_params* P, const float* acts, const float* feat, const float* post,
                                     float* dfeat, float* dpost, float* dprior, const dm_rssm_grads* G, float* dembed,
@@ -539,6 +546,30 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   // all rows by two batched launches after the loop.
   const bool fuse_b = lds_bwd || (p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
                                   dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0);
+  // ... in FOLDED form (common.h DmGemm::eg_x): the product that makes dpin (dza) also turns it into g = dy ELU'(pre) gamma in
+  // its epilogue - once, by the workgroup that owns the element, instead of once per consuming workgroup in a prologue - and
+  // the consuming product is a plain one whose epilogue applies the two row-mean terms.  That needs x2 W_post_h and x1 W_z for
+  // all rows (two batched products here, the ones the persistent kernel uses) and the weights' column sums.
+  bool fold = fuse_b && !lds_bwd && g_bptt_fold && B <= 64 && (int64_t)Hd * ZP >= (int64_t)64 * 1024 &&
+              (int64_t)Hd * 3 * D >= (int64_t)64 * 1024 && (ZP & 3) == 0 && ((3 * D) & 3) == 0 && ZP >= 16;
+  float *cs2 = nullptr, *csz = nullptr, *eps2 = nullptr, *eps1 = nullptr;
+  const int nstrip = (Hd + 15) / 16;
+  if (fold) {
+    const size_t mark = ar.off;
+    xw2 = ar.take((size_t)N * D);
+    xwz = ar.take((size_t)N * Z);
+    cs2 = ar.take((size_t)D);
+    csz = ar.take((size_t)Z);
+    eps2 = ar.take((size_t)nstrip * 128);
+    eps1 = ar.take((size_t)nstrip * 128);
+    if (!ar.ok) { ar.off = mark; ar.ok = true; fold = false; }       // a small caller workspace keeps the prologue form
+  }
+  if (fold) {
+    DM_TRY(dgrad(st, sk, skb, N, Hd, D, a.x2, Hd, p[DM_RSSM_POST_H_W], xw2, D, 0, nullptr));      // x2 W_post_h
+    DM_TRY(dgrad(st, sk, skb, N, Hd, Z, a.x1, Hd, p[DM_RSSM_Z_W], xwz, Z, 0, nullptr));           // x1 W_z
+    DM_TRY(dm_colsum_launch(Hd, D, p[DM_RSSM_POST_H_W], D, cs2, sk, skb, st));
+    DM_TRY(dm_colsum_launch(Hd, Z, p[DM_RSSM_Z_W], Z, csz, sk, skb, st));
+  }
   // fragment-major copies (common.h dm_frag_off) of the two K = 3D operands of a step, dgi and dgh: written by the gates
   // backward epilogue, read by the two products that follow it
   static const int no_frag = getenv("DM_SKINNY_NO_FRAG") ? 1 : 0;
@@ -588,6 +619,11 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       DmGemm q3;   // dpin = dpost Wpost
       q3.M = B; q3.N = Hd; q3.K = ZP; q3.A = dpt; q3.lda = ZP; q3.B = wt_post; q3.ldb = ZP; q3.C = dpin + r0 * Hd; q3.ldc = Hd;
       q3.C_frag = dpinf;
+      if (fold) {      // + g2 = dpin ELU'(pre2) gamma (row-major into the dx2 rows - re-made in batch after the loop - and fragment-major)
+        q3.C_frag = nullptr;
+        q3.eg_x = a.x2 + r0 * Hd; q3.eg_ldx = Hd; q3.eg_stats = a.st2 + r0 * 2; q3.eg_gamma = p[DM_RSSM_POST_G]; q3.eg_beta = p[DM_RSSM_POST_B];
+        q3.eg_G = dx2 + r0 * Hd; q3.eg_ldg = Hd; q3.eg_Gf = dpinf; q3.eg_ps = eps2;
+      }
       DM_TRY(dm_gemm_launch(q3, sk, skb, st));
     } else {
       DM_TRY(dgrad_t(st, sk, skb, B, ZP, Hd, dpt, ZP, wt_post, dpin + r0 * Hd, Hd, 0, nullptr));
@@ -604,11 +640,20 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
       q4.C = dft; q4.ldc = F; q4.flags = DM_GEMM_ACCUM;
       q4.ln_g = p[DM_RSSM_POST_G]; q4.ln_b = p[DM_RSSM_POST_B]; q4.lnb_x = a.x2 + r0 * Hd; q4.lnb_ldx = Hd;
       q4.lnb_stats = a.st2 + r0 * 2; q4.gates = &gb; q4.A_frag = dpinf;
+      if (fold) {      // a plain product on g2; the row-mean terms enter in the epilogue, in front of the gates backward
+        q4.A = dx2 + r0 * Hd; q4.ln_g = nullptr; q4.ln_b = nullptr; q4.lnb_x = nullptr; q4.lnb_stats = nullptr;
+        q4.lnf_ps = eps2; q4.lnf_nps = nstrip; q4.lnf_stats = a.st2 + r0 * 2; q4.lnf_xw = xw2 + r0 * D; q4.lnf_ldxw = D; q4.lnf_cs = cs2;
+      }
       DM_TRY(dm_gemm_launch(q4, sk, skb, st));
       {
         DmGemm q5;   // dza = dgi Wih
         q5.M = B; q5.N = Hd; q5.K = 3 * D; q5.A = dgi + r0 * 3 * D; q5.lda = 3 * D; q5.B = wt_ih; q5.ldb = 3 * D;
         q5.C = dza + r0 * Hd; q5.ldc = Hd; q5.A_frag = dgif; q5.C_frag = dzaf;
+        if (fold) {
+          q5.C_frag = nullptr;
+          q5.eg_x = a.x1 + r0 * Hd; q5.eg_ldx = Hd; q5.eg_stats = a.st1 + r0 * 2; q5.eg_gamma = p[DM_RSSM_IN_G]; q5.eg_beta = p[DM_RSSM_IN_B];
+          q5.eg_G = dx1 + r0 * Hd; q5.eg_ldg = Hd; q5.eg_Gf = dzaf; q5.eg_ps = eps1;
+        }
         DM_TRY(dm_gemm_launch(q5, sk, skb, st));
       }
       if (t > 0) {   // both products into step t-1's [dh' | dz']; the second one consumes LNbwd(dza)
@@ -620,6 +665,10 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
         qz.C = dprev + D; qz.ldc = F; qz.flags = DM_GEMM_ACCUM; qz.row_zero = rz;
         qz.ln_g = p[DM_RSSM_IN_G]; qz.ln_b = p[DM_RSSM_IN_B]; qz.lnb_x = a.x1 + r0 * Hd; qz.lnb_ldx = Hd;
         qz.lnb_stats = a.st1 + r0 * 2; qz.A_frag = dzaf;
+        if (fold) {
+          qz.A = dx1 + r0 * Hd; qz.ln_g = nullptr; qz.ln_b = nullptr; qz.lnb_x = nullptr; qz.lnb_stats = nullptr;
+          qz.lnf_ps = eps1; qz.lnf_nps = nstrip; qz.lnf_stats = a.st1 + r0 * 2; qz.lnf_xw = xwz + r0 * Z; qz.lnf_ldxw = Z; qz.lnf_cs = csz;
+        }
         DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));
       }
       DM_TRY(side_chunk(t));

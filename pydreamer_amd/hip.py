@@ -189,6 +189,7 @@ _SIGNATURES = {
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
     'dm_rssm_lds_bwd_enable': (c_int, [c_int]),
+    'dm_bptt_fold_enable': (c_int, [c_int]),
     'dm_rssm_lds_status': (c_int, []),
     'dm_rssm_lds_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),
@@ -199,7 +200,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 8      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 9      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

@@ -72,8 +72,9 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
     Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
     dembed = torch.zeros(T * B, E, device='cuda')
     keep_g = None
-    for on in (1, 0):
+    for on, fold in ((1, 1), (0, 1), (0, 0)):
         lib.dm_rssm_lds_bwd_enable(on)
+        lib.dm_bptt_fold_enable(fold)      # launch schedule only: the LayerNorm backward stages folded into the products that consume them
         per = []
         for rep in range(6):
             dfeat, dpost, dprior = Gf.clone(), Gp.clone(), Gq.clone()
@@ -87,8 +88,9 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
                 per.append(e0.elapsed_time(e1) * 1e3)
         per.sort()
         flat = torch.cat([x.flatten() for x in grads if x is not None])
-        print(f'B={B} bwd lds={on}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}), status {lib.dm_rssm_lds_status()}'
+        print(f'B={B} bwd lds={on} fold={fold}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}), status {lib.dm_rssm_lds_status()}'
               + ('' if keep_g is None else f'; gradients vs the persistent kernel: rel-L2 {float((flat - keep_g).norm() / keep_g.norm()):.2e}'))
         keep_g = flat.clone() if keep_g is None else keep_g
     lib.dm_rssm_lds_bwd_enable(1)
+    lib.dm_bptt_fold_enable(1)
 lib.dm_rssm_lds_enable(1)

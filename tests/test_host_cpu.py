@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
     lib = hip.lib()
-    assert lib.dm_version() == hip.DM_ABI_VERSION == 8
+    assert lib.dm_version() == hip.DM_ABI_VERSION == 9
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
@@ -239,6 +239,7 @@ def test_runtime_switch_defaults():
     if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_LDS', 'DM_CHAIN_GRAPH')):
         assert lib.dm_bf16_twins_enable(-1) == 1
         assert lib.dm_rssm_lds_enable(-1) == 1
+        assert lib.dm_bptt_fold_enable(-1) == 1 or os.environ.get('DM_BPTT_FOLD')
         assert lib.dm_rssm_lds_bwd_enable(-1) == 0 or os.environ.get('DM_RSSM_LDS_BWD')      # (slower inside the multi-stream step)
         assert lib.dm_chain_graph_enable(-1) == 0
     assert lib.dm_rssm_lds_status() == 0
