@@ -78,7 +78,7 @@ __device__ __forceinline__ void skinny_load(const SkinnyArgs& g, int m0, int n0,
   for (int mb = 0; mb < NRB; ++mb) {
     const int m = m0 + mb * 16 + l15;
     const bool ok = kin && m < g.M;
-    const float* ap = g.Af ? g.Af + ((((size_t)cc * 4 + mb) * 4 + q) * 16 + l15) * 4      // one contiguous KiB per instruction (rows past M hold stale data: masked like the clamped loads)
+    const float* ap = g.Af ? g.Af + ((((size_t)cc * 4 + (m0 >> 4) + mb) * 4 + q) * 16 + l15) * 4      // one contiguous KiB per instruction (rows past M hold stale data: masked like the clamped loads)
                            : g.A + (ok ? (size_t)m * g.lda + k : 0);
     a[mb] = COH ? sk_ld4_coh(ap) : *reinterpret_cast<const float4*>(ap);
     mask |= ok ? (1u << mb) : 0u;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       if (g.lnf_ps) {
         float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) { p0 += sh->psum[pt][lr][0]; p1 += sh->psum[pt][lr][1]; }
+        for (int pt = 0; pt < 8; ++pt) { p0 += sh->psum[pt][row][0]; p1 += sh->psum[pt][row][1]; }      // (M <= 64: row = the row of the 64)
         const float mg = p0 / (float)g.K, mgx = p1 / (float)g.K;
         const float mean = g.lnf_stats[2 * (size_t)row], rstd = g.lnf_stats[2 * (size_t)row + 1];
         const float cs = g.lnf_cs[col];
@@ -370,7 +370,7 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       // the 16 columns of a row sit in 16 consecutive lanes (e = lr * 16 + lc): the strip's row sums, in a fixed order
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { gg += __shfl_xor(gg, o); gx += __shfl_xor(gx, o); }
-      if (lc == 0) { g.eg_ps[((size_t)strip * 64 + lr) * 2] = gg; g.eg_ps[((size_t)strip * 64 + lr) * 2 + 1] = gx; }
+      if (lc == 0 && row < 64) { g.eg_ps[((size_t)strip * 64 + row) * 2] = gg; g.eg_ps[((size_t)strip * 64 + row) * 2 + 1] = gx; }
     }
     if (SAMPLE) tile[lr * 33 + lc] = v;
   }
@@ -438,7 +438,7 @@ template <int BL, int NRB, int MODE, int EPI = 0>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
   __shared__ float part[SK_WAVES * 64 * 16];
   __shared__ SkinnyShared sh;
-  skinny_strip<BL, NRB, 1, MODE, EPI, MODE == 2 ? 2 : 4>(g, blockIdx.x, blockIdx.y * 64, part, &sh, nullptr);   // grid.y = 64-row chunks of M
+  skinny_strip<BL, NRB, 1, MODE, EPI, MODE == 2 ? 2 : 4>(g, blockIdx.x, blockIdx.y * (16 * NRB), part, &sh, nullptr);   // grid.y = (16 NRB)-row chunks of M
 }
 // Posterior / prior head with the sampler in the epilogue: LayerNorm+ELU prologue, 32-wide strips (one categorical group
 // per workgroup), M <= 64.
@@ -453,15 +453,15 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
 // feed step t-1's state gradient.  Workgroups [0, nb0) serve the first product, the rest the second.
 // LNA0: the FIRST product's A operand goes through the LayerNorm+ELU prologue (gi = ELU(in_norm(x)) W_ih^T).
-struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0; };
+struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0, nb; };      // nb = strips of both products; blocks beyond it serve the next (16 NRB)-row chunk
 // MODE0 / MODE1: prologue of the first / second product (0 none, 1 LayerNorm+ELU forward, 2 LayerNorm+ELU backward)
 template <int NRB, int MODE0, int MODE1>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
   __shared__ float part[SK_WAVES * 64 * 16];
   __shared__ SkinnyShared sh;
-  const int b = blockIdx.x;
-  if (b < a.nb0) skinny_strip<0, NRB, 1, MODE0, 0, MODE0 == 2 ? 2 : 4>(a.g[0], b, 0, part, &sh, nullptr);
-  else skinny_strip<0, NRB, 1, MODE1, 0, MODE1 == 2 ? 2 : 4>(a.g[1], b - a.nb0, 0, part, &sh, nullptr);
+  const int b = blockIdx.x % a.nb, m0 = (blockIdx.x / a.nb) * (16 * NRB);
+  if (b < a.nb0) skinny_strip<0, NRB, 1, MODE0, 0, MODE0 == 2 ? 2 : 4>(a.g[0], b, m0, part, &sh, nullptr);
+  else skinny_strip<0, NRB, 1, MODE1, 0, MODE1 == 2 ? 2 : 4>(a.g[1], b - a.nb0, m0, part, &sh, nullptr);
 }
 
 // max_m: 64 for the pair kernel (one chunk); the single-product kernel walks M in 64-row chunks (grid.y) up to
@@ -497,6 +497,7 @@ static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
 }
 static const int g_skinny_disabled = getenv("DM_GEMM_NO_SKINNY") ? 1 : 0;      // A/B switch for scripts/gemm_bench.py
 static const int g_skinny_nofuse = getenv("DM_SKINNY_NO_FUSE") ? 1 : 0;        // A/B switch: keep LayerNorm / sampler launches
+static const int g_skinny_msplit = getenv("DM_SKINNY_MSPLIT") ? atoi(getenv("DM_SKINNY_MSPLIT")) : 2;      // A/B switch: 0 one workgroup per strip, 1 32-row halves, 2 also 16-row quarters
 
 // Can a <= 64-row product with reduction length K take the LayerNorm+ELU prologue (and, for N % 32 == 0, the sampler
 // epilogue)?  Shape-only test: rssm.hip picks the fused or the unfused schedule of the T loop with it.
@@ -527,12 +528,17 @@ int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
   if (q.gates && ((!lnb && !q.lnf_ps) || q.N != q.gates->D || q.b_layout != 0)) return 0;
   SkinnyArgs a;
   skinny_fill(q, a);
-  const dim3 grid((unsigned)dm_cdiv(q.N, 16), (unsigned)dm_cdiv(q.M, 64));
+  // 33..64 rows: two 32-row workgroups per strip instead of one 64-row one (half the matrix-pipe and operand work per
+  // workgroup on the chain's critical path; the strip's weights are read twice, from L2) while both fit the chip
+  const int nst = dm_cdiv(q.N, 16);
+  const bool quarters = g_skinny_msplit >= 2 && q.M > 16 && q.M <= 64 && dm_cdiv(q.M, 16) * nst <= 256;
+  const bool halves = !quarters && g_skinny_msplit && q.M > 32 && q.M <= 64 && 2 * nst <= 256;
+  const dim3 grid((unsigned)nst, (unsigned)(quarters ? dm_cdiv(q.M, 16) : halves ? 2 : dm_cdiv(q.M, 64)));
   const dim3 blk(SK_WAVES * 64);
 #define SK_LAUNCH(BL_, MODE_, EPI_)                                                                                     \
   do {                                                                                                                  \
-    if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 1, MODE_, EPI_>), grid, blk, 0, stream, a);              \
-    else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 2, MODE_, EPI_>), grid, blk, 0, stream, a);         \
+    if (q.M <= 16 || quarters) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 1, MODE_, EPI_>), grid, blk, 0, stream, a);  \
+    else if (q.M <= 32 || halves) hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 2, MODE_, EPI_>), grid, blk, 0, stream, a); \
     else hipLaunchKernelGGL((skinny_gemm_kernel<BL_, 4, MODE_, EPI_>), grid, blk, 0, stream, a);                        \
   } while (0)
   if (!lnb && q.gates) SK_LAUNCH(0, 0, 2);      // (consumer side of the folded LayerNorm backward)
@@ -563,12 +569,15 @@ int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
     a.nb0 = dm_cdiv(q0.N, 16);
-    const dim3 grid((unsigned)(a.nb0 + dm_cdiv(q1.N, 16))), blk(SK_WAVES * 64);
+    a.nb = a.nb0 + dm_cdiv(q1.N, 16);
     const int mmax = q0.M > q1.M ? q0.M : q1.M;
+    const bool quarters = g_skinny_msplit >= 2 && mmax > 16 && dm_cdiv(mmax, 16) * a.nb <= 256;
+    const bool halves = !quarters && g_skinny_msplit && mmax > 32 && 2 * a.nb <= 256;
+    const dim3 grid((unsigned)(quarters ? dm_cdiv(mmax, 16) * a.nb : halves ? 2 * a.nb : a.nb)), blk(SK_WAVES * 64);
 #define SKP_LAUNCH(M0_, M1_)                                                                                            \
   do {                                                                                                                  \
-    if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, M0_, M1_>), grid, blk, 0, stream, a);                \
-    else if (mmax <= 32) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, M0_, M1_>), grid, blk, 0, stream, a);           \
+    if (mmax <= 16 || quarters) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, M0_, M1_>), grid, blk, 0, stream, a);    \
+    else if (mmax <= 32 || halves) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, M0_, M1_>), grid, blk, 0, stream, a); \
     else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, M0_, M1_>), grid, blk, 0, stream, a);                           \
   } while (0)
     if (ln0 && !lnb1) SKP_LAUNCH(1, 0);
