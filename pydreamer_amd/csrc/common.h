@@ -133,6 +133,9 @@ struct DmGemm {
   float* eg_G = nullptr; int eg_ldg = 0; float* eg_Gf = nullptr; float* eg_ps = nullptr;
   const float* lnf_ps = nullptr; int lnf_nps = 0; const float* lnf_stats = nullptr;
   const float* lnf_xw = nullptr; int lnf_ldxw = 0; const float* lnf_cs = nullptr;
+  // straight-through softmax BACKWARD in the epilogue (skinny pair, second product, 32-class groups): the strip is one categorical
+  // group of the completed C row (C = dz'), and  sm_dlogits += p (dz' - sum_group p dz'),  p = softmax(sm_logits)  (rssm.py:147-148)
+  const float* sm_logits = nullptr; int sm_ld = 0; float* sm_dlogits = nullptr; int sm_ldd = 0;
   const struct DmGatesBwd* gates = nullptr;       // GRU gates backward in the epilogue (C = dh', N = D), skinny products only
   // Fragment-major copies of <= 64-row chain operands (dm_frag_off): A_frag mirrors A (the skinny kernel then loads its
   // MFMA fragments as contiguous KiB instead of 16 rows x 64 B per instruction); C_frag receives such a copy of C for

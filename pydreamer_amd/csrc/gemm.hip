@@ -1273,7 +1273,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
       return DM_OK;
     }
   }
-  DM_REQUIRE(!q.ln_g && !q.lnb_x && !q.gates && !q.eg_x && !q.lnf_ps, DM_E_SHAPE,
+  DM_REQUIRE(!q.ln_g && !q.lnb_x && !q.gates && !q.eg_x && !q.lnf_ps && !q.sm_logits, DM_E_SHAPE,
              "gemm: LayerNorm prologues / the gates epilogue are built for the <= 64-row skinny products only (M=%d K=%d)", q.M, q.K);
   // bf16-storage operands: given explicitly (both or neither), or found in the call's twin map (common.h DmTwinScope) when
   // BOTH operands have a valid twin and the shape meets the 16-byte chunk rules (8 elements along the minor axis); the

@@ -39,6 +39,8 @@ struct SkinnyArgs {
   const float* eg_x; int eg_ldx; const float* eg_stats; const float* eg_gamma; const float* eg_beta;
   float* eg_G; int eg_ldg; float* eg_Gf; float* eg_ps;
   const float* lnf_ps; int lnf_nps; const float* lnf_stats; const float* lnf_xw; int lnf_ldxw; const float* lnf_cs;
+  // straight-through softmax backward on the completed strip (32-wide strips: one categorical group), see DmGemm::sm_logits
+  const float* sm_logits; int sm_ld; float* sm_dlogits; int sm_ldd;
   // EPI 2 (GRU gates backward in the epilogue; the strip holds 16 hidden units of dh' = C): see skinny_gates_bwd
   const float* gb_gi; const float* gb_gh; const float* gb_hin; int gb_ldh, gb_D;
   float* gb_dgi; float* gb_dgh; float* gb_dprev; int gb_ldp; const uint8_t* gb_rz;
@@ -372,6 +374,22 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
       for (int o = 1; o < 16; o <<= 1) { gg += __shfl_xor(gg, o); gx += __shfl_xor(gx, o); }
       if (lc == 0 && row < 64) { g.eg_ps[((size_t)strip * 64 + row) * 2] = gg; g.eg_ps[((size_t)strip * 64 + row) * 2 + 1] = gx; }
     }
+    if (PW == 32 && g.sm_logits) {      // (workgroup-uniform) v = dz'[row][group `strip`], complete: same operation order as st_softmax_bwd_kernel<32>
+      const float x = valid ? g.sm_logits[(size_t)row * g.sm_ld + col] : -INFINITY;
+      const float gz = valid ? v : 0.f;
+      float mx = x;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float ex = valid ? expf(x - mx) : 0.f;
+      float se = ex, sg = ex * gz;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sg += __shfl_xor(sg, o, 64); }
+      if (valid) {
+        const float pr = ex / se;
+        float* o = g.sm_dlogits + (size_t)row * g.sm_ldd + col;
+        *o = *o + pr * (gz - sg / se);
+      }
+    }
     if (SAMPLE) tile[lr * 33 + lc] = v;
   }
   if (SAMPLE) {
@@ -455,13 +473,14 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const
 // LNA0: the FIRST product's A operand goes through the LayerNorm+ELU prologue (gi = ELU(in_norm(x)) W_ih^T).
 struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0, nb; };      // nb = strips of both products; blocks beyond it serve the next (16 NRB)-row chunk
 // MODE0 / MODE1: prologue of the first / second product (0 none, 1 LayerNorm+ELU forward, 2 LayerNorm+ELU backward)
-template <int NRB, int MODE0, int MODE1>
+// NCB1 = 2: the second product in 32-wide strips (softmax-backward epilogue: a strip is one categorical group)
+template <int NRB, int MODE0, int MODE1, int NCB1 = 1>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
-  __shared__ float part[SK_WAVES * 64 * 16];
+  __shared__ float part[SK_WAVES * 64 * 16 * NCB1];
   __shared__ SkinnyShared sh;
   const int b = blockIdx.x % a.nb, m0 = (blockIdx.x / a.nb) * (16 * NRB);
   if (b < a.nb0) skinny_strip<0, NRB, 1, MODE0, 0, MODE0 == 2 ? 2 : 4>(a.g[0], b, m0, part, &sh, nullptr);
-  else skinny_strip<0, NRB, 1, MODE1, 0, MODE1 == 2 ? 2 : 4>(a.g[1], b - a.nb0, m0, part, &sh, nullptr);
+  else skinny_strip<0, NRB, NCB1, MODE1, 0, (MODE1 == 2 || NCB1 == 2) ? 2 : 4>(a.g[1], b - a.nb0, m0, part, &sh, nullptr);
 }
 
 // max_m: 64 for the pair kernel (one chunk); the single-product kernel walks M in 64-row chunks (grid.y) up to
@@ -483,6 +502,7 @@ static void skinny_fill(const DmGemm& q, SkinnyArgs& a) {
   a.lnb_x = q.lnb_x; a.lnb_ldx = q.lnb_ldx; a.lnb_stats = q.lnb_stats;
   a.eg_x = q.eg_x; a.eg_ldx = q.eg_ldx; a.eg_stats = q.eg_stats; a.eg_gamma = q.eg_gamma; a.eg_beta = q.eg_beta;
   a.eg_G = q.eg_G; a.eg_ldg = q.eg_ldg; a.eg_Gf = q.M <= 64 ? q.eg_Gf : nullptr; a.eg_ps = q.eg_ps;
+  a.sm_logits = q.sm_logits; a.sm_ld = q.sm_ld; a.sm_dlogits = q.sm_dlogits; a.sm_ldd = q.sm_ldd;
   a.lnf_ps = q.lnf_ps; a.lnf_nps = q.lnf_nps; a.lnf_stats = q.lnf_stats; a.lnf_xw = q.lnf_xw; a.lnf_ldxw = q.lnf_ldxw; a.lnf_cs = q.lnf_cs;
   a.gb_gi = nullptr; a.gb_gh = nullptr; a.gb_hin = nullptr; a.gb_ldh = 0; a.gb_D = 0; a.gb_dgi = nullptr; a.gb_dgh = nullptr;
   a.gb_dprev = nullptr; a.gb_ldp = 0; a.gb_rz = nullptr; a.gb_dgif = nullptr; a.gb_dghf = nullptr;
@@ -508,6 +528,7 @@ bool dm_skinny_ln_ok(int M, int N, int K) {
 
 // Returns 1 if the launch was taken by the skinny kernel, 0 if the shape / alignment does not qualify, < 0 on error.
 int dm_gemm_skinny_try(const DmGemm& q, hipStream_t stream) {
+  if (q.sm_logits) return dm_fail(DM_E_SHAPE, "skinny gemm: the softmax-backward epilogue exists in the pair launch only");
   const bool folded = q.eg_x || q.lnf_ps;      // folded LayerNorm backward (producer / consumer side): skinny-only epilogues
   if (folded) {
     if (g_skinny_disabled || !skinny_ok(q, 64) || q.b_layout != 0 || q.ln_g || q.lnb_x)
@@ -568,8 +589,11 @@ int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_
     SkinnyPairArgs a;
     skinny_fill(q0, a.g[0]);
     skinny_fill(q1, a.g[1]);
+    const bool sm1 = q1.sm_logits != nullptr;      // 32-wide strips for the second product
+    if (sm1 && (ln0 || lnb1 || !q1.sm_dlogits || (q1.N & 31)))
+      return dm_fail(DM_E_SHAPE, "gemm pair: the softmax-backward epilogue is built for plain products with N %% 32 == 0");
     a.nb0 = dm_cdiv(q0.N, 16);
-    a.nb = a.nb0 + dm_cdiv(q1.N, 16);
+    a.nb = a.nb0 + dm_cdiv(q1.N, sm1 ? 32 : 16);
     const int mmax = q0.M > q1.M ? q0.M : q1.M;
     const bool quarters = g_skinny_msplit >= 2 && mmax > 16 && dm_cdiv(mmax, 16) * a.nb <= 256;
     const bool halves = !quarters && g_skinny_msplit && mmax > 32 && 2 * a.nb <= 256;
@@ -582,13 +606,17 @@ int dm_gemm_pair_launch(const DmGemm& q0, const DmGemm& q1, void* ws, size_t ws_
   } while (0)
     if (ln0 && !lnb1) SKP_LAUNCH(1, 0);
     else if (lnb1 && !ln0) SKP_LAUNCH(0, 2);
-    else if (!ln0 && !lnb1) SKP_LAUNCH(0, 0);
+    else if (sm1) {
+      if (mmax <= 16 || quarters) hipLaunchKernelGGL((skinny_gemm_pair_kernel<1, 0, 0, 2>), grid, blk, 0, stream, a);
+      else if (mmax <= 32 || halves) hipLaunchKernelGGL((skinny_gemm_pair_kernel<2, 0, 0, 2>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((skinny_gemm_pair_kernel<4, 0, 0, 2>), grid, blk, 0, stream, a);
+    } else if (!ln0 && !lnb1) SKP_LAUNCH(0, 0);
     else return dm_fail(DM_E_SHAPE, "gemm pair: forward and backward LayerNorm prologues in one launch are not built");
 #undef SKP_LAUNCH
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
-  DM_REQUIRE(!fused && !q1.lnf_ps, DM_E_SHAPE, "gemm pair: LayerNorm prologue / folded backward requested but the one-launch skinny path does not apply");
+  DM_REQUIRE(!fused && !q1.lnf_ps && !q1.sm_logits && !q0.sm_logits, DM_E_SHAPE, "gemm pair: LayerNorm prologue / folded backward requested but the one-launch skinny path does not apply");
   DM_TRY(dm_gemm_launch(q0, ws, ws_bytes, stream));
   return dm_gemm_launch(q1, ws, ws_bytes, stream);
 }

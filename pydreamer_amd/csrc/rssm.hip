@@ -564,6 +564,8 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     eps1 = ar.take((size_t)nstrip * 128);
     if (!ar.ok) { ar.off = mark; ar.ok = true; fold = false; }       // a small caller workspace keeps the prologue form
   }
+  static const int no_fold_sm = getenv("DM_BPTT_NO_FOLD_SM") ? 1 : 0;      // A/B switch
+  const bool fold_sm = fold && !gauss && C == 32 && Z == ZP && !no_fold_sm;
   if (fold) {
     DM_TRY(dgrad(st, sk, skb, N, Hd, D, a.x2, Hd, p[DM_RSSM_POST_H_W], xw2, D, 0, nullptr));      // x2 W_post_h
     DM_TRY(dgrad(st, sk, skb, N, Hd, Z, a.x1, Hd, p[DM_RSSM_Z_W], xwz, Z, 0, nullptr));           // x1 W_z
@@ -612,8 +614,9 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
     float* dpt = dpost + r0 * ZP;
     // straight-through sample: dpost += softmax'(post)^T dz'   (Gaussian: the reparameterised sample's (dmean, draw std))
+    // (folded schedule, 32 classes: done in the epilogue of the product that completed dz' - the pair launch of step t+1)
     if (gauss) DM_TRY(dm_gauss_sample_bwd_launch(B, S, post + r0 * ZP, ZP, feat + r0 * F + D, F, dft + D, F, dpt, ZP, 1, st));
-    else DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * ZP, ZP, dft + D, F, dpt, ZP, 1, st));
+    else if (!(fold_sm && t < T - 1)) DM_TRY(dm_st_softmax_bwd_launch(B, S, C, post + r0 * ZP, ZP, dft + D, F, dpt, ZP, 1, st));
     // post_mlp, post_norm+ELU, post_mlp_h
     if (fuse_b) {
       DmGemm q3;   // dpin = dpost Wpost
@@ -667,6 +670,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
         qz.lnb_stats = a.st1 + r0 * 2; qz.A_frag = dzaf;
         if (fold) {
           qz.A = dx1 + r0 * Hd; qz.ln_g = nullptr; qz.ln_b = nullptr; qz.lnb_x = nullptr; qz.lnb_stats = nullptr;
+          if (fold_sm) { qz.sm_logits = post + (r0 - B) * ZP; qz.sm_ld = ZP; qz.sm_dlogits = dpost + (r0 - B) * ZP; qz.sm_ldd = ZP; }
           qz.lnf_ps = eps1; qz.lnf_nps = nstrip; qz.lnf_stats = a.st1 + r0 * 2; qz.lnf_xw = xwz + r0 * Z; qz.lnf_ldxw = Z; qz.lnf_cs = csz;
         }
         DM_TRY(dm_gemm_pair_launch(qh, qz, sk, skb, st));

@@ -35,7 +35,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
                ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
 
     keep = None
-    for on in (1, 0):
+    for on in ((0,) if os.environ.get('NO_LDS') else (1, 0)):      # NO_LDS=1: launch schedules only (e.g. under rocprofv3)
         lib.dm_rssm_lds_enable(on)
         for _ in range(2):
             run()
@@ -63,16 +63,17 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
                   + f'; sum {sum(out) * 0.01 / den:.2f}')
             keep = idx.clone()
         else:
-            print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')
+            if keep is not None:
+                print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')
     # ---- the BPTT loop (dm_rssm_sequence_bwd: prior branch, loop, batched weight gradients) with the persistent kernel on / off
-    lib.dm_rssm_lds_enable(1)
+    lib.dm_rssm_lds_enable(0 if os.environ.get('NO_LDS') else 1)
     run(); torch.cuda.synchronize()
     Gf, Gp, Gq = (torch.randn(T * B, n, generator=g).cuda() / (T * B) for n in (F_, Z, Z))
     grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
     Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
     dembed = torch.zeros(T * B, E, device='cuda')
     keep_g = None
-    for on, fold in ((1, 1), (0, 1), (0, 0)):
+    for on, fold in (((0, 1),) if os.environ.get('NO_LDS') else ((1, 1), (0, 1), (0, 0))):
         lib.dm_rssm_lds_bwd_enable(on)
         lib.dm_bptt_fold_enable(fold)      # launch schedule only: the LayerNorm backward stages folded into the products that consume them
         per = []
