@@ -526,7 +526,7 @@ def main():
                     param_checksum=[float(o.flat_param.double().sum()) for o in opts] + [float(o.flat_param.double().abs().sum()) for o in opts],
                     host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     host_enqueue_unthrottled_ms_per_step=host_free_ms,
-                    fp32_products=('split-bf16 x3 pieces / 6 MFMA products, fp32 accumulate (DM_FP32_SPLIT=1)' if hip.lib().dm_fp32_mode() else 'fp32 MFMA'),
+                    fp32_products='fp32 MFMA',
                     chain_graphs=hip.chain_graph_stats(),
                     step_tflops=alg_tflop / (ms * 1e-3), step_frac_of_fp32_peak=alg_tflop / (ms * 1e-3) / 157.3,
                     h2d_included=h2d, distributed=dist_info,

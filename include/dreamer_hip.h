@@ -75,7 +75,7 @@ int dm_version(void);                 /* ABI version, currently 9 (v2: LayerNorm
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
                                          v8: dm_rssm_lds_* replace dm_rssm_persist_*;
-                                         v9: dm_bptt_fold_enable added, dm_fp32_mode (split-bf16 fp32 products) removed) */
+                                         v9: dm_bptt_fold_enable added; the split-bf16 fp32 product mode and its dm_fp32_mode query removed) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -421,7 +421,7 @@ int dm_mlp_chain_min_rows(int rows);
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
 /* Per-launch rows of the armed region (call before dm_prof_end): rows[i*8 + {0..7}] = {kind, M, N, K, split count, flags
- * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands, 16 split-bf16 fp32 products), flops, milliseconds};
+ * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands, 32 bf16-storage operands), flops, milliseconds};
  * returns the row count. */
 int dm_prof_rows(double* rows, int max_rows);
 /* The launch chains (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout: hundreds of small dependent kernels on one stream) can be
@@ -434,10 +434,6 @@ int dm_prof_rows(double* rows, int max_rows);
 int dm_chain_graph_stats(long long* out, int max_chains);
 int dm_chain_graph_reset(void);
 int dm_chain_graph_enable(int on);   /* on >= 0: set the switch (A/B, tests), returns the previous value; on < 0: query */
-/* 0 = fp32 contractions run on the fp32 MFMA (default); 1 = as split-bf16 products (each fp32 operand = three bf16 pieces,
- * six MFMA products, fp32 accumulation: fp32-class results, csrc/gemm.hip; experimental environment switch DM_FP32_SPLIT=1,
- * read once). */
-int dm_fp32_mode(void);
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
 

@@ -58,7 +58,6 @@ int dm_wgrad_side_mark(hipStream_t sw, hipStream_t st);
 // different host threads / streams with different precisions do not interact.  0 = fp32, 1 = bf16 operands (RNE) with
 // fp32 accumulation.
 int dm_cur_precision();
-int dm_fp32_split();      // gemm.hip: 1 = fp32 products run as split-bf16 (3 pieces, 6 MFMA products; DM_FP32_SPLIT=1), 0 = fp32 MFMA (default)
 struct DmPrecisionScope {
   int prev;
   explicit DmPrecisionScope(int p);

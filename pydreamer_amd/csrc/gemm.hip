@@ -10,8 +10,6 @@
 //
 // Three arithmetic modes, all with fp32 accumulation and fp32 results (template parameter BF):
 //   0  fp32 operands on v_mfma_f32_32x32x2_f32 - an exact k-ordered fmaf chain (no TF32/xf32 on gfx950): the default
-//   2  fp32 operands split into three bf16 pieces, six products on v_mfma_f32_32x32x16_bf16 (gemm_store_tile_split):
-//      fp32-class results at 6/16 of the fp32 matrix-pipe time; experimental (DM_FP32_SPLIT=1), see dm_fp32_split()
 //   1  bf16 operands (conf.amp, BASELINE configs[2])
 //
 // Tiling: BMxBNx32 block tile, 4 waves in a 2x2 grid, each wave (BM/2)x(BN/2) as 32x32 MFMA blocks.
@@ -203,97 +201,6 @@ __device__ __forceinline__ void gemm_store_tile_bf16(const float4 (&rr)[NF4], un
   }
 }
 
-// ---- split-bf16 path ("fp32 on the bf16 matrix pipe"): an fp32 operand x is written into LDS as THREE bf16 pieces
-// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round-to-nearest-even; both residuals are exact in
-// fp32 and l is exact in bf16, so the three pieces carry all 24 significand bits), and a product A B^T is the SIX MFMA
-// products  l h + h l + m m + m h + h m + h h  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms
-// (m l, l m, l l) are <= 2^-24 |a b| each, the rounding quantum of an fp32 product, so the result is fp32-class (measured
-// against fp64 next to the native fp32 MFMA chain: tests/test_gpu_primitives.py::test_gemm_split_bf16_is_fp32_class).
-// Six bf16 MFMAs cost 6/16 of the fp32 MFMA time of the same tile: the fp32 matrix pipe is no longer the bound of the step.
-// LDS: three [row][k] bf16 images per operand (piece-major), same row stride and fragment reads as the bf16 path.
-struct DmBf3 { unsigned h, m, l; };
-__device__ __forceinline__ DmBf3 dm_split3x2(float x, float y) {      // two fp32 -> three packed bf16 pairs (x in bits 0-15)
-  DmBf3 o;
-  o.h = dm_pack_bf16x2(x, y);
-  const dm_f32x2 v = {x, y};
-  const dm_f32x2 hf = {__uint_as_float(o.h << 16), __uint_as_float(o.h & 0xFFFF0000u)};
-  const dm_f32x2 r1 = v - hf;
-  o.m = dm_pack_bf16x2(r1.x, r1.y);
-  const dm_f32x2 mf = {__uint_as_float(o.m << 16), __uint_as_float(o.m & 0xFFFF0000u)};
-  const dm_f32x2 r2 = r1 - mf;
-  o.l = dm_pack_bf16x2(r2.x, r2.y);
-  return o;
-}
-template <int ROWS, int LAYOUT, int NF4, bool KSEQ = false>
-__device__ __forceinline__ void gemm_store_tile_split(const float4 (&rr)[NF4], unsigned mask, unsigned short* S, int tid) {
-  constexpr int PIECE = ROWS * LDKB;             // elements between two pieces of the operand's image
-  if (LAYOUT == 1 && KSEQ) {      // rr[i] = rows r4..r4+3 at k = kq*NF4 + i: one packed write of NF4 bf16 per row and piece
-    constexpr int F4_PER_K = ROWS / 4;
-    const int kq = (tid / F4_PER_K) * NF4;
-    const int r4 = (tid % F4_PER_K) << 2;
-    float h[4][NF4];
-#pragma unroll
-    for (int i = 0; i < NF4; ++i) {
-      h[0][i] = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
-      h[1][i] = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
-      h[2][i] = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
-      h[3][i] = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      unsigned short* d = &S[(r4 + j) * LDKB + kq];
-      if (NF4 == 4) {
-        const DmBf3 p = dm_split3x2(h[j][0], h[j][1]), q = dm_split3x2(h[j][2], h[j][3]);
-        *reinterpret_cast<uint2*>(d) = make_uint2(p.h, q.h);
-        *reinterpret_cast<uint2*>(d + PIECE) = make_uint2(p.m, q.m);
-        *reinterpret_cast<uint2*>(d + 2 * PIECE) = make_uint2(p.l, q.l);
-      } else if (NF4 == 2) {
-        const DmBf3 p = dm_split3x2(h[j][0], h[j][1]);
-        *reinterpret_cast<unsigned*>(d) = p.h;
-        *reinterpret_cast<unsigned*>(d + PIECE) = p.m;
-        *reinterpret_cast<unsigned*>(d + 2 * PIECE) = p.l;
-      } else {
-#pragma unroll
-        for (int i = 0; i < NF4; ++i) {
-          const DmBf3 p = dm_split3x2(h[j][i], 0.f);
-          d[i] = (unsigned short)(p.h & 0xFFFFu);
-          d[PIECE + i] = (unsigned short)(p.m & 0xFFFFu);
-          d[2 * PIECE + i] = (unsigned short)(p.l & 0xFFFFu);
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < NF4; ++i) {
-    const float x = (mask >> (4 * i + 0)) & 1u ? rr[i].x : 0.f;
-    const float y = (mask >> (4 * i + 1)) & 1u ? rr[i].y : 0.f;
-    const float z = (mask >> (4 * i + 2)) & 1u ? rr[i].z : 0.f;
-    const float w = (mask >> (4 * i + 3)) & 1u ? rr[i].w : 0.f;
-    const DmBf3 p = dm_split3x2(x, y), q = dm_split3x2(z, w);
-    const int f = tid + i * 256;
-    if (LAYOUT == 0) {
-      unsigned short* d = &S[(f >> 3) * LDKB + ((f & 7) << 2)];
-      *reinterpret_cast<uint2*>(d) = make_uint2(p.h, q.h);
-      *reinterpret_cast<uint2*>(d + PIECE) = make_uint2(p.m, q.m);
-      *reinterpret_cast<uint2*>(d + 2 * PIECE) = make_uint2(p.l, q.l);
-    } else {
-      constexpr int F4_PER_K = ROWS / 4;
-      const int kr = f / F4_PER_K;
-      const int r4 = (f % F4_PER_K) << 2;
-      const unsigned pc[3][2] = {{p.h, q.h}, {p.m, q.m}, {p.l, q.l}};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        unsigned short* d = &S[c * PIECE + r4 * LDKB + kr];
-        d[0] = (unsigned short)(pc[c][0] & 0xFFFFu);
-        d[LDKB] = (unsigned short)(pc[c][0] >> 16);
-        d[2 * LDKB] = (unsigned short)(pc[c][1] & 0xFFFFu);
-        d[3 * LDKB] = (unsigned short)(pc[c][1] >> 16);
-      }
-    }
-  }
-}
-
 // Work item -> (tile, split).  Workgroup b is observed to run on XCD b % 8 (used for L2 affinity only, never for
 // correctness): each XCD is given one CONTIGUOUS chunk of the item list, so the tiles an XCD's L2 sees share B panels
 // (tile_m runs fastest inside a chunk).  Bijective for any item count (q = n/8, r = n%8).
@@ -426,9 +333,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   constexpr int MB = BM / (32 * WGM), NB = BN / (32 * WGN);
   constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
   constexpr bool A_KSEQ = BF != 0 && AL == 1 && 256 % (BM / 4) == 0, B_KSEQ = BF != 0 && BL == 1 && 256 % (BN / 4) == 0;
-  // BF: 0 = fp32 operands on v_mfma_f32_32x32x2_f32, 1 = bf16 operands (conf.amp), 2 = split-bf16 (3 pieces, 6 products)
-  constexpr int SPLIT_FLOATS = 3 * (BM + BN) * LDKB / 2;
-  constexpr int SMEM_FLOATS = (BF == 2 && SPLIT_FLOATS > A_FLOATS + B_FLOATS) ? SPLIT_FLOATS : A_FLOATS + B_FLOATS;
+  // BF: 0 = fp32 operands on v_mfma_f32_32x32x2_f32, 1 = bf16 operands (conf.amp)
+  constexpr int SMEM_FLOATS = A_FLOATS + B_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* As = smem;
   float* Bs = smem + A_FLOATS;
@@ -458,11 +364,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
   }
   for (int kt = 0; kt < cur.nkt; ++kt) {
     unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* Bh = Ah + (BF == 2 ? 3 : 1) * BM * LDKB;
-    if (BF == 2) {
-      gemm_store_tile_split<BM, AL, A_F4, A_KSEQ>(ra, ma, Ah, tid);
-      gemm_store_tile_split<BN, BL, B_F4, B_KSEQ>(rb, mb_, Bh, tid);
-    } else if (BF == 1) {
+    unsigned short* Bh = Ah + BM * LDKB;
+    if (BF == 1) {
       gemm_store_tile_bf16<BM, AL, A_F4, A_KSEQ>(ra, ma, Ah, tid);
       gemm_store_tile_bf16<BN, BL, B_F4, B_KSEQ>(rb, mb_, Bh, tid);
     } else {
@@ -476,30 +379,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
       gemm_load_tile<BN, BL, B_F4, GB, VEC, B_KSEQ>(rb, g.B, g.ldb, cur.n0, g.N, k0, cur.kend, g.b_maj, g.b_min, tid, mb_);
     }
     __builtin_amdgcn_sched_barrier(0);                        // keep the loads AHEAD of the MFMAs (hipcc sinks them otherwise)
-    if (BF == 2) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {                        // two 16-k steps per 32-k tile, six products each
-        bf16x8 a8[3][MB], b8[3][NB];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-            a8[c][mb] = *reinterpret_cast<const bf16x8*>(&Ah[c * BM * LDKB + (wm * (BM / WGM) + mb * 32 + l31) * LDKB + ks * 16 + half * 8]);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            b8[c][nb] = *reinterpret_cast<const bf16x8*>(&Bh[c * BN * LDKB + (wn * (BN / WGN) + nb * 32 + l31) * LDKB + ks * 16 + half * 8]);
-        }
-        // smallest terms first; the (mb, nb) loops are innermost so consecutive MFMAs hit different accumulators
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[PA[t]][mb], b8[PB[t]][nb], acc[mb][nb], 0, 0, 0);
-      }
-    } else if (BF == 1) {
+    if (BF == 1) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {                        // two 16-k MFMA steps per 32-k tile
         bf16x8 a8[MB], b8[NB];
@@ -556,11 +436,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
                                               reinterpret_cast<unsigned short*>(smem) + wave * 32 * EPI_STAGE_LD);
 }
 
-// ---- software-pipelined tile kernel for the bf16-pipe modes (PR 1: bf16 operands, PR 2: split-bf16 fp32 products) -------
+// ---- software-pipelined tile kernel for bf16 operands held as fp32 in memory ------------------------------------------
 // gemm_f32_kernel's loop (store tile t, barrier, issue the loads of t+1, MFMAs of t, barrier) hides a load behind ONE tile's
 // MFMAs.  That is right for the fp32 MFMA (4096 matrix-pipe cycles per 128x128x32 tile) and wrong for the bf16 pipe (256
-// cycles, 1536 for the six split products): measured with that loop, bf16 operands reach 385 TF/s at 4096^3 (15 % of the
-// pipe) and the split products 135 TF/s-equivalent - the k-step is as long as the load -> convert -> LDS chain, not the MFMAs.
+// cycles): measured with that loop, bf16 operands reach 385 TF/s at 4096^3 (15 % of the pipe) - the k-step is as long as the
+// load -> convert -> LDS chain, not the MFMAs.
 // Here:
 //   * two LDS slots and two register sets: while the MFMAs of tile t read slot t&1, the registers holding tile t+1 (loaded
 //     during step t-1) are converted into slot (t+1)&1 and the loads of tile t+2 are in flight - every load has a whole
@@ -616,22 +496,17 @@ struct PipeOperand {
   }
 };
 
-// Registers -> LDS in UNITS of one operand pair (2 fp32 -> NP packed bf16 pairs, ~9 VALU for NP = 3), so the kernel can deal
-// them one at a time into the issue shadow of its MFMAs.  Same LDS image as gemm_store_tile_bf16 / gemm_store_tile_split.
+// Registers -> LDS in UNITS of one operand pair (2 fp32 -> one packed bf16 pair), so the kernel can deal
+// them one at a time into the issue shadow of its MFMAs.  Same LDS image as gemm_store_tile_bf16.
 // Units run in order u = 0, 1, ...; an even unit may leave its packed pieces in `hold` for the odd unit that completes the
 // 8-byte LDS write.
-template <int ROWS, int LAYOUT, int NF4, bool KSEQ, int NP>
+template <int ROWS, int LAYOUT, int NF4, bool KSEQ>
 struct PipeStash {
   static constexpr bool ROWWISE = LAYOUT == 1 && KSEQ;                 // one packed write per row: units walk the 4 rows
   static constexpr int UNITS = ROWWISE ? (NF4 == 4 ? 8 : 4) : 2 * NF4;
-  static constexpr int PIECE = ROWS * LDKB;
   static __device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-  static __device__ __forceinline__ DmBf3 pack(float x, float y) {
-    if (NP == 3) return dm_split3x2(x, y);
-    DmBf3 o; o.h = dm_pack_bf16x2(x, y); o.m = 0u; o.l = 0u;
-    return o;
-  }
-  static __device__ __forceinline__ void unit(const float4 (&rr)[NF4], int u, unsigned short* S, int tid, DmBf3& hold) {
+  static __device__ __forceinline__ unsigned pack(float x, float y) { return dm_pack_bf16x2(x, y); }
+  static __device__ __forceinline__ void unit(const float4 (&rr)[NF4], int u, unsigned short* S, int tid, unsigned& hold) {
     if (ROWWISE) {
       static_assert(!ROWWISE || NF4 == 4 || NF4 == 2, "row-wise packing covers 64- and 128-row operands");
       constexpr int F4_PER_K = ROWS / 4;
@@ -639,59 +514,41 @@ struct PipeStash {
       if (NF4 == 4) {
         const int j = u >> 1;
         if ((u & 1) == 0) { hold = pack(comp(rr[0], j), comp(rr[1], j)); return; }
-        const DmBf3 q = pack(comp(rr[NF4 > 2 ? 2 : 0], j), comp(rr[NF4 - 1], j));
+        const unsigned q = pack(comp(rr[NF4 > 2 ? 2 : 0], j), comp(rr[NF4 - 1], j));
         unsigned short* d = &S[(r4 + j) * LDKB + kq];
-        *reinterpret_cast<uint2*>(d) = make_uint2(hold.h, q.h);
-        if (NP == 3) {
-          *reinterpret_cast<uint2*>(d + PIECE) = make_uint2(hold.m, q.m);
-          *reinterpret_cast<uint2*>(d + 2 * PIECE) = make_uint2(hold.l, q.l);
-        }
+        *reinterpret_cast<uint2*>(d) = make_uint2(hold, q);
       } else {
-        const DmBf3 q = pack(comp(rr[0], u), comp(rr[NF4 - 1], u));
+        const unsigned q = pack(comp(rr[0], u), comp(rr[NF4 - 1], u));
         unsigned short* d = &S[(r4 + u) * LDKB + kq];
-        *reinterpret_cast<unsigned*>(d) = q.h;
-        if (NP == 3) {
-          *reinterpret_cast<unsigned*>(d + PIECE) = q.m;
-          *reinterpret_cast<unsigned*>(d + 2 * PIECE) = q.l;
-        }
+        *reinterpret_cast<unsigned*>(d) = q;
       }
       return;
     }
     const int i = u >> 1, f = tid + i * 256;
     if (LAYOUT == 0) {
       if ((u & 1) == 0) { hold = pack(rr[i].x, rr[i].y); return; }
-      const DmBf3 q = pack(rr[i].z, rr[i].w);
+      const unsigned q = pack(rr[i].z, rr[i].w);
       unsigned short* d = &S[(f >> 3) * LDKB + ((f & 7) << 2)];
-      *reinterpret_cast<uint2*>(d) = make_uint2(hold.h, q.h);
-      if (NP == 3) {
-        *reinterpret_cast<uint2*>(d + PIECE) = make_uint2(hold.m, q.m);
-        *reinterpret_cast<uint2*>(d + 2 * PIECE) = make_uint2(hold.l, q.l);
-      }
+      *reinterpret_cast<uint2*>(d) = make_uint2(hold, q);
     } else {      // 4 rows at one k: transposing 2-byte stores, two rows per unit
       constexpr int F4_PER_K = ROWS / 4;
       const int kr = f / F4_PER_K, r4 = ((f % F4_PER_K) << 2) + 2 * (u & 1);
-      const DmBf3 q = (u & 1) ? pack(rr[i].z, rr[i].w) : pack(rr[i].x, rr[i].y);
-      const unsigned pc[3] = {q.h, q.m, q.l};
-#pragma unroll
-      for (int c = 0; c < NP; ++c) {
-        unsigned short* d = &S[c * PIECE + r4 * LDKB + kr];
-        d[0] = (unsigned short)(pc[c] & 0xFFFFu);
-        d[LDKB] = (unsigned short)(pc[c] >> 16);
-      }
+      const unsigned q = (u & 1) ? pack(rr[i].z, rr[i].w) : pack(rr[i].x, rr[i].y);
+      unsigned short* d = &S[r4 * LDKB + kr];
+      d[0] = (unsigned short)(q & 0xFFFFu);
+      d[LDKB] = (unsigned short)(q >> 16);
     }
   }
 };
 
-template <int BM, int BN, int AL, int BL, bool GA, bool GB, int WGM, int WGN, int PR, bool SC>
+template <int BM, int BN, int AL, int BL, bool GA, bool GB, int WGM, int WGN, bool SC>
 __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
   static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
-  static_assert(PR == 1 || PR == 2, "bf16-pipe modes only");
   constexpr int BK = 32;
-  constexpr int NP = PR == 2 ? 3 : 1;                          // bf16 pieces per operand element
   constexpr int MB = BM / (32 * WGM), NB = BN / (32 * WGN);
   constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
   constexpr bool A_KSEQ = AL == 1 && 256 % (BM / 4) == 0, B_KSEQ = BL == 1 && 256 % (BN / 4) == 0;
-  constexpr int SLOT = NP * (BM + BN) * LDKB;                  // bf16 elements per LDS slot
+  constexpr int SLOT = (BM + BN) * LDKB;                       // bf16 elements per LDS slot
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * SLOT];
 
   const int tid = threadIdx.x;
@@ -713,10 +570,9 @@ __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
     sa.init(g.A, g.lda, cur.m0, g.M, g.a_maj, g.a_min, tid);
     sb.init(g.B, g.ldb, cur.n0, g.N, g.b_maj, g.b_min, tid);
     float4 ra[A_F4], rb[B_F4];                      // ONE register set: tile t+1 while step t runs (see `step`)
-    typedef PipeStash<BM, AL, A_F4, A_KSEQ, NP> SA;
-    typedef PipeStash<BN, BL, B_F4, B_KSEQ, NP> SB;
-    constexpr int N_PROD = PR == 2 ? 6 : 1;
-    constexpr int N_MFMA = 2 * MB * NB * N_PROD;
+    typedef PipeStash<BM, AL, A_F4, A_KSEQ> SA;
+    typedef PipeStash<BN, BL, B_F4, B_KSEQ> SB;
+    constexpr int N_MFMA = 2 * MB * NB;
     // One k-step = the MFMAs of the tile in LDS slot `rs`, in a hand-made issue order (sched_barrier(0) pins it; left alone
     // the compiler emits all MFMAs first and the conversions behind them, and an in-order wave then leaves the matrix pipe
     // idle for the whole conversion - an MFMA occupies the pipe for 32 cycles = ~8 issue slots, which is where they go):
@@ -728,34 +584,26 @@ __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
     auto step = [&](auto stash_tag, auto fetch_tag, int rs, int ws, int k_next2) {
       constexpr bool STASH = decltype(stash_tag)::value, FETCH = decltype(fetch_tag)::value;
       const unsigned short* Ah = smem + rs * SLOT;
-      const unsigned short* Bh = Ah + NP * BM * LDKB;
+      const unsigned short* Bh = Ah + BM * LDKB;
       unsigned short* Aw = smem + ws * SLOT;
-      unsigned short* Bw = Aw + NP * BM * LDKB;
-      DmBf3 hold = {0u, 0u, 0u};
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+      unsigned short* Bw = Aw + BM * LDKB;
+      unsigned hold = 0u;
       constexpr int A_LO = N_MFMA / 8, A_HI = N_MFMA / 2, B_LO = N_MFMA / 2, B_HI = N_MFMA - N_MFMA / 8;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {                        // two 16-k MFMA steps per 32-k tile
-        bf16x8 a8[NP][MB], b8[NP][NB];
+        bf16x8 a8[MB], b8[NB];
 #pragma unroll
-        for (int t = 0; t < NP; ++t) {                        // fragments in the order the products consume them
-          const int ca = PR == 2 ? PA[t] : 0, cb = PR == 2 ? PB[t] : 0;
+        for (int mb = 0; mb < MB; ++mb)
+          a8[mb] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * (BM / WGM) + mb * 32 + l31) * LDKB + ks * 16 + half * 8]);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-            a8[ca][mb] = *reinterpret_cast<const bf16x8*>(&Ah[ca * BM * LDKB + (wm * (BM / WGM) + mb * 32 + l31) * LDKB + ks * 16 + half * 8]);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            b8[cb][nb] = *reinterpret_cast<const bf16x8*>(&Bh[cb * BN * LDKB + (wn * (BN / WGN) + nb * 32 + l31) * LDKB + ks * 16 + half * 8]);
-        }
-#pragma unroll
-        for (int t = 0; t < N_PROD; ++t)
+        for (int nb = 0; nb < NB; ++nb)
+          b8[nb] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * (BN / WGN) + nb * 32 + l31) * LDKB + ks * 16 + half * 8]);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-              const int j = ((ks * N_PROD + t) * MB + mb) * NB + nb;          // MFMA index inside the k-step
-              const int ca = PR == 2 ? PA[t] : 0, cb = PR == 2 ? PB[t] : 0;
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[ca][mb], b8[cb][nb], acc[mb][nb], 0, 0, 0);
+              const int j = (ks * MB + mb) * NB + nb;                         // MFMA index inside the k-step
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mb], b8[nb], acc[mb][nb], 0, 0, 0);
               if (STASH && j >= A_LO && j < A_HI) {           // units [ceil((j-LO) U / span), ceil((j+1-LO) U / span)) of A
 #pragma unroll
                 for (int u = 0; u < SA::UNITS; ++u)
@@ -783,8 +631,8 @@ __global__ void __launch_bounds__(256) gemm_pipe_kernel(const GemmKArgs g) {
       sa.load(ra, cur.kbeg, cur.kend);
       sb.load(rb, cur.kbeg, cur.kend);
       unsigned short* Aw = smem;
-      unsigned short* Bw = Aw + NP * BM * LDKB;
-      DmBf3 hold = {0u, 0u, 0u};
+      unsigned short* Bw = Aw + BM * LDKB;
+      unsigned hold = 0u;
 #pragma unroll
       for (int u = 0; u < SA::UNITS; ++u) SA::unit(ra, u, Aw, tid, hold);
 #pragma unroll
@@ -1102,30 +950,29 @@ extern "C" int dm_prof_end(double* out, int nkinds) {
   return (int)g_prof.n;
 }
 
-template <int BM, int BN, int WGM, int WGN, int PR>
+template <int BM, int BN, int WGM, int WGN>
 static int gemm_pipe_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if (a.c_tab) {
     if (gather != 1 || al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0), 16-byte loads");
-    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, true, false, WGM, WGN, PR, true>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, true, false, WGM, WGN, true>), grid, dim3(256), 0, stream, a);
   } else if (gather == 1) {
     if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
-    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, true, false, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, true, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
   } else if (gather == 2) {
     if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
-    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 1, false, true, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
-  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, false, false, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
-  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 1, false, false, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
-  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 0, false, false, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 1, false, false, WGM, WGN, PR, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 1, false, true, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  } else if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 0, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 0, 1, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 0, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, 1, 1, false, false, WGM, WGN, false>), grid, dim3(256), 0, stream, a);
   return DM_OK;
 }
-template <int PR>
 static int gemm_pipe_tiles(int tc, const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
-  if (tc == 0) return gemm_pipe_dispatch<128, 128, 2, 2, PR>(a, al, bl, gather, grid, stream);
-  if (tc == 1) return gemm_pipe_dispatch<128, 64, 2, 2, PR>(a, al, bl, gather, grid, stream);
-  if (tc == 3) return gemm_pipe_dispatch<128, 96, 4, 1, PR>(a, al, bl, gather, grid, stream);
-  if (tc == 4) return gemm_pipe_dispatch<96, 128, 1, 4, PR>(a, al, bl, gather, grid, stream);
-  return gemm_pipe_dispatch<64, 64, 2, 2, PR>(a, al, bl, gather, grid, stream);
+  if (tc == 0) return gemm_pipe_dispatch<128, 128, 2, 2>(a, al, bl, gather, grid, stream);
+  if (tc == 1) return gemm_pipe_dispatch<128, 64, 2, 2>(a, al, bl, gather, grid, stream);
+  if (tc == 3) return gemm_pipe_dispatch<128, 96, 4, 1>(a, al, bl, gather, grid, stream);
+  if (tc == 4) return gemm_pipe_dispatch<96, 128, 1, 4>(a, al, bl, gather, grid, stream);
+  return gemm_pipe_dispatch<64, 64, 2, 2>(a, al, bl, gather, grid, stream);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -1172,17 +1019,6 @@ static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 gr
   return DM_OK;
 }
 
-// fp32 products run on the fp32 MFMA.  DM_FP32_SPLIT=1 (read once; experimental, bench.py --fp32-split times it in its own
-// process) runs them as split-bf16 products instead: three bf16 pieces per operand, six MFMA products, fp32-class results
-// (tests/test_gpu_primitives.py::test_gemm_split_bf16_is_fp32_class).  Measured on MI355X (profiles/r03_gemm_modes.txt): the
-// matrix pipe is no longer the bound, but the conversion VALU work and the operand stream are - 4096^3 135-142 TF/s vs 105-111
-// native, the step's 2 500-row products -20 %, gathered / transposed-source products slower than native - so the step as a
-// whole does not gain and the fp32 MFMA stays the default.
-int dm_fp32_split() {
-  static const int split = getenv("DM_FP32_SPLIT") ? atoi(getenv("DM_FP32_SPLIT")) : 0;
-  return split ? 1 : 0;
-}
-extern "C" int dm_fp32_mode(void) { return dm_fp32_split(); }
 // operand precision of the call in progress on this host thread (common.h: DmPrecisionScope)
 // ---- bf16 twin map of the composite call in progress (common.h DmTwinScope)
 struct TwinRange { const float* base; size_t n; unsigned short* twin; bool valid; };
@@ -1445,7 +1281,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   if (slot >= 0) {
     long long* sh = &g_prof.shape[5 * (size_t)slot];
     sh[0] = q.M; sh[1] = q.N; sh[2] = q.K; sh[3] = nsplit; sh[4] = (q.a_maj ? 1 : 0) | (q.b_maj ? 2 : 0) | (q.c_tab ? 4 : 0) | (q.bf16 ? 8 : 0) |
-            ((!q.bf16 && a.a_vec && a.b_vec && dm_fp32_split()) ? 16 : 0) | (hstore ? 32 : 0);
+            (hstore ? 32 : 0);
   }
   int rc;
   const bool vec = a.a_vec && a.b_vec;
@@ -1453,21 +1289,13 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   // the pipelined kernel clamps edge rows instead of masking them: it needs >= 1 full row (layout 0) / >= 4 (layout 1 groups)
   const bool pipe_ok = vec && !no_pipe && (q.a_layout == 0 ? q.M >= 1 : q.M >= 4) && (q.b_layout == 0 ? q.N >= 1 : q.N >= 4);
   if (hstore) rc = gemm_h_tiles(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
-  else if (pipe_ok && q.bf16) rc = gemm_pipe_tiles<1>(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
-  else if (pipe_ok && dm_fp32_split() && gather == 0 && q.a_layout == 0 && q.b_layout == 0)      // where the pipelined split wins
-    rc = gemm_pipe_tiles<2>(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
+  else if (pipe_ok && q.bf16) rc = gemm_pipe_tiles(tc, a, q.a_layout, q.b_layout, gather, grid, stream);
   else if (vec && q.bf16) {
     if (tc == 0) rc = gemm_dispatch<128, 128, true, 2, 2, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 1) rc = gemm_dispatch<128, 64, true, 2, 2, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 4) rc = gemm_dispatch<96, 128, true, 1, 4, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else rc = gemm_dispatch<64, 64, true, 2, 2, 1>(a, q.a_layout, q.b_layout, gather, grid, stream);
-  } else if (vec && dm_fp32_split()) {      // fp32 operands as three bf16 pieces, six products (see gemm_store_tile_split)
-    if (tc == 0) rc = gemm_dispatch<128, 128, true, 2, 2, 2>(a, q.a_layout, q.b_layout, gather, grid, stream);
-    else if (tc == 1) rc = gemm_dispatch<128, 64, true, 2, 2, 2>(a, q.a_layout, q.b_layout, gather, grid, stream);
-    else if (tc == 3) rc = gemm_dispatch<128, 96, true, 4, 1, 2>(a, q.a_layout, q.b_layout, gather, grid, stream);
-    else if (tc == 4) rc = gemm_dispatch<96, 128, true, 1, 4, 2>(a, q.a_layout, q.b_layout, gather, grid, stream);
-    else rc = gemm_dispatch<64, 64, true, 2, 2, 2>(a, q.a_layout, q.b_layout, gather, grid, stream);
   } else if (vec) {
     if (tc == 0) rc = gemm_dispatch<128, 128, true>(a, q.a_layout, q.b_layout, gather, grid, stream);
     else if (tc == 1) rc = gemm_dispatch<128, 64, true>(a, q.a_layout, q.b_layout, gather, grid, stream);

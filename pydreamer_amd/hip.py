@@ -185,7 +185,6 @@ _SIGNATURES = {
     'dm_chain_graph_stats': (c_int, [POINTER(ctypes.c_longlong), c_int]),
     'dm_chain_graph_reset': (c_int, []),
     'dm_chain_graph_enable': (c_int, [c_int]),
-    'dm_fp32_mode': (c_int, []),
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
     'dm_rssm_lds_bwd_enable': (c_int, [c_int]),

@@ -39,8 +39,8 @@ python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json 
 # per-queue timelines of one step (which stream is busy when), fp32 and bf16
 bash scripts/gpu_trace.sh f32 $TAG > /dev/null 2>&1; cp $OUT/queues_f32.txt $OUT/${TAG}_queues_f32.txt
 bash scripts/gpu_trace.sh bf16 $TAG > /dev/null 2>&1; cp $OUT/queues_bf16.txt $OUT/${TAG}_queues_bf16.txt
-# (the split-bf16 fp32 mode line and the per-CU load-rate microbenchmark, scripts/microbench/l2_stream.hip, concern code that has
-#  not changed since they were taken: profiles/<tag>_bench_fp32_split.json, <tag>_l2_stream.txt are kept from the earlier collection)
+# (the per-CU load-rate microbenchmark, scripts/microbench/l2_stream.hip, concerns code that has not changed since it was taken:
+#  profiles/<tag>_l2_stream.txt is kept from the earlier collection)
 python - << PY
 import json
 d = json.load(open('$OUT/${TAG}_bench.json'))

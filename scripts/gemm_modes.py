@@ -1,6 +1,6 @@
 """GPU microbenchmark (not a test): dm_gemm_f32 on the step's shapes - time AND error against an fp64 product, for the
-arithmetic mode the process runs in (default: fp32 MFMA; DM_FP32_SPLIT=1: split-bf16, 3 pieces / 6 products; --bf16: bf16
-operands; DM_GEMM_NO_PIPE=1: the single-stage loop instead of the software-pipelined kernel).  One JSON line per shape; profiles/r03_gemm_modes.txt keeps the table."""
+arithmetic mode the process runs in (default: fp32 MFMA; --bf16: bf16 operands; DM_GEMM_NO_PIPE=1: the single-stage loop instead of the software-pipelined kernel).  One JSON line per shape; profiles/r03_gemm_modes.txt keeps the
+round-3 table (which also has the split-bf16 mode, removed in round 4)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--dist', default='normal', choices=('normal', 'positive'))     # positive: no cancellation (worst case for a biased product)
     args = ap.parse_args()
-    mode = 'bf16' if args.bf16 else ('split' if hip.lib().dm_fp32_mode() else 'native')
+    mode = 'bf16' if args.bf16 else 'native'
     gflags = hip.DM_GEMM_BF16 if args.bf16 else 0
     shapes = [SHAPES[int(i)] for i in args.only.split(',')] if args.only else SHAPES
     ws = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')

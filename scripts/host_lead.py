@@ -21,7 +21,7 @@ conf = config.atari_literal(amp=(dtype == 'bf16'))
 torch.manual_seed(0)
 model = M.Dreamer(conf).to(dev)
 opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-ring = bench.make_ring(conf, conf.batch_size, 2, dev, 1234)
+ring = bench.make_ring(conf, conf.batch_size, 0, conf.batch_size, 2, dev, 1234)
 noise = bench.GlobalNoise(conf, conf.batch_size, 0, conf.batch_size, dev, 777)
 state = {'s': model.init_state(conf.batch_size)}
 log = []            # (host_t, label, event or None)

@@ -1,7 +1,7 @@
 """Diagnostic: time of the posterior T loop (dm_rssm_sequence_fwd, T = 50, Atari-literal cell width) with the LDS-weight-stationary
 persistent kernel (csrc/rssm_lds.hip) on and off, and the kernel's per-phase clock ticks (workgroup 0, 100 MHz wall clock).
     python scripts/persist_prof.py [B ...]"""
-import ctypes, os, sys
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
@@ -51,6 +51,8 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
         torch.cuda.synchronize()
         lib.dm_rssm_lds_prof(out, 0)
         per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(reps))
+        th0 = time.perf_counter(); run(); th1 = time.perf_counter(); torch.cuda.synchronize()      # host time of one call's enqueue (idle queue)
+        print(f'   host enqueue time of one call: {(th1 - th0) * 1e6:.0f} us')
         total_us = per[reps // 2]
         print(f'B={B} lds={on}: median {total_us:.0f} us per sequence call (T={T}; min {per[0]:.0f}, max {per[-1]:.0f}), status {lib.dm_rssm_lds_status()}')
         if on:
@@ -81,15 +83,18 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
             dfeat, dpost, dprior = Gf.clone(), Gp.clone(), Gq.clone()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+            hb0 = time.perf_counter()
             H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), ctypes.byref(P), H.fptr(acts),
                    H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
                    H.ptr(ws), ws.numel(), H.stream())
+            hb1 = time.perf_counter()
             e1.record(); torch.cuda.synchronize()
             if rep:
                 per.append(e0.elapsed_time(e1) * 1e3)
+                host_us = (hb1 - hb0) * 1e6
         per.sort()
         flat = torch.cat([x.flatten() for x in grads if x is not None])
-        print(f'B={B} bwd lds={on} fold={fold}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}), status {lib.dm_rssm_lds_status()}'
+        print(f'B={B} bwd lds={on} fold={fold}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}; host enqueue {host_us:.0f} us), status {lib.dm_rssm_lds_status()}'
               + ('' if keep_g is None else f'; gradients vs the persistent kernel: rel-L2 {float((flat - keep_g).norm() / keep_g.norm()):.2e}'))
         keep_g = flat.clone() if keep_g is None else keep_g
     lib.dm_rssm_lds_bwd_enable(1)

@@ -41,3 +41,30 @@ for b in range(nb):
         else:
             cells.append(' ' * 40)
     print(f'{b * binms:5.1f} ' + ' | '.join(cells))
+# ---- every idle gap > 0.3 ms inside a queue's active span: what ended last on the OTHER queues before the gap closed
+print('gaps > 0.3 ms inside a queue (start of the kernel that ends the gap; last kernels to end on the other queues before it):')
+for q in queues:
+    ks = [x for x in st if x[3] == q]
+    for p, n in zip(ks, ks[1:]):
+        if n[0] - p[1] > 300000:
+            others = []
+            for qq in queues:
+                if qq == q:
+                    continue
+                prev = [x for x in st if x[3] == qq and x[1] <= n[0]]
+                if prev:
+                    o = max(prev, key=lambda x: x[1])
+                    others.append(f'q{qq} {short(o[2])[:30]} ended {1e-6 * (o[1] - s):.2f}')
+            print(f'  q{q}: idle {1e-6 * (p[1] - s):.2f} -> {1e-6 * (n[0] - s):.2f} ms, then {short(n[2])[:40]} (after {short(p[2])[:30]}); ' + '; '.join(others))
+for q in queues:      # ... and what ended last elsewhere before each queue's FIRST kernel of the step
+    k0 = [x for x in st if x[3] == q][0]
+    others = []
+    for qq in queues:
+        prev = [x for x in st if x[3] == qq and x[1] <= k0[0]]
+        if qq != q and prev:
+            o = max(prev, key=lambda x: x[1])
+            others.append(f'q{qq} {short(o[2])[:30]} ended {1e-6 * (o[1] - s):.3f}')
+    print(f'  q{q} starts {1e-6 * (k0[0] - s):.3f} with {short(k0[2])[:30]}; ' + '; '.join(others))
+for q in queues:
+    ks = [x for x in st if x[3] == q][:4]
+    print(f'  q{q} first kernels: ' + ', '.join(f'{short(x[2])[:28]}@{1e-6 * (x[0] - s):.2f}' for x in ks))
