@@ -266,6 +266,11 @@ def main():
     from pydreamer_amd import dist as DP
     from pydreamer_amd.models import Dreamer
     hip.call('dm_device_check')
+    if one_device:
+        # the persistent posterior kernel needs every CU of the device at once (one workgroup per CU, resident together): two
+        # PROCESSES launching theirs on the same device can each hold part of the chip and spin until their poll bounds trip.
+        # One process per GPU - the only supported deployment - never sees this; the one-device smoke mode takes the launch chain.
+        hip.lib().dm_rssm_lds_enable(0)
 
     def make_conf(**kw):
         if args.workload == 'atari-native':
