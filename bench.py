@@ -473,7 +473,7 @@ def main():
         peak = 157.3 if args.dtype == 'f32' else 2500.0       # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE
         # and WRITE_SIZE cannot share a pass), summarised by scripts/pmc_traffic.py into profiles/ - read back here
-        traffic, traffic_note = None, None
+        traffic, traffic_note, components = None, None, None
         try:
             with open(args.pmc_json) as f:
                 pj = json.load(f)
@@ -493,6 +493,29 @@ def main():
                     traffic_note = (f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE in separate rocprofv3 passes of this command "
                                     f"({os.path.relpath(args.pmc_json, ROOT)}, kernel sources {pj['csrc_sha']}); whole step "
                                     f"{pj.get('total_gb_per_step')} GB")
+                # per-component view: the step's heaviest kernels, each against the bound that applies to it - the
+                # MFMA rate (live, from this run's profiled pass) for the tile kernels, the HBM rate (bytes and undisturbed
+                # durations of the counter passes) for everything that streams
+                comps = []
+                stepsp = max(int(pj.get('steps_total', pj.get('steps_profiled', 1))), 1)
+                for kname, v in (pmc.items() if all('avg_us' in v for v in list(pmc.values())[:1]) else []):
+                    if not v.get('avg_us'):
+                        continue
+                    lps = v['launches'] / stepsp
+                    tile = any(t in kname for t in ('gemm_f32_kernel', 'gemm_pipe_kernel', 'gemm_h_kernel', 'panel_linear', 'mlp_chain_fwd'))
+                    c = dict(kernel=kname[:60], launches_per_step=round(lps, 1), avg_us=round(v['avg_us'], 1), ms_per_step=round(lps * v['avg_us'] * 1e-3, 3),
+                             hbm_gb_per_s=round(v['hbm_gb_per_s'], 1) if v.get('hbm_gb_per_s') else None,
+                             hbm_frac=round(v['hbm_gb_per_s'] / 8000.0, 3) if v.get('hbm_gb_per_s') else None, bound='mfma' if tile else 'hbm')
+                    if tile:
+                        k2 = kname.replace(' ', '')
+                        hit = [d for d in kinds if k2.startswith(d['kernel'].replace('>', '').replace(' ', '') + ',') or
+                               k2.startswith(d['kernel'].replace(' ', '')) or
+                               (args.dtype == 'bf16' and k2.replace('gemm_h_kernel', 'gemm_pipe_kernel').startswith(d['kernel'].replace('>', '').replace(' ', '') + ','))]
+                        if hit:
+                            c.update(mfma_tflops=round(hit[0]['tflops'], 1), mfma_frac=round(hit[0]['tflops'] / peak, 3))
+                    comps.append(c)
+                comps.sort(key=lambda c: -c['ms_per_step'])
+                components = comps[:16] or None
         except (OSError, KeyError, ValueError) as e:
             traffic_note = f'no PMC file ({type(e).__name__})' 
         roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=traffic,
@@ -500,6 +523,10 @@ def main():
                     # not observed by THIS run: read back from the committed counter passes of the same command (fingerprint-checked)
                     traffic_source=('committed profile ' + os.path.relpath(args.pmc_json, ROOT)) if traffic is not None else None,
                     algorithmic_bytes_per_launch=dom.get('alg_bytes_per_launch'),
+                    components=components,
+                    components_note=('the 16 heaviest kernels of the step; launches, durations and HBM rates from the counter passes (dispatches '
+                                     'serialised, single stream), MFMA rates from this run; bound = the roof that applies to the kernel (peak '
+                                     f'{peak} TFLOP/s dense / 8000 GB/s)') if components else None,
                     kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                   gflop_per_step=tot_fl / 1e9 / args.prof_steps, ms_per_step=tot_ms / args.prof_steps,

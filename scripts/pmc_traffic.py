@@ -13,6 +13,7 @@ import sys
 
 
 STEADY = {}      # counter -> (KB inside the steady-state steps, number of such steps)
+DUR = collections.defaultdict(lambda: [0, 0])      # kernel -> [ns, dispatches] in the FETCH_SIZE pass (serialised dispatches: undisturbed durations)
 
 
 def load(path, counter):
@@ -26,6 +27,10 @@ def load(path, counter):
         a = acc[name]
         a[0] += float(r['Counter_Value'])
         a[1] += 1
+        if counter == 'FETCH_SIZE' and r.get('Start_Timestamp') and r.get('End_Timestamp'):      # dispatches run one at a time under PMC
+            d = DUR[name]
+            d[0] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            d[1] += 1
     if rows and 'Dispatch_Id' in rows[0]:
         rows.sort(key=lambda r: int(r['Dispatch_Id']))
         ad = [int(r['Dispatch_Id']) for r in rows if r['Kernel_Name'].startswith('adamw_kernel')]
@@ -45,6 +50,9 @@ for name in sorted(set(fetch) | set(write)):
     wb = 1024.0 * w / max(nw, 1)
     out[name] = dict(launches=max(nf, nw), fetch_bytes_per_launch_raw=fb, fetch_bytes_per_launch=2.0 * fb,
                      write_bytes_per_launch=wb, hbm_bytes_per_launch=2.0 * fb + wb)
+    if DUR[name][1]:      # mean duration of a launch (counter pass: dispatches serialised) and the HBM rate that goes with it
+        us = DUR[name][0] / DUR[name][1] / 1e3
+        out[name].update(avg_us=us, hbm_gb_per_s=(2.0 * fb + wb) / (us * 1e-6) / 1e9 if us > 0 else None)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3        # bench.py --steps S --warmup W --prof-steps 0: S + W steps in total
 sha = sys.argv[4] if len(sys.argv) > 4 else None            # `python bench.py --csrc-sha`: fingerprint of the kernel sources
 total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values()) / steps / 1e9
@@ -53,7 +61,8 @@ scope = 'all dispatches of the process / steps (includes the benchmark set-up ke
 if 'FETCH_SIZE' in STEADY and 'WRITE_SIZE' in STEADY and STEADY['FETCH_SIZE'][1] == STEADY['WRITE_SIZE'][1] >= 1:
     total = 1024.0 * (2.0 * STEADY['FETCH_SIZE'][0] + STEADY['WRITE_SIZE'][0]) / STEADY['FETCH_SIZE'][1] / 1e9
     scope = f"dispatches after the first gradient step only ({STEADY['FETCH_SIZE'][1]} step(s)); with set-up kernels: {total_all:.2f}"
+steps_total = STEADY['FETCH_SIZE'][1] + 1 if 'FETCH_SIZE' in STEADY else steps      # gradient steps the process ran (4 adamw launches close one)
 json.dump(dict(note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 2 '
                     '--warmup 1 --no-overlap --prof-steps 0; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes',
-               csrc_sha=sha, steps_profiled=steps, total_gb_per_step=round(total, 2), total_scope=scope, kernels=out),
+               csrc_sha=sha, steps_profiled=steps, steps_total=steps_total, total_gb_per_step=round(total, 2), total_scope=scope, kernels=out),
           sys.stdout, indent=1)
