@@ -474,7 +474,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DmChainKey ck;
   ck.add(s).add(embed).add(action).add(reset).add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(dfeat).add(dpost)
       .add(dprior).add_words(G, sizeof(*G)).add(dembed).add(ws).add((long long)ws_bytes).add((long long)dm_cur_precision())
-      .add((long long)dm_rssm_lds_bwd_ok(B, D, Hd, S, C));
+      .add((long long)dm_rssm_lds_bwd_ok(B, D, Hd, S, C)).add((long long)g_bptt_fold);
   DmChainGraph cg("rssm_sequence_bwd", ck, st);
   if (cg.replay_only()) return cg.finish();
   st = cg.launch_stream();

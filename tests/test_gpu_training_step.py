@@ -531,7 +531,9 @@ def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
     ~6-launches-per-step schedule it replaces, on the same forward pass: Atari-literal cell width, T = 12, every row-count
     layout (8 / 16 / 32 / 64 rows per k-group).  Every parameter gradient and dembed within 2e-4 relative L2 (fp32
     summation order differs: K split over waves / k-groups, the expanded LayerNorm backward); the kernel never gave up.
-    (Against the fp64 oracle: test_rssm_sequence_fwd_bwd_vs_oracle runs this kernel too.)"""
+    The launch schedule itself exists in two forms - LayerNorm backward folded and split over two launches (default, DESIGN
+    4.2.2; 16-row quarter / 32-row half strips) and in the consumer's prologue (dm_bptt_fold_enable(0)) - and both are compared.
+    (Against the fp64 oracle: test_rssm_sequence_fwd_bwd_vs_oracle runs the persistent kernel and the default schedule.)"""
     import ctypes
     from pydreamer_amd import hip as H
     T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
@@ -557,10 +559,13 @@ def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
            H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
            H.ptr(ws), ws.numel(), H.stream())
     outs = []
-    was = H.lib().dm_rssm_lds_bwd_enable(-1)
+    was, was_f = H.lib().dm_rssm_lds_bwd_enable(-1), H.lib().dm_bptt_fold_enable(-1)
     try:
-        for on in (1, 0):
+        # persistent kernel / the launch schedule with the LayerNorm backward folded and split over producer epilogue and plain
+        # consumer (the default) / the launch schedule with it in the consumer's prologue (rounds 2-3)
+        for on, fold in ((1, 1), (0, 1), (0, 0)):
             H.lib().dm_rssm_lds_bwd_enable(on)
+            H.lib().dm_bptt_fold_enable(fold)
             for rep in range(2):      # twice: the second call reuses the exchange addresses with caches warm
                 grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
                 Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
@@ -573,19 +578,22 @@ def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
             outs.append((grads, dembed, dpost))
     finally:
         H.lib().dm_rssm_lds_bwd_enable(was)
+        H.lib().dm_bptt_fold_enable(was_f)
     assert H.lib().dm_rssm_lds_status() == 0, 'the persistent kernel gave up in a spin loop'
     names = H.rssm_param_names('gru')
     worst = 0.0
-    for name, a, b in zip(names, outs[0][0], outs[1][0]):
-        if name is None or a is None:
-            continue
-        assert torch.isfinite(a).all(), name
-        e = _rel_l2(a, b)
-        worst = max(worst, e)
-        assert e < 2e-4, (name, e)
-    assert _rel_l2(outs[0][1], outs[1][1]) < 2e-4, 'dembed'
-    assert _rel_l2(outs[0][2], outs[1][2]) < 2e-4, 'dpost (final, with the straight-through part)'
-    print(f'B={B}: worst parameter-gradient rel-L2 vs the launch schedule {worst:.2e}')
+    for tag, x, y in (('persistent kernel vs folded launch schedule', outs[0], outs[1]),
+                      ('folded vs prologue-form launch schedule', outs[1], outs[2])):
+        for name, a, b in zip(names, x[0], y[0]):
+            if name is None or a is None:
+                continue
+            assert torch.isfinite(a).all(), (tag, name)
+            e = _rel_l2(a, b)
+            worst = max(worst, e)
+            assert e < 2e-4, (tag, name, e)
+        assert _rel_l2(x[1], y[1]) < 2e-4, (tag, 'dembed')
+        assert _rel_l2(x[2], y[2]) < 2e-4, (tag, 'dpost (final, with the straight-through part)')
+    print(f'B={B}: worst parameter-gradient rel-L2 between the three BPTT schedules {worst:.2e}')
 
 
 # ------------------------------------------------------------------------------------------- end to end
