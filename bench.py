@@ -503,11 +503,14 @@ def main():
                         continue
                     lps = v['launches'] / stepsp
                     tile = any(t in kname for t in ('gemm_f32_kernel', 'gemm_pipe_kernel', 'gemm_h_kernel', 'panel_linear', 'mlp_chain_fwd'))
+                    chain = any(t in kname for t in ('skinny_gemm', 'rssm_lds', 'gru_gates', 'sample_onehot', 'st_softmax', 'z_embed'))
                     c = dict(kernel=kname[:60], launches_per_step=round(lps, 1), avg_us=round(v['avg_us'], 1), ms_per_step=round(lps * v['avg_us'] * 1e-3, 3),
                              hbm_gb_per_s=round(v['hbm_gb_per_s'], 1) if v.get('hbm_gb_per_s') else None,
-                             hbm_frac=round(v['hbm_gb_per_s'] / 8000.0, 3) if v.get('hbm_gb_per_s') else None, bound='mfma' if tile else 'hbm')
+                             hbm_frac=round(v['hbm_gb_per_s'] / 8000.0, 3) if v.get('hbm_gb_per_s') else None,
+                             bound='mfma' if tile else ('latency (<= 64-row steps of the sequential chains: neither roof applies)' if chain else 'hbm'))
                     if tile:
-                        k2 = kname.replace(' ', '')
+                        k2 = kname.replace(' ', '').replace('panel_linear_bf16_kernel<25,1,', 'panel_linear_kernel<25,0,1,').replace(
+                            'panel_linear_bf16_kernel<25,2,', 'panel_linear_kernel<25,1,2,')      # (bf16 panel kernels: <25, 1 = fwd | 2 = bwd, ...>)
                         hit = [d for d in kinds if k2.startswith(d['kernel'].replace('>', '').replace(' ', '') + ',') or
                                k2.startswith(d['kernel'].replace(' ', '')) or
                                (args.dtype == 'bf16' and k2.replace('gemm_h_kernel', 'gemm_pipe_kernel').startswith(d['kernel'].replace('>', '').replace(' ', '') + ','))]

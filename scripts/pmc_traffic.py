@@ -23,7 +23,7 @@ def load(path, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     for r in rows:
-        name = re.sub(r'\(.*$', '', r['Kernel_Name']).replace('void ', '')
+        name = re.sub(r'\(.*$', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('void ', '')
         a = acc[name]
         a[0] += float(r['Counter_Value'])
         a[1] += 1
