@@ -433,6 +433,10 @@ def main():
     if args.prof_steps > 0:
         hip.call('dm_prof_begin', 8192 * args.prof_steps)
         model.overlap_backward = False      # one stream, one launcher thread: per-launch events then time that launch alone
+        model.pipeline_ac_optimizer = False      # ... and no optimizer tail of the previous step beside the next forward
+        if hasattr(model, 'join_optimizers'):
+            model.join_optimizers()
+        torch.cuda.synchronize()
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
