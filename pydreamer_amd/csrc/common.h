@@ -197,7 +197,8 @@ int dm_sparse_rows_launch(int rows, int n, int Zc, const float* z, int ldz, cons
                           hipStream_t st);
 int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
                       const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
-                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st);
+                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st,
+                      float* y_frag = nullptr, float* stats = nullptr);      // y_frag (rows <= 64): one workgroup per row, LayerNorm + ELU behind the sums, fragment-major copy of y
 struct DmGatesBwd {
   const float* gi; const float* gh; const float* h_in; int ldh, D;
   float* dgi; float* dgh; float* dprev; int ldp; const uint8_t* row_zero;   // dprev (nullable) += mask * dh' * u

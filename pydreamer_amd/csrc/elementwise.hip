@@ -926,9 +926,71 @@ __global__ void __launch_bounds__(256) z_embed_wide_kernel(int n, int S, int C, 
   }
 }
 
+// ... and with the LayerNorm + ELU of the row behind the sums (the workgroup holds the complete row: two block reductions),
+// for the chain steps whose consuming product then runs WITHOUT a LayerNorm prologue - the prologue form makes every one of
+// the product's 100-230 workgroups normalise the whole 64 x n operand again.  Two-pass statistics like ln_elu_fwd_kernel.
+// x (raw sums, what backward reads), y = ELU(LN(x)), y_frag (fragment-major copy of y for the skinny product), stats (mean, rstd).
+__global__ void __launch_bounds__(256) z_embed_wide_ln_kernel(int n, int S, int C, const int32_t* __restrict__ idx,
+                                                              const uint8_t* __restrict__ row_zero, const float* __restrict__ Wt,
+                                                              const float* __restrict__ bias, const float* __restrict__ add, int ldadd,
+                                                              const int32_t* __restrict__ idx2, const float* __restrict__ Wt2,
+                                                              float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+                                                              float* __restrict__ y_frag, float* __restrict__ stats) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = threadIdx.x * 4;                       // this thread's 4 columns
+  const bool in = c < n;
+  const int off = in ? c : 0;
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (add) {
+    const float4 a = *reinterpret_cast<const float4*>(add + (size_t)row * ldadd + off);
+    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  }
+  if (idx2) {
+    const float4 a = *reinterpret_cast<const float4*>(Wt2 + (size_t)idx2[row] * n + off);
+    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  }
+  if (!(row_zero && row_zero[row])) {
+    const int mine = idx[(size_t)row * S + min(lane, S - 1)];      // S <= 32 (host-checked): every wave holds the row's indices
+    float4 w[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int sc = s < S ? s : S - 1;                  // past S: re-read the last row (not added)
+      w[s] = *reinterpret_cast<const float4*>(Wt + ((size_t)sc * C + __shfl(mine, sc, 64)) * n + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+      if (s < S) { acc.x += w[s].x; acc.y += w[s].y; acc.z += w[s].z; acc.w += w[s].w; }
+  }
+  if (in && x) *reinterpret_cast<float4*>(x + (size_t)row * ldx + c) = acc;
+  // LayerNorm over the n columns of the row: the four waves' sums meet in LDS in a fixed order
+  const float s1 = dm_wave_sum(in ? (acc.x + acc.y) + (acc.z + acc.w) : 0.f);
+  if (lane == 0) red[wave] = s1;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+  const float4 d = make_float4(acc.x - mean, acc.y - mean, acc.z - mean, acc.w - mean);
+  const float s2 = dm_wave_sum(in ? (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w) : 0.f);
+  if (lane == 0) red[4 + wave] = s2;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)n + eps);
+  if (stats && threadIdx.x == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+  if (in) {
+    const float4 ga = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);      // (parameter slices of a flat buffer: no 16-byte promise)
+    const float4 be = make_float4(beta[c], beta[c + 1], beta[c + 2], beta[c + 3]);
+    const float4 o = make_float4(dm_elu(d.x * rstd * ga.x + be.x), dm_elu(d.y * rstd * ga.y + be.y), dm_elu(d.z * rstd * ga.z + be.z),
+                                 dm_elu(d.w * rstd * ga.w + be.w));
+    if (y) *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+    if (y_frag) *reinterpret_cast<float4*>(y_frag + dm_frag_off(row, c)) = o;
+  }
+}
+
 int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const uint8_t* row_zero, const float* Wt,
                       const float* bias, const float* add, int ldadd, const int32_t* idx2, const float* Wt2, float* x, int ldx,
-                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st) {
+                      float* x_frag, const float* gamma, const float* beta, float eps, float* y, int ldy, hipStream_t st,
+                      float* y_frag, float* stats) {
   if (rows <= 0) return DM_OK;
   DM_REQUIRE(!idx2 || Wt2, DM_E_NULL, "z_embed: second index list without its table");
   DM_REQUIRE(dm_z_embed_ok(n) && idx && Wt && (x || y), DM_E_SHAPE, "z_embed: n=%d needs n <= 1024, n %% 4 == 0", n);
@@ -939,6 +1001,14 @@ int dm_z_embed_launch(int rows, int n, int S, int C, const int32_t* idx, const u
   if (!y && x && rows <= 64 && S <= 32 && !no_wide) {      // the chain's steps: latency only, one workgroup per row
     hipLaunchKernelGGL(z_embed_wide_kernel, dim3(rows), dim3(256), 0, st, n, S, C, idx, row_zero, Wt, bias, add, ldadd, idx2, Wt2, x,
                        ldx, x_frag);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  if (y_frag) {      // the chain's steps with the LayerNorm + ELU behind the sums: one workgroup per row
+    DM_REQUIRE(y && gamma && beta && rows <= 64 && S <= 32 && !x_frag, DM_E_SHAPE,
+               "z_embed: the row-per-workgroup LayerNorm form needs y, gamma / beta, rows <= 64, S <= 32");
+    hipLaunchKernelGGL(z_embed_wide_ln_kernel, dim3(rows), dim3(256), 0, st, n, S, C, idx, row_zero, Wt, bias, add, ldadd, idx2, Wt2, x,
+                       ldx, gamma, beta, eps, y, ldy, y_frag, stats);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const
   __shared__ float part[SK_WAVES * 64 * 32];
   __shared__ SkinnyShared sh;
   __shared__ float tile[64 * 33];
-  skinny_strip<0, NRB, 2, 1, 1, 2>(g, blockIdx.x, 0, part, &sh, tile);
+  skinny_strip<0, NRB, 2, 1, 1, 2>(g, blockIdx.x, blockIdx.y * (16 * NRB), part, &sh, tile);      // grid.y = (16 NRB)-row chunks of M
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
 // host time each): the GRU's input and hidden gate products of a posterior step, the two backward-data products that
@@ -634,9 +634,14 @@ int dm_gemm_sample_launch(const DmGemm& q, const DmSample& sm, hipStream_t strea
   a.u = sm.u; a.forced = sm.forced; a.onehot = sm.onehot; a.ldo = sm.ldo; a.idx = sm.idx; a.z_next = sm.z_next;
   a.next_reset = sm.next_reset;
   a.znf = sm.z_next ? sm.z_next_frag : nullptr;
-  const dim3 grid((unsigned)(q.N / 32)), blk(SK_WAVES * 64);
-  if (q.M <= 16) hipLaunchKernelGGL((skinny_gemm_sample_kernel<1>), grid, blk, 0, stream, a);
-  else if (q.M <= 32) hipLaunchKernelGGL((skinny_gemm_sample_kernel<2>), grid, blk, 0, stream, a);
+  // row-split strips as in dm_gemm_skinny_try: every workgroup redoes the LayerNorm + ELU of ITS rows only, so quarters also
+  // quarter that prologue (27 -> 1x us at 64 rows)
+  const int nst = q.N / 32;
+  const bool quarters = g_skinny_msplit >= 2 && q.M > 16 && dm_cdiv(q.M, 16) * nst <= 256;
+  const bool halves = !quarters && g_skinny_msplit && q.M > 32 && 2 * nst <= 256;
+  const dim3 grid((unsigned)nst, (unsigned)(quarters ? dm_cdiv(q.M, 16) : halves ? 2 : 1)), blk(SK_WAVES * 64);
+  if (q.M <= 16 || quarters) hipLaunchKernelGGL((skinny_gemm_sample_kernel<1>), grid, blk, 0, stream, a);
+  else if (q.M <= 32 || halves) hipLaunchKernelGGL((skinny_gemm_sample_kernel<2>), grid, blk, 0, stream, a);
   else hipLaunchKernelGGL((skinny_gemm_sample_kernel<4>), grid, blk, 0, stream, a);
   DM_LAUNCH_CHECK();
   return DM_OK;

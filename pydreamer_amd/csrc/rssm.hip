@@ -17,6 +17,8 @@ struct RssmActs {
   float *ea, *ee, *hin, *zin, *x1, *st1, *za, *gi, *gh, *x2, *st2, *pin, *x3, *st3, *prin;
   float *gs, *gst;      // LayerNorm GRU cells: pre-LayerNorm gate sums (N,3D) and their statistics (N,6 per stack layer)
 };
+// A/B switch (DM_FWD_LN_Z=0): the posterior launch chain's gather kernel normalises its rows itself (see ln_z in dm_rssm_sequence_fwd_steps)
+static const int g_fwd_ln_z = getenv("DM_FWD_LN_Z") ? atoi(getenv("DM_FWD_LN_Z")) : 1;
 static inline int rssm_gru_kind(const dm_shape* s) { return (s->flags & DM_FLAG_GRU_MASK) >> DM_FLAG_GRU_SHIFT; }
 static inline int rssm_gru_layers(const dm_shape* s) {
   return 1 + ((s->flags & DM_FLAG_GRU_LAYERS_MASK) >> DM_FLAG_GRU_LAYERS_SHIFT);
@@ -309,7 +311,14 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     float* zin_next = more ? a.zin + (r0 + B) * Z : nullptr;
     const uint8_t* reset_next = more ? reset + r0 + B : nullptr;
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
-    if (wzt && t > t0) {
+    // (ln_z: the gather kernel owns complete rows, so it also normalises them and the gate product below runs plain - the
+    //  prologue form makes each of that product's 226 workgroups redo the LayerNorm + ELU of the whole operand)
+    const bool ln_z = fuse_ln && g_fwd_ln_z && wzt && t > t0 && x1f && !stacked;
+    if (ln_z) {
+      DM_TRY(dm_z_embed_launch(B, Hd, S, C, idx + (r0 - B) * S, reset + r0, wzt, p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd,
+                               nullptr, nullptr, a.x1 + r0 * Hd, Hd, nullptr, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f,
+                               a.za + r0 * Hd, Hd, st, x1f, a.st1 + r0 * 2));
+    } else if (wzt && t > t0) {
       DM_TRY(dm_z_embed_launch(B, Hd, S, C, idx + (r0 - B) * S, reset + r0, wzt, p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd,
                                nullptr, nullptr, a.x1 + r0 * Hd, Hd, x1f, nullptr, nullptr, 0.f, nullptr, 0, st));
     } else {
@@ -330,7 +339,9 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     } else {
       DmGemm gi_q, gh_q;
       gi_q.M = B; gi_q.N = 3 * D; gi_q.K = Hd; gi_q.A = a.za + r0 * Hd; gi_q.lda = Hd; gi_q.B = p[DM_RSSM_GRU_WIH]; gi_q.ldb = Hd;
-      if (fuse_ln) {
+      if (ln_z) {
+        gi_q.A_frag = x1f;      // (holds ELU(in_norm(x1)) in this form)
+      } else if (fuse_ln) {
         gi_q.A = a.x1 + r0 * Hd; gi_q.ln_g = p[DM_RSSM_IN_G]; gi_q.ln_b = p[DM_RSSM_IN_B]; gi_q.ln_eps = 1e-3f;
         gi_q.A_frag = x1f;
       }

@@ -1287,9 +1287,15 @@ extern "C" int dm_rssm_lds_enable(int on) {
 // Sticky: non-zero once a persistent kernel of this process has given up inside a spin loop (its outputs are garbage).
 extern "C" int dm_rssm_lds_status(void) { return g_host_err ? (int)*(volatile unsigned*)g_host_err : 0; }
 
+// Above 32 rows the launch chain is the faster posterior loop since its LayerNorm stages are done once per row instead of once
+// per consuming workgroup (rssm.hip ln_z, gemm_skinny.hip row-split strips): T = 50, B = 50 2.15 vs 2.8-2.9 ms alone, the
+// step 34.26 vs 34.64 ms (bf16 19.71 vs 20.21); at 25 / 13 / 7 rows the persistent kernel wins inside the step (19.69 vs 20.30,
+// 13.53 vs 14.41, 9.84 vs 10.84 ms; profiles/r04_bench_fwdchain.txt).  Switch level 2 (tests, microbenchmarks) lifts the cap.
+static const int g_rssm_lds_max_b = getenv("DM_RSSM_LDS_MAX_B") ? atoi(getenv("DM_RSSM_LDS_MAX_B")) : 32;
 bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C) {
   RlPlan p;
-  return g_rssm_lds && rl_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes) && rl_fwd_ready(p.rl);
+  return g_rssm_lds && (B <= g_rssm_lds_max_b || g_rssm_lds >= 2) && rl_plan(B, D, Hd, S, C, &p) &&
+         rl_device_ok(p.G, p.lds_bytes) && rl_fwd_ready(p.rl);
 }
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
   RlPlan p;

@@ -36,7 +36,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
 
     keep = None
     for on in ((0,) if os.environ.get('NO_LDS') else (1, 0)):      # NO_LDS=1: launch schedules only (e.g. under rocprofv3)
-        lib.dm_rssm_lds_enable(on)
+        lib.dm_rssm_lds_enable(2 if on else 0)      # (level 2: any row count <= 64; the default level leaves B > 32 to the launch chain)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
@@ -68,7 +68,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
             if keep is not None:
                 print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')
     # ---- the BPTT loop (dm_rssm_sequence_bwd: prior branch, loop, batched weight gradients) with the persistent kernel on / off
-    lib.dm_rssm_lds_enable(0 if os.environ.get('NO_LDS') else 1)
+    lib.dm_rssm_lds_enable(0 if os.environ.get('NO_LDS') else 2)
     run(); torch.cuda.synchronize()
     Gf, Gp, Gq = (torch.randn(T * B, n, generator=g).cuda() / (T * B) for n in (F_, Z, Z))
     grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
