@@ -70,12 +70,13 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 9 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 10 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
                                          v8: dm_rssm_lds_* replace dm_rssm_persist_*;
-                                         v9: dm_bptt_fold_enable added; the split-bf16 fp32 product mode and its dm_fp32_mode query removed) */
+                                         v9: dm_bptt_fold_enable added; the split-bf16 fp32 product mode and its dm_fp32_mode query removed;
+                                         v10: dm_gemm_dma_enable added) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -121,6 +122,12 @@ int dm_gemm_bf16h(int a_layout, int b_layout, int M, int N, int K, const uint16_
  * the arena twins only if the forward call that filled that `acts` buffer wrote them - the library keeps a host-side note per
  * buffer).  1 / 0 switches that path on / off, -1 queries; returns the state.  Off = the fp32-storage products of dm_gemm_f32(DM_GEMM_BF16); results agree to fp32 summation order. */
 int dm_bf16_twins_enable(int on);
+/* fp32 products whose operands take the 16-byte load path run gemm_dma_kernel: global_load_lds (LDS-DMA) into a 2-3 stage LDS
+ * ring, counted vmcnt across a raw s_barrier, inline-asm fragment reads (csrc/gemm.hip).  Same tiles, k order and epilogue as the
+ * register-staged gemm_f32_kernel: bit-identical results, so the library picks per call: the LDS-DMA loop from 14 k-tiles per
+ * work item up, the register-staged loop (higher residency) below.  1 / 0 switches it on / off, 2 = on for every k extent (the
+ * bit-identity test), -1 queries; returns the state (default 1; DM_GEMM_DMA=0 / 2 in the environment). */
+int dm_gemm_dma_enable(int on);
 /* The posterior T loop (rssm.py:38-58, cell rssm.py:125-153, nn.GRUCell rnn.py:40-67) runs, when the shape qualifies (plain
  * single-layer GRU, LayerNorm, categorical latents, B <= 64, the layer slices fit one CU's LDS), as ONE persistent kernel with
  * one workgroup per compute unit that keeps its 4-column slice of every layer's weights in LDS for all T steps and exchanges

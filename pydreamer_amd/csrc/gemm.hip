@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <type_traits>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -436,6 +437,233 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
                                               reinterpret_cast<unsigned short*>(smem) + wave * 32 * EPI_STAGE_LD);
 }
 
+__device__ __attribute__((aligned(16))) const float dm_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+// ---- fp32 tile kernel with a direct-to-LDS operand pipeline (round 5) -----------------------------------------------------
+// gemm_f32_kernel's k-step is: registers -> LDS (ds_write_b128), barrier, global loads of tile t+1 into registers, MFMAs,
+// barrier.  Here the operand stream never touches a register:
+//   * global_load_lds_dwordx4 (LDS-DMA) writes each 1-KiB piece of a tile straight into one of NS LDS stages, one barrier per
+//     k-tile; tile t+NS-1 is issued right behind the barrier that retires tile t-1's reads, and a COUNTED s_waitcnt vmcnt leaves
+//     the younger tiles in flight across it (raw s_barrier: __syncthreads() would drain them);
+//   * an LDS-DMA lands lane-linear (wave-uniform base + 16 B x lane), so the conflict-free image of a k-contiguous operand -
+//     [row][32 k] with the 16-byte chunk index XORed with (row >> 1) & 7 - is produced by permuting the SOURCE address of
+//     each lane inside its row's 128-byte line (coalescing unchanged) and un-permuting in the fragment read; a row-contiguous
+//     operand's [k][row] image is lane-linear as it is;
+//   * the fragment reads are inline asm: hipcc treats an LDS-DMA in flight as an LDS store every ds_read may alias and puts
+//     s_waitcnt vmcnt(0) in front of the first fragment read of a k-tile, which serialises the stream with the MFMAs
+//     (scripts/microbench/gemm_lab.hip, profiles/r05_gemm_lab.txt: 117.9 -> 122.7 TF/s at 4096^3, production loop 110.8);
+//     fragments are double-buffered by 8-k group, lgkmcnt counted by hand, sched_barrier(0) behind every wait.
+// Same tiles, work-item order, k -> (MFMA step, lane half) map and epilogue as gemm_f32_kernel: results are BIT-IDENTICAL to
+// it (tests/test_gpu_primitives.py::test_gemm_dma_equals_register_staged_loop).  16-byte-load shapes only (the host routes
+// the rest to gemm_f32_kernel); edge rows read a clamped row, k-groups past the end of a ragged last tile a page of zeros.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ void dma_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void dma_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int ROWS, int LAYOUT, bool GATHER>
+struct DmaOperand {
+  static constexpr int NP = ROWS / 32;        // 1-KiB pieces of a (ROWS x 32) tile per wave (4 waves)
+  const float* P;
+  const int* tk;                              // GATHER: the table indexed by k (layout 0: minor table, layout 1: major table)
+  int ld;
+  const float* base[GATHER ? 1 : NP];         // plain: address of this lane's 16-byte chunk in the tile at k = 0 (a k-step adds a UNIFORM
+                                              //   offset: no per-lane multiply, no branch around one - hipcc branches around 64-bit products)
+  unsigned off[GATHER ? NP : 1];              // GATHER: k-independent element offset (the other table's entry)
+  int kof[NP];                                // the chunk's k offset inside a 32-k tile
+  int tv[GATHER ? NP : 1];                    // GATHER: tk[k] of the tile to issue next (fetched one tile ahead)
+  __device__ __forceinline__ void init(const float* P_, int ld_, int row0, int nrows, const int* tmaj, const int* tmin, int wave,
+                                       int lane) {
+    P = P_; ld = ld_;
+    tk = LAYOUT == 0 ? tmin : tmaj;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = wave + 4 * i;
+      if (LAYOUT == 0) {                      // piece = 8 rows x 128 B; lane -> (row l >> 3, LDS slot l & 7); fetches chunk slot ^ swz(row)
+        const int row = 8 * p + (lane >> 3);
+        kof[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+        const int gr = min(row0 + row, nrows - 1);
+        if constexpr (GATHER) off[i] = (unsigned)tmaj[gr];
+        else base[i] = P + (size_t)gr * ld + kof[i];
+      } else {                                // image [k][ROWS]: 16-byte chunk e = 64 p + lane -> (k e / (ROWS/4), rows 4 (e % (ROWS/4)) ..)
+        constexpr int CPR = ROWS / 4;
+        const int e = p * 64 + lane;
+        kof[i] = e / CPR;
+        const int col = min(row0 + ((e % CPR) << 2), nrows - 4);
+        if constexpr (GATHER) off[i] = (unsigned)tmin[col];
+        else base[i] = P + (size_t)kof[i] * ld + col;
+      }
+    }
+    if constexpr (GATHER)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) tv[i] = 0;
+  }
+  __device__ __forceinline__ void fetch_tab(int k0, int kend) {
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) tv[i] = tk[min(k0 + kof[i], kend - 1)];
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, int kend, unsigned char* img, int wave) const {
+    const size_t koff = LAYOUT == 0 ? (size_t)k0 : (size_t)k0 * (size_t)ld;      // uniform
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = k0 + kof[i] < kend;
+      const float* at;
+      if constexpr (GATHER) at = P + ((size_t)off[i] + (size_t)tv[i]);
+      else at = base[i] + koff;
+      const uintptr_t src = ok ? (uintptr_t)at : (uintptr_t)dm_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(img + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  }
+};
+
+// One 8-k group of fragments of one 32-row block: 4 floats per lane (k = 8 kg + 4 half + j).
+template <int LAYOUT> struct DmaFrag;
+template <> struct DmaFrag<0> {
+  f32x4v v;
+  __device__ __forceinline__ float get(int j) const { return v[j]; }
+  static constexpr int READS = 1;
+};
+template <> struct DmaFrag<1> {
+  f32x2v lo, hi;
+  __device__ __forceinline__ float get(int j) const { return j < 2 ? lo[j & 1] : hi[j & 1]; }
+  static constexpr int READS = 2;
+};
+
+template <int BM, int BN, int AL, int BL, bool GA, bool GB, int WGM, int WGN, bool SC, int NS>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmKArgs g) {
+  static_assert(WGM * WGN == 4 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave grid must tile the block tile");
+  static_assert(NS >= 2 && NS <= 3, "two or three LDS stages");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int MB = WM / 32, NB = WN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int RD = MB * DmaFrag<AL>::READS + NB * DmaFrag<BL>::READS;       // LDS reads per 8-k group
+  static_assert(RD <= 15, "lgkmcnt is a 4-bit counter");
+  static_assert((AL == 0 || (MB - 1) * 32 + BM <= 255) && (BL == 0 || (NB - 1) * 32 + BN <= 255), "ds_read2_b32 offsets are 8 bits");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dma_smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const GemmItem cur = gemm_decode<BM, BN>(g, blockIdx.x);
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (cur.nkt > 0) {
+    DmaOperand<BM, AL, GA> sa;
+    DmaOperand<BN, BL, GB> sb;
+    sa.init(g.A, g.lda, cur.m0, g.M, g.a_maj, g.a_min, wave, lane);
+    sb.init(g.B, g.ldb, cur.n0, g.N, g.b_maj, g.b_min, wave, lane);
+    constexpr int NPT = DmaOperand<BM, AL, GA>::NP + DmaOperand<BN, BL, GB>::NP;       // LDS-DMA instructions per wave and tile
+
+    // fragment addresses (bytes from the start of a stage).  Layout 0: row * 128 + ((2 kg + half) ^ swz) * 16 with
+    // swz = (row >> 1) & 7 = (l31 >> 1) & 7 (block offsets are multiples of 32 rows); one VGPR per kg, blocks by immediate.
+    // Layout 1: ((8 kg + 4 half + j) * ROWS + row) * 4; ds_read2_b32 takes (j, j+1) with dword offsets (32 mb, 32 mb + ROWS).
+    const int swz = (l31 >> 1) & 7;
+    unsigned fa[4], fb[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      fa[kg] = AL == 0 ? lds0 + (wm * WM + l31) * 128 + (((2 * kg + half) ^ swz) << 4)
+                       : lds0 + (((8 * kg + 4 * half) * BM + wm * WM + l31) << 2);
+      fb[kg] = BL == 0 ? lds0 + A_BYTES + (wn * WN + l31) * 128 + (((2 * kg + half) ^ swz) << 4)
+                       : lds0 + A_BYTES + (((8 * kg + 4 * half) * BN + wn * WN + l31) << 2);
+    }
+    auto read_frags = [&](DmaFrag<AL> (&a)[MB], DmaFrag<BL> (&b)[NB], int kg, unsigned so) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        if constexpr (AL == 0) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mb].v) : "v"(fa[kg] + so), "n"(mb * 32 * 128));
+        } else {
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a[mb].lo) : "v"(fa[kg] + so), "n"(mb * 32), "n"(mb * 32 + BM));
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a[mb].hi) : "v"(fa[kg] + so + 8 * BM), "n"(mb * 32), "n"(mb * 32 + BM));
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if constexpr (BL == 0) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[nb].v) : "v"(fb[kg] + so), "n"(nb * 32 * 128));
+        } else {
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(b[nb].lo) : "v"(fb[kg] + so), "n"(nb * 32), "n"(nb * 32 + BN));
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(b[nb].hi) : "v"(fb[kg] + so + 8 * BN), "n"(nb * 32), "n"(nb * 32 + BN));
+        }
+      }
+    };
+
+    // prologue: tiles 0 .. NS-2 into stages 0 .. NS-2.
+    // Gathered operands (NS == 2 only): the table entry of a lane's chunk, tk[k], is an ordinary load.  hipcc does not let an
+    // LDS-DMA issue while a VGPR-destination load is pending (it drains vmcnt to 0 first - seen in the .s), so the fetch for
+    // tile t+2 sits at the END of step t, behind the last MFMAs, where that drain coincides with the wait the two-stage ring
+    // performs anyway at the top of step t+1.
+    static_assert(!(GA || GB) || NS == 2, "gathered operands take the two-stage ring");
+    sa.fetch_tab(cur.kbeg, cur.kend);
+    sb.fetch_tab(cur.kbeg, cur.kend);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+      if (s < cur.nkt) {
+        sa.issue(cur.kbeg + s * 32, cur.kend, dma_smem + s * STAGE, wave);
+        sb.issue(cur.kbeg + s * 32, cur.kend, dma_smem + s * STAGE + A_BYTES, wave);
+      }
+    }
+    sa.fetch_tab(cur.kbeg + 32, cur.kend);
+    sb.fetch_tab(cur.kbeg + 32, cur.kend);
+
+    int stage = 0;
+    for (int kt = 0; kt < cur.nkt; ++kt) {
+      // this wave's pieces of tile kt have landed once at most the (NS - 2) younger tiles are outstanding
+      if (NS == 3 && kt + 1 < cur.nkt) dma_wait_vm<NPT>();
+      else dma_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();           // ... and everybody else's; every wave is also done reading stage (kt - 1) % NS
+      const unsigned so = (unsigned)stage * STAGE;
+      DmaFrag<AL> a[2][MB];
+      DmaFrag<BL> b[2][NB];
+      read_frags(a[0], b[0], 0, so);
+      const int nt = kt + NS - 1;
+      int ns = stage + NS - 1;
+      if (ns >= NS) ns -= NS;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        const int c = kg & 1, n = c ^ 1;
+        if (kg < 3) {
+          read_frags(a[n], b[n], kg + 1, so);
+          dma_wait_lgkm<RD>();
+        } else dma_wait_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][mb].get(j), b[c][nb].get(j), acc[mb][nb], 0, 0, 0);
+        // the LDS-DMA of tile kt + NS - 1 goes out behind the first two groups' MFMAs: its address arithmetic and M0 writes run
+        // in the matrix pipe's shadow instead of in front of it (stage ns was last read during step kt - 1: the barrier above)
+        if (kg == 0 && nt < cur.nkt) sa.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE, wave);
+        if (kg == 1 && nt < cur.nkt) sb.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE + A_BYTES, wave);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((GA || GB) && nt + 1 < cur.nkt) {
+        sa.fetch_tab(cur.kbeg + (nt + 1) * 32, cur.kend);
+        sb.fetch_tab(cur.kbeg + (nt + 1) * 32, cur.kend);
+      }
+      if (++stage == NS) stage = 0;
+    }
+  }
+  unsigned short* stg = nullptr;
+  if (g.Ch) {      // (uniform) the twin leaves through LDS: every wave must be done reading its fragments first
+    __syncthreads();
+    stg = reinterpret_cast<unsigned short*>(dma_smem) + wave * 32 * EPI_STAGE_LD;
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, SC, MB, NB>(acc, g, cur, wm, wn, l31, half, stg);
+}
+
 // ---- software-pipelined tile kernel for bf16 operands held as fp32 in memory ------------------------------------------
 // gemm_f32_kernel's loop (store tile t, barrier, issue the loads of t+1, MFMAs of t, barrier) hides a load behind ONE tile's
 // MFMAs.  That is right for the fp32 MFMA (4096 matrix-pipe cycles per 128x128x32 tile) and wrong for the bf16 pipe (256
@@ -451,7 +679,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmKArgs g) {
 //     operands) instead of re-deriving addresses.
 // Same LDS images, fragment reads, work-item order and epilogue as gemm_f32_kernel; 16-byte loads only (the host routes
 // scalar-load shapes to gemm_f32_kernel).
-__device__ __attribute__((aligned(16))) const float dm_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 template <int ROWS, int LAYOUT, int NF4, bool GATHER, bool KSEQ>
 struct PipeOperand {
   const float* P;
@@ -1000,9 +1227,58 @@ static int gemm_h_tiles(int tc, const GemmKArgs& a, int al, int bl, int gather, 
   return gemm_h_dispatch<64, 64, 2, 2>(a, al, bl, gather, grid, stream);
 }
 
+// ---- gemm_dma_kernel launch: dynamic LDS (NS stages of (BM + BN) x 128 B), attribute set once per instantiation
+static int g_dma_enabled = getenv("DM_GEMM_DMA") ? atoi(getenv("DM_GEMM_DMA")) : 1;
+// 1 / 0: the direct-to-LDS main loop for fp32 16-byte-load products on / off (A/B and the bit-identity test), -1: query.
+extern "C" int dm_gemm_dma_enable(int on) {
+  if (on >= 0) g_dma_enabled = on > 2 ? 2 : on;      // 2: also for products of a few k-tiles (the bit-identity test)
+  return g_dma_enabled;
+}
+template <void (*KERN)(const GemmKArgs)>
+static int dma_launch(int lds_bytes, const GemmKArgs& a, dim3 grid, hipStream_t stream) {
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [&]() { attr_rc = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+  if (attr_rc != hipSuccess) return dm_fail(DM_E_HIP, "gemm: hipFuncSetAttribute(%d B of LDS): %s", lds_bytes, hipGetErrorString(attr_rc));
+  hipLaunchKernelGGL(KERN, grid, dim3(256), (size_t)lds_bytes, stream, a);
+  return DM_OK;
+}
+template <int BM, int BN, int WGM, int WGN>
+static int gemm_dma_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
+  // stages: three where two workgroups still fit a CU's 160 KiB with them (64 x 64: 48 KiB, 128 x 64: 72 KiB), else two
+  constexpr int NS = (BM + BN) * 128 * 3 <= 72 * 1024 ? 3 : 2;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  constexpr int LDS2 = 2 * (BM + BN) * 128;       // gathered operands: two stages (see the kernel's prologue comment)
+  if (a.c_tab) {
+    if (gather != 1 || al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0), 16-byte loads");
+    return dma_launch<gemm_dma_kernel<BM, BN, 0, 0, true, false, WGM, WGN, true, 2>>(LDS2, a, grid, stream);
+  }
+  if (gather == 1) {
+    if (al != 0 || bl != 0) return dm_fail(DM_E_SHAPE, "gemm: gathered A is built for layout (0,0) only");
+    return dma_launch<gemm_dma_kernel<BM, BN, 0, 0, true, false, WGM, WGN, false, 2>>(LDS2, a, grid, stream);
+  }
+  if (gather == 2) {
+    if (al != 1 || bl != 1) return dm_fail(DM_E_SHAPE, "gemm: gathered B is built for layout (1,1) only");
+    return dma_launch<gemm_dma_kernel<BM, BN, 1, 1, false, true, WGM, WGN, false, 2>>(LDS2, a, grid, stream);
+  }
+  if (al == 0 && bl == 0) return dma_launch<gemm_dma_kernel<BM, BN, 0, 0, false, false, WGM, WGN, false, NS>>(LDS, a, grid, stream);
+  if (al == 0 && bl == 1) return dma_launch<gemm_dma_kernel<BM, BN, 0, 1, false, false, WGM, WGN, false, NS>>(LDS, a, grid, stream);
+  if (al == 1 && bl == 0) return dma_launch<gemm_dma_kernel<BM, BN, 1, 0, false, false, WGM, WGN, false, NS>>(LDS, a, grid, stream);
+  return dma_launch<gemm_dma_kernel<BM, BN, 1, 1, false, false, WGM, WGN, false, NS>>(LDS, a, grid, stream);
+}
+
 // gather: 0 none, 1 = A gathered (NT: conv forward / conv-transpose backward-data), 2 = B gathered (TN: conv weight grads)
 template <int BM, int BN, bool V, int WGM = 2, int WGN = 2, int BF = 0>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
+  if constexpr (V && BF == 0) {
+    // layout 0 clamps edge rows to the last row, layout 1 to the last full group of 4: >= 1 / >= 4 rows
+    // ... and enough k-tiles per work item to amortise the ring's fill: below that the register-staged loop's higher residency
+    // (one LDS stage, 4-7 workgroups per CU) hides a tile's prologue and epilogue better (profiles/r05_gemm_dma_ab.txt:
+    // K = 144 / 192 / 384 products lost 9-17 %); both loops give the same bits, so the choice is free per call
+    static const int min_kt = getenv("DM_GEMM_DMA_MIN_KT") ? atoi(getenv("DM_GEMM_DMA_MIN_KT")) : 14;
+    if (g_dma_enabled && (a.k_per_split >= 32 * min_kt || g_dma_enabled >= 2) && (al == 0 ? a.M >= 1 : a.M >= 4) && (bl == 0 ? a.N >= 1 : a.N >= 4))
+      return gemm_dma_dispatch<BM, BN, WGM, WGN>(a, al, bl, gather, grid, stream);
+  }
   if (a.c_tab) {
     if (gather != 1 || al != 0 || bl != 0 || !V) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0), 16-byte loads");
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 0, 0, true, true, false, WGM, WGN, BF, true>), grid, dim3(256), 0, stream, a);

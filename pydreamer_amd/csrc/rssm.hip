@@ -313,7 +313,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
     // x = z_mlp(z) + a_mlp(a) ; za = ELU(in_norm(x))                                   rssm.py:138-140
     // (ln_z: the gather kernel owns complete rows, so it also normalises them and the gate product below runs plain - the
     //  prologue form makes each of that product's 226 workgroups redo the LayerNorm + ELU of the whole operand)
-    const bool ln_z = fuse_ln && g_fwd_ln_z && wzt && t > t0 && x1f && !stacked;
+    const bool ln_z = fuse_ln && g_fwd_ln_z && wzt && t > t0 && x1f && !stacked && S <= 32;     // the row-per-workgroup form holds <= 32 groups (stoch_dim 64 / 96 take the branch below)
     if (ln_z) {
       DM_TRY(dm_z_embed_launch(B, Hd, S, C, idx + (r0 - B) * S, reset + r0, wzt, p[DM_RSSM_Z_B], a.ea + r0 * Hd, Hd,
                                nullptr, nullptr, a.x1 + r0 * Hd, Hd, nullptr, p[DM_RSSM_IN_G], p[DM_RSSM_IN_B], 1e-3f,

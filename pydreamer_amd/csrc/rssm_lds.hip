@@ -1241,7 +1241,17 @@ int rl_launch_exclusive(const void* fn, unsigned grid, void** args, size_t lds_b
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   if (!capturing && hipStreamWaitEvent(st, g_chip_lease, 0) != hipSuccess) (void)hipGetLastError();      // (never recorded yet: no-op)
-  if (hipLaunchKernel(fn, dim3(grid), dim3(RL_THREADS), args, lds_bytes, st) != hipSuccess)
+  // Co-residency of the whole grid is REQUESTED, not assumed: a cooperative launch is validated by the runtime against the
+  // kernel's occupancy (it refuses a grid that cannot be resident at once); rl_occupancy_ok() has already checked the same
+  // bound with the occupancy API and a margin.  Inside a stream capture (and if the runtime refuses cooperative launches
+  // altogether) the plain launch is used; the spin loops stay bounded either way.
+  static const int coop = getenv("DM_RSSM_LDS_COOP") ? atoi(getenv("DM_RSSM_LDS_COOP")) : 1;
+  bool launched = false;
+  if (coop && !capturing) {
+    if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(RL_THREADS), args, (unsigned)lds_bytes, st) == hipSuccess) launched = true;
+    else (void)hipGetLastError();
+  }
+  if (!launched && hipLaunchKernel(fn, dim3(grid), dim3(RL_THREADS), args, lds_bytes, st) != hipSuccess)
     return dm_fail(DM_E_HIP, "rssm_lds: launch failed: %s", hipGetErrorString(hipGetLastError()));
   if (!capturing && hipEventRecord(g_chip_lease, st) != hipSuccess) (void)hipGetLastError();
   return DM_OK;
@@ -1256,6 +1266,16 @@ bool rl_raise_lds(FN fn, int slot) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_max);
     if (e != hipSuccess) (void)hipGetLastError();
     state[slot] = e == hipSuccess ? 1 : -1;
+    // ... and the occupancy API must grant at least one workgroup of this variant per CU at the LARGEST LDS size it is launched
+    // with (registers, waves): the grid never exceeds the CU count (rl_device_ok), so one per CU makes it co-resident.
+    if (state[slot] == 1) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), RL_THREADS, (size_t)g_lds_max) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+      }
+      if (nb < 1) state[slot] = -1;
+    }
   }
   return state[slot] == 1;
 }
@@ -1294,7 +1314,8 @@ extern "C" int dm_rssm_lds_status(void) { return g_host_err ? (int)*(volatile un
 static const int g_rssm_lds_max_b = getenv("DM_RSSM_LDS_MAX_B") ? atoi(getenv("DM_RSSM_LDS_MAX_B")) : 32;
 bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C) {
   RlPlan p;
-  return g_rssm_lds && (B <= g_rssm_lds_max_b || g_rssm_lds >= 2) && rl_plan(B, D, Hd, S, C, &p) &&
+  // (once a persistent kernel has given up - dm_rssm_lds_status - every later call takes the launch chain instead of failing)
+  return g_rssm_lds && dm_rssm_lds_status() == 0 && (B <= g_rssm_lds_max_b || g_rssm_lds >= 2) && rl_plan(B, D, Hd, S, C, &p) &&
          rl_device_ok(p.G, p.lds_bytes) && rl_fwd_ready(p.rl);
 }
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps) {

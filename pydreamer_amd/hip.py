@@ -186,6 +186,7 @@ _SIGNATURES = {
     'dm_chain_graph_reset': (c_int, []),
     'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_bf16_twins_enable': (c_int, [c_int]),
+    'dm_gemm_dma_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
     'dm_rssm_lds_bwd_enable': (c_int, [c_int]),
     'dm_bptt_fold_enable': (c_int, [c_int]),
@@ -199,7 +200,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 9      # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 10     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

@@ -1523,6 +1523,21 @@ class Dreamer(nn.Module):
         self.join_optimizers()
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):
+        self.join_optimizers()      # (pipelined mode: an actor / critic AdamW step may still be writing the parameters)
+        return super().load_state_dict(*args, **kwargs)
+
+    def check_device_status(self):
+        """Raises if a persistent posterior kernel of this process has given up in a spin loop (csrc/rssm_lds.hip: it needs every
+        workgroup resident at once; a second process on the GPU can starve it).  The flag is host-visible memory the kernel
+        writes, so this costs nothing; it is meaningful behind a device synchronisation - packed_metrics_host() and the
+        trainer's logging sync are where it is called.  After a give-up the library falls back to the launch chain for every
+        later call (dm_rssm_lds_ok), but the step that gave up produced garbage and must not be trusted."""
+        st = H.lib().dm_rssm_lds_status()
+        if st != 0:
+            raise RuntimeError(f'a persistent RSSM kernel gave up in a spin loop (status {st}): the outputs of that training step '
+                               'are invalid - restore the last checkpoint; later steps run the launch chain')
+
     def packed_metrics(self):
         """(names, buffer, idx): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
         has run) sits in ONE 1-D device tensor `buffer`; `idx` (a python list) are the slots of `names` in it, so
@@ -1532,6 +1547,14 @@ class Dreamer(nn.Module):
         self.join_optimizers()      # (pipelined mode: the actor / critic gradient norms were written on the actor-critic stream)
         names = list(METRIC_SLOTS)
         return names, self.metric_buffer, [METRIC_SLOTS[n] for n in names]
+
+    def packed_metrics_host(self):
+        """{name: float} of packed_metrics() with ONE device-to-host copy (= the step's only sync), followed by
+        check_device_status() - the logging call of a trainer (train.py:204-214)."""
+        names, buf, idx = self.packed_metrics()
+        vals = buf.tolist()
+        self.check_device_status()
+        return {n: vals[i] for n, i in zip(names, idx)}
 
     def init_state(self, batch_size):
         return self.wm.init_state(batch_size)

@@ -274,6 +274,7 @@ class FusedAdamW(torch.optim.Optimizer):
     # tools.mlflow_save_checkpoint / mlflow_load_checkpoint (tools.py:164-197) move `optimizer_{i}_state_dict` between a
     # reference run and this build in both directions.  The flat moments are sliced at the parameter offsets.
     def state_dict(self):
+        self.join()       # (pipelined mode: the moments may still be being written on the group's own stream)
         g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         for k, v in dict(amsgrad=False, foreach=None, maximize=False, capturable=False, differentiable=False, fused=None).items():
             g.setdefault(k, v)
@@ -290,6 +291,7 @@ class FusedAdamW(torch.optim.Optimizer):
         return dict(state=state, param_groups=[g])
 
     def load_state_dict(self, sd):
+        self.join()       # an AdamW step in flight on the group's own stream must not race with the copies below
         groups = sd['param_groups']
         if len(groups) != 1:
             raise ValueError(f'FusedAdamW holds one parameter group, the state dict has {len(groups)}')

@@ -165,6 +165,14 @@ class SequentialReplay:
     def relist_due(self):
         return bool(self.reload_interval) and time.time() - self.listed_at > self.reload_interval
 
+    # the names the reference trainer reads on its DataSequential (train.py:68-79, 227-229; data.py:147-170)
+    @property
+    def stats_steps(self):
+        return self.listed_steps
+
+    reload_files = relist
+    should_reload_files = relist_due
+
     # ---- artificial resets: a long episode is cut into 1..steps/interval+1 backprop spans at random window-aligned rows
     def scatter_resets(self, resets, reset_interval, batch_length):
         """Same draws, same result as data.py:280-300."""
@@ -227,7 +235,13 @@ class SequentialReplay:
         for ep, a, z in pieces:
             n = z - a
             for k, dst in out.items():
-                dst[t:t + n, b] = ep.fields[k][a:z]
+                src = ep.fields.get(k)
+                if src is None:
+                    if k != 'terminal':
+                        raise KeyError(f'an episode file lacks the field {k!r} the batch was laid out with')
+                    dst[t:t + n, b] = 0                       # files written before `terminal` existed: no terminal rows
+                else:
+                    dst[t:t + n, b] = src[a:z]
             if ep.marks is not None and ep.marks[a:z].any():
                 if ep.fields['reset'][a:z].any():
                     raise ValueError('an artificial reset fell into a window that holds a real one')
@@ -290,11 +304,16 @@ class ReplayFeed:
         if clip_rewards not in (None, '', False, 'tanh', 'log1p'):
             raise ValueError(clip_rewards)
         self.replay, self.action_dim, self.clip_rewards, self.image_key = replay, int(action_dim), clip_rewards, image_key
+        if not replay.files:
+            raise ValueError('ReplayFeed needs at least one episode file to lay out its slots (the repository is empty)')
         probe = _Episode(replay.files[0].load_data()).fields      # shapes only; draws nothing from the random stream
         T, B = replay.batch_length, replay.batch_size
-        self._has_terminal = 'terminal' in probe
+        # `terminal` always has a column: an episode without the field contributes zeros (SequentialReplay._copy), so a
+        # repository that mixes files with and without it still yields the flags of those that carry them
+        self._has_terminal = True
         self._small = {k: np.empty((T, B) + probe[k].shape[1:], probe[k].dtype)
-                       for k in ('action', 'action_next', 'reward', 'terminal') if k in probe}
+                       for k in ('action', 'action_next', 'reward') if k in probe}
+        self._small['terminal'] = np.empty((T, B), probe['terminal'].dtype if 'terminal' in probe else np.float32)
         img = probe[image_key]
         if img.dtype != np.uint8 or img.ndim != 4:
             raise ValueError(f'expected uint8 (T,H,W,C) frames in the episode files, got {img.dtype} {img.shape}')

@@ -106,6 +106,55 @@ def test_gemm_bf16_storage(hip, al, bl, M, N, K):
     assert torch.equal(Ch, C.bfloat16())
 
 
+DMA_CASES = [
+    # (al, bl, M, N, K, flags): 16-byte-load shapes on every tile of the menu (64x64, 128x64, 128x128, 128x96, 96x128), ragged
+    # edges in M / N / K, split-K weight-gradient shapes, a single k-tile, fewer k-tiles than LDS stages
+    (0, 0, 2500, 1800, 1000, 0), (0, 0, 2500, 1000, 600, 2), (0, 0, 4096, 4096, 512, 0), (0, 0, 40000, 400, 400, 3),
+    (0, 0, 3000, 192, 864, 0), (0, 0, 300, 200, 160, 0), (0, 0, 70, 40, 8, 0), (0, 0, 129, 67, 36, 1), (0, 0, 5, 3, 4, 0),
+    (0, 1, 2500, 1624, 400, 0), (0, 1, 2500, 4800, 1536, 0), (0, 1, 4096, 2048, 300, 2), (0, 1, 257, 96, 100, 0), (0, 1, 131, 8, 33, 0),
+    (1, 1, 400, 1624, 2500, 0), (1, 1, 96, 1728, 42250, 0), (1, 1, 1536, 4800, 2500, 0), (1, 1, 48, 48, 30000, 0), (1, 1, 64, 132, 259, 1),
+    (1, 1, 4, 400, 5000, 0), (1, 0, 100, 92, 80, 0), (1, 0, 2048, 1024, 777 * 4, 0),
+]
+
+
+@pytest.mark.parametrize('al,bl,M,N,K,flags', DMA_CASES)
+def test_gemm_dma_equals_register_staged_loop(hip, al, bl, M, N, K, flags):
+    """gemm_dma_kernel (LDS-DMA operand pipeline, round 5) against gemm_f32_kernel (register-staged loop) on the same call:
+    same tiles, same k -> MFMA-step map, same epilogue => BIT-IDENTICAL results (torch.equal), with and without the bias /
+    addend / accumulate / ELU epilogue; and both against the fp64 product."""
+    A = _rand(M, K, seed=31)
+    B = _rand(N, K, seed=32)
+    Ad = A if al == 0 else A.t().contiguous()
+    Bd = B if bl == 0 else B.t().contiguous()
+    bias = _rand(N, seed=33) if flags else None
+    add = _rand(M, N, seed=34) if flags & 1 else None
+    C0 = _rand(M, N, seed=35)
+    ws = _ws()
+    outs = []
+    try:
+        for on in (2, 0):      # 2: the LDS-DMA loop for every k extent (by default it serves products of >= 14 k-tiles)
+            assert hip.lib().dm_gemm_dma_enable(on) == on
+            C = C0.clone()
+            hip.call('dm_gemm_f32', al, bl, M, N, K, hip.fptr(Ad), Ad.shape[1], hip.fptr(Bd), Bd.shape[1], hip.fptr(C), N,
+                     hip.fptr(bias) if bias is not None else None, hip.fptr(add) if add is not None else None, N, flags,
+                     hip.ptr(ws), ws.numel(), hip.stream())
+            torch.cuda.synchronize()
+            outs.append(C)
+    finally:
+        hip.lib().dm_gemm_dma_enable(1)
+    assert torch.equal(outs[0], outs[1]), f'{int((outs[0] != outs[1]).sum())} of {outs[0].numel()} elements differ'
+    ref = A.double() @ B.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    if add is not None:
+        ref = ref + add.double()
+    if flags & 1:
+        ref = ref + C0.double()
+    if flags & 2:
+        ref = F.elu(ref)
+    _close(outs[0], ref, 2e-6, 3e-6 * np.sqrt(K) * 4 + 1e-5, f'dma gemm {al}{bl} {M}x{N}x{K}')
+
+
 def test_gemm_epilogue_and_strides(hip):
     """bias + addend + accumulate + ELU, with sub-matrix leading dimensions (feature-matrix slices)."""
     M, N, K, ldc, lda = 70, 200, 100, 264, 164
