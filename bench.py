@@ -260,12 +260,19 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if not one_device and torch.cuda.device_count() < world:
+            raise SystemExit(f'--gpus {world} needs {world} visible GPUs (one process per GPU over RCCL); this box has '
+                             f'{torch.cuda.device_count()} (DM_BENCH_ONE_DEVICE=1 runs the N-rank code path on one device over gloo: a smoke mode, not a metric)')
         dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
+        if not one_device and (dist.get_backend() != 'nccl' or dist.get_world_size() != args.gpus):
+            raise SystemExit(f'--gpus {args.gpus}: expected {args.gpus} ranks over nccl (= RCCL), got {dist.get_world_size()} over {dist.get_backend()}')
 
     from pydreamer_amd import config, hip
     from pydreamer_amd import dist as DP
     from pydreamer_amd.models import Dreamer
     hip.call('dm_device_check')
+    lds_clk = (ctypes.c_ulonglong * 16)()
+    hip.lib().dm_rssm_lds_prof(lds_clk, 1)             # (allocates and zeroes the persistent kernel's phase clocks: non-zero at the end = it ran)
     if one_device:
         # the persistent posterior kernel needs every CU of the device at once (one workgroup per CU, resident together): two
         # PROCESSES launching theirs on the same device can each hold part of the chip and spin until their poll bounds trip.
@@ -385,7 +392,15 @@ def main():
         gl = torch.tensor([loss_model * (hi - lo) / B], device=dev, dtype=torch.float64)
         dist.all_reduce(gl)
         shard_sizes = [DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]
+        # the persistent posterior kernel (csrc/rssm_lds.hip; default for <= 32-column shards): did it run on every rank, and did
+        # any rank's kernel give up in a spin loop (dm_rssm_lds_status, sticky)?
+        hip.lib().dm_rssm_lds_prof(lds_clk, 0)
+        pk = torch.tensor([1.0 if sum(lds_clk) > 0 else 0.0, float(hip.lib().dm_rssm_lds_status())], device=dev, dtype=torch.float64)
+        allp = [torch.zeros_like(pk) for _ in range(world)]
+        dist.all_gather(allp, pk)
         dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), rccl_version=rccl,
+                         persistent_posterior_kernel_ran=[bool(x[0].item()) for x in allp],
+                         rssm_lds_status=[int(x[1].item()) for x in allp],
                          shard_columns=shard_sizes, replicas_identical=replicas_identical,
                          param_checksum_rank0=[float(x) for x in allc[0].tolist()], loss_model_global=float(gl.item()),
                          ms_per_step_per_rank=rank_ms, host_enqueue_ms_per_rank=host_ms, allreduce_standalone=ar_ms,
@@ -455,24 +470,34 @@ def main():
                 for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
                     f.write(' '.join(str(x) for x in key) + f' {a[0] / args.prof_steps:.1f} {a[2] / args.prof_steps:.3f} '
                             f'{1e3 * a[2] / a[0]:.1f} {a[1] / (a[2] * 1e-3) / 1e12 if a[2] > 0 else 0:.1f}\n')
-        out = (ctypes.c_double * 92)()
-        n = hip.lib().dm_prof_end(out, 23)
+        NK = 44
+        out = (ctypes.c_double * (4 * NK))()
+        n = hip.lib().dm_prof_end(out, NK)
         kinds = []
         names = {0: 'NT', 1: 'NN', 2: 'TN*', 3: 'TN'}
         tiles = ('128,128', '128,64', '64,64', '128,96', '96,128')
-        for k in range(23):
+        for k in range(NK):
             cnt, fl, ms, by = out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]
             if cnt:
+                # kinds: 0..19 register-staged tile kernel (tile*4 + layouts), 20..22 panel / whole-MLP kernels, 24+ the same tiles on
+                # gemm_dma_kernel (csrc/gemm.hip dm_gemm_launch)
                 # (bf16 mode: the same tile / layout runs as gemm_pipe_kernel, or gemm_h_kernel when both operands have bf16 twins)
-                kname = (f"{'gemm_pipe_kernel' if args.dtype == 'bf16' else 'gemm_f32_kernel'}<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>" if k < 20 else
-                         ('panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2' if k == 21 else 'mlp_chain_fwd_kernel'))
+                kk = k - 24 if k >= 24 else k
+                if k >= 24:
+                    kname, lay = f'gemm_dma_kernel<{tiles[kk >> 2]},{(kk >> 1) & 1},{kk & 1}>', names[kk & 3]
+                elif k < 20:
+                    kname = f"{'gemm_pipe_kernel' if args.dtype == 'bf16' else 'gemm_f32_kernel'}<{tiles[k >> 2]},{(k >> 1) & 1},{k & 1}>"
+                    lay = names[k & 3]
+                else:
+                    kname = 'panel_linear_kernel<25,0,1' if k == 20 else 'panel_linear_kernel<25,1,2' if k == 21 else 'mlp_chain_fwd_kernel'
+                    lay = 'row panel fwd' if k == 20 else 'row panel bwd' if k == 21 else 'whole-MLP forward, 16-row blocks'
                 kinds.append(dict(kernel=kname,
-                                  layout=names[k & 3] if k < 20 else ('row panel fwd' if k == 20 else 'row panel bwd' if k == 21 else 'whole-MLP forward, 16-row blocks'), launches_per_step=cnt / args.prof_steps,
+                                  layout=lay, launches_per_step=cnt / args.prof_steps,
                                   avg_launch_us=1e3 * ms / cnt, gflop_per_step=fl / 1e9 / args.prof_steps,
                                   ms_per_step=ms / args.prof_steps, tflops=fl / (ms * 1e-3) / 1e12,
                                   alg_bytes_per_launch=by / cnt, alg_flops_per_launch=fl / cnt))
-        tot_fl = sum(out[4 * k + 1] for k in range(23))
-        tot_ms = sum(out[4 * k + 2] for k in range(23))
+        tot_fl = sum(out[4 * k + 1] for k in range(NK))
+        tot_ms = sum(out[4 * k + 2] for k in range(NK))
         dom = max(kinds, key=lambda d: d['ms_per_step'])
         peak = 157.3 if args.dtype == 'f32' else 2500.0       # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 PMC passes of this same command (FETCH_SIZE
@@ -568,7 +593,7 @@ def main():
                     fp32_products='fp32 MFMA',
                     chain_graphs=hip.chain_graph_stats(),
                     step_tflops=alg_tflop / (ms * 1e-3), step_frac_of_fp32_peak=alg_tflop / (ms * 1e-3) / 157.3,
-                    h2d_included=h2d, distributed=dist_info,
+                    h2d_included=h2d, distributed=dist_info, rccl_version=(dist_info or {}).get('rccl_version'),
                     **({} if args.workload == 'atari-literal' else {'INVALID_diagnostic_workload': args.workload}),
                     **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),
                     roofline=roof, cpu_baseline=cpu)

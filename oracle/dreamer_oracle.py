@@ -40,6 +40,7 @@ DEFAULTS = dict(
     gamma=0.995, lambda_gae=0.95, entropy=0.003, target_interval=100, imag_horizon=15,
     actor_grad='reinforce', actor_dist='onehot',
     aux_critic=False, aux_critic_weight=1.0, gamma_aux=0.99, lambda_gae_aux=0.95, target_interval_aux=1000,
+    probe_gradients=False,
 )
 ATARI = dict(action_dim=18, deter_dim=1024, kl_weight=0.1, gamma=0.99, entropy=0.001)
 
@@ -650,8 +651,11 @@ class OracleDreamer:
     def init_optimizers(self):
         c = self.conf
         mk = lambda g, lr: torch.optim.AdamW(self.group(g), lr=lr, eps=c.adam_eps)   # dreamer.py:60-66
-        self.optimizers = (mk('wm', c.adam_lr), mk('probe', c.adam_lr), mk('actor', c.adam_lr_actor),
-                           mk('critic', c.adam_lr_critic))
+        if getattr(c, 'probe_gradients', False):                                       # dreamer.py:67-71: the probe head has no optimizer
+            self.optimizers = (mk('wm', c.adam_lr), mk('actor', c.adam_lr_actor), mk('critic', c.adam_lr_critic))
+        else:
+            self.optimizers = (mk('wm', c.adam_lr), mk('probe', c.adam_lr), mk('actor', c.adam_lr_actor),
+                               mk('critic', c.adam_lr_critic))
         return self.optimizers
 
     def init_state(self, batch):
@@ -699,6 +703,8 @@ class OracleDreamer:
                 extras['dream_tensors'] = dict(action_pred=torch.cat([obs['action'][:1], a2]), reward_pred=r2,
                                                terminal_pred=t2, image_pred=image_dream, **t_ac2)
                 extras['dream_log_idx'] = dx2
+        if getattr(c, 'probe_gradients', False):                                       # dreamer.py:183-186
+            return (loss_model + loss_probe, loss_actor, loss_critic), out_state, metrics, tensors, extras
         return (loss_model, loss_probe, loss_actor, loss_critic), out_state, metrics, tensors, extras
 
     def backward_clip_step(self, losses):
@@ -709,9 +715,14 @@ class OracleDreamer:
         for loss in losses:
             loss.backward()
         clip = torch.nn.utils.clip_grad_norm_
-        grad_metrics = dict(grad_norm=clip(self.group('wm'), c.grad_clip), grad_norm_probe=clip(self.group('probe'), c.grad_clip),
-                            grad_norm_actor=clip(self.group('actor'), c.grad_clip_ac),
-                            grad_norm_critic=clip(self.group('critic'), c.grad_clip_ac))
+        if getattr(c, 'probe_gradients', False):                                       # dreamer.py:81-86
+            grad_metrics = dict(grad_norm=clip(self.group('wm'), c.grad_clip),
+                                grad_norm_actor=clip(self.group('actor'), c.grad_clip_ac),
+                                grad_norm_critic=clip(self.group('critic'), c.grad_clip_ac))
+        else:
+            grad_metrics = dict(grad_norm=clip(self.group('wm'), c.grad_clip), grad_norm_probe=clip(self.group('probe'), c.grad_clip),
+                                grad_norm_actor=clip(self.group('actor'), c.grad_clip_ac),
+                                grad_norm_critic=clip(self.group('critic'), c.grad_clip_ac))
         grads = OrderedDict((k, v.grad.detach().clone()) for k, v in self.p.items() if v.grad is not None)
         for opt in self.optimizers:
             opt.step()

@@ -241,6 +241,49 @@ def run_amp(name, sections, overrides):
     print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def run_amp_grads(name, sections, overrides):
+    """Gradient side of run_amp: the same full-size step under torch.autocast('cpu', bfloat16) WITH the four backward passes
+    (train.py:166-198 without the GradScaler, which bf16 does not need); stores the losses (they must equal run_amp's bf16
+    losses: same inputs, same uniforms) and the per-parameter gradient norms BEFORE clipping.  Separate small fixture
+    (<name>_grads.npz) so the forward fixture stays untouched.  Several minutes of CPU per backward at full width."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REF)
+    from pydreamer.models import Dreamer
+    import torch.distributions as D
+    D.Distribution.set_default_validate_args(False)
+    rconf = reference_conf(sections, overrides)
+    oconf = O.make_conf(**{k: getattr(rconf, k) for k in O.DEFAULTS})
+    model = Dreamer(rconf)
+    model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    T, B, S, H = rconf.batch_length, rconf.batch_size, rconf.stoch_dim, rconf.imag_horizon
+    obs = O.preprocess(O.synthetic_batch(oconf, seed=1234, first=True), oconf)
+    noise = O.make_noise(oconf, seed=777)
+    with MultinomialPatch() as mp:
+        mp.queue = [noise['u_post'][t] for t in range(T)]
+        for i in range(H):
+            if rconf.actor_dist == 'onehot':
+                mp.queue.append(noise['u_act'][i])
+            else:
+                mp.eps_queue.append(noise['eps_act'][i])
+            mp.queue.append(noise['u_prior'][i])
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=True):
+            losses, _, metrics, _, _ = model.training_step(obs, model.init_state(B))
+        post_idx = torch.stack(mp.idx[:T]).reshape(T, B, S)
+    for loss in losses:
+        loss.backward()
+    named = dict(model.named_parameters())
+    grads = {k: v.grad.detach() for k, v in named.items() if v.grad is not None}
+    out = {'conf_json': np.array(repr(sorted(vars(oconf).items()))),
+           'bf16_losses': np.array([float(l) for l in losses], dtype=np.float64),
+           'bf16_idx_post': post_idx.numpy().astype(np.uint8),
+           'bf16_grad_names': np.array(list(grads.keys())),
+           'bf16_grad_norms': np.array([float(g.double().norm()) for g in grads.values()])}
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}_grads.npz')
+    np.savez_compressed(path, **out)
+    print(f'[{name}_grads] losses', out['bf16_losses'], 'wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def run_eval(name, sections, overrides, do_open_loop=False, iwae_samples=None):
     """Logging variants of training_step (train.py:353-359,380-385 call it with do_image_pred / do_dream_tensors):
     one forward with both flags; inputs, extra uniforms and every extra output are stored.
@@ -505,6 +548,14 @@ if __name__ == '__main__':
             dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
                  cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
                  imag_horizon=t.imag_horizon, iwae_samples=3), steps=2, full_grads=SMALL_GRADS)
+    if 'probe_gradients' in which:
+        # probe_gradients=True with probe_model=none (dreamer.py:60-87,183-186): THREE optimizers (wm, actor, critic), the first loss
+        # is loss_model + loss_probe, grad_clip() returns three norms; the probe head's dummy parameter gets a gradient but no step
+        t = O.tiny_conf()
+        run('tiny_probe_gradients', ['defaults', 'atari'],
+            dict(deter_dim=t.deter_dim, hidden_dim=t.hidden_dim, stoch_dim=t.stoch_dim, stoch_discrete=t.stoch_discrete,
+                 cnn_depth=t.cnn_depth, action_dim=t.action_dim, batch_length=t.batch_length, batch_size=t.batch_size,
+                 imag_horizon=t.imag_horizon, probe_gradients=True), steps=2, full_grads=SMALL_GRADS)
     if 'dmc_native' in which:
         # BASELINE.json configs[4] at its native width: defaults+dmc (deter_dim 2048, tanh_normal actor) with
         # actor_grad=reinforce, action_dim 6, B=50, T=50, H=15; slim fixture (several minutes per step on 8 vCPU)
@@ -519,6 +570,12 @@ if __name__ == '__main__':
         # posterior indices)
         run_amp('atari_literal_amp', ['defaults', 'atari'],
                 dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18))
+    if 'atari_amp_grads' in which:
+        run_amp_grads('atari_literal_amp', ['defaults', 'atari'],
+                      dict(batch_size=50, batch_length=50, imag_horizon=15, deter_dim=600, action_dim=18))
+    if 'dmc_amp_grads' in which:
+        run_amp_grads('dmc_native_amp', ['defaults', 'dmc'],
+                      dict(batch_size=50, batch_length=50, imag_horizon=15, action_dim=6, actor_grad='reinforce'))
     if 'dmc_amp' in which:
         # BASELINE.json configs[4] as named: DMC continuous actions (defaults+dmc, deter_dim 2048, tanh_normal, action_dim 6,
         # actor_grad=reinforce) at B=50, T=50, H=15 forward under torch.autocast('cpu', bfloat16) and in fp32

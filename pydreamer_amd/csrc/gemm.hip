@@ -52,6 +52,7 @@ struct GemmKArgs {
   int tiles_n, n_fast;
   int a_vec, b_vec;
   unsigned short* Ch;         // optional bf16 twin of C (same ldc), written with the final value
+  int use_dma;                // host-side: this launch takes gemm_dma_kernel (not read by the kernels)
 };
 
 // Load a (ROWS x 32) operand tile into registers, zero-filled outside [0,nrows) x [k0,kend).  Branch-free: out-of-range
@@ -1157,10 +1158,11 @@ extern "C" int dm_prof_rows(double* rows, int max_rows) {
   return n;
 }
 // out[kind*4 + {0,1,2,3}] = {launches, flops, milliseconds, algorithmic bytes (4*(M*K + N*K + M*N))} for
-// kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x96, 4: 96x128); returns the number of recorded launches
+// kind = tile*4 + a_layout*2 + b_layout (tile 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x96, 4: 96x128), + 24 when the launch took
+// gemm_dma_kernel; 20..22 panel / whole-MLP kernels; returns the number of recorded launches
 // (negative on error).  Synchronises on the recorded events.
 extern "C" int dm_prof_end(double* out, int nkinds) {
-  DM_REQUIRE(out && nkinds >= 23, DM_E_SHAPE, "prof_end: need room for 23 kinds");
+  DM_REQUIRE(out && nkinds >= 44, DM_E_SHAPE, "prof_end: need room for 44 kinds");
   g_prof.on = false;
   for (int i = 0; i < nkinds * 4; ++i) out[i] = 0.0;
   for (size_t i = 0; i < g_prof.n; ++i) {
@@ -1271,13 +1273,7 @@ static int gemm_dma_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim
 template <int BM, int BN, bool V, int WGM = 2, int WGN = 2, int BF = 0>
 static int gemm_dispatch(const GemmKArgs& a, int al, int bl, int gather, dim3 grid, hipStream_t stream) {
   if constexpr (V && BF == 0) {
-    // layout 0 clamps edge rows to the last row, layout 1 to the last full group of 4: >= 1 / >= 4 rows
-    // ... and enough k-tiles per work item to amortise the ring's fill: below that the register-staged loop's higher residency
-    // (one LDS stage, 4-7 workgroups per CU) hides a tile's prologue and epilogue better (profiles/r05_gemm_dma_ab.txt:
-    // K = 144 / 192 / 384 products lost 9-17 %); both loops give the same bits, so the choice is free per call
-    static const int min_kt = getenv("DM_GEMM_DMA_MIN_KT") ? atoi(getenv("DM_GEMM_DMA_MIN_KT")) : 14;
-    if (g_dma_enabled && (a.k_per_split >= 32 * min_kt || g_dma_enabled >= 2) && (al == 0 ? a.M >= 1 : a.M >= 4) && (bl == 0 ? a.N >= 1 : a.N >= 4))
-      return gemm_dma_dispatch<BM, BN, WGM, WGN>(a, al, bl, gather, grid, stream);
+    if (a.use_dma) return gemm_dma_dispatch<BM, BN, WGM, WGN>(a, al, bl, gather, grid, stream);
   }
   if (a.c_tab) {
     if (gather != 1 || al != 0 || bl != 0 || !V) return dm_fail(DM_E_SHAPE, "gemm: the scatter epilogue is built for a gathered A, layout (0,0), 16-byte loads");
@@ -1474,6 +1470,7 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   int BM = 64, BN = 64, nsplit = 1;
   double best_cost = -1.0;
   const int kt1 = ktiles > 0 ? ktiles : 1;
+  const bool dma_shape_pre = !hstore && !q.bf16 && a.a_vec && a.b_vec;
   for (int c = 0; c < 5; ++c) {
     static const int sc_tile = getenv("DM_SC_TILE") ? atoi(getenv("DM_SC_TILE")) : 0;      // tuning override: scatter-epilogue products only
     if (force_tile && c != force_tile - 1) continue;
@@ -1530,9 +1527,27 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
         if (c == 2 && q.K <= 800) cost *= 0.8;
         if (c == 3 && q.N % 96 == 0 && q.K > 800) cost *= 0.8;
       }
+      // with the LDS-DMA loop (scripts/gemm_tile_sweep.py, profiles/r05_tile_sweep.txt): a row-contiguous B on the 128 x 128 tile
+      // is the one combination it does not speed up (2500 x 4800 x 1536: 425 us against 342 on 128 x 64); split weight gradients
+      // of the 400-wide heads run 6-14 % faster on 64 x 64 tiles (three resident workgroups per CU with the 3-stage ring)
+      if (!q.a_maj && !q.b_maj && !q.c_tab && dma_shape_pre && g_dma_enabled) {
+        if (c == 0 && q.a_layout == 0 && q.b_layout == 1) cost *= 1.3;
+        if (c == 2 && q.a_layout == 1 && q.b_layout == 1 && sp > 1 && t < 256 && dm_cdiv(kt1, sp) >= 14) cost *= 0.8;
+      }
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; BM = bm; BN = bn; nsplit = sp; }
     }
   }
+  // ---- which main loop (fp32 operands, 16-byte loads): gemm_dma_kernel when a work item has enough k-tiles to amortise the
+  // ring's fill - below that the register-staged loop's higher residency (one LDS stage, 4-7 workgroups per CU) hides a
+  // tile's prologue and epilogue better (profiles/r05_gemm_shapes_dma.txt vs _regstaged.txt with the switch at 2: K = 144 /
+  // 192 / 384 products lose 8-15 %); both loops give the same bits, so the choice is free per call.  Layout 0 clamps edge
+  // rows to the last row, layout 1 to the last full group of 4: >= 1 / >= 4 rows.
+  static const int dma_min_kt = getenv("DM_GEMM_DMA_MIN_KT") ? atoi(getenv("DM_GEMM_DMA_MIN_KT")) : 14;
+  const bool dma_shape = !hstore && !q.bf16 && a.a_vec && a.b_vec && (q.a_layout == 0 ? q.M >= 1 : q.M >= 4) && (q.b_layout == 0 ? q.N >= 1 : q.N >= 4);
+  auto dma_for = [&](int sp) { return g_dma_enabled && dma_shape && (dm_cdiv(kt1, sp) >= dma_min_kt || g_dma_enabled >= 2); };
+  // (A one-round 128 x 160 tile for the rollout's 2 500 x 1 800 gate products - 240 workgroups, one per CU, instead of 1 160
+  // tiles of 64 x 64 = 4.53 per CU - was built and measured: 104.8 vs 106.3 us at K = 1000, 71.3 vs 68.4 at K = 600, step 33.94
+  // vs 33.50 ms.  One 4-wave workgroup per CU leaves nobody to hide its barrier skew, prologue and epilogue: removed.)
   const int tiles_m = dm_cdiv(q.M, BM), tiles_n = dm_cdiv(q.N, BN);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   int k_per_split = dm_cdiv(ktiles > 0 ? ktiles : 1, nsplit) * 32;
@@ -1551,7 +1566,10 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   dim3 grid((unsigned)a.n_items);
   const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
   DM_REQUIRE(!(q.a_maj && q.b_maj), DM_E_SHAPE, "gemm: only one gathered operand per call");
-  const int kind = tc * 4 + q.a_layout * 2 + q.b_layout;
+  a.use_dma = dma_for(nsplit) ? 1 : 0;
+  // profiling kinds: tile * 4 + layouts for the register-staged loop (0..19), 20..22 the panel / whole-MLP kernels (panel.hip,
+  // mlp_chain.hip), 24 + (tile * 4 + layouts) for gemm_dma_kernel
+  const int kind = tc * 4 + q.a_layout * 2 + q.b_layout + (a.use_dma ? 24 : 0);
   const int slot = prof_before(kind, 2.0 * q.M * q.N * (double)q.K,
                                4.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N), stream);
   if (slot >= 0) {

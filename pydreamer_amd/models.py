@@ -1422,7 +1422,7 @@ class Dreamer(nn.Module):
     def __init__(self, conf):
         super().__init__()
         assert conf.action_dim > 0, 'Need to set action_dim to match environment'
-        if conf.probe_model != 'none' or conf.probe_gradients:
+        if conf.probe_model != 'none':
             raise NotImplementedError('probe models are research heads outside the hot path')
         features_dim = conf.deter_dim + conf.stoch_dim * (conf.stoch_discrete or 1)
         self.conf = conf
@@ -1460,6 +1460,8 @@ class Dreamer(nn.Module):
                          critic=FusedAdamW(groups['critic'], lr=lr_critic or lr, eps=eps))
         # the backward passes write straight into these optimizers' gradient buffers (see _flat_views)
         self.wm._fused, self.ac.actor._fused, self.ac.critic._fused = self._opt['wm'], self._opt['actor'], self._opt['critic']
+        if self.probe_gradients:      # dreamer.py:67-71: three optimizers; the probe head's parameters belong to none of them
+            return self._opt['wm'], self._opt['actor'], self._opt['critic']
         return self._opt['wm'], self._opt['probe'], self._opt['actor'], self._opt['critic']
 
     def grad_clip(self, grad_clip, grad_clip_ac=None):
@@ -1472,6 +1474,10 @@ class Dreamer(nn.Module):
         if mb is not None and o['actor'].home is not None:
             mb.record_stream(o['actor'].home)      # (pipelined mode: two of its slots are written on the actor-critic stream)
         out = lambda name: None if mb is None else mb[METRIC_SLOTS[name]:METRIC_SLOTS[name] + 2]   # [norm, clip coefficient]
+        if self.probe_gradients:      # dreamer.py:81-86
+            return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip, out('grad_norm')),
+                        grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_actor')),
+                        grad_norm_critic=o['critic'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_critic')))
         return dict(grad_norm=o['wm'].clip_grad_norm(grad_clip, out('grad_norm')),
                     grad_norm_probe=o['probe'].clip_grad_norm(grad_clip, out('grad_norm_probe')),
                     grad_norm_actor=o['actor'].clip_grad_norm(grad_clip_ac or grad_clip, out('grad_norm_actor')),
@@ -1802,7 +1808,10 @@ class Dreamer(nn.Module):
                                      terminal_pred=t2.mean, image_pred=image_dream.view(T, B, *image_dream.shape[-3:]),
                                      **t_ac2)
                 self.last_extras.update(dream_log_act_idx=dpk2['act_idx'].clone())
-        losses = (loss_model, loss_probe, loss_actor, loss_critic)
+        if self.probe_gradients:      # dreamer.py:183-186
+            losses = (loss_model + loss_probe, loss_actor, loss_critic)
+        else:
+            losses = (loss_model, loss_probe, loss_actor, loss_critic)
         return losses, out_state, metrics, tensors, dream_tensors
 
     def __str__(self):

@@ -192,3 +192,33 @@ def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
     c8, c1 = dd['param_checksum_rank0'], d1['param_checksum']
     for i in range(4):
         assert abs(c8[i] - c1[i]) <= 2e-5 * c1[4 + i] + 1e-6, (i, c8, c1)
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_default_deployment_over_rccl_on_real_gpus(hip, world):
+    """The deployment every real shard runs - one process per GPU over RCCL ("nccl"), data-parallel FusedAdamW with the early
+    all-reduce and the B_r/B weight folded into the backward kernels, the pipelined actor / critic optimizer, AND the persistent
+    posterior kernel ON (its default for <= 32-column shards: 25/25, 13/13/12/12, 7/7/6/6/6/6/6/6 of the 50 columns) - at the
+    full Atari-literal size, through bench.py as the driver launches it.  Needs `world` GPUs: two trainers cannot share one
+    device with the persistent kernel on (each needs every CU at once), which is why the one-device smoke mode of the tests
+    above switches it off; this test is the first place the real thing runs.  Asserted: RCCL saw `world` ranks, the persistent
+    kernel ran on every rank and none gave up (dm_rssm_lds_status 0 everywhere), every rank holds bit-identical parameters
+    after 2 steps, and the global batch's loss / parameter checksums equal the 1-rank run's up to fp32 summation order."""
+    ndev = torch.cuda.device_count()
+    if ndev < world:
+        pytest.skip(f'needs {world} GPUs for one process per GPU over RCCL; this box has {ndev}')
+    flags = ('--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
+    dn = _run_bench(world, {}, *flags)
+    d1 = _run_bench(1, {}, *flags)
+    dd = dn['distributed']
+    assert dn['n_gpus'] == world and dd['world_size'] == world and dd['backend'] == 'nccl' and dn['rccl_version']
+    assert 'INVALID_smoke_all_ranks_on_one_device' not in dn
+    assert sum(dd['shard_columns']) == 50 and max(dd['shard_columns']) <= 32
+    assert all(dd['persistent_posterior_kernel_ran']), dd['persistent_posterior_kernel_ran']
+    assert dd['rssm_lds_status'] == [0] * world
+    assert dd['replicas_identical'] is True
+    l8, l1 = dd['loss_model_global'], d1['loss_model_last']
+    assert abs(l8 - l1) <= 1e-4 * abs(l1), (l8, l1)
+    c8, c1 = dd['param_checksum_rank0'], d1['param_checksum']
+    for i in range(4):
+        assert abs(c8[i] - c1[i]) <= 2e-5 * c1[4 + i] + 1e-6, (i, c8, c1)

@@ -524,6 +524,61 @@ def test_rssm_lds_chain_matches_launch_schedule(hip, B, D_):
         off += (N * width + 63) // 64 * 64      # the arena is carved in 64-float granules (csrc/common.h DmArena)
 
 
+def test_rssm_lds_kernel_with_a_busy_chip(hip):
+    """The persistent posterior kernel needs one workgroup resident on every CU at the same time.  It is launched
+    cooperatively (the runtime validates that the grid CAN be co-resident; csrc/rssm_lds.hip rl_launch_exclusive) and its spin
+    loops are bounded; this test runs it while a second stream keeps every CU busy with LDS-heavy work - a queue of 4096^3
+    products on 128 x 128 tiles, 64 KiB of LDS per workgroup, two per CU, ~1 ms each - so that its workgroups become
+    resident one by one as the tiles of the other stream retire, and the early ones wait for the late ones.  Asserted: the
+    kernel never gives up (dm_rssm_lds_status() == 0) and every output equals the quiet run's BIT FOR BIT (the exchange
+    protocol makes the arithmetic independent of arrival order)."""
+    import ctypes
+    from pydreamer_amd import hip as H
+    T, B, D_, Hd, S, C, A, depth = 12, 13, 600, 1000, 32, 32, 18, 8
+    oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
+                        batch_size=B, batch_length=T)
+    model = _build(oconf, O.make_params(oconf, seed=4))
+    cell = model.wm.core.cell
+    E, Z, F_ = 32 * depth, S * C, D_ + S * C
+    g = torch.Generator().manual_seed(13)
+    embed = torch.randn(T * B, E, generator=g).to(DEV)
+    action = F.one_hot(torch.randint(0, A, (T * B,), generator=g), A).float().to(DEV)
+    reset = (torch.rand(T * B, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    h0, z0 = torch.tanh(torch.randn(B, D_, generator=g)).to(DEV), torch.zeros(B, Z).to(DEV)
+    u = torch.rand(T * B, S, generator=g).to(DEV)
+    shp = model.wm.shape(T, B, 1)
+    ws = model.wm.workspace(shp, torch.device(DEV, 0))
+    P = H.rssm_struct(cell.ordered())
+    n = 4096
+    ga, gb, gc = torch.randn(n, n, device=DEV), torch.randn(n, n, device=DEV), torch.empty(n, n, device=DEV)
+    gws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    clk = (ctypes.c_ulonglong * 16)()
+    H.lib().dm_rssm_lds_prof(clk, 1)
+    assert H.lib().dm_rssm_lds_status() == 0 and H.lib().dm_rssm_lds_enable(-1) >= 1
+    outs = []
+    for busy in (False, True):
+        acts = torch.zeros(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
+        feat, post, prior = torch.zeros(T * B, F_, device=DEV), torch.zeros(T * B, Z, device=DEV), torch.zeros(T * B, Z, device=DEV)
+        idx = torch.zeros(T * B, S, dtype=torch.int32, device=DEV)
+        torch.cuda.synchronize()
+        if busy:
+            with torch.cuda.stream(side):
+                for _ in range(40):      # ~45 ms of back-to-back tiles on the other stream; the sequence below is ~1 ms of work
+                    H.call('dm_gemm_f32', 0, 0, n, n, n, H.fptr(ga), n, H.fptr(gb), n, H.fptr(gc), n, None, None, 0, 0,
+                           H.ptr(gws), gws.numel(), ctypes.c_void_p(side.cuda_stream))
+        H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
+               H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
+               H.ptr(ws), ws.numel(), H.stream())
+        torch.cuda.synchronize()
+        outs.append((feat, post, prior, idx))
+    H.lib().dm_rssm_lds_prof(clk, 0)
+    assert sum(clk) > 0, 'the persistent posterior kernel did not run (13 rows at deter 600 is inside its default range)'
+    assert H.lib().dm_rssm_lds_status() == 0, 'the persistent kernel gave up in a spin loop while the other stream held CUs'
+    for a, b, what in zip(outs[0], outs[1], ('feat', 'post', 'prior', 'idx')):
+        assert torch.equal(a, b), what
+
+
 @pytest.mark.parametrize('B', [6, 7, 13, 25, 50, 64])
 def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
     """The BPTT loop of dm_rssm_sequence_bwd as ONE persistent kernel (csrc/rssm_lds.hip rssm_lds_bwd_kernel: untransposed
@@ -739,11 +794,12 @@ def test_training_step_matches_reference_goldens(hip):
     SURVEY 8(f) N4; layer_norm=False, common.py:68-74 NoNorm: tiny_no_layernorm.npz; Gaussian latents, stoch_discrete=0,
     rssm.py:195-203: tiny_gaussian_latents.npz; a 2-layer stack of NormGRUCells: tiny_gru_layernorm_layers2.npz; the
     normal_tanh actor of functions.py:59-66: tiny_normal_tanh.npz; the plain-KL branch kl_balance = 0.5 of dreamer.py:241,334-335:
-    tiny_kl_plain.npz; every scalar hyper-parameter off its default with binding gradient clips, 3 steps: tiny_scalars.npz)."""
+    tiny_kl_plain.npz; every scalar hyper-parameter off its default with binding gradient clips, 3 steps: tiny_scalars.npz;
+    probe_gradients=True - three optimizers, summed first loss, dreamer.py:60-87,183-186: tiny_probe_gradients.npz)."""
     for name, steps in (('tiny', 2), ('debug_literal', 1), ('tiny_dmc', 1), ('tiny_gru_layernorm', 2),
                         ('tiny_gru_layernorm_dv2', 2), ('tiny_aux_critic', 2), ('tiny_gru_layers3', 2), ('tiny_no_layernorm', 2),
                         ('tiny_gaussian_latents', 2), ('tiny_gru_layernorm_layers2', 1), ('tiny_normal_tanh', 2), ('tiny_kl_plain', 2),
-                        ('tiny_scalars', 3)):
+                        ('tiny_scalars', 3), ('tiny_probe_gradients', 2)):
         _check_reference_golden(name, steps)
 
 
@@ -1998,3 +2054,44 @@ def test_amp_against_reference_autocast_golden(hip, fixture):
     assert abs(float(losses[0]) - ref_fp32) < 1e-3 * ref_fp32
     for k in ('loss_image', 'loss_reward', 'loss_terminal', 'entropy_post'):
         assert _rel(metrics[k], float(g['bf16_metric_' + k])) < 2e-2, k
+
+
+@pytest.mark.parametrize('fixture', ['atari_literal_amp', 'dmc_native_amp'])
+def test_amp_gradients_against_reference_autocast_golden(hip, fixture):
+    """The GRADIENT side of the mixed-precision pin (BASELINE configs[2] / [4] at full size): tests/golden/<fixture>_grads.npz holds
+    the real reference's per-parameter gradient norms of the same step run under torch.autocast('cpu', bfloat16) WITH its four
+    backward passes (oracle/gen_golden.py run_amp_grads; the losses in it equal the forward fixture's, same inputs and
+    uniforms).  The build's amp mode (bf16 MFMA operands, fp32 accumulation and storage) against it, posterior indices
+    teacher-forced to the reference's: loss_model within 1e-3 relative, every WORLD-MODEL parameter's gradient norm within the
+    bf16-class bar below (autocast also rounds every layer OUTPUT to bf16, the build does not; the actor / critic gradients
+    follow sampled imagination actions, which bf16 logits legitimately flip, so they are pinned by the fp32 fixtures only)."""
+    path = os.path.join(GOLD, fixture + '_grads.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{path} not generated (oracle/gen_golden.py {fixture.split("_")[0]}_amp_grads: minutes of CPU)')
+    g = np.load(path)
+    oconf = O.make_conf(**dict(ast.literal_eval(str(g['conf_json']))))
+    obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=1234, first=True), oconf))
+    noise = _to_dev(O.make_noise(oconf, seed=777))
+    from pydreamer_amd import config
+    from pydreamer_amd.models import Dreamer
+    section = 'dmc' if fixture.startswith('dmc') else 'atari'
+    conf = config.load_config('defaults', section, **{**{k: getattr(oconf, k) for k in vars(oconf)}, 'amp': True})
+    model = Dreamer(conf)
+    model.load_state_dict(O.make_params(oconf, seed=0), strict=True)
+    model = model.to(DEV)
+    opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+    fidx = torch.from_numpy(g['bf16_idx_post'].astype(np.int64)).to(DEV)
+    losses, _, metrics, _, _ = model.training_step(obs, model.init_state(oconf.batch_size), noise=noise, forced_idx=fidx)
+    for opt in opts:
+        opt.zero_grad()
+    for loss in losses:
+        loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - float(g['bf16_losses'][0])) < 1e-3 * float(g['bf16_losses'][0])
+    named = dict(model.named_parameters())
+    errs = {str(n): abs(float(named[str(n)].grad.double().norm()) - r) / max(r, 1e-7)
+            for n, r in zip(g['bf16_grad_names'], g['bf16_grad_norms']) if str(n).startswith('wm.')}
+    worst = max(errs, key=errs.get)
+    print(fixture, 'worst world-model grad-norm rel err vs the reference autocast backward:', worst, errs[worst],
+          'median', float(np.median(list(errs.values()))))
+    assert errs[worst] < 5e-2, (worst, errs[worst])

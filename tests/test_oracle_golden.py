@@ -113,6 +113,17 @@ def test_oracle_matches_reference_tiny_two_steps():
         _check_step(g, conf, res)
 
 
+def test_oracle_matches_reference_probe_gradients():
+    """probe_gradients=True with probe_model=none (dreamer.py:60-87,183-186): three optimizers, losses = (loss_model + loss_probe,
+    loss_actor, loss_critic), three gradient norms; the probe head's dummy parameter accumulates a gradient nobody zeroes or
+    steps (0.5 after step 0, 1.0 after step 1 - it is in the fixture's grad_names).  Two consecutive steps."""
+    g, conf, results = _replay('tiny_probe_gradients', 2)
+    assert conf.probe_gradients is True
+    for res in results:
+        assert len(res[1]) == 3 and set(res[6]) == {'grad_norm', 'grad_norm_actor', 'grad_norm_critic'}
+        _check_step(g, conf, res)
+
+
 def test_oracle_matches_reference_iwae():
     """iwae_samples = 3 as a training step (two consecutive steps): batch expansion by I (rssm.py:35-41),
     sampled KL (dreamer.py:340-343), loss_model = -logavgexp(-loss_tbi) (functions.py:97-102), gradients included."""
