@@ -226,14 +226,14 @@ def main():
     ap.add_argument('--pmc-json', default='',
                     help='per-kernel HBM traffic from two rocprofv3 PMC passes of THIS command (scripts/pmc_traffic.py); it carries a '
                          'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
-    ap.add_argument('--graph', action='store_true', help='replay training_step+backward as one captured hipGraph (pydreamer_amd/graph.py); '
-                    'off by default: on ROCm 7.2 a graph with concurrent branches replays slower than the side streams run eagerly')
     ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
-    ap.add_argument('--no-pipeline', action='store_true', help='actor / critic clip + AdamW on the caller\'s stream (A/B switch; default: on the '
-                    'actor-critic stream behind their backward pass, Dreamer.pipeline_ac_optimizer, so the next step\'s forward does not wait for it)')
+    ap.add_argument('--pipeline', action='store_true', help='actor / critic clip + AdamW on the actor-critic stream behind their backward pass '
+                    '(Dreamer.pipeline_ac_optimizer = True, OFF by default in the product: a trainer must then not touch actor / critic .grad between '
+                    'backward() and step()).  The default line runs the product default; -0.1 ms at 50 columns, -0.3..-0.55 ms on 7..25-column shards')
+    ap.add_argument('--no-pipeline', action='store_true', help='(kept for old command lines: the default now)')
     ap.add_argument('--workload', choices=('atari-literal', 'atari-native', 'dmc'), default='atari-literal',
                     help="atari-literal = BASELINE configs[1] (the metric); atari-native = pydreamer's own defaults+atari (B=32, T=48, deter 1024; "
                          "README.md:90-97); dmc = configs[4] at one GPU (defaults+dmc, actor_grad=reinforce, action_dim 6, B=T=50); the last two are diagnostic lines")
@@ -296,30 +296,21 @@ def main():
     torch.manual_seed(0)                               # identical replicas on every rank
     model = Dreamer(conf).to(dev)
     model.overlap_backward = not args.no_overlap
-    model.pipeline_ac_optimizer = not (args.no_pipeline or args.no_overlap or args.graph)
+    model.pipeline_ac_optimizer = bool(args.pipeline) and not (args.no_pipeline or args.no_overlap)
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
     DP.attach(opts, hi - lo, B, model=model)           # the B_r/B weight rides in the backward kernels' scale arguments
     ring = make_ring(conf, B, lo, hi, args.ring, dev, 1234)      # the global batch, this rank's columns
     noise = GlobalNoise(conf, B, lo, hi, dev, 777)     # global-layout sampler uniforms, the rank's columns sliced out
     state = {'s': model.init_state(hi - lo)}
 
-    graphed = None
-    if args.graph:
-        from pydreamer_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opts, ring[0], state['s'])
-
     def step(i, eager=False):
         obs = ring[i % len(ring)]
-        if graphed is not None and not eager:       # hipGraph replay of training_step + zero_grad + 4 backward (pydreamer_amd/graph.py)
-            losses, new_state, metrics, tensors, _ = graphed(obs, state['s'])
-            state['s'] = new_state                      # keep_state (train.py:177-178)
-        else:
-            losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'], noise=noise.draw())
-            state['s'] = new_state
-            for opt in opts:
-                opt.zero_grad()
-            for loss in losses:
-                loss.backward()
+        losses, new_state, metrics, tensors, _ = model.training_step(obs, state['s'], noise=noise.draw())
+        state['s'] = new_state                          # keep_state (train.py:177-178)
+        for opt in opts:
+            opt.zero_grad()
+        for loss in losses:
+            loss.backward()
         model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
         for opt in opts:
             opt.step()
@@ -409,7 +400,7 @@ def main():
 
     # H2D-included leg: the same step fed from host memory through the DeviceRing (pinned uint8 frames, copies prefetched behind the forward)
     h2d = None
-    if world == 1 and not args.no_h2d_leg and args.emulate_world <= 1 and not args.graph:
+    if world == 1 and not args.no_h2d_leg and args.emulate_world <= 1:
         from pydreamer_amd.replay import DeviceRing
         import itertools
         host_ring = make_host_ring(conf, hi - lo, 4, 4321)
@@ -580,7 +571,7 @@ def main():
                                          'deter_dim 1024, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ',
                                           'dmc': 'dmc (BASELINE configs[4] at one GPU): defaults+dmc, batch_size 50, batch_length 50, imag_horizon 15, deter_dim 2048, '
                                          'action_dim 6, tanh_normal actor, actor_grad reinforce, '}[args.workload] + ('fp32' if args.dtype == 'f32' else 'amp/bf16') + '; '
-                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM' + ('; fwd+bwd section replayed as one hipGraph' if args.graph else ''),
+                                         'fwd + 4 bwd + clip + 4 AdamW per step; replay resident in HBM',
                                 global_batch=B, batch_length=conf.batch_length, imag_horizon=conf.imag_horizon,
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=alg_tflop),
@@ -591,7 +582,6 @@ def main():
                     host_enqueue_ms_per_step=1e3 * t_enqueued / args.steps,
                     host_enqueue_unthrottled_ms_per_step=host_free_ms,
                     fp32_products='fp32 MFMA',
-                    chain_graphs=hip.chain_graph_stats(),
                     step_tflops=alg_tflop / (ms * 1e-3), step_frac_of_fp32_peak=alg_tflop / (ms * 1e-3) / 157.3,
                     h2d_included=h2d, distributed=dist_info, rccl_version=(dist_info or {}).get('rccl_version'),
                     **({} if args.workload == 'atari-literal' else {'INVALID_diagnostic_workload': args.workload}),

@@ -76,7 +76,9 @@ int dm_version(void);                 /* ABI version, currently 10 (v2: LayerNor
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
                                          v8: dm_rssm_lds_* replace dm_rssm_persist_*;
                                          v9: dm_bptt_fold_enable added; the split-bf16 fp32 product mode and its dm_fp32_mode query removed;
-                                         v10: dm_gemm_dma_enable added) */
+                                         v10: dm_gemm_dma_enable added; the dm_chain_graph_ family (hipGraph replay of the launch chains: GPU-neutral in three rounds of
+                                         measurement) and the persistent BPTT kernel with its switch dm_rssm_lds_bwd_enable - slower inside the step at every shard size - removed;
+                                         dm_prof_end reports 44 kinds) */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -135,12 +137,12 @@ int dm_gemm_dma_enable(int on);
  * dependent launches per step that re-stream the weights.  Same arithmetic up to fp32 summation order, same sampler rule.
  * dm_rssm_lds_enable: 1 / 0 switches it on / off, 2 = on also for small models (slices under half a CU's LDS: tests), -1 queries;
  * returns the state (default 1; DM_RSSM_LDS=0 / 2 in the environment).
- * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (bounded polls; later calls are refused).
+ * The kernel is launched cooperatively (hipLaunchCooperativeKernel: the runtime checks that the grid can be co-resident; the library
+ * checks the occupancy API too) and its spin loops are bounded.
+ * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (that step's outputs are invalid; every later call
+ * takes the launch chain).  Dreamer.check_device_status() / packed_metrics_host() raise on it.
  * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */
 int dm_rssm_lds_enable(int on);
-int dm_rssm_lds_bwd_enable(int on);     /* the BPTT loop of dm_rssm_sequence_bwd as a second persistent kernel of the same kind: 1.6x faster alone, slower
-                                            inside the multi-stream training step (it needs every CU at once) - OFF by default, DM_RSSM_LDS_BWD=1;
-                                            needs dm_rssm_lds_enable too */
 int dm_bptt_fold_enable(int on);        /* launch schedule of the BPTT loop: the two LayerNorm+ELU backward stages of a step folded into the products
                                             that consume them, dx W = rstd (g W - mean(g) colsum(W) - mean(g xhat) xhat W), so those products start
                                             with their operand loads instead of a row reduction.  ON by default (DM_BPTT_FOLD=0); -1 queries. */
@@ -423,24 +425,14 @@ int dm_mlp_chain_min_rows(int rows);
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for
  * kind = tile*4 + a_layout*2 + b_layout with tile 0..4 = 128x128 / 128x64 / 64x64 / 128x96 / 96x128, kind 20 = row-panel
- * Linear+LayerNorm+ELU forward, 21 = row-panel backward, 22 = whole-MLP forward chain (23 kinds; nkinds >= 23; `out` holds 4*nkinds doubles) and returns the
- * number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
+ * Linear+LayerNorm+ELU forward, 21 = row-panel backward, 22 = whole-MLP forward chain, 24 + kind = the same tile / layouts on the LDS-DMA
+ * loop gemm_dma_kernel (44 kinds; nkinds >= 44; `out` holds 4*nkinds doubles) and returns the number of launches recorded.  (The <= 64-row skinny products are not in this set.) */
 int dm_prof_begin(int max_launches);
 int dm_prof_end(double* out, int nkinds);
 /* Per-launch rows of the armed region (call before dm_prof_end): rows[i*8 + {0..7}] = {kind, M, N, K, split count, flags
  * (1 gathered A, 2 gathered B, 4 scatter epilogue, 8 bf16 operands, 32 bf16-storage operands), flops, milliseconds};
  * returns the row count. */
 int dm_prof_rows(double* rows, int max_rows);
-/* The launch chains (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout: hundreds of small dependent kernels on one stream) can be
- * stream-captured once per distinct argument set and replayed as ONE linear hipGraph afterwards (csrc/chain_graph.hip;
- * bit-identical to the eager launch sequence).  Off by default - measured on MI355X the chains are GPU-latency-bound, the
- * replay only removes host time (~9 us -> ~0.3 us per launch); DM_CHAIN_GRAPH=1 or dm_chain_graph_enable(1) switches it on.
- * No reference counterpart: it removes the host launch cost the reference pays per ATen op.
- * dm_chain_graph_stats: out[3*i + {0,1,2}] = {replays, captures, switched off (arguments never repeat)} per chain in
- * first-use order; returns the number of chains.  dm_chain_graph_reset drops every cached graph. */
-int dm_chain_graph_stats(long long* out, int max_chains);
-int dm_chain_graph_reset(void);
-int dm_chain_graph_enable(int on);   /* on >= 0: set the switch (A/B, tests), returns the previous value; on < 0: query */
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
 

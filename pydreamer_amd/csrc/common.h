@@ -176,20 +176,6 @@ bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C);
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps);
 int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st);
 extern "C" int dm_rssm_lds_enable(int on);
-// The BPTT loop of the same chain (all T steps) as one persistent kernel (rssm_lds.hip rssm_lds_bwd_kernel): saved forward
-// activations and the external gradients in, dpost (final) / dpin / dgi / dgh / dza out; xw2 = x2 W_post_h and xwz = x1 W_z are
-// batched products over all rows made by the caller before the launch.
-struct DmRssmLdsBwd {
-  int B, D, Hd, S, C, F, T;
-  const float *w_post, *w_post_h, *w_ih, *w_hh, *w_z, *g_post, *g_in;
-  const uint8_t* reset;
-  const float *post, *pin, *x2, *st2, *za, *x1, *st1, *gi, *gh, *hin, *xw2, *xwz, *dfeat;
-  float *dpost, *dpin, *dgi, *dgh, *dza;
-  float* ws; size_t ws_floats;
-};
-bool dm_rssm_lds_bwd_ok(int B, int D, int Hd, int S, int C);
-size_t dm_rssm_lds_bwd_ws_floats(int B, int D, int Hd, int S, int C, int steps);
-int dm_rssm_lds_bwd_launch(const DmRssmLdsBwd& q, hipStream_t st);
 bool dm_z_embed_ok(int n);
 // x[r][:] = sum over the non-zero e of z[r][e] * Wt[e][:]   (Wt: (Zc, n) row-major, n <= 1024, n % 4 == 0): exact for any z,
 // cheap for rows of concatenated one-hot groups
@@ -339,45 +325,6 @@ int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);   
 void dm_prof_slot_end(int slot, hipStream_t st);
 extern "C" int dm_mlp_chain_min_rows(int rows);                                    // mlp_chain.hip: rows < 1 queries
 bool dm_prof_active();                                                             // the per-launch profiler is recording
-
-// ---- linear hipGraph replay of a launch chain (chain_graph.hip) -----------------------------------------------------
-// The key: every value the chain's kernel arguments are computed from.
-struct DmChainKey {
-  uint64_t w[144];
-  int n = 0;
-  bool overflow = false;                               // more words than the key holds: the chain then runs eagerly
-  DmChainKey& add(const void* p) { if (n < 144) w[n++] = (uint64_t)(uintptr_t)p; else overflow = true; return *this; }
-  DmChainKey& add(long long v) { if (n < 144) w[n++] = (uint64_t)v; else overflow = true; return *this; }
-  DmChainKey& add_words(const void* p, size_t bytes) {   // a struct of pointers / 8-byte words (zero-padded tail)
-    const unsigned char* b = static_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < bytes; i += 8) {
-      uint64_t v = 0;
-      for (size_t j = 0; j < 8 && i + j < bytes; ++j) v |= (uint64_t)b[i + j] << (8 * j);
-      add((long long)v);
-    }
-    return *this;
-  }
-  DmChainKey& add(const dm_shape* s) {
-    const int32_t* f = reinterpret_cast<const int32_t*>(s);
-    for (size_t i = 0; i + 1 < sizeof(dm_shape) / 4; i += 2) add((long long)(((uint64_t)(uint32_t)f[i] << 32) | (uint32_t)f[i + 1]));
-    return *this;
-  }
-};
-class DmChainGraph {
- public:
-  DmChainGraph(const char* tag, const DmChainKey& key, hipStream_t st);
-  ~DmChainGraph();
-  bool replay_only() const { return mode_ == 1; }      // a cached graph exists: skip the launch sequence
-  hipStream_t launch_stream() const { return mode_ == 2 ? cap_ : st_; }   // where the launch sequence must go
-  int finish();                                        // replay it / close the capture, instantiate and launch
- private:
-  const char* tag_;
-  DmChainKey key_;
-  hipStream_t st_;
-  hipStream_t cap_ = nullptr;
-  hipGraphExec_t exec_ = nullptr;
-  int mode_ = 0;                                       // 0 eager, 1 replay, 2 capturing
-};
 
 // split-K partial region carved at the front of every operator workspace
 static const size_t DM_SPLITK_FLOATS = (size_t)16 * 1024 * 1024;

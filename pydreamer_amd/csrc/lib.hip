@@ -175,12 +175,11 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t rssm_bwd = 2 * SK + 8 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg
                           2 * pad64((3 * D + 15) / 16 * 1024) + 2 * pad64((Hd + 15) / 16 * 1024);   // + fragment-major dgi / dgh / dpin / dza
-  // persistent posterior chain / BPTT kernels (rssm_lds.hip): per-step exchange buffers, x2 W_post_h and x1 W_z (0 if the shape does not qualify)
+  // persistent posterior chain kernel (rssm_lds.hip): per-step exchange buffers (0 if the shape does not qualify)
   const size_t Zw = (size_t)s->S * (s->C ? s->C : 1);
   const size_t lds_fwd = SK + pad64(Zw * Hd) + 5 * pad64((Zw + 15) / 16 * 1024) +
                          (s->C ? pad64(dm_rssm_lds_ws_floats(s->B, s->D, s->Hd, s->S, s->C, s->T)) : 0) + 1024;
-  const size_t rssm_bwd_lds = rssm_bwd + pad64(N * D) + pad64(N * Zw) + pad64(D) + pad64(Zw) + 2 * pad64((Hd + 15) / 16 * 128) +      // (+ the folded launch schedule's column sums and strip sums)
-                              (s->C ? pad64(dm_rssm_lds_bwd_ws_floats(s->B, s->D, s->Hd, s->S, s->C, s->T)) : 0);
+  const size_t rssm_bwd_lds = rssm_bwd + pad64(N * D) + pad64(N * Zw) + pad64(D) + pad64(Zw) + 2 * pad64((Hd + 15) / 16 * 128);      // (+ the folded launch schedule's x W products, column sums and strip sums)
   const size_t rows = (H + 1) * N;
   const size_t mlp_bwd = dm_mlp_ws_floats((int)rows, (int)Hm, (int)L);      // = SK + ping-pong + panel column partials
   const size_t dream = SK + L * (2 * pad64(N * Hm) + pad64(N * 2)) + pad64(N * 2 * A) + 3 * pad64(N * Hd) + pad64(N * 2) +

@@ -218,14 +218,6 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
   rssm_carve(s, acts, &a);
   const float* const* p = P->p;
 
-  // the whole launch sequence below depends on nothing but these values: replayed as one linear hipGraph (chain_graph.hip)
-  DmChainKey ck;
-  ck.add(s).add((long long)t0).add((long long)t1).add(embed).add(action).add(reset).add(h0).add(z0).add(u).add(forced_idx)
-      .add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(prior).add(idx).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision()).add((long long)dm_twins_on()).add((long long)dm_rssm_lds_enable(-1));      // + every run-time switch that changes the launch sequence
-  DmChainGraph cg("rssm_sequence_fwd", ck, st);
-  if (cg.replay_only()) return cg.finish();
-  st = cg.launch_stream();
 
   DM_TRY(linear(st, ws, skb, N, Hd, A, action + q0 * A, A, p[DM_RSSM_A_W], nullptr, nullptr, 0, a.ea + q0 * Hd, Hd));
   DM_TRY(linear(st, ws, skb, N, Hd, E, embed + q0 * E, E, p[DM_RSSM_POST_E_W], nullptr, nullptr, 0, a.ee + q0 * Hd, Hd));
@@ -417,7 +409,7 @@ extern "C" int dm_rssm_sequence_fwd_steps(const dm_shape* s, int t0, int t1, con
                               Hd, a.st3 + q0 * 2, st));
   DM_TRY(linear(st, ws, skb, N, ZP, Hd, a.prin + q0 * Hd, Hd, p[DM_RSSM_PRIOR_W], p[DM_RSSM_PRIOR_OB], nullptr, 0,
                 prior + q0 * ZP, ZP));
-  return cg.finish();
+  return DM_OK;
 }
 extern "C" int dm_rssm_sequence_fwd(const dm_shape* s, const float* embed, const float* action, const uint8_t* reset,
                                     const float* h0, const float* z0, const float* u, const int32_t* forced_idx,
@@ -482,13 +474,6 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "rssm_sequence_bwd: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
 
-  DmChainKey ck;
-  ck.add(s).add(embed).add(action).add(reset).add_words(P, sizeof(*P)).add(acts).add(feat).add(post).add(dfeat).add(dpost)
-      .add(dprior).add_words(G, sizeof(*G)).add(dembed).add(ws).add((long long)ws_bytes).add((long long)dm_cur_precision())
-      .add((long long)dm_rssm_lds_bwd_ok(B, D, Hd, S, C)).add((long long)g_bptt_fold);
-  DmChainGraph cg("rssm_sequence_bwd", ck, st);
-  if (cg.replay_only()) return cg.finish();
-  st = cg.launch_stream();
   // Parameter gradients are leaves of this pass: nothing reads them before the gradient clip.  They go to `sw` - the
   // library's weight-gradient side stream when the calling thread is armed (include/dreamer_hip.h dm_wgrad_side_arm), else
   // `st` itself - and the big ones are cut into up to four time chunks that are launched as soon as the BPTT loop has finished
@@ -510,60 +495,34 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   DM_TRY(wgrad(sw, sk_w, skb, N, Hd, D, dx3, Hd, feat, F, g[DM_RSSM_PRIOR_H_W]));
   DM_TRY(dm_colsum_launch(N, Hd, dx3, Hd, g[DM_RSSM_PRIOR_H_B], sk_w, skb, sw));
 
-  // ---- BPTT as ONE persistent kernel with the (untransposed) weight slices stationary in LDS (rssm_lds.hip), when the shape
-  // qualifies: plain single-layer GRU, LayerNorm, categorical latents with <= 32 classes, B <= 64.  The two LayerNorm backward
-  // stages are folded into the products that follow them (rssm_lds.hip header), which needs x2 W_post_h and x1 W_z for all rows:
-  // two batched products here, before the loop.
-  bool lds_bwd = p[DM_RSSM_IN_G] != nullptr && rssm_gru_layers(s) == 1 && !gauss && kind == 0 && (F & 3) == 0 && T >= 2 &&
-                 dm_rssm_lds_bwd_ok(B, D, Hd, S, C);      // (dx2 / dx1 are re-made in batch after the loop, like the fused launch schedule)
-  float *xw2 = nullptr, *xwz = nullptr, *xws = nullptr;
-  size_t xfl = 0;
-  if (lds_bwd) {
-    const size_t mark = ar.off;
-    xw2 = ar.take((size_t)N * D);
-    xwz = ar.take((size_t)N * Z);
-    xfl = dm_rssm_lds_bwd_ws_floats(B, D, Hd, S, C, T);
-    xws = ar.take(xfl);
-    if (!ar.ok) { ar.off = mark; ar.ok = true; lds_bwd = false; }      // a small caller workspace keeps the launch schedule
-  }
-  if (lds_bwd) {
-    DM_TRY(dgrad(st, sk, skb, N, Hd, D, a.x2, Hd, p[DM_RSSM_POST_H_W], xw2, D, 0, nullptr));      // x2 W_post_h
-    DM_TRY(dgrad(st, sk, skb, N, Hd, Z, a.x1, Hd, p[DM_RSSM_Z_W], xwz, Z, 0, nullptr));           // x1 W_z
-    DmRssmLdsBwd q;
-    q.B = B; q.D = D; q.Hd = Hd; q.S = S; q.C = C; q.F = F; q.T = T;
-    q.w_post = p[DM_RSSM_POST_W]; q.w_post_h = p[DM_RSSM_POST_H_W]; q.w_ih = p[DM_RSSM_GRU_WIH]; q.w_hh = p[DM_RSSM_GRU_WHH];
-    q.w_z = p[DM_RSSM_Z_W]; q.g_post = p[DM_RSSM_POST_G]; q.g_in = p[DM_RSSM_IN_G];
-    q.reset = reset; q.post = post; q.pin = a.pin; q.x2 = a.x2; q.st2 = a.st2; q.za = a.za; q.x1 = a.x1; q.st1 = a.st1;
-    q.gi = a.gi; q.gh = a.gh; q.hin = a.hin; q.xw2 = xw2; q.xwz = xwz; q.dfeat = dfeat;
-    q.dpost = dpost; q.dpin = dpin; q.dgi = dgi; q.dgh = dgh; q.dza = dza;
-    q.ws = xws; q.ws_floats = xfl;
-    DM_TRY(dm_rssm_lds_bwd_launch(q, st));
-  }
+  // (The BPTT loop as a second persistent LDS-weight-stationary kernel was built in round 4 - 1.6x faster than these launches
+  // when it has the chip to itself, slower INSIDE the multi-stream step at every shard size measured, because it needs every CU
+  // at once while the decoder backward wants them too: profiles/r04_ab_bptt.txt - and removed in round 5.)
   // ---- BPTT as launches.  The five backward-data products of a step multiply a B-row block by W (not W^T); transposing the
   // weights once here (22 MB, ~20 us) lets all 5*T of them stream k-contiguous rows.
-  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, ZP, Hd));
-  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
+  DM_TRY(transpose(st, p[DM_RSSM_POST_W], wt_post, ZP, Hd));
+  DM_TRY(transpose(st, p[DM_RSSM_POST_H_W], wt_post_h, Hd, D));
   GruStack gk;
   DM_TRY(gru_stack(s, p, g, &gk));
   const bool stacked = gk.L > 1;
-  if (!stacked && !lds_bwd) {
+  if (!stacked) {
     DM_TRY(transpose(st, p[DM_RSSM_GRU_WIH], wt_ih, 3 * D, Hd));
     DM_TRY(transpose(st, p[DM_RSSM_GRU_WHH], wt_hh, 3 * D, D));
   }
-  if (!lds_bwd) DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
+  DM_TRY(transpose(st, p[DM_RSSM_Z_W], wt_z, Hd, Z));
   // Fused schedule (5 launches per step instead of 8), mirror of the forward T loop: both LayerNorm+ELU BACKWARD stages
   // ride in the prologue of the <= 64-row product that consumes their result, and the GRU gates backward rides in the
   // epilogue of the product that completes dh'.  dx1 / dx2 (needed by the batched weight gradients) are then produced for
   // all rows by two batched launches after the loop.
-  const bool fuse_b = lds_bwd || (p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
-                                  dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0);
+  const bool fuse_b = p[DM_RSSM_IN_G] != nullptr && !stacked && !gauss && kind == 0 && dm_skinny_ln_ok(B, D, Hd) &&
+                      dm_skinny_ln_ok(B, Z, Hd) && (F & 3) == 0;
   // ... in FOLDED form (common.h DmGemm::eg_x): the product that makes dpin (dza) also turns it into g = dy ELU'(pre) gamma in
   // its epilogue - once, by the workgroup that owns the element, instead of once per consuming workgroup in a prologue - and
   // the consuming product is a plain one whose epilogue applies the two row-mean terms.  That needs x2 W_post_h and x1 W_z for
-  // all rows (two batched products here, the ones the persistent kernel uses) and the weights' column sums.
-  bool fold = fuse_b && !lds_bwd && g_bptt_fold && B <= 64 && (int64_t)Hd * ZP >= (int64_t)64 * 1024 &&
+  // all rows (two batched products here) and the weights' column sums.
+  bool fold = fuse_b && g_bptt_fold && B <= 64 && (int64_t)Hd * ZP >= (int64_t)64 * 1024 &&
               (int64_t)Hd * 3 * D >= (int64_t)64 * 1024 && (ZP & 3) == 0 && ((3 * D) & 3) == 0 && ZP >= 16;
-  float *cs2 = nullptr, *csz = nullptr, *eps2 = nullptr, *eps1 = nullptr;
+  float *xw2 = nullptr, *xwz = nullptr, *cs2 = nullptr, *csz = nullptr, *eps2 = nullptr, *eps1 = nullptr;
   const int nstrip = (Hd + 15) / 16;
   if (fold) {
     const size_t mark = ar.off;
@@ -593,7 +552,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
   if (!ar.ok) { dgif = nullptr; dghf = nullptr; dpinf = nullptr; dzaf = nullptr; }
   // time chunks of the batched weight gradients (single-layer cells): chunk c = steps [T*c/nchunk, T*(c+1)/nchunk); the loop
   // runs t downwards, so the LAST chunk completes first - it overwrites the gradient, the others accumulate
-  const int nchunk = (stacked || B < 16 || lds_bwd) ? 1 : (T >= 16 ? 4 : T >= 8 ? 2 : 1);      // (a few-column shard: the chunks' extra launches cost more than they hide; the persistent kernel finishes all rows at once)
+  const int nchunk = (stacked || B < 16) ? 1 : (T >= 16 ? 4 : T >= 8 ? 2 : 1);      // (a few-column shard: the chunks' extra launches cost more than they hide)
   int next_chunk = nchunk - 1;
   const float* dx2s = fuse_b ? dx2_w : dx2;
   const float* dx1s = fuse_b ? dx1_w : dx1;
@@ -619,8 +578,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     DM_TRY(wgrad(sw, sk_w, skb, rows, Hd, A, dx1s + c0 * Hd, Hd, action + c0 * A, A, g[DM_RSSM_A_W], acc));
     return DM_OK;
   };
-  if (lds_bwd) DM_TRY(side_chunk(0));      // all rows are final: the batched weight gradients (one chunk) on the side stream
-  for (int t = lds_bwd ? -1 : T - 1; t >= 0; --t) {
+  for (int t = T - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * B;
     float* dft = dfeat + r0 * F;             // [dh' | dz'] of step t, complete at this point
     float* dpt = dpost + r0 * ZP;
@@ -803,7 +761,7 @@ extern "C" int dm_rssm_sequence_bwd(const dm_shape* s, const float* embed, const
     DM_TRY(wgrad(st, sk, skb, N, Hd, A, dx1, Hd, action, A, g[DM_RSSM_A_W]));
   }
   DM_TRY(dm_wgrad_side_mark(sw, st_main));
-  return cg.finish();
+  return DM_OK;
 }
 
 // ---------------------------------------------------------------- imagination -------------------
@@ -889,15 +847,7 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
   unsigned short* feats_h = (unsigned short*)ar.take(tw_on ? dm_half_floats((size_t)(H + 1) * M * F) : 0);
   DM_REQUIRE(ar.ok, DM_E_WORKSPACE, "dream_rollout: workspace too small (need %zu floats)", ar.off);
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
-  DmChainKey ck;
-  ck.add(s).add((long long)M).add(start).add_words(P, sizeof(*P)).add_words(actor, sizeof(*actor)).add(u_act).add(u_prior)
-      .add(feats).add(actions).add(act_idx).add(actor_acts).add(actor_logits).add(ws).add((long long)ws_bytes)
-      .add((long long)dm_cur_precision()).add((long long)dm_mlp_chain_min_rows(0))       // + the one mutable dispatch threshold
-      .add((long long)tw_on);
-  DmRolloutMarks marks(st);          // (declared before the graph object: its destructor runs after the graph was launched)
-  DmChainGraph cg("dream_rollout", ck, st);
-  if (cg.replay_only()) return cg.finish();
-  st = cg.launch_stream();
+  DmRolloutMarks marks(st);
   const bool marks_eager = st == (hipStream_t)stream;
   // the actor's weights, fragment-major for the whole-MLP kernel: packed once for all H steps
   GruStack gk;
@@ -1009,5 +959,5 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
                                    nullptr, st));
     marks.at_step(i, st, marks_eager);
   }
-  return cg.finish();
+  return DM_OK;
 }

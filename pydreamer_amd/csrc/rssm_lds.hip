@@ -797,404 +797,6 @@ bool rl_plan_one(int B, int D, int Hd, int S, int C, int wz_global, RlPlan* pl) 
   return true;
 }
 
-// ================================================================================================================
-// BPTT of the posterior chain (the backward of RSSMCore.forward's T loop, rssm.py:38-58 / rssm.py:125-153 / rnn.py:48-49) as
-// ONE persistent kernel on the same machinery: weight slices stationary in LDS, poison-polled per-step exchange buffers,
-// lane = batch row, 4x4x1 fp32 MFMA.  Step t (downwards) of the fused launch schedule in rssm.hip:
-//   Z   dpost[t] += softmax'(post[t])^T dz'[t]                  (straight-through sample, rssm.py:147-148)
-//   H2  dpin = dpost W_post ;  g2 = dpin ELU'(pin) gamma_post   (post_mlp, post_norm + ELU)
-//   D3  dh' += LNbwd(dpin) W_post_h ; GRU gates backward -> dgi, dgh ; the direct path dh' u into step t-1
-//   H4  dza = dgi W_ih ;  g1 = dza ELU'(za) gamma_in            (GRU input product, in_norm + ELU)
-//   D5  dh'[t-1] += mask_t dgh W_hh        Z5  dz'[t-1] += mask_t LNbwd(dza) W_z
-// Roles by column ownership (4 columns each): Rz = z / logit columns (S C / 4 workgroups), Rh = hidden columns (Hd / 4),
-// Rd = GRU units (D / 4).  What a workgroup produces for ITS columns at step t+1 and needs at step t (dz', dh' parts) stays
-// in its LDS; only product operands cross CUs.
-//
-// LayerNorm backward without a redundant pass.  dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy ELU'(y) gamma, needs two
-// row means over ALL hidden columns before the next product can start.  Instead of a reduction hop, the next product is
-// expanded:  dx W = rstd (g W - mean(g) colsum(W) - mean(g xhat) (xhat W)),  where g W is the product of the RAW g blocks the
-// consumer sweeps anyway (mean(g) falls out of the same registers), colsum(W) is a constant of the slice, xhat W =
-// rstd (x W - mean colsum(W)) comes from ONE batched product x W over all T*B rows before the loop (x = the saved
-// pre-LayerNorm rows), and mean(g xhat) is the sum of per-producer 4-byte partials published next to the g blocks.  So every
-// element's ELU' / gamma work happens once, on the workgroup that owns the column.
-struct RbArgs {
-  int B, D, Hd, S, C, Z, F, T;
-  int nZ, nH, nD;
-  const float *w_post, *w_post_h, *w_ih, *w_hh, *w_z, *g_post, *g_in;      // row-major (out, in) weights; LayerNorm gains
-  const uint8_t* reset;
-  const float *post, *pin, *x2, *st2, *za, *x1, *st1, *gi, *gh, *hin;        // saved by the forward pass (row-major)
-  const float *xw2, *xwz;                                                    // x2 W_post_h (N, D), x1 W_z (N, Z): batched, before the loop
-  const float* dfeat;                                                        // (N, F) external gradient w.r.t. [h' | z']
-  float *dpost, *dpin, *dgi, *dgh, *dza;                                     // outputs (row-major); dpost holds the external part on entry
-  char* xch;
-  unsigned step_bytes, off_a, off_b, off_bs, off_c, off_d, off_e, off_es;    // per step: xq | xa | xb | xbs | xc | xd | xe | xes
-  unsigned* err;
-  unsigned* host_err;
-  int l_w2, l_w3, l_w4, l_w5a, l_w5b, l_red, l_cdh, l_cdz, l_stage, l_cw, l_flag;
-};
-
-// LDS image [granule p][col i][4 k] of a 4-column slice of a (K, ldw) row-major matrix: granule p covers rows kmap(p)..+3
-template <class KMAP>
-__device__ __forceinline__ void rb_fill(float* dst, const float* W, int ldw, int P, int Ppad, int c0, int tid, KMAP kmap, float* cw_part) {
-  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-  f32x4 cw = {0.f, 0.f, 0.f, 0.f};
-  for (int p = tid; p < Ppad; p += RL_THREADS) {
-    f32x4 r[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      r[kk] = p < P ? *reinterpret_cast<const f32x4*>(W + (size_t)(kmap(p) + kk) * ldw + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    d4[p * 4 + 0] = f32x4{r[0].x, r[1].x, r[2].x, r[3].x};
-    d4[p * 4 + 1] = f32x4{r[0].y, r[1].y, r[2].y, r[3].y};
-    d4[p * 4 + 2] = f32x4{r[0].z, r[1].z, r[2].z, r[3].z};
-    d4[p * 4 + 3] = f32x4{r[0].w, r[1].w, r[2].w, r[3].w};
-    cw.x += (r[0].x + r[1].x) + (r[2].x + r[3].x); cw.y += (r[0].y + r[1].y) + (r[2].y + r[3].y);
-    cw.z += (r[0].z + r[1].z) + (r[2].z + r[3].z); cw.w += (r[0].w + r[1].w) + (r[2].w + r[3].w);
-  }
-  if (cw_part) reinterpret_cast<f32x4*>(cw_part)[tid] = cw;      // column sums of the slice, one partial per thread
-}
-
-// sum over all producers of their 4-byte per-row partials: block p = RL dwords; polls like rl_sweep.  Returns the lane's partial
-// (granules past P are bounds-checked zeros).
-template <int RL, class ARGS>
-__device__ __forceinline__ float rb_sweep_partials(const ARGS& a, __amdgpu_buffer_rsrc_t rs, int row, int kg, int wave, bool& alive) {
-  constexpr int KG = 64 / RL, MAXJ = 32 / KG;
-  unsigned raw[MAXJ];
-  const unsigned voff = (unsigned)(wave * KG + kg) * (RL * 4u) + (unsigned)row * 4u, js = (unsigned)(RL_WAVES * KG) * (RL * 4u);
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)j * js, 0, 16);
-  unsigned spins = 0;
-  while (true) {
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-      if (raw[j] == RL_POISON) { ok = false; raw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)j * js, 0, 16); }
-    if (__all(ok)) break;
-    if (++spins > RL_SPIN_LIMIT || ((spins & 63u) == 0 && rl_dead(a))) { rl_give_up(a); alive = false; break; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) s += __uint_as_float(raw[j]);
-  return s;
-}
-
-// row totals over the workgroup of a per-lane partial (k-groups by shuffle, waves through LDS scratch `st`, fixed order)
-template <int RL>
-__device__ __forceinline__ float rb_row_total(float s, int row, int kg, int wave, float* st) {
-  s = rl_kg_sum<RL>(s);
-  __syncthreads();
-  if (kg == 0) st[wave * RL + row] = s;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < RL_WAVES; ++w) tot += st[w * RL + row];
-  return tot;
-}
-
-template <int RL>
-__global__ void __launch_bounds__(RL_THREADS) rssm_lds_bwd_kernel(const RbArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int KG = 64 / RL, MAXJ = 32 / KG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = lane % RL, kg = lane / RL;
-  const int me = blockIdx.x;
-  const int B = a.B, D = a.D, Hd = a.Hd, C = a.C, Z = a.Z, F = a.F;
-  const int rowc = row < B ? row : B - 1;
-  const bool roleZ = me < a.nZ, roleH = me < a.nH, roleD = me < a.nD;
-  const int cpg = C / 4;
-  float* w2 = lds + a.l_w2; float* w3 = lds + a.l_w3; float* w4 = lds + a.l_w4; float* w5a = lds + a.l_w5a; float* w5b = lds + a.l_w5b;
-  float* red = lds + a.l_red; float* cdh = lds + a.l_cdh; float* cdz = lds + a.l_cdz; float* stage = lds + a.l_stage;
-  float* cw = lds + a.l_cw;                                   // [0..3] colsum(W_post_h slice), [4..7] colsum(W_z slice)
-  unsigned* lflag = reinterpret_cast<unsigned*>(lds + a.l_flag);
-  constexpr int GRID = RL_WAVES * KG;
-  const int PZ = rl_pad_blocks<RL>(Z / 4), PH = rl_pad_blocks<RL>(Hd / 4);
-  const int P3D = 3 * (D / 4), P3Dpad = rl_pad_blocks<RL>(P3D);
-
-  // ---- weight slices into LDS (K-major sources: W[k][4 own columns] is one 16-byte load)
-  if (roleH) rb_fill(w2, a.w_post, Hd, Z / 4, PZ, 4 * me, tid, [](int p) { return 4 * p; }, nullptr);
-  if (roleD) {
-    rb_fill(w3, a.w_post_h, D, Hd / 4, PH, 4 * me, tid, [](int p) { return 4 * p; }, red);
-    __syncthreads();
-    if (tid < 4) { float s = 0.f; for (int i = 0; i < RL_THREADS; ++i) s += red[i * 4 + tid]; cw[tid] = s; }
-    __syncthreads();
-  }
-  // K = 3D operands arrive as granules (unit block pb, gate q) -> rows q D + 4 pb .. + 3
-  const int nDb = D / 4;
-  if (roleH) rb_fill(w4, a.w_ih, Hd, P3D, P3Dpad, 4 * me, tid, [=](int p) { return (p % 3) * D + 4 * (p / 3); }, nullptr);
-  if (roleD) rb_fill(w5a, a.w_hh, D, P3D, P3Dpad, 4 * me, tid, [=](int p) { return (p % 3) * D + 4 * (p / 3); }, nullptr);
-  if (roleZ) {
-    __syncthreads();
-    rb_fill(w5b, a.w_z, Z, Hd / 4, PH, 4 * me, tid, [](int p) { return 4 * p; }, red);
-    __syncthreads();
-    if (tid < 4) { float s = 0.f; for (int i = 0; i < RL_THREADS; ++i) s += red[i * 4 + tid]; cw[4 + tid] = s; }
-  }
-  for (int i = tid; i < RL * 4; i += RL_THREADS) { cdh[i] = 0.f; cdz[i] = 0.f; }
-  if (tid == 0) lflag[0] = 0u;
-  __syncthreads();
-  (void)nDb;
-
-  const unsigned blk = RL * 16u, pblk = RL * 4u;
-  f32x4 v[MAXJ];
-  const unsigned xoff = (unsigned)(wave * KG + kg) * blk + (unsigned)rowc * 16u, xjs = (unsigned)GRID * blk;
-  const float invHd = 1.0f / (float)Hd;
-
-  for (int t = a.T - 1; t >= 0; --t) {
-    const size_t r0 = (size_t)t * B;
-    const bool prop = t > 0;                                  // gradients flow on into step t - 1
-    char* xs = a.xch + (size_t)t * a.step_bytes;
-    __amdgpu_buffer_rsrc_t xr = rl_rsrc(xs, a.step_bytes);
-    unsigned xo = xoff;
-    asm volatile("" : "+v"(xo));
-    bool alive = true;
-
-    // ---- Z. dpost[t] += softmax'(post[t])^T dz'[t] for 4 logit columns; 8 lanes per row (lane c: logits 4c..4c+3 of the group)
-    if (roleZ && cpg <= 8) {
-      const int g = me / cpg, cown = me % cpg;
-      const int c = lane & 7, srow = wave * 8 + (lane >> 3);
-      const bool rowok = srow < B, mine = rowok && c < cpg;
-      f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (mine) x = *reinterpret_cast<const f32x4*>(a.post + (r0 + srow) * Z + g * C + 4 * c);
-      float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-      if (!rowok) mx = 0.f;
-      f32x4 e = {0.f, 0.f, 0.f, 0.f};
-      if (mine) { e.x = expf(x.x - mx); e.y = expf(x.y - mx); e.z = expf(x.z - mx); e.w = expf(x.w - mx); }
-      float se = (e.x + e.y) + (e.z + e.w);
-      se += __shfl_xor(se, 1, 64); se += __shfl_xor(se, 2, 64); se += __shfl_xor(se, 4, 64);
-      // own columns' dz' = external part + what step t+1 sent down (kept in LDS); the group's sum of e dz' crosses 8 CUs
-      f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-      const bool own = mine && c == cown;
-      if (own) {
-        const f32x4 ext = *reinterpret_cast<const f32x4*>(a.dfeat + (r0 + srow) * F + D + 4 * me);
-        const f32x4 car = *reinterpret_cast<const f32x4*>(cdz + srow * 4);
-        dz = f32x4{ext.x + car.x, ext.y + car.y, ext.z + car.z, ext.w + car.w};
-        const float part = (e.x * dz.x + e.y * dz.y) + (e.z * dz.z + e.w * dz.w);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(xs) + (unsigned)me * RL + srow, __float_as_uint(part), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      float sg = 0.f;
-      if (mine) {                                             // lane c polls the partial of the group's c-th workgroup
-        const unsigned* pp = reinterpret_cast<const unsigned*>(xs) + (unsigned)(g * cpg + c) * RL + srow;
-        unsigned rawp = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (rawp == RL_POISON) {
-          if (++spins > RL_SPIN_LIMIT || ((spins & 63u) == 0 && rl_dead(a))) { rl_give_up(a); alive = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-          rawp = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        sg = alive ? __uint_as_float(rawp) : 0.f;
-      }
-      sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64);
-      if (own) {
-        const float m = sg / se;
-        f32x4 dp = *reinterpret_cast<const f32x4*>(a.dpost + (r0 + srow) * Z + 4 * me);
-        dp.x += (e.x / se) * (dz.x - m); dp.y += (e.y / se) * (dz.y - m);
-        dp.z += (e.z / se) * (dz.z - m); dp.w += (e.w / se) * (dz.w - m);
-        __builtin_amdgcn_raw_buffer_store_b128(rl_asu(dp), xr, a.off_a + (unsigned)me * blk + (unsigned)srow * 16u, 0, 16);
-        *reinterpret_cast<f32x4*>(a.dpost + (r0 + srow) * Z + 4 * me) = dp;
-      }
-      if (!alive) lflag[0] = 1u;
-    }
-    // ---- H2. dpin = dpost W_post (4 hidden columns); g2 = dpin ELU'(pin) gamma ; partial of sum_k g2 xhat2
-    if (roleH) {
-      __amdgpu_buffer_rsrc_t ra = rl_rsrc(xs + a.off_a, (unsigned)a.nZ * blk);
-      if (!rl_sweep<RL>(a, ra, xo, xjs, true, v)) lflag[0] = 1u;
-      f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      rl_dot<RL, 1, false>(acc1, v, a.nZ, kg, wave, lane, w2);
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL && tid < B) {
-        const size_t rr = r0 + tid;
-        f32x4 dp;
-        dp.x = rl_red_sum<RL, 1>(red, tid, 0); dp.y = rl_red_sum<RL, 1>(red, tid, 1);
-        dp.z = rl_red_sum<RL, 1>(red, tid, 2); dp.w = rl_red_sum<RL, 1>(red, tid, 3);
-        *reinterpret_cast<f32x4*>(a.dpin + rr * Hd + 4 * me) = dp;
-        const f32x4 y = *reinterpret_cast<const f32x4*>(a.pin + rr * Hd + 4 * me);
-        const f32x4 xx = *reinterpret_cast<const f32x4*>(a.x2 + rr * Hd + 4 * me);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g_post + 4 * me);
-        const float mean = a.st2[rr * 2], rstd = a.st2[rr * 2 + 1];
-        f32x4 g;
-        g.x = dp.x * dm_elu_grad_from_y(y.x) * gm.x; g.y = dp.y * dm_elu_grad_from_y(y.y) * gm.y;
-        g.z = dp.z * dm_elu_grad_from_y(y.z) * gm.z; g.w = dp.w * dm_elu_grad_from_y(y.w) * gm.w;
-        const float sq = (g.x * ((xx.x - mean) * rstd) + g.y * ((xx.y - mean) * rstd)) + (g.z * ((xx.z - mean) * rstd) + g.w * ((xx.w - mean) * rstd));
-        __builtin_amdgcn_raw_buffer_store_b128(rl_asu(g), xr, a.off_b + (unsigned)me * blk + (unsigned)tid * 16u, 0, 16);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(xs + a.off_bs) + (unsigned)me * RL + tid, __float_as_uint(sq), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    // ---- D3. dh' += LNbwd(dpin) W_post_h for 4 units; GRU gates backward; the direct path into step t-1
-    if (roleD) {
-      __amdgpu_buffer_rsrc_t rb = rl_rsrc(xs + a.off_b, (unsigned)a.nH * blk);
-      if (!rl_sweep<RL>(a, rb, xo, xjs, true, v)) lflag[0] = 1u;
-      float sgl = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) sgl += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-      f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      rl_dot<RL, 1, false>(acc1, v, a.nH, kg, wave, lane, w3);
-      const float sum_g = rb_row_total<RL>(sgl, row, kg, wave, red);
-      __amdgpu_buffer_rsrc_t rbs = rl_rsrc(xs + a.off_bs, (unsigned)a.nH * pblk);
-      const float sql = rb_sweep_partials<RL>(a, rbs, rowc, kg, wave, alive);
-      const float sum_q = rb_row_total<RL>(sql, row, kg, wave, red);
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL * 4) {                                     // thread (row r = tid % RL = its lane's row, unit un): the row totals are its own
-        const int r = tid % RL, un = tid / RL, d = 4 * me + un;
-        const size_t rr = r0 + (r < B ? r : B - 1);
-        const float mean = a.st2[rr * 2], rstd = a.st2[rr * 2 + 1];
-        const float G = rl_red_sum<RL, 1>(red, r, un);
-        const float xw = rstd * (a.xw2[rr * D + d] - mean * cw[un]);                    // (xhat2 W_post_h)[row][unit]
-        const float dh_post = rstd * (G - (sum_g * invHd) * cw[un] - (sum_q * invHd) * xw);
-        const float dh = a.dfeat[rr * F + d] + dh_post + cdh[r * 4 + un];
-        const float gir = a.gi[rr * 3 * D + d], giz = a.gi[rr * 3 * D + D + d], gin = a.gi[rr * 3 * D + 2 * D + d];
-        const float ghr = a.gh[rr * 3 * D + d], ghz = a.gh[rr * 3 * D + D + d], ghn = a.gh[rr * 3 * D + 2 * D + d];
-        const float rg = rl_sigmoid(gir + ghr), ug = rl_sigmoid(giz + ghz), ng = tanhf(gin + rg * ghn);
-        const float h = a.hin[rr * D + d];
-        const float dn = dh * (1.f - ug), du = dh * (h - ng);
-        const float dpn = dn * (1.f - ng * ng);
-        const float dpr = dpn * ghn * rg * (1.f - rg);
-        const float dpu = du * ug * (1.f - ug);
-        stage[r * 16 + un] = dpr; stage[r * 16 + 4 + un] = dpu; stage[r * 16 + 8 + un] = dpn;      // dgi (r, z, n)
-        red[RL_WAVES * RL * 4 + r * 4 + un] = dpn * rg;                                             // dgh's n column
-        cdh[r * 4 + un] = (prop && !a.reset[rr]) ? dh * ug : 0.f;                                   // direct path, masked by step t's reset
-      }
-      __syncthreads();
-      if (tid < RL && tid < B) {
-        const size_t rr = r0 + tid;
-        const f32x4 dr = *reinterpret_cast<const f32x4*>(stage + tid * 16), du4 = *reinterpret_cast<const f32x4*>(stage + tid * 16 + 4);
-        const f32x4 dn4 = *reinterpret_cast<const f32x4*>(stage + tid * 16 + 8);
-        const f32x4 dhn = *reinterpret_cast<const f32x4*>(red + RL_WAVES * RL * 4 + tid * 4);
-        const unsigned o = (unsigned)me * 3u * blk + (unsigned)tid * 16u;
-        __builtin_amdgcn_raw_buffer_store_b128(rl_asu(dr), xr, a.off_c + o, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(rl_asu(du4), xr, a.off_c + o + blk, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(rl_asu(dn4), xr, a.off_c + o + 2 * blk, 0, 16);
-        if (prop) {
-          __builtin_amdgcn_raw_buffer_store_b128(rl_asu(dr), xr, a.off_d + o, 0, 16);
-          __builtin_amdgcn_raw_buffer_store_b128(rl_asu(du4), xr, a.off_d + o + blk, 0, 16);
-          __builtin_amdgcn_raw_buffer_store_b128(rl_asu(dhn), xr, a.off_d + o + 2 * blk, 0, 16);
-        }
-        float* gi_o = a.dgi + rr * 3 * D + 4 * me; float* gh_o = a.dgh + rr * 3 * D + 4 * me;
-        *reinterpret_cast<f32x4*>(gi_o) = dr; *reinterpret_cast<f32x4*>(gi_o + D) = du4; *reinterpret_cast<f32x4*>(gi_o + 2 * D) = dn4;
-        *reinterpret_cast<f32x4*>(gh_o) = dr; *reinterpret_cast<f32x4*>(gh_o + D) = du4; *reinterpret_cast<f32x4*>(gh_o + 2 * D) = dhn;
-      }
-      __syncthreads();
-    }
-    // ---- H4. dza = dgi W_ih (K = 3D in chunks of 256 granules); g1 = dza ELU'(za) gamma_in ; partial of sum_k g1 xhat1
-    if (roleH) {
-      f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      for (int base = 0; base < P3D; base += 32 * RL_WAVES) {
-        __amdgpu_buffer_rsrc_t rc = rl_rsrc(xs + a.off_c, (unsigned)P3D * blk);
-        if (!rl_sweep<RL>(a, rc, xo + (unsigned)base * blk, xjs, true, v)) lflag[0] = 1u;
-        const int left = P3D - base;
-        rl_dot<RL, 1, false>(acc1, v, left < 32 * RL_WAVES ? left : 32 * RL_WAVES, kg, wave, lane, w4 + base * 16);
-      }
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL && tid < B) {
-        const size_t rr = r0 + tid;
-        f32x4 dzz;
-        dzz.x = rl_red_sum<RL, 1>(red, tid, 0); dzz.y = rl_red_sum<RL, 1>(red, tid, 1);
-        dzz.z = rl_red_sum<RL, 1>(red, tid, 2); dzz.w = rl_red_sum<RL, 1>(red, tid, 3);
-        *reinterpret_cast<f32x4*>(a.dza + rr * Hd + 4 * me) = dzz;
-        if (prop) {
-          const f32x4 y = *reinterpret_cast<const f32x4*>(a.za + rr * Hd + 4 * me);
-          const f32x4 xx = *reinterpret_cast<const f32x4*>(a.x1 + rr * Hd + 4 * me);
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g_in + 4 * me);
-          const float mean = a.st1[rr * 2], rstd = a.st1[rr * 2 + 1];
-          f32x4 g;
-          g.x = dzz.x * dm_elu_grad_from_y(y.x) * gm.x; g.y = dzz.y * dm_elu_grad_from_y(y.y) * gm.y;
-          g.z = dzz.z * dm_elu_grad_from_y(y.z) * gm.z; g.w = dzz.w * dm_elu_grad_from_y(y.w) * gm.w;
-          const float sq = (g.x * ((xx.x - mean) * rstd) + g.y * ((xx.y - mean) * rstd)) + (g.z * ((xx.z - mean) * rstd) + g.w * ((xx.w - mean) * rstd));
-          __builtin_amdgcn_raw_buffer_store_b128(rl_asu(g), xr, a.off_e + (unsigned)me * blk + (unsigned)tid * 16u, 0, 16);
-          __hip_atomic_store(reinterpret_cast<unsigned*>(xs + a.off_es) + (unsigned)me * RL + tid, __float_as_uint(sq), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    // ---- D5. dh'[t-1] += mask_t dgh W_hh for 4 units
-    if (roleD && prop) {
-      f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      for (int base = 0; base < P3D; base += 32 * RL_WAVES) {
-        __amdgpu_buffer_rsrc_t rd = rl_rsrc(xs + a.off_d, (unsigned)P3D * blk);
-        if (!rl_sweep<RL>(a, rd, xo + (unsigned)base * blk, xjs, true, v)) lflag[0] = 1u;
-        const int left = P3D - base;
-        rl_dot<RL, 1, false>(acc1, v, left < 32 * RL_WAVES ? left : 32 * RL_WAVES, kg, wave, lane, w5a + base * 16);
-      }
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL * 4) {
-        const int r = tid % RL, un = tid / RL;
-        const size_t rr = r0 + (r < B ? r : B - 1);
-        if (!a.reset[rr]) cdh[r * 4 + un] += rl_red_sum<RL, 1>(red, r, un);
-      }
-      __syncthreads();
-    }
-    // ---- Z5. dz'[t-1] = mask_t LNbwd(dza) W_z for 4 z columns
-    if (roleZ && prop) {
-      __amdgpu_buffer_rsrc_t re = rl_rsrc(xs + a.off_e, (unsigned)a.nH * blk);
-      if (!rl_sweep<RL>(a, re, xo, xjs, true, v)) lflag[0] = 1u;
-      float sgl = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) sgl += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-      f32x4 acc1[1] = {f32x4{0, 0, 0, 0}};
-      rl_dot<RL, 1, false>(acc1, v, a.nH, kg, wave, lane, w5b);
-      const float sum_g = rb_row_total<RL>(sgl, row, kg, wave, red);
-      __amdgpu_buffer_rsrc_t res = rl_rsrc(xs + a.off_es, (unsigned)a.nH * pblk);
-      const float sql = rb_sweep_partials<RL>(a, res, rowc, kg, wave, alive);
-      const float sum_q = rb_row_total<RL>(sql, row, kg, wave, red);
-      rl_reduce_store<RL, 1>(acc1, row, kg, wave, red);
-      if (tid < RL * 4) {
-        const int r = tid % RL, un = tid / RL, zc = 4 * me + un;
-        const size_t rr = r0 + (r < B ? r : B - 1);
-        const float mean = a.st1[rr * 2], rstd = a.st1[rr * 2 + 1];
-        const float mg = sum_g * invHd, mq = sum_q * invHd;      // (r = tid % RL is this lane's own row: the totals are local)
-        const float xw = rstd * (a.xwz[rr * Z + zc] - mean * cw[4 + un]);
-        const float G = rl_red_sum<RL, 1>(red, r, un);
-        cdz[r * 4 + un] = a.reset[rr] ? 0.f : rstd * (G - mg * cw[4 + un] - mq * xw);
-      }
-      __syncthreads();
-    }
-    if (!alive) lflag[0] = 1u;
-    __syncthreads();
-    if (lflag[0]) return;
-  }
-}
-
-struct RbPlan {
-  int rl, nZ, nH, nD, G;
-  size_t lds_bytes;
-  unsigned step_bytes, off_a, off_b, off_bs, off_c, off_d, off_e, off_es;
-  int l_w2, l_w3, l_w4, l_w5a, l_w5b, l_red, l_cdh, l_cdz, l_stage, l_cw, l_flag;
-};
-bool rb_plan(int B, int D, int Hd, int S, int C, RbPlan* pl) {
-  if (B < 1 || B > 64 || C < 4 || C > 32 || (C & 3) || S < 1 || (D & 3) || (Hd & 3)) return false;
-  RbPlan p;
-  p.rl = B <= 8 ? 8 : (B <= 16 ? 16 : (B <= 32 ? 32 : 64));
-  const int Z = S * C;
-  p.nZ = Z / 4; p.nH = Hd / 4; p.nD = D / 4;
-  p.G = p.nZ > p.nH ? p.nZ : p.nH;
-  if (p.nD > p.G) p.G = p.nD;
-  if (p.G > 256) return false;
-  const int grid = RL_WAVES * (64 / p.rl);
-  auto pad = [&](int P) { return (P + grid - 1) / grid * grid; };
-  int off = 0;
-  auto take = [&](int floats) { const int o = off; off += (floats + 3) & ~3; return o; };
-  p.l_w2 = take(pad(p.nZ) * 16); p.l_w3 = take(pad(p.nH) * 16); p.l_w4 = take(pad(3 * p.nD) * 16); p.l_w5a = take(pad(3 * p.nD) * 16);
-  p.l_w5b = take(pad(p.nH) * 16);
-  int red = RL_WAVES * p.rl * 4 + p.rl * 4;
-  if (red < RL_THREADS * 4) red = RL_THREADS * 4;
-  p.l_red = take(red);
-  p.l_cdh = take(p.rl * 4); p.l_cdz = take(p.rl * 4); p.l_stage = take(p.rl * 16); p.l_cw = take(8); p.l_flag = take(4);
-  p.lds_bytes = (size_t)off * 4;
-  const unsigned blk = (unsigned)p.rl * 16u, pblk = (unsigned)p.rl * 4u;
-  auto al = [](unsigned x) { return (x + 255u) & ~255u; };
-  p.off_a = al((unsigned)p.nZ * pblk);
-  p.off_b = p.off_a + al((unsigned)p.nZ * blk);
-  p.off_bs = p.off_b + al((unsigned)p.nH * blk);
-  p.off_c = p.off_bs + al((unsigned)p.nH * pblk);
-  p.off_d = p.off_c + al(3u * p.nD * blk);
-  p.off_e = p.off_d + al(3u * p.nD * blk);
-  p.off_es = p.off_e + al((unsigned)p.nH * blk);
-  p.step_bytes = p.off_es + al((unsigned)p.nH * pblk);
-  *pl = p;
-  return true;
-}
-
 bool rl_plan(int B, int D, int Hd, int S, int C, RlPlan* pl) {
   // everything in LDS if it fits 160 KB; else z_mlp^T stays in L2 (16 KB less: pydreamer's shipped Atari configuration, deter 1024, B <= 32)
   if (!rl_plan_one(B, D, Hd, S, C, 0, pl)) return false;
@@ -1287,15 +889,6 @@ bool rl_fwd_ready(int rl) {
     default: return rl_raise_lds(rssm_lds_fwd_kernel<64>, 3);
   }
 }
-bool rl_bwd_ready(int rl) {
-  switch (rl) {
-    case 8: return rl_raise_lds(rssm_lds_bwd_kernel<8>, 4);
-    case 16: return rl_raise_lds(rssm_lds_bwd_kernel<16>, 5);
-    case 32: return rl_raise_lds(rssm_lds_bwd_kernel<32>, 6);
-    default: return rl_raise_lds(rssm_lds_bwd_kernel<64>, 7);
-  }
-}
-
 }  // namespace
 
 // 1 / 0: run the posterior chain's steps as the LDS-weight-stationary persistent kernel when the shape qualifies / always
@@ -1379,63 +972,3 @@ int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st) {
   return DM_OK;
 }
 
-// ---- BPTT
-// OFF by default.  Measured (profiles/r04_ab_bptt.txt): alone, dm_rssm_sequence_bwd with this kernel takes 4.1 instead of 6.5 ms at
-// B = 50 and 1.29 instead of 2.15 ms at B = 7 (gradients equal to 6e-7).  Inside the training step it LOSES (fp32 38.3 vs 36.1 ms,
-// bf16 22.9 vs 22.0, 7-column shard 11.1 vs 10.2): there the world-model backward runs beside the imagination rollout and the
-// actor-critic passes on other streams, the launch schedule's small kernels fill CUs those leave idle, and a kernel that needs
-// ALL compute units resident at once (100+ KB of LDS each) first waits - its early workgroups spinning on CUs - until the
-// other streams' tiles have drained from every CU, then holds the whole chip.  (The forward T loop runs while nothing else
-// does, which is why the same design wins there.)  For callers that run the backward passes on one stream.
-static int g_rssm_lds_bwd = getenv("DM_RSSM_LDS_BWD") ? atoi(getenv("DM_RSSM_LDS_BWD")) : 0;
-extern "C" int dm_rssm_lds_bwd_enable(int on) {
-  if (on >= 0) g_rssm_lds_bwd = on ? 1 : 0;
-  return g_rssm_lds_bwd;
-}
-bool dm_rssm_lds_bwd_ok(int B, int D, int Hd, int S, int C) {
-  RbPlan p;
-  return g_rssm_lds && g_rssm_lds_bwd && rb_plan(B, D, Hd, S, C, &p) && rl_device_ok(p.G, p.lds_bytes) && rl_bwd_ready(p.rl);
-}
-size_t dm_rssm_lds_bwd_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
-  RbPlan p;
-  if (!rb_plan(B, D, Hd, S, C, &p)) return 0;
-  return ((size_t)p.step_bytes * (size_t)steps + 256) / 4 + 64;
-}
-int dm_rssm_lds_bwd_launch(const DmRssmLdsBwd& q, hipStream_t st) {
-  RbPlan p;
-  if (!rb_plan(q.B, q.D, q.Hd, q.S, q.C, &p) || !rl_device_ok(p.G, p.lds_bytes)) return dm_fail(DM_E_SHAPE, "rssm_lds_bwd: shape does not qualify");
-  DM_REQUIRE(dm_rssm_lds_status() == 0, DM_E_HIP, "rssm_lds_bwd: an earlier persistent kernel gave up in a spin loop");
-  if (q.T <= 0) return DM_OK;
-  RbArgs a;
-  a.B = q.B; a.D = q.D; a.Hd = q.Hd; a.S = q.S; a.C = q.C; a.Z = q.S * q.C; a.F = q.F; a.T = q.T;
-  a.nZ = p.nZ; a.nH = p.nH; a.nD = p.nD;
-  a.w_post = q.w_post; a.w_post_h = q.w_post_h; a.w_ih = q.w_ih; a.w_hh = q.w_hh; a.w_z = q.w_z; a.g_post = q.g_post; a.g_in = q.g_in;
-  a.reset = q.reset; a.post = q.post; a.pin = q.pin; a.x2 = q.x2; a.st2 = q.st2; a.za = q.za; a.x1 = q.x1; a.st1 = q.st1;
-  a.gi = q.gi; a.gh = q.gh; a.hin = q.hin; a.xw2 = q.xw2; a.xwz = q.xwz; a.dfeat = q.dfeat;
-  a.dpost = q.dpost; a.dpin = q.dpin; a.dgi = q.dgi; a.dgh = q.dgh; a.dza = q.dza;
-  char* base = reinterpret_cast<char*>(dm_align_up(reinterpret_cast<size_t>(q.ws), 256));
-  a.err = reinterpret_cast<unsigned*>(base);
-  a.xch = base + 256;
-  a.step_bytes = p.step_bytes; a.off_a = p.off_a; a.off_b = p.off_b; a.off_bs = p.off_bs; a.off_c = p.off_c; a.off_d = p.off_d;
-  a.off_e = p.off_e; a.off_es = p.off_es;
-  a.host_err = g_host_err_dev;
-  a.l_w2 = p.l_w2; a.l_w3 = p.l_w3; a.l_w4 = p.l_w4; a.l_w5a = p.l_w5a; a.l_w5b = p.l_w5b; a.l_red = p.l_red; a.l_cdh = p.l_cdh;
-  a.l_cdz = p.l_cdz; a.l_stage = p.l_stage; a.l_cw = p.l_cw; a.l_flag = p.l_flag;
-  const size_t xbytes = (size_t)p.step_bytes * q.T;
-  DM_REQUIRE((size_t)(a.xch - reinterpret_cast<char*>(q.ws)) + xbytes <= q.ws_floats * sizeof(float), DM_E_WORKSPACE,
-             "rssm_lds_bwd: exchange region needs %zu bytes", xbytes + 512);
-  if (hipMemsetAsync(a.err, 0, 256, st) != hipSuccess || hipMemsetAsync(a.xch, 0xFF, xbytes, st) != hipSuccess)
-    return dm_fail(DM_E_HIP, "rssm_lds_bwd: memset failed");
-  const void* fn = nullptr;
-  switch (p.rl) {
-    case 8: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<8>); break;
-    case 16: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<16>); break;
-    case 32: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<32>); break;
-    default: fn = reinterpret_cast<const void*>(rssm_lds_bwd_kernel<64>); break;
-  }
-  if (!rl_bwd_ready(p.rl)) return dm_fail(DM_E_HIP, "rssm_lds_bwd: the driver refused %zu bytes of dynamic LDS", p.lds_bytes);
-  void* args[] = {&a};
-  DM_TRY(rl_launch_exclusive(fn, (unsigned)p.G, args, p.lds_bytes, st));
-  DM_LAUNCH_CHECK();
-  return DM_OK;
-}

@@ -182,13 +182,9 @@ _SIGNATURES = {
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_prof_rows': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
-    'dm_chain_graph_stats': (c_int, [POINTER(ctypes.c_longlong), c_int]),
-    'dm_chain_graph_reset': (c_int, []),
-    'dm_chain_graph_enable': (c_int, [c_int]),
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_gemm_dma_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
-    'dm_rssm_lds_bwd_enable': (c_int, [c_int]),
     'dm_bptt_fold_enable': (c_int, [c_int]),
     'dm_rssm_lds_status': (c_int, []),
     'dm_rssm_lds_prof': (c_int, [_P, c_int]),
@@ -234,13 +230,6 @@ def call(name, *args):
         msg = lib().dm_last_error().decode('utf-8', 'replace')
         raise DreamerHipError(f'{name} failed with code {rc}: {msg}')
     return rc
-
-
-def chain_graph_stats():
-    """[(replays, captures, switched_off)] of the library's hipGraph-replayed launch chains (csrc/chain_graph.hip), first-use order."""
-    out = (ctypes.c_longlong * (3 * 16))()
-    n = lib().dm_chain_graph_stats(out, 16)
-    return [dict(replays=int(out[3 * i]), captures=int(out[3 * i + 1]), off=bool(out[3 * i + 2])) for i in range(n)]
 
 
 def ptr(t):

@@ -591,47 +591,22 @@ class _Done:
 
 
 class _StepArena:
-    """Buffers of everything the library's launch chains read or write (dm_rssm_sequence_fwd / _bwd, dm_dream_rollout).
-    With the chains' hipGraph replay switched on (csrc/chain_graph.hip, DM_CHAIN_GRAPH=1 / dm_chain_graph_enable) they are
-    PERSISTENT per geometry, because a replayed graph is keyed by its pointer arguments and the caching allocator does not
-    hand a training loop the same addresses step after step (measured: 0 replays in 24 steps): `get(name, shape)` then
-    returns the same tensor for the same (name, shape, dtype, device) on every step; the two most recent geometries per name
-    are kept (training / evaluation batch shapes alternate).  Consequence in that mode: the buffers are overwritten by the NEXT
-    training_step(); nothing in them is handed to the caller (features / states are cloned on the way out of
-    WorldModel.training_step, Dreamer.last_extras documents its own lifetime) and a backward() on the losses of an older
-    step is refused (the generation stamp).  With the replay off (the default) `get` is torch.empty and nothing is shared."""
+    """Allocator of everything the library's launch chains read or write in one step (dm_rssm_sequence_fwd / _bwd,
+    dm_dream_rollout).  Rounds 3-4 kept these buffers persistent per geometry for the hipGraph replay of the chains
+    (csrc/chain_graph.hip), which removed host time only and was deleted in round 5 (the chains are GPU-latency-bound); what is
+    left is `get` = torch.empty - nothing is shared between steps, a backward() on an older step's losses is always valid -
+    behind the same interface, so the call sites did not move."""
 
-    KEEP = 2
-
-    def __init__(self):
-        self.bufs = {}
-        self.gens = {}                     # geometry -> generation of the step whose activations the buffers hold
-        self.on = False
+    on = False
 
     def begin_step(self, geometry):
-        self.on = H.lib().dm_chain_graph_enable(-1) == 1
-        if not self.on:
-            self.bufs.clear()
-            return None
-        self.gens[geometry] = self.gens.get(geometry, 0) + 1
-        return geometry, self.gens[geometry]
+        return None
 
     def current(self, stamp):
-        return stamp is None or self.gens.get(stamp[0]) == stamp[1]
+        return True
 
     def get(self, name, shape, dtype=torch.float32, device=None):
-        shape = tuple(int(x) for x in shape)
-        if not self.on:
-            return torch.empty(shape, dtype=dtype, device=device)
-        key = (shape, dtype, str(device))
-        slot = self.bufs.setdefault(name, {})
-        t = slot.pop(key, None)
-        if t is None:
-            t = torch.empty(shape, dtype=dtype, device=device)
-            while len(slot) >= self.KEEP:
-                slot.pop(next(iter(slot)))
-        slot[key] = t                      # most recently used last
-        return t
+        return torch.empty(tuple(int(x) for x in shape), dtype=dtype, device=device)
 
 
 def _require_cuda(t, what):
@@ -1309,7 +1284,7 @@ class ActorCritic(_Params):
         self.critic_target.requires_grad_(False)
         self.train_steps = 0
         self.sparse_cols = 0                  # trailing feature columns known to be one-hot samples (set by the owner)
-        self.defer_target_update = False      # set by pydreamer_amd.graph while capturing (refresh + counter done there)
+        self.defer_target_update = False      # a caller that captures the step into a graph does the refresh + counter itself
 
     def update_critic_target(self):
         """a2c.py:151-152."""

@@ -67,7 +67,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
         else:
             if keep is not None:
                 print(f'   indices equal to the persistent kernel: {float((keep == idx).float().mean()):.6f}')
-    # ---- the BPTT loop (dm_rssm_sequence_bwd: prior branch, loop, batched weight gradients) with the persistent kernel on / off
+    # ---- the BPTT loop (dm_rssm_sequence_bwd: prior branch, loop, batched weight gradients): folded / unfolded launch schedule
     lib.dm_rssm_lds_enable(0 if os.environ.get('NO_LDS') else 2)
     run(); torch.cuda.synchronize()
     Gf, Gp, Gq = (torch.randn(T * B, n, generator=g).cuda() / (T * B) for n in (F_, Z, Z))
@@ -75,8 +75,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
     Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
     dembed = torch.zeros(T * B, E, device='cuda')
     keep_g = None
-    for on, fold in (((0, 1),) if os.environ.get('NO_LDS') else ((1, 1), (0, 1), (0, 0))):
-        lib.dm_rssm_lds_bwd_enable(on)
+    for on, fold in ((0, 1), (0, 0)):
         lib.dm_bptt_fold_enable(fold)      # launch schedule only: the LayerNorm backward stages folded into the products that consume them
         per = []
         for rep in range(6):
@@ -95,8 +94,7 @@ for B in [int(x) for x in sys.argv[1:]] or [50, 25, 13, 7]:
         per.sort()
         flat = torch.cat([x.flatten() for x in grads if x is not None])
         print(f'B={B} bwd lds={on} fold={fold}: median {per[len(per) // 2]:.0f} us per dm_rssm_sequence_bwd call (T={T}; min {per[0]:.0f}; host enqueue {host_us:.0f} us), status {lib.dm_rssm_lds_status()}'
-              + ('' if keep_g is None else f'; gradients vs the persistent kernel: rel-L2 {float((flat - keep_g).norm() / keep_g.norm()):.2e}'))
+              + ('' if keep_g is None else f'; gradients vs the first schedule: rel-L2 {float((flat - keep_g).norm() / keep_g.norm()):.2e}'))
         keep_g = flat.clone() if keep_g is None else keep_g
-    lib.dm_rssm_lds_bwd_enable(1)
     lib.dm_bptt_fold_enable(1)
 lib.dm_rssm_lds_enable(1)

@@ -579,79 +579,6 @@ def test_rssm_lds_kernel_with_a_busy_chip(hip):
         assert torch.equal(a, b), what
 
 
-@pytest.mark.parametrize('B', [6, 7, 13, 25, 50, 64])
-def test_rssm_lds_bptt_matches_launch_schedule(hip, B):
-    """The BPTT loop of dm_rssm_sequence_bwd as ONE persistent kernel (csrc/rssm_lds.hip rssm_lds_bwd_kernel: untransposed
-    weight slices resident in LDS, the two LayerNorm backward stages folded into the products that follow them) against the
-    ~6-launches-per-step schedule it replaces, on the same forward pass: Atari-literal cell width, T = 12, every row-count
-    layout (8 / 16 / 32 / 64 rows per k-group).  Every parameter gradient and dembed within 2e-4 relative L2 (fp32
-    summation order differs: K split over waves / k-groups, the expanded LayerNorm backward); the kernel never gave up.
-    The launch schedule itself exists in two forms - LayerNorm backward folded and split over two launches (default, DESIGN
-    4.2.2; 16-row quarter / 32-row half strips) and in the consumer's prologue (dm_bptt_fold_enable(0)) - and both are compared.
-    (Against the fp64 oracle: test_rssm_sequence_fwd_bwd_vs_oracle runs the persistent kernel and the default schedule.)"""
-    import ctypes
-    from pydreamer_amd import hip as H
-    T, D_, Hd, S, C, A, depth = 12, 600, 1000, 32, 32, 18, 8
-    oconf = O.make_conf(deter_dim=D_, hidden_dim=Hd, stoch_dim=S, stoch_discrete=C, cnn_depth=depth, action_dim=A,
-                        batch_size=B, batch_length=T)
-    model = _build(oconf, O.make_params(oconf, seed=4))
-    cell = model.wm.core.cell
-    E, Z, F_, N = 32 * depth, S * C, D_ + S * C, T * B
-    g = torch.Generator().manual_seed(13)
-    embed = torch.randn(N, E, generator=g).to(DEV)
-    action = F.one_hot(torch.randint(0, A, (N,), generator=g), A).float().to(DEV)
-    reset = (torch.rand(N, generator=g) < 0.1).to(torch.uint8).to(DEV)
-    h0, z0 = torch.tanh(torch.randn(B, D_, generator=g)).to(DEV), torch.zeros(B, Z).to(DEV)
-    u = torch.rand(N, S, generator=g).to(DEV)
-    Gf, Gp, Gq = (torch.randn(N, n, generator=g).to(DEV) / N for n in (F_, Z, Z))
-    shp = model.wm.shape(T, B, 1)
-    ws = model.wm.workspace(shp, torch.device(DEV, 0))
-    P = H.rssm_struct(cell.ordered())
-    acts = torch.zeros(int(H.lib().dm_rssm_acts_floats(ctypes.byref(shp))), device=DEV)
-    feat, post, prior = torch.zeros(N, F_, device=DEV), torch.zeros(N, Z, device=DEV), torch.zeros(N, Z, device=DEV)
-    idx = torch.zeros(N, S, dtype=torch.int32, device=DEV)
-    H.call('dm_rssm_sequence_fwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), H.fptr(h0), H.fptr(z0),
-           H.fptr(u), None, ctypes.byref(P), H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(prior), H.ptr(idx),
-           H.ptr(ws), ws.numel(), H.stream())
-    outs = []
-    was, was_f = H.lib().dm_rssm_lds_bwd_enable(-1), H.lib().dm_bptt_fold_enable(-1)
-    try:
-        # persistent kernel / the launch schedule with the LayerNorm backward folded and split over producer epilogue and plain
-        # consumer (the default) / the launch schedule with it in the consumer's prologue (rounds 2-3)
-        for on, fold in ((1, 1), (0, 1), (0, 0)):
-            H.lib().dm_rssm_lds_bwd_enable(on)
-            H.lib().dm_bptt_fold_enable(fold)
-            for rep in range(2):      # twice: the second call reuses the exchange addresses with caches warm
-                grads = [None if p_ is None else torch.zeros_like(p_) for p_ in cell.ordered()]
-                Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
-                dembed = torch.zeros(N, E, device=DEV)
-                dfeat, dpost, dprior = Gf.clone(), Gp.clone(), Gq.clone()
-                H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(embed), H.fptr(action), H.ptr(reset), ctypes.byref(P),
-                       H.fptr(acts), H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs),
-                       H.fptr(dembed), H.ptr(ws), ws.numel(), H.stream())
-                torch.cuda.synchronize()
-            outs.append((grads, dembed, dpost))
-    finally:
-        H.lib().dm_rssm_lds_bwd_enable(was)
-        H.lib().dm_bptt_fold_enable(was_f)
-    assert H.lib().dm_rssm_lds_status() == 0, 'the persistent kernel gave up in a spin loop'
-    names = H.rssm_param_names('gru')
-    worst = 0.0
-    for tag, x, y in (('persistent kernel vs folded launch schedule', outs[0], outs[1]),
-                      ('folded vs prologue-form launch schedule', outs[1], outs[2])):
-        for name, a, b in zip(names, x[0], y[0]):
-            if name is None or a is None:
-                continue
-            assert torch.isfinite(a).all(), (tag, name)
-            e = _rel_l2(a, b)
-            worst = max(worst, e)
-            assert e < 2e-4, (tag, name, e)
-        assert _rel_l2(x[1], y[1]) < 2e-4, (tag, 'dembed')
-        assert _rel_l2(x[2], y[2]) < 2e-4, (tag, 'dpost (final, with the straight-through part)')
-    print(f'B={B}: worst parameter-gradient rel-L2 between the three BPTT schedules {worst:.2e}')
-
-
-# ------------------------------------------------------------------------------------------- end to end
 def _run_pair(oconf, steps, forced=False, seed=0):
     """One or more full trainer iterations (train.py:165-198) on the oracle (CPU) and the HIP model (GPU)."""
     params = O.make_params(oconf, seed=seed)
@@ -854,8 +781,8 @@ def _check_reference_golden(name, steps):
 
 @pytest.mark.parametrize('name,steps', [('tiny', 2), ('tiny_aux_critic', 2), ('tiny_scalars', 3), ('tiny_kl_plain', 2)])
 def test_reference_goldens_through_the_persistent_chain_kernels(hip, name, steps):
-    """The fixtures written by the real reference replayed with BOTH persistent chain kernels forced on (csrc/rssm_lds.hip: the
-    posterior T loop and its BPTT loop; switch level 2 admits models whose weight slices need less than half a CU's LDS, which
+    """The fixtures written by the real reference replayed with the persistent posterior kernel forced on (csrc/rssm_lds.hip;
+    switch level 2 admits models whose weight slices need less than half a CU's LDS, which
     the default leaves to the launch chain): sampled indices bit-exact, losses / metrics / gradient norms / post-AdamW parameter
     checksums at the same bars as the launch schedule - incl. two consecutive steps with the carried state, binding gradient
     clips and off-default loss weights (tiny_scalars), the un-balanced KL, the auxiliary critic.  (debug_literal and the two full-size
@@ -863,9 +790,8 @@ def test_reference_goldens_through_the_persistent_chain_kernels(hip, name, steps
     posterior kernel by default in test_training_step_matches_reference_at_atari_literal.)"""
     from pydreamer_amd import hip as H
     lib = H.lib()
-    was, was_b = lib.dm_rssm_lds_enable(-1), lib.dm_rssm_lds_bwd_enable(-1)
+    was = lib.dm_rssm_lds_enable(-1)
     lib.dm_rssm_lds_enable(2)
-    lib.dm_rssm_lds_bwd_enable(1)
     try:
         out = (ctypes_ull16 := (__import__('ctypes').c_ulonglong * 16)())
         lib.dm_rssm_lds_prof(out, 1)                  # (allocates and zeroes the phase clocks: non-zero afterwards = the kernel ran)
@@ -876,7 +802,6 @@ def test_reference_goldens_through_the_persistent_chain_kernels(hip, name, steps
         assert lib.dm_rssm_lds_status() == 0
     finally:
         lib.dm_rssm_lds_enable(was)
-        lib.dm_rssm_lds_bwd_enable(was_b)
 
 
 def test_gaussian_latents_iwae_matches_reference_golden(hip):
@@ -994,8 +919,8 @@ def test_dream_rollout_vs_oracle(hip):
     _close(th.mean, to, 1e-4, 1e-5, 'dream terminals')
 
 
-@pytest.mark.parametrize('B,T,lds_bwd', [(6, 4, 0), (7, 4, 0), (50, 4, 0), (50, 10, 0), (7, 10, 1), (50, 10, 1)])
-def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T, lds_bwd):
+@pytest.mark.parametrize('B,T', [(6, 4), (7, 4), (50, 4), (50, 10), (7, 10)])
+def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T):
     """dm_rssm_sequence_fwd / dm_rssm_sequence_bwd stand-alone through the C-ABI at the Atari-literal cell width (deter 600,
     hidden 1000, stoch 32x32) for a 7-column data-parallel shard and the full 50 columns: at these sizes the T loop runs its
     FUSED schedule: the first step as launches (LayerNorm+ELU in the prologue of the consuming <= 64-row product, sampler in
@@ -1069,15 +994,10 @@ def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T, lds_bwd):
     Gs = H.rssm_struct(grads, cls=H.dm_rssm_grads)
     dembed = torch.empty(N, E, device=DEV)
     dfeat, dpost, dprior = dev(Gf), dev(Gp), dev(Gq)
-    was = H.lib().dm_rssm_lds_bwd_enable(-1)
-    H.lib().dm_rssm_lds_bwd_enable(lds_bwd)          # 1: the BPTT loop as the persistent kernel (off by default)
-    try:
-        H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), ctypes.byref(P), H.fptr(acts),
-               H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
-               H.ptr(ws), ws.numel(), H.stream())
-        torch.cuda.synchronize()
-    finally:
-        H.lib().dm_rssm_lds_bwd_enable(was)
+    H.call('dm_rssm_sequence_bwd', ctypes.byref(shp), H.fptr(e_d), H.fptr(a_d), H.ptr(r_d), ctypes.byref(P), H.fptr(acts),
+           H.fptr(feat), H.fptr(post), H.fptr(dfeat), H.fptr(dpost), H.fptr(dprior), ctypes.byref(Gs), H.fptr(dembed),
+           H.ptr(ws), ws.numel(), H.stream())
+    torch.cuda.synchronize()
     assert H.lib().dm_rssm_lds_status() == 0
     for name, gh in zip(H.rssm_param_names('gru'), grads):
         if name is not None:
@@ -1169,51 +1089,6 @@ def test_no_cpu_fallback(hip):
     with pytest.raises(Exception) as e:
         model.training_step(obs, (torch.zeros(3, 64), torch.zeros(3, 64)))
     assert 'CPU' in str(e.value) or 'cuda' in str(e.value).lower()
-
-
-@pytest.mark.parametrize('overlap', [False, True])
-def test_graphed_step_is_bit_identical_to_eager(hip, overlap):
-    """pydreamer_amd.graph.GraphedTrainStep replays exactly the eager kernels: same losses, gradients, parameters and
-    carried state over three trainer iterations (incl. the step-0 critic-target refresh)."""
-    from pydreamer_amd.graph import GraphedTrainStep
-    oconf = O.tiny_conf()
-    params = O.make_params(oconf, seed=3)
-    runs = []
-    for graphed in (False, True):
-        model = _build(oconf, params)
-        model.overlap_backward = overlap
-        opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
-        st = model.init_state(oconf.batch_size)
-        g, hist = None, []
-        for s in range(3):
-            obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=50 + s, first=(s == 0)), oconf))
-            noise = _to_dev(O.make_noise(oconf, seed=90 + s))
-            if graphed:
-                if g is None:
-                    g = GraphedTrainStep(model, opts, obs, st, noise=noise)
-                losses, st2, metrics, _, _ = g(obs, st, noise=noise)
-            else:
-                losses, st2, metrics, _, _ = model.training_step(obs, st, noise=noise)
-                for opt in opts:
-                    opt.zero_grad()
-                for loss in losses:
-                    loss.backward()
-            gm = model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
-            grads = torch.cat([o.flat_grad for o in opts]).clone()
-            for opt in opts:
-                opt.step()
-            st = tuple(x.clone() for x in st2)
-            hist.append(dict(losses=[float(x) for x in losses], gn=float(gm['grad_norm']), grads=grads.cpu(),
-                             state=[x.cpu() for x in st], params=torch.cat([o.flat_param for o in opts]).cpu(),
-                             steps=model.ac.train_steps))
-        runs.append(hist)
-    for s, (e, g) in enumerate(zip(*runs)):
-        assert e['losses'] == g['losses'], (s, e['losses'], g['losses'])
-        assert e['gn'] == g['gn']
-        assert torch.equal(e['grads'], g['grads']), f'step {s}: gradients differ'
-        assert torch.equal(e['params'], g['params']), f'step {s}: parameters differ'
-        assert all(torch.equal(a, b) for a, b in zip(e['state'], g['state']))
-        assert e['steps'] == g['steps'] == s + 1
 
 
 @pytest.mark.parametrize('amp', [False, True])
@@ -1743,79 +1618,34 @@ def test_literal_trainer_section(hip, amp):
     assert scaler.get_scale() == scale0 * 0.5
 
 
-@pytest.mark.parametrize('cfg', ['tiny', 'shard'])
-def test_chain_graphs_replay_bit_identical(hip, cfg):
-    """csrc/chain_graph.hip: dm_rssm_sequence_fwd / _bwd and dm_dream_rollout are stream-captured once per argument set and
-    replayed as linear hipGraphs.  Six optimizer steps with the replay on equal the same steps with eager launches bit for
-    bit (losses of every step, parameters after the last one), and the chains really are replayed (the step arena keeps
-    their pointer arguments stable).  'shard': the 7-column data-parallel shard of Atari-literal (fused 5-launch T steps)."""
-    oconf = O.tiny_conf() if cfg == 'tiny' else O.atari_literal_conf(batch_size=7, batch_length=6, imag_horizon=3)
-    conf = _hip_conf(oconf)
-    params = O.make_params(oconf, seed=5)
-    batches = [_to_dev(O.preprocess(O.synthetic_batch(oconf, seed=40 + i, first=(i == 0)), oconf)) for i in range(2)]
-    noises = [{k: v.to(DEV) for k, v in O.make_noise(oconf, seed=60 + s).items()} for s in range(6)]
-
-    def run():
-        model = _build(oconf, params)
-        opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-        state, out = model.init_state(oconf.batch_size), []
-        for s_ in range(6):
-            losses, state, metrics, tensors, _ = model.training_step(batches[s_ % 2], state, noise=noises[s_])
-            for opt in opts:
-                opt.zero_grad()
-            for loss in losses:
-                loss.backward()
-            model.grad_clip(conf.grad_clip, conf.grad_clip_ac)
-            for opt in opts:
-                opt.step()
-            out.append(torch.stack([l.detach().reshape(()) for l in losses] + [metrics['loss_kl'].reshape(())]))
-        return torch.stack(out).cpu(), opts[0].flat_param.clone().cpu(), opts[2].flat_param.clone().cpu()
-    prev = hip.lib().dm_chain_graph_enable(1)
-    try:
-        hip.call('dm_chain_graph_reset')
-        a = run()
-        stats = hip.chain_graph_stats()
-        hip.lib().dm_chain_graph_enable(0)
-        b = run()
-    finally:
-        hip.lib().dm_chain_graph_enable(prev)
-        hip.call('dm_chain_graph_reset')
-    assert torch.isfinite(a[0]).all()
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    assert len(stats) == 3 and all(st['replays'] >= 2 and not st['off'] for st in stats), stats
-
-
-def test_backward_on_overwritten_activations_is_refused(hip):
-    """With the chains' hipGraph replay on, their buffers live in a per-model arena with stable addresses: with overlap_backward off (gradients computed inside
-    backward()), a backward() on the losses of an OLDER training_step() must fail loudly, not use the newer step's activations."""
+def test_backward_of_an_older_step_is_valid(hip):
+    """Every training_step() owns its buffers (the per-geometry arena of the chains' hipGraph replay is gone with the replay):
+    with overlap_backward off (gradients computed inside backward()) the losses of an OLDER step can still be backpropagated
+    after a newer step ran, and give that older step's gradients."""
     oconf = O.tiny_conf()
     model = _build(oconf, O.make_params(oconf, seed=1))
     model.overlap_backward = False
     opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
     obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=3, first=True), oconf))
+    obs2 = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=4, first=True), oconf))
+    noise = _to_dev(O.make_noise(oconf, seed=5))
     st = model.init_state(oconf.batch_size)
-    prev = hip.lib().dm_chain_graph_enable(1)          # the arena (and with it this refusal) exists only with the replay on
-    try:
-        losses1, *_ = model.training_step(obs, st)
-        losses2, *_ = model.training_step(obs, st)
-        for opt in opts:
-            opt.zero_grad()
-        with pytest.raises(RuntimeError, match='overwritten'):
-            losses1[0].backward()
-        for loss in losses2:
-            loss.backward()
-    finally:
-        hip.lib().dm_chain_graph_enable(prev)
-        hip.call('dm_chain_graph_reset')
-    # replay off (the default): every step owns its buffers, an older step's losses can still be backpropagated
-    losses1, *_ = model.training_step(obs, st)
-    losses2, *_ = model.training_step(obs, st)
+    losses1, *_ = model.training_step(obs, st, noise=noise)
     for opt in opts:
         opt.zero_grad()
-    for loss in losses1:
+    losses1[0].backward()
+    want = opts[0].flat_grad.clone()
+    losses1, *_ = model.training_step(obs, st, noise=noise)
+    losses2, *_ = model.training_step(obs2, st, noise=noise)
+    for opt in opts:
+        opt.zero_grad()
+    losses1[0].backward()
+    assert torch.equal(opts[0].flat_grad, want)
+    for opt in opts:
+        opt.zero_grad()
+    for loss in losses2:
         loss.backward()
-
+    assert not torch.equal(opts[0].flat_grad, want)
 
 def test_stale_prelaunched_gradients_are_refused(hip):
     """Pre-launched backward passes write into a per-optimizer scratch buffer; a backward() on losses of an OLDER

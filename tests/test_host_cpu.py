@@ -233,15 +233,12 @@ def test_graft_entry_build_passes():
 
 def test_runtime_switch_defaults():
     """Library-wide switches that change WHICH kernels run (never what they compute): the bf16-storage operand path is on, the
-    LDS-weight-stationary persistent posterior chain is on (where the shape qualifies) and the chain graphs are off unless the
-    environment says otherwise."""
+    LDS-weight-stationary persistent posterior chain is on (where the shape qualifies) unless the environment says otherwise."""
     lib = hip.lib()
-    if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_LDS', 'DM_CHAIN_GRAPH')):
+    if not any(os.environ.get(k) for k in ('DM_BF16_NO_TWINS', 'DM_RSSM_LDS')):
         assert lib.dm_bf16_twins_enable(-1) == 1
         assert lib.dm_rssm_lds_enable(-1) == 1
         assert lib.dm_bptt_fold_enable(-1) == 1 or os.environ.get('DM_BPTT_FOLD')
-        assert lib.dm_rssm_lds_bwd_enable(-1) == 0 or os.environ.get('DM_RSSM_LDS_BWD')      # (slower inside the multi-stream step)
-        assert lib.dm_chain_graph_enable(-1) == 0
     assert lib.dm_rssm_lds_status() == 0
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
     assert lib.dm_gemm_dma_enable(-1) == 1 and lib.dm_gemm_dma_enable(0) == 0 and lib.dm_gemm_dma_enable(1) == 1
