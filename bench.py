@@ -37,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = 'grad-steps/sec (world-model+AC) at B=50,T=50,H=15, 64×64 obs, 1/2/4/8 GPU'
-ORACLE_VS_REF = next((f for f in ('r04_oracle_vs_reference.json', 'r03_oracle_vs_reference.json', 'r02_oracle_vs_reference.json')
+ORACLE_VS_REF = next((f for f in ('r05_oracle_vs_reference.json', 'r04_oracle_vs_reference.json', 'r03_oracle_vs_reference.json', 'r02_oracle_vs_reference.json')
                       if os.path.exists(os.path.join(ROOT, 'profiles', f))), 'r04_oracle_vs_reference.json')
 
 
@@ -242,7 +242,7 @@ def main():
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
     if not args.pmc_json:       # the committed counter summary of the same command (fp32 / bf16 step), if its fingerprint matches the tree
-        args.pmc_json = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r04_pmc_traffic.json')
+        args.pmc_json = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r05_pmc_traffic.json')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -629,6 +629,15 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmKArgs g) {
       const int nt = kt + NS - 1;
       int ns = stage + NS - 1;
       if (ns >= NS) ns -= NS;
+      // the LDS-DMA of tile kt + NS - 1 goes out right here, in front of this tile's MFMAs (stage ns was last read during step
+      // kt - 1: the barrier above).  Dealing it into the shadow of the first two groups' MFMAs instead - its address arithmetic
+      // and M0 writes then cost no matrix-pipe time - was measured and is SLOWER (profiles/r05_dma_issue_placement.txt: 4096^3
+      // 117.4 vs 118.8 TF/s, 2500 x 1800 x 1000 103.7 vs 99.8 us, step 34.03 vs 33.84 ms): with two stages a load has one
+      // k-tile to land, and a quarter to a half of it was given away; the other resident workgroup covers the issue gap.
+      if (nt < cur.nkt) {
+        sa.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE, wave);
+        sb.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE + A_BYTES, wave);
+      }
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         const int c = kg & 1, n = c ^ 1;
@@ -644,10 +653,6 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmKArgs g) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][mb].get(j), b[c][nb].get(j), acc[mb][nb], 0, 0, 0);
-        // the LDS-DMA of tile kt + NS - 1 goes out behind the first two groups' MFMAs: its address arithmetic and M0 writes run
-        // in the matrix pipe's shadow instead of in front of it (stage ns was last read during step kt - 1: the barrier above)
-        if (kg == 0 && nt < cur.nkt) sa.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE, wave);
-        if (kg == 1 && nt < cur.nkt) sb.issue(cur.kbeg + nt * 32, cur.kend, dma_smem + ns * STAGE + A_BYTES, wave);
         __builtin_amdgcn_sched_barrier(0);
       }
       if ((GA || GB) && nt + 1 < cur.nkt) {

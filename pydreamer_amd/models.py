@@ -1757,7 +1757,7 @@ class Dreamer(nn.Module):
         # Diagnostics for tests / debugging (not part of the reference API).  The index tensors are copies; `actions`,
         # `dream_features`, `post` and `prior` are views of the step arena: valid until the next training_step().
         self.last_extras = dict(post_idx=pk['idx'].view(T, B * I, -1).clone(), act_idx=dpk['act_idx'].clone(),
-                                actions=actions_dream, dream_features=features_dream,
+                                actions=actions_dream, dream_features=features_dream, actor_logits=dpk.get('actor_logits'),
                                 ac_tensors=tensors_ac, post=pk['post'], prior=pk['prior'], pred_idx=pk.get('pred_idx'))
         # Dream for a log sample (dreamer.py:163-180): T-1 imagined steps from the B first states, decoded to images
         dream_tensors = {}

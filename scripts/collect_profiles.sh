@@ -6,7 +6,7 @@
 #   3. the bench line itself, reading the fresh PMC file -> <tag>_bench.json
 # Everything lands in gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -27,15 +27,22 @@ python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_
 cd $REPO
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # where bench.py looks by default (on this box; copy gpurun_out/<tag>/ into profiles/ afterwards)
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
-for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
+for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --dtype bf16 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50_bf16.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --pipeline --dtype bf16 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50_bf16.json 2>/dev/null
 python scripts/persist_prof.py 50 25 13 7 2>/dev/null | grep -v Warning > $OUT/${TAG}_rssm_lds.txt
 bash scripts/collect_pmc_bf16.sh $TAG > $OUT/collect_bf16.log 2>&1      # bf16 step: its own counter passes, then the bf16 bench line
 DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
+# the tile-kernel laboratory (LDS-DMA loop variants, ablations, in-kernel clock probe; production dm_gemm_f32 beside them) and the SQ counters
+LAB_REPS=20 bash scripts/microbench/run_gemm_lab.sh > /dev/null 2>&1; cp gpurun_out/gemm_lab.txt $OUT/${TAG}_gemm_lab.txt
+bash scripts/gemm_sq_counters.sh $TAG > /dev/null 2>&1
+python scripts/gemm_tile_sweep.py > $OUT/${TAG}_tile_sweep.txt 2>&1
+# kernel statistics of the 7-column shard (the rollout / posterior / BPTT chains at 350 rows: DESIGN 6)
+cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks_shard -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --emulate-world 8 --no-overlap > /dev/null 2> $OUT/ks_shard.err
+cp $(find /tmp/prof_ks_shard -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_shard7of50_serial.csv; cd $REPO
 # per-queue timelines of one step (which stream is busy when), fp32 and bf16
 bash scripts/gpu_trace.sh f32 $TAG > /dev/null 2>&1; cp $OUT/queues_f32.txt $OUT/${TAG}_queues_f32.txt
 bash scripts/gpu_trace.sh bf16 $TAG > /dev/null 2>&1; cp $OUT/queues_bf16.txt $OUT/${TAG}_queues_bf16.txt

@@ -199,6 +199,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gasm_kernel(const LabArgs g) {
   const int item = lab_item_of(blockIdx.x, g.n_tiles);
   const int m0 = (item % g.tiles_m) * BM, n0 = (item / g.tiles_m) * BN;
   const int nkt = (g.K + 31) / 32;
+  if (PRIO >= 2) {      // de-phase the workgroups that share a SIMD: the wave in an odd hardware slot starts half a k-tile late
+    const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID bits 3:0 = wave slot on its SIMD
+    if (hw & 1) { if (PRIO == 2) __builtin_amdgcn_s_sleep(40); else if (PRIO == 3) __builtin_amdgcn_s_sleep(20); else __builtin_amdgcn_s_sleep(80); }
+  }
 
   const float* pa[PA]; const float* pb[PB];
   int chk[PA > PB ? PA : PB];
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gasm_kernel(const LabArgs g) {
         wait_lgkm<MB + NB>();
       } else wait_lgkm<0>();
       __builtin_amdgcn_sched_barrier(0);
-      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gasm_kernel(const LabArgs g) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mb][j], b[cur][nb][j], acc[mb][nb], 0, 0, 0);
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (++stage == NS) stage = 0;
@@ -350,10 +354,8 @@ int main(int argc, char** argv) {
   }
   std::vector<Variant> vars = {
     V(128, 128, 2, 2, 2, 0), V(128, 128, 2, 2, 2, 1), V(128, 128, 2, 2, 2, 2),
-    W(128, 128, 2, 2, 2, 0), W(128, 128, 2, 2, 3, 0), W(128, 128, 2, 2, 2, 1),
-    W(256, 128, 4, 2, 2, 0), W(256, 128, 2, 2, 2, 0), W(128, 256, 2, 2, 2, 0), W(256, 256, 2, 2, 2, 0), W(256, 256, 4, 2, 2, 0),
-    W(128, 64, 2, 2, 3, 0), W(128, 64, 2, 2, 2, 0), W(64, 64, 2, 2, 3, 0), W(64, 64, 2, 2, 2, 0), W(64, 64, 2, 2, 4, 0),
-    W(128, 128, 4, 2, 2, 0), W(64, 128, 2, 2, 3, 0),
+    W(128, 128, 2, 2, 2, 0), W(128, 128, 2, 2, 2, 2), W(128, 128, 2, 2, 2, 3), W(128, 128, 2, 2, 2, 4), W(128, 128, 2, 2, 2, 1),
+    W(256, 256, 2, 2, 2, 0), W(128, 64, 2, 2, 3, 0), W(128, 64, 2, 2, 3, 2), W(64, 64, 2, 2, 3, 0), W(64, 64, 2, 2, 3, 2), W(64, 64, 2, 2, 3, 3),
   };
   struct Shape { int M, N, K; } shapes[] = {
     {4096, 4096, 4096}, {2500, 1800, 1000}, {2500, 1024, 1000}, {2500, 1800, 600}, {2500, 1000, 600},

@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out/r05
+timeout 1500 python -m pytest tests -m gpu -s -q -k "atari_literal or dmc_native or autocast or amp_gradients" 2>&1 | grep -v "^$" | grep -iv "warning\|warn(\|autocast(enabled" > gpurun_out/r05/parity_margins.txt
+tail -3 gpurun_out/r05/parity_margins.txt
