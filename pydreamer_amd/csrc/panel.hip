@@ -537,6 +537,13 @@ __global__ void __launch_bounds__(1024) panel_colsum_final_kernel(const PanelFin
   }
 }
 
+// (Round 5 built and removed a 32 x 32-block version of these panels on the LDS-DMA operand pipeline of gemm_dma_kernel - a wave
+//  owns 32 rows x 416 columns as 13 blocks of v_mfma_f32_32x32x2_f32, a workgroup 128 complete rows, half the LDS fragment traffic
+//  per MAC, same epilogue arithmetic on the 32 x 32 accumulator layout, parity-green on every test_mlp_head_* case.  It is SLOWER:
+//  forward 54 vs 67 TF/s, backward 22 vs 50, step 36.4 vs 34.1 ms (profiles/r05_panel32.txt).  The weight tile (416 x 32 floats
+//  = 53 KB per stage) forces one 4-wave workgroup per CU, and 40 000 rows are 313 such workgroups on 256 CUs: two rounds at 61 %.
+//  The 64-row panels below are 625 workgroups on 512 resident slots.  What bounds these kernels is that quantisation
+//  (DESIGN 7), not the fragment traffic.)
 // ---------------------------------------------------------------- host side ---------------------
 static const int g_panel_min_rows = getenv("DM_PANEL_MIN_ROWS") ? atoi(getenv("DM_PANEL_MIN_ROWS")) : 16384;
 
