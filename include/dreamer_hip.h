@@ -137,8 +137,9 @@ int dm_gemm_dma_enable(int on);
  * dependent launches per step that re-stream the weights.  Same arithmetic up to fp32 summation order, same sampler rule.
  * dm_rssm_lds_enable: 1 / 0 switches it on / off, 2 = on also for small models (slices under half a CU's LDS: tests), -1 queries;
  * returns the state (default 1; DM_RSSM_LDS=0 / 2 in the environment).
- * The kernel is launched cooperatively (hipLaunchCooperativeKernel: the runtime checks that the grid can be co-resident; the library
- * checks the occupancy API too) and its spin loops are bounded.
+ * Co-residency is checked with the occupancy API before the first launch of a variant (>= 1 workgroup per CU at its LDS size; the grid
+ * never exceeds the CU count) and the spin loops are bounded; DM_RSSM_LDS_COOP=1 launches cooperatively instead (measured slower: it drains
+ * the other streams around the kernel).
  * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (that step's outputs are invalid; every later call
  * takes the launch chain).  Dreamer.check_device_status() / packed_metrics_host() raise on it.
  * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */

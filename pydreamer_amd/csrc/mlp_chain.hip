@@ -20,6 +20,10 @@
 // normalise their own columns in registers, write the next layer's LDS block; the output layer is one more small MFMA
 // product with all loads issued up front.
 //
+// (Round 5 measured a 13-wave x 2-block split of the same 16-row block - a quarter of the dependent MFMA chain per wave, 3-4 waves per
+//  SIMD, double-buffered fragments within 128 registers, parity-green: 141.8 us per 2 500-row call against 141.9 for the 4 x 7 split,
+//  bf16 step 20.25 vs 19.86 ms.  The call is bound by what one CU can pull of the weight stream (2.9 MB per 16-row block: 20 GB/s per
+//  CU with ~40-50 KB in flight), not by the MFMA chain: removed.)
 // Work split: ceil(rows/16) workgroups - 157 for the 2500-row rollout step; a row block costs 16 x 1.13 M MACs whatever
 // the tiling (the 7-block wave: 102 + 3*25 groups x 28 MFMAs x 32 clk = 158 k cycles = 66 us in fp32).  Measured per
 // 2500-row call: 130 us fp32, 65 us bf16 (per-layer launches: 167 / 136).

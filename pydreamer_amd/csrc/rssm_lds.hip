@@ -843,11 +843,12 @@ int rl_launch_exclusive(const void* fn, unsigned grid, void** args, size_t lds_b
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   if (!capturing && hipStreamWaitEvent(st, g_chip_lease, 0) != hipSuccess) (void)hipGetLastError();      // (never recorded yet: no-op)
-  // Co-residency of the whole grid is REQUESTED, not assumed: a cooperative launch is validated by the runtime against the
-  // kernel's occupancy (it refuses a grid that cannot be resident at once); rl_occupancy_ok() has already checked the same
-  // bound with the occupancy API and a margin.  Inside a stream capture (and if the runtime refuses cooperative launches
-  // altogether) the plain launch is used; the spin loops stay bounded either way.
-  static const int coop = getenv("DM_RSSM_LDS_COOP") ? atoi(getenv("DM_RSSM_LDS_COOP")) : 1;
+  // Co-residency of the whole grid is CHECKED, not assumed: rl_raise_lds() asks the occupancy API for >= 1 workgroup of this
+  // variant per CU at the LDS size it is launched with, and the grid never exceeds the CU count (rl_device_ok); the spin loops
+  // are bounded.  A cooperative launch (hipLaunchCooperativeKernel: the runtime validates the same bound) was measured and is
+  // NOT the default: it drains the other streams' queues around the kernel - the 25-column shard goes from 19.2 to 25.2 ms
+  // per step, 13 / 7 columns +0.15 ms (profiles/r05_lds_coop.txt).  DM_RSSM_LDS_COOP=1 selects it.
+  static const int coop = getenv("DM_RSSM_LDS_COOP") ? atoi(getenv("DM_RSSM_LDS_COOP")) : 0;
   bool launched = false;
   if (coop && !capturing) {
     if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(RL_THREADS), args, (unsigned)lds_bytes, st) == hipSuccess) launched = true;

@@ -525,9 +525,9 @@ def test_rssm_lds_chain_matches_launch_schedule(hip, B, D_):
 
 
 def test_rssm_lds_kernel_with_a_busy_chip(hip):
-    """The persistent posterior kernel needs one workgroup resident on every CU at the same time.  It is launched
-    cooperatively (the runtime validates that the grid CAN be co-resident; csrc/rssm_lds.hip rl_launch_exclusive) and its spin
-    loops are bounded; this test runs it while a second stream keeps every CU busy with LDS-heavy work - a queue of 4096^3
+    """The persistent posterior kernel needs one workgroup resident on every CU at the same time.  The library checks with the
+    occupancy API that the grid CAN be co-resident (csrc/rssm_lds.hip rl_raise_lds / rl_device_ok) and its spin loops are
+    bounded; this test runs it while a second stream keeps every CU busy with LDS-heavy work - a queue of 4096^3
     products on 128 x 128 tiles, 64 KiB of LDS per workgroup, two per CU, ~1 ms each - so that its workgroups become
     resident one by one as the tiles of the other stream retire, and the early ones wait for the late ones.  Asserted: the
     kernel never gives up (dm_rssm_lds_status() == 0) and every output equals the quiet run's BIT FOR BIT (the exchange
