@@ -551,6 +551,11 @@ def main():
                                      'serialised, single stream), MFMA rates from this run; bound = the roof that applies to the kernel (peak '
                                      f'{peak} TFLOP/s dense / 8000 GB/s)') if components else None,
                     kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], launches_per_step=dom['launches_per_step'],
+                    # the part holds ~2.07 GHz (not 2.4) under a full fp32 GEMM (in-kernel s_memtime / s_memrealtime probe and
+                    # GRBM_GUI_ACTIVE: profiles/r05_gemm_lab.txt, r05_gemm_sq_counters.txt): `peak` stays nominal
+                    **({'peak_at_measured_clock': round(157.3 * 2.07 / 2.4, 1), 'frac_of_peak_at_measured_clock': dom['tflops'] / (157.3 * 2.07 / 2.4),
+                        'measured_clock_ghz': 2.07, 'measured_clock_source': 'profiles/r05_gemm_lab.txt (4096^3, in-kernel clock probe), profiles/r05_gemm_sq_counters.txt'}
+                       if args.dtype == 'f32' else {}),
                     all_gemm=dict(tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                   gflop_per_step=tot_fl / 1e9 / args.prof_steps, ms_per_step=tot_ms / args.prof_steps,
                                   launches_per_step=n / args.prof_steps),
