@@ -1262,29 +1262,40 @@ def test_training_step_matches_reference_at_atari_literal(hip, fixture):
     # every posterior index of the full-size step equals the reference's (measured 100 % in every round; an ulp-edge escape
     # would be added here only with a measured mismatch to justify it)
     assert same.all(), f'{int((~same).sum())} of {same.size} posterior indices differ from the reference'
-    # imagination actor indices (H, T*B): EXACT, except for trajectories that diverge at a draw whose uniform sits on a CDF edge -
-    # measured in round 5 (profiles/r05_parity_margins.txt): atari_native 100 %, atari_literal 99.955 % = 17 of 37 500 indices,
-    # all of them downstream of such first divergences.  Each FIRST divergence of a trajectory must be an edge case: the
-    # uniform within 5e-6 of the boundary between the two classes under THIS build's fp64-softmaxed logits (fp32 logits summed
-    # in another order than torch's move a boundary by ~1e-6); a trajectory that has diverged carries another state afterwards.
+    # imagination indices: EXACT, except for trajectories that diverge at a draw whose uniform sits on a CDF edge - measured in
+    # round 5 (profiles/r05_parity_margins.txt): atari_native 100 %, atari_literal 99.955 % = 17 of 37 500 action indices, all of
+    # them downstream of a handful of first divergences.  A trajectory's FIRST divergence is either an ACTION draw - then the
+    # uniform must lie within 5e-6 of the boundary between the two classes under THIS build's fp64-softmaxed actor logits (fp32
+    # logits summed in another order than torch's move a boundary by ~1e-6) - or a LATENT draw of the prior at an earlier step
+    # (seen in the fixture's per-step sums of the 32 latent indices; the rollout does not keep its prior logits, so that margin
+    # cannot be re-derived here); a trajectory that has diverged carries another state afterwards.  At most 8 of 2 500.
     act = model.last_extras['act_idx'].cpu().numpy().astype(np.int64)
     ref_act = g['s0_idx_act'].astype(np.int64)
     act_same = act == ref_act
     print('imagination actor indices equal:', act_same.mean())
     if not act_same.all():
         Hh, M = act.shape
+        D_ = oconf.deter_dim
+        zz = model.last_extras['dream_features'][1:, :, D_:].reshape(Hh, M, oconf.stoch_dim, oconf.stoch_discrete)
+        lat_sum = zz.argmax(-1).sum(-1).cpu().numpy().astype(np.int64)           # the latent sampled at step i is the z of state i + 1
+        lat_same = lat_sum == g['s0_idx_lat_rowsum'].astype(np.int64)
         logits = model.last_extras['actor_logits'].view(Hh, M, -1).double().cpu()
         u_act = noise['u_act'].view(Hh, M).double()
         rows = np.flatnonzero(~act_same.all(axis=0))
-        worst = 0.0
+        worst, n_act, n_lat = 0.0, 0, 0
         for r in rows:
             h = int(np.argmax(~act_same[:, r]))
+            if h > 0 and not lat_same[:h, r].all():      # a latent draw flipped first: the actor saw another state at step h
+                n_lat += 1
+                continue
             cdf = torch.softmax(logits[h, r], -1).cumsum(-1)
             lo, hi = sorted((int(act[h, r]), int(ref_act[h, r])))
             margin = float((cdf[lo:hi] - u_act[h, r] * cdf[-1]).abs().min())
             worst = max(worst, margin)
-            assert margin < 5e-6, f'trajectory {r} diverges at step {h} away from a CDF edge (margin {margin:.3e})'
-        print(f'{len(rows)} of {M} imagined trajectories diverge at a CDF-edge draw; worst edge margin {worst:.3e}')
+            n_act += 1
+            assert margin < 5e-6, f'trajectory {r} diverges at action step {h} away from a CDF edge (margin {margin:.3e})'
+        print(f'{len(rows)} of {M} imagined trajectories diverge: {n_act} at an action draw on a CDF edge (worst margin {worst:.3e}), '
+              f'{n_lat} after a latent draw flipped at an earlier step')
         assert len(rows) <= 8 and act_same.mean() >= 0.999
     # the north-star bar: world-model loss within 1e-3 (absolute) of the reference on the fixed full-size batch
     assert abs(float(losses[0]) - g['s0_losses'][0]) < 1e-3
