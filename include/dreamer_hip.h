@@ -70,7 +70,7 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 10 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 11 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
@@ -78,7 +78,8 @@ int dm_version(void);                 /* ABI version, currently 10 (v2: LayerNor
                                          v9: dm_bptt_fold_enable added; the split-bf16 fp32 product mode and its dm_fp32_mode query removed;
                                          v10: dm_gemm_dma_enable added; the dm_chain_graph_ family (hipGraph replay of the launch chains: GPU-neutral in three rounds of
                                          measurement) and the persistent BPTT kernel with its switch dm_rssm_lds_bwd_enable - slower inside the step at every shard size - removed;
-                                         dm_prof_end reports 44 kinds) */
+                                         dm_prof_end reports 44 kinds;
+                                         v11: dm_dec_l4_bwd_direct_enable added */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -130,6 +131,12 @@ int dm_bf16_twins_enable(int on);
  * work item up, the register-staged loop (higher residency) below.  1 / 0 switches it on / off, 2 = on for every k extent (the
  * bit-identity test), -1 queries; returns the state (default 1; DM_GEMM_DMA=0 / 2 in the environment). */
 int dm_gemm_dma_enable(int on);
+/* The image layer of the decoder (ConvTranspose2d(d -> 3, k6, s2), decoders.py:154-155) runs its backward - data gradient with
+ * the ELU' of the layer below folded in, weight gradient - as two direct MFMA kernels that read the 3-channel output gradient
+ * of a frame from LDS (csrc/conv_direct.hip) instead of as gather-form products through the generic tile (3 -> 4 channel pad, 48
+ * columns in a 64-wide tile).  Same sums in another order (fp32 rounding only).  1 / 0 switches it on / off, -1 queries; returns
+ * the state (default 1; DM_DEC_L4_BWD_GEMM=1 in the environment = off). */
+int dm_dec_l4_bwd_direct_enable(int on);
 /* The posterior T loop (rssm.py:38-58, cell rssm.py:125-153, nn.GRUCell rnn.py:40-67) runs, when the shape qualifies (plain
  * single-layer GRU, LayerNorm, categorical latents, B <= 64, the layer slices fit one CU's LDS), as ONE persistent kernel with
  * one workgroup per compute unit that keeps its 4-column slice of every layer's weights in LDS for all T steps and exchanges

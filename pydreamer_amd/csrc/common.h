@@ -279,6 +279,13 @@ bool dm_dec_l4_direct_ok(int ch, int d, int hs, int k);
 size_t dm_dec_l4_w4_floats(int d);
 int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, const float* bias, float* w4, float* out,
                          hipStream_t st);
+bool dm_dec_l4_bwd_direct_ok(int ch, int d, int hs, int k);      // the image layer's backward as direct kernels (conv_direct.hip)
+size_t dm_dec_l4_wp_floats(int d);
+size_t dm_dec_l4_wgrad_part_floats(int frames, int d);
+int dm_dec_l4_dgrad_launch(int frames, int d, const float* G4, const float* w, float* wp, const float* x3, float* dx,
+                           unsigned short* dx_h, hipStream_t st);
+int dm_dec_l4_wgrad_launch(int frames, int d, const float* G4, const float* x3, float* part, float* dW, void* ws,
+                           size_t ws_bytes, hipStream_t st);
 
 // fused MLP (mlp.hip)
 // chain_wpack (optional): fragment-major weights already packed by the caller (dm_mlp_chain_pack_launch) for the whole-MLP

@@ -995,6 +995,10 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     koff_l[l] = (int*)ar.take((size_t)g.k[l] * g.k[l] * co4[l]);
   }
   float* splitk_w = ar.take(DM_SPLITK_FLOATS);          // the side stream's own split-K scratch
+  // image layer (d -> 3 channels): both backward products as direct kernels (conv_direct.hip) reading the padded gradient
+  const bool direct4 = dm_dec_l4_bwd_direct_ok(g.ch, g.d, g.hsm[4], g.k[4]);
+  float* l4_wp = ar.take(direct4 ? dm_dec_l4_wp_floats(g.d) : 0);
+  float* l4_part = ar.take(direct4 ? dm_dec_l4_wgrad_part_floats(g.N, g.d) : 0);
   // bf16 mode: twins of the gradient buffers and of the padded image-layer weights
   DmTwinScope tw((shp->flags & DM_FLAG_BF16) != 0);
   const bool tw_on = dm_twins_on();
@@ -1004,7 +1008,8 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
   const size_t skb = DM_SPLITK_FLOATS * sizeof(float);
   const bool arena_tw = dm_twin_arena_valid(acts);      // the forward that filled `acts` wrote its twins
   dec_register_twins(g, a, arena_tw, arena_tw);
-  for (int l = 0; l <= 4; ++l) dm_twin_add(Gl[l], gsz[l], Gl_h[l], false);
+  for (int l = 0; l <= 4; ++l)
+    if (!(direct4 && l == 4)) dm_twin_add(Gl[l], gsz[l], Gl_h[l], false);      // (the direct kernels read the fp32 gradient)
   dm_twin_add(wpad, wpadmax, wpad_h, false);
   hipStream_t sw = dm_wgrad_side_stream(st);
 
@@ -1020,6 +1025,19 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
     const int rows_s = (int)g.rows_s[l];
     int* rowoff = rowoff_l[l];
     int* koff = koff_l[l];
+    float* Gn = Gl[l - 1];
+    if (direct4 && l == 4) {
+      DM_TRY(dm_wgrad_side_fork(st, sw));
+      unsigned short* gnh = dm_twin_of(Gn, false);
+      DM_TRY(dm_dec_l4_dgrad_launch(g.N, g.d, G, p->w[4], l4_wp, a.x[3], Gn, gnh, st));
+      if (gnh) dm_twin_mark(Gn);
+      DM_TRY(dm_colsum_launch((int)g.rows_b[l], co, G, co, bsum, splitk_w, skb, sw));
+      hipError_t e = hipMemcpyAsync(gr->b[l], bsum, (size_t)g.cout[l] * sizeof(float), hipMemcpyDeviceToDevice, sw);
+      if (e != hipSuccess) return dm_fail(DM_E_HIP, "conv_decoder_bwd: %s", hipGetErrorString(e));
+      DM_TRY(dm_dec_l4_wgrad_launch(g.N, g.d, G, a.x[3], l4_part, gr->w[4], splitk_w, skb, sw));
+      G = Gn;
+      continue;
+    }
     // patches of the output gradient, gathered implicitly (16-byte gathers: co is a multiple of 4)
     DM_TRY(conv_tables_launch(g.N, g.hbg[l], g.hbg[l], co, g.k[l], rowoff, koff, st));
     DM_TRY(dm_wgrad_side_fork(st, sw));                  // G[l] and its tables are enqueued: the side stream may read them
@@ -1034,7 +1052,6 @@ static int conv_decoder_mse_bwd_impl(const dm_shape* shp, const float* feat, int
         dm_twin_mark(wpad);
       }
     }
-    float* Gn = Gl[l - 1];
     {
       DmGemm d;   // dX[row][i] = sum_col dYcol[row][col] * Wr[i][col]   (* ELU'(X_{l-1}) for l-1 >= 1)
       d.a_layout = 0; d.b_layout = 0;

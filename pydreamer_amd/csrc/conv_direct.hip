@@ -299,3 +299,245 @@ int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, cons
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
+
+// ---------------------------------------------------------------- decoder layer 4, backward --------
+// The image layer's backward as two direct MFMA kernels (round 5).  As gather-form products they ran through the generic
+// 64 x 64 tile with the 3-channel gradient padded to 4 channels and d = 48 in a 64-wide tile: 2 250 000 x 48 x 144 and
+// 48 x 144 x 2 250 000 at 48 TF/s of useful work (0.65 + 0.64 ms per step at Atari-literal) - 44 % of the issued MFMA work
+// was padding.  Here a workgroup stages one frame of the output gradient dY (64 x 64 pixels, THREE channels, row stride RS
+// floats) in LDS and both products read their dY operand from that image with computed addresses (the patch of input pixel
+// (y, x) is the 6 x 18-float window at (2y, 6x)), on v_mfma_f32_16x16x4_f32 with K = 108 exactly:
+//   dec_l4_dgrad_kernel   dX[pixel][c] = ELU'(x3[pixel][c]) * sum_k dYcol[pixel][k] W[c][k]      k = (ky*6 + kx)*3 + o
+//                         M = channels (the weights: A operand, 27 x CB registers per lane for the whole kernel), N = 16
+//                         pixels per MFMA, a wave walks the frame's 57 pixel blocks; each lane ends up with 4 consecutive
+//                         channels of one pixel (16-byte loads of x3, 16-byte stores of dX, 8-byte stores of its bf16 twin)
+//   dec_l4_wgrad_kernel   dW[c][k] = sum_pixels x3[pixel][c] dYcol[pixel][k]       K = pixels, 4 per MFMA; x3 straight from
+//                         global memory (each 64-byte segment is read once), IB x 7 accumulator tiles per wave over ALL its
+//                         frames; per-wave partials in the torch (d, 3, 6, 6) order, summed in fixed order by
+//                         dm_colsum_launch (deterministic)
+static int g_l4_bwd_direct = getenv("DM_DEC_L4_BWD_GEMM") ? 0 : 1;
+extern "C" int dm_dec_l4_bwd_direct_enable(int on) {
+  if (on >= 0) g_l4_bwd_direct = on ? 1 : 0;
+  return g_l4_bwd_direct;
+}
+bool dm_dec_l4_bwd_direct_ok(int ch, int d, int hs, int k) { return g_l4_bwd_direct && dm_dec_l4_direct_ok(ch, d, hs, k); }
+
+constexpr int L4_K = 108, L4_KS = 27;
+// wp[(s*CB + cb)*64 + q*16 + l15] = W[c = 16 cb + l15][k = 4 s + q]  (0 for c >= d); W is the torch (d, 3, 6, 6) tensor
+__global__ void __launch_bounds__(256) dec_l4_dgrad_repack_kernel(int d, int CB, const float* __restrict__ w,
+                                                                  float* __restrict__ wp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= L4_KS * CB * 64) return;
+  const int l15 = e & 15, q = (e >> 4) & 3, cb = (e >> 6) % CB, s = e / (64 * CB);
+  const int c = 16 * cb + l15, k = 4 * s + q;
+  const int o = k % 3, kx = (k / 3) % 6, ky = k / 18;
+  wp[e] = c < d ? w[(((size_t)c * 3 + o) * 6 + ky) * 6 + kx] : 0.f;
+}
+
+template <int RS>
+__device__ __forceinline__ void l4_stage_frame(float* img, const float* __restrict__ G4, int n, int tid) {
+  const float4* src = reinterpret_cast<const float4*>(G4) + (size_t)n * 4096;      // (64, 64, 4): channel 3 is the pad
+#pragma unroll 4
+  for (int e = tid; e < 4096; e += 256) {
+    const float4 v = src[e];
+    float* dst = &img[(e >> 6) * RS + (e & 63) * 3];
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+  }
+}
+
+template <int CB, int RS>
+__global__ void __launch_bounds__(256) dec_l4_dgrad_kernel(int frames, int d, const float* __restrict__ G4,
+                                                           const float* __restrict__ wp, const float* __restrict__ x3,
+                                                           float* __restrict__ dx, unsigned short* __restrict__ dx_h) {
+  extern __shared__ __attribute__((aligned(16))) float img[];      // [64 rows][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  float wreg[L4_KS][CB];
+#pragma unroll
+  for (int s = 0; s < L4_KS; ++s)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) wreg[s][cb] = wp[(s * CB + cb) * 64 + lane];
+  int koff[L4_KS];
+#pragma unroll
+  for (int s = 0; s < L4_KS; ++s) {
+    const int k = 4 * s + q, ky = k / 18;
+    koff[s] = ky * RS + (k - 18 * ky);
+  }
+  for (int n = blockIdx.x; n < frames; n += gridDim.x) {
+    __syncthreads();                                               // the previous frame's readers are done
+    l4_stage_frame<RS>(img, G4, n, tid);
+    __syncthreads();
+    for (int blk = wave; blk < 57; blk += 4) {
+      const int p = blk * 16 + l15;
+      const int pc = p < 900 ? p : 899;
+      const int y = pc / 30, x = pc - 30 * y;
+      const float* base = &img[2 * y * RS + 6 * x];
+      f32x4c acc[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < L4_KS; ++s) {
+        const float b = base[koff[s]];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][cb], b, acc[cb], 0, 0, 0);
+      }
+      // C/D map: row (channel) = 16 cb + 4 q + r, column (pixel) = l15
+      if (p < 900) {
+        const size_t row = ((size_t)n * 900 + p) * d;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const int c0 = 16 * cb + 4 * q;
+          if (c0 < d) {
+            const float4 m = *reinterpret_cast<const float4*>(x3 + row + c0);
+            const float4 v = make_float4(acc[cb][0] * dm_elu_grad_from_y(m.x), acc[cb][1] * dm_elu_grad_from_y(m.y),
+                                         acc[cb][2] * dm_elu_grad_from_y(m.z), acc[cb][3] * dm_elu_grad_from_y(m.w));
+            *reinterpret_cast<float4*>(dx + row + c0) = v;
+            if (dx_h) *reinterpret_cast<uint2*>(dx_h + row + c0) = dm_pack_bf16x4(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// part[(block*4 + wave)][c][o][ky][kx] (c < d): this wave's sum over its pixels of x3[pixel][c] * dYcol[pixel][k]
+template <int IB, int RS>
+__global__ void __launch_bounds__(256) dec_l4_wgrad_kernel(int frames, int d, const float* __restrict__ G4,
+                                                           const float* __restrict__ x3, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float img[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  f32x4c acc[IB][7];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+  int koff[7];
+#pragma unroll
+  for (int kb = 0; kb < 7; ++kb) {
+    const int k = 16 * kb + l15 < L4_K ? 16 * kb + l15 : L4_K - 1, ky = k / 18;      // columns >= 108 are never written out
+    koff[kb] = ky * RS + (k - 18 * ky);
+  }
+  int cofs[IB];
+  float cmask[IB];
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib) {
+    const int c = 16 * ib + l15;
+    cofs[ib] = c < d ? c : d - 1;
+    cmask[ib] = c < d ? 1.f : 0.f;
+  }
+  for (int n = blockIdx.x; n < frames; n += gridDim.x) {
+    __syncthreads();
+    l4_stage_frame<RS>(img, G4, n, tid);
+    __syncthreads();
+    const float* xn = x3 + (size_t)n * 900 * d;
+    // 57 chunks of 16 pixels (the last holds 4), dealt to the waves round-robin, the deal rotated per frame
+    const int w0 = (wave + n) & 3;
+    float a[4][IB], an[4][IB];
+    auto load = [&](int chunk, float (&dst)[4][IB]) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int p = chunk * 16 + 4 * ks + q;
+        const int pc = p < 900 ? p : 899;
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) dst[ks][ib] = xn[(size_t)pc * d + cofs[ib]] * (p < 900 ? cmask[ib] : 0.f);
+      }
+    };
+    if (w0 < 57) load(w0, a);
+    for (int chunk = w0; chunk < 57; chunk += 4) {
+      if (chunk + 4 < 57) load(chunk + 4, an);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int p = chunk * 16 + 4 * ks + q;
+        const int pc = p < 900 ? p : 899;                        // a pixel past the frame multiplies a zeroed x3 row
+        const int y = pc / 30, x = pc - 30 * y;
+        const float* base = &img[2 * y * RS + 6 * x];
+        float b[7];
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb) b[kb] = base[koff[kb]];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+          for (int kb = 0; kb < 7; ++kb) acc[ib][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][ib], b[kb], acc[ib][kb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) a[ks][ib] = an[ks][ib];
+    }
+  }
+  // C/D map: row (channel) = 16 ib + 4 q + r, column (k) = 16 kb + l15
+  float* dst = part + (size_t)(blockIdx.x * 4 + wave) * d * L4_K;
+#pragma unroll
+  for (int kb = 0; kb < 7; ++kb) {
+    const int k = 16 * kb + l15;
+    if (k < L4_K) {
+      const int o = k % 3, kx = (k / 3) % 6, ky = k / 18;
+      const int kt = o * 36 + ky * 6 + kx;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * ib + 4 * q + r;
+          if (c < d) dst[(size_t)c * L4_K + kt] = acc[ib][kb][r];
+        }
+    }
+  }
+}
+
+constexpr int L4_RS_D = 196, L4_RS_W = 228;      // row strides of the staged frame: see the bank notes in DESIGN 4.1
+size_t dm_dec_l4_wp_floats(int d) { return (size_t)L4_KS * ((d + 15) / 16) * 64; }
+static int dec_l4_wgrad_blocks(int frames) { return frames > 512 ? 512 : frames; }
+size_t dm_dec_l4_wgrad_part_floats(int frames, int d) { return (size_t)dec_l4_wgrad_blocks(frames) * 4 * d * L4_K; }
+
+template <typename K>
+static int l4_raise_lds(K kern, size_t lds, bool* done) {
+  if (!*done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return dm_fail(DM_E_HIP, "dec_l4 backward: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    *done = true;
+  }
+  return DM_OK;
+}
+
+// dx (frames*900, d) = ELU'(x3) * (dY patches) W^T; G4 (frames, 64, 64, 4) = the padded output gradient; wp: scratch of
+// dm_dec_l4_wp_floats(d) (written here); dx_h: optional bf16 twin of dx
+int dm_dec_l4_dgrad_launch(int frames, int d, const float* G4, const float* w, float* wp, const float* x3, float* dx,
+                           unsigned short* dx_h, hipStream_t st) {
+  if (frames <= 0) return DM_OK;
+  const int CB = (d + 15) / 16;
+  DM_REQUIRE(CB >= 1 && CB <= 4 && (d & 3) == 0, DM_E_SHAPE, "dec_l4_dgrad: cnn_depth %d", d);
+  hipLaunchKernelGGL(dec_l4_dgrad_repack_kernel, dim3(grid_for_px(dm_dec_l4_wp_floats(d), 256)), dim3(256), 0, st, d, CB, w, wp);
+  DM_LAUNCH_CHECK();
+  const size_t lds = (size_t)64 * L4_RS_D * sizeof(float);
+#define DM_L4_DG(CB_)                                                                                                \
+  if (CB == CB_) {                                                                                                   \
+    static bool attr_set = false;                                                                                    \
+    DM_TRY(l4_raise_lds(dec_l4_dgrad_kernel<CB_, L4_RS_D>, lds, &attr_set));                                         \
+    hipLaunchKernelGGL((dec_l4_dgrad_kernel<CB_, L4_RS_D>), dim3(frames), dim3(256), lds, st, frames, d, G4, wp, x3, dx, dx_h); \
+  }
+  DM_L4_DG(1) DM_L4_DG(2) DM_L4_DG(3) DM_L4_DG(4)
+#undef DM_L4_DG
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dW (d, 3, 6, 6) = sum over all pixels; part: dm_dec_l4_wgrad_part_floats(frames, d) of scratch
+int dm_dec_l4_wgrad_launch(int frames, int d, const float* G4, const float* x3, float* part, float* dW, void* ws,
+                           size_t ws_bytes, hipStream_t st) {
+  if (frames <= 0) return DM_OK;
+  const int IB = (d + 15) / 16;
+  DM_REQUIRE(IB >= 1 && IB <= 4, DM_E_SHAPE, "dec_l4_wgrad: cnn_depth %d", d);
+  const int blocks = dec_l4_wgrad_blocks(frames);
+  const size_t lds = (size_t)64 * L4_RS_W * sizeof(float);
+#define DM_L4_WG(IB_)                                                                                                \
+  if (IB == IB_) {                                                                                                   \
+    static bool attr_set = false;                                                                                    \
+    DM_TRY(l4_raise_lds(dec_l4_wgrad_kernel<IB_, L4_RS_W>, lds, &attr_set));                                         \
+    hipLaunchKernelGGL((dec_l4_wgrad_kernel<IB_, L4_RS_W>), dim3(blocks), dim3(256), lds, st, frames, d, G4, x3, part); \
+  }
+  DM_L4_WG(1) DM_L4_WG(2) DM_L4_WG(3) DM_L4_WG(4)
+#undef DM_L4_WG
+  DM_LAUNCH_CHECK();
+  return dm_colsum_launch(blocks * 4, d * L4_K, part, d * L4_K, dW, ws, ws_bytes, st);
+}

@@ -16,7 +16,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 10; }
+extern "C" int dm_version(void) { return 11; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -170,7 +170,9 @@ extern "C" size_t dm_workspace_bytes(const dm_shape* s) {
   const size_t dec_tabs = pad64(N) + pad64(N * 25) + pad64(N * 169) + pad64(N * 900) + pad64(25 * up4(4 * d)) + pad64(25 * up4(2 * d)) +
                           pad64(36 * up4(d)) + pad64(36 * r4);
   (void)gmax;
-  const size_t dec_bwd = 2 * SK + g_sum + 2 * pad64(wmax + 36 * 4 * d) + dec_tabs + 1024 +
+  const size_t l4_direct = dm_dec_l4_direct_ok((int)ch, (int)d, 30, 6)       // (sized whether or not the switch is on)
+                               ? pad64(dm_dec_l4_wp_floats((int)d)) + pad64(dm_dec_l4_wgrad_part_floats((int)N, (int)d)) : 0;
+  const size_t dec_bwd = 2 * SK + g_sum + 2 * pad64(wmax + 36 * 4 * d) + dec_tabs + 1024 + l4_direct +
                          tw * (g_tw + pad64((wmax + 36 * 4 * d) / 2 + 1));
   const size_t rssm_bwd = 2 * SK + 8 * pad64(N * Hd) + 3 * pad64(N * 3 * D) + 2 * pad64(Z * Hd) + pad64(Hd * D) +
                           pad64(3 * D * Hd) + pad64(3 * D * D) + 2 * pad64(3 * D) +   // + the transposed BPTT weights, LN-GRU dg

@@ -184,6 +184,7 @@ _SIGNATURES = {
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_gemm_dma_enable': (c_int, [c_int]),
+    'dm_dec_l4_bwd_direct_enable': (c_int, [c_int]),
     'dm_rssm_lds_enable': (c_int, [c_int]),
     'dm_bptt_fold_enable': (c_int, [c_int]),
     'dm_rssm_lds_status': (c_int, []),
@@ -196,7 +197,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 10     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 11     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

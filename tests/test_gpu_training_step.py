@@ -301,11 +301,23 @@ def test_conv_encoder_fwd_bwd(hip, depth, T, B):
         assert _rel_l2(grads[1][i], p[f'wm.encoder.encoder_image.model.{2 * i}.bias'].grad) < 2e-4, f'conv{i} db'
 
 
-@pytest.mark.parametrize('depth', [8, 48])
-def test_conv_decoder_mse_fwd_bwd(hip, depth):
+@pytest.mark.parametrize('depth,l4_direct', [(8, 1), (8, 0), (16, 1), (48, 1), (48, 0), (64, 1)])
+def test_conv_decoder_mse_fwd_bwd(hip, depth, l4_direct):
     """dm_conv_decoder_mse_fwd / _bwd through the C-ABI against the fp64 oracle (decoders.py:144-167), FULL tensors: the decoded
     image, the per-frame loss, the feature gradient and every weight / bias gradient.  depth 48 (the shipped cnn_depth)
-    reaches dec_l4_fwd_kernel<48>, which depth 8 does not."""
+    reaches dec_l4_fwd_kernel<48>, which depth 8 does not.  l4_direct: the image layer's backward as the two direct MFMA
+    kernels (dec_l4_dgrad_kernel / dec_l4_wgrad_kernel; depth 8 = a partly filled 16-channel block, 64 = four blocks) or as
+    gather-form products through the tile kernels."""
+    import ctypes
+    from pydreamer_amd import hip as H
+    H.lib().dm_dec_l4_bwd_direct_enable(l4_direct)
+    try:
+        _conv_decoder_mse_fwd_bwd(depth)
+    finally:
+        H.lib().dm_dec_l4_bwd_direct_enable(1)
+
+
+def _conv_decoder_mse_fwd_bwd(depth):
     import ctypes
     from pydreamer_amd import hip as H
     oconf = O.tiny_conf(cnn_depth=depth)
