@@ -5,6 +5,6 @@ O=$PWD/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp PYTHONPATH=$PWD
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tq_$DT -o t -- python $REPO/bench.py --dtype $DT --steps 6 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --pmc-json /nonexistent > $O/bench_$DT.json 2> $O/err_$DT.txt
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tq_$DT -o t -- python $REPO/bench.py --dtype $DT --steps 6 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --pmc-json /nonexistent > $O/bench_$DT.json 2> $O/err_$DT.txt
 python $REPO/scripts/trace_queues.py $(find /tmp/prof_tq_$DT -name "*kernel_trace.csv" | head -1) 2 0.5 > $O/queues_$DT.txt 2>&1
 head -8 $O/queues_$DT.txt
