@@ -12,6 +12,7 @@ gru_layernorm_dv2}, gru_layers 1..4, stoch_discrete>0 or 0 (Gaussian latents, al
 aux_critic, image_encoder/decoder='cnn' at 64x64, actor_dist in {onehot, tanh_normal, normal_tanh}, actor_grad='reinforce',
 probe_model='none', no vecobs / reward_input.
 """
+import contextlib
 import ctypes
 import os
 import math
@@ -479,6 +480,7 @@ class _Overlap:
         self.s_ac = torch.cuda.Stream(device, priority=int(os.environ.get('DM_AC_PRIO', '0')))
         self.ev_wm_fwd = torch.cuda.Event()
         self.ev_fwd = torch.cuda.Event()
+        self.ev_fork, self.ev_tail = torch.cuda.Event(), torch.cuda.Event()      # the world-model forward's tail on s_wm (WorldModel._forward)
         # the rollout's progress mark (recorded by the library, dm_dream_rollout_marks) and the early head window's completion
         self.ev_mark, self.ev_heads = torch.cuda.Event(), torch.cuda.Event()
         with torch.cuda.device(device):
@@ -623,6 +625,10 @@ class _WMStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, wm, pack, *params):
         ctx.wm, ctx.pack = wm, pack
+        tail = pack.get('tail')
+        if tail is not None:                  # the loss was written on the world-model stream (WorldModel._forward)
+            with torch.cuda.stream(tail.s_wm):
+                return pack['loss'].clone()
         return pack['loss'].clone()
 
     @staticmethod
@@ -739,7 +745,7 @@ class WorldModel(_Params):
 
     # ---- forward through the C-ABI
     def _forward(self, obs, in_state, u_post, forced_idx, forward_only=False, imag_horizon=1, open_loop=False, mbuf=None,
-                 iwae=1):
+                 iwae=1, tail=None):
         """iwae = I > 1 (rssm.py:35-41): every row-wise stage runs on T*B*I rows, row n = (t*B + b)*I + i; only the conv
         encoder sees the T*B frames once.  Three geometry structs: `shp` (T,B,I: conv decoder + workspace), `shp_e`
         (T,B,1: encoder), `shp_r` (T, B*I, 1: the RSSM calls take the expanded batch as their batch)."""
@@ -874,9 +880,6 @@ class WorldModel(_Params):
             H.call('dm_rssm_sequence_fwd', ctypes.byref(shp_r), H.fptr(embed_rssm), H.fptr(action_x), H.ptr(reset_x), H.fptr(h0),
                    H.fptr(z0), u_ptr, H.ptr(fidx), ctypes.byref(rssm_p), H.fptr(rssm_acts), H.fptr(feat), H.fptr(post),
                    H.fptr(prior), H.ptr(idx), H.ptr(ws), ws.numel(), H.stream())
-            if not forward_only:
-                H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(image), ctypes.byref(dec_p),
-                       H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(), H.stream())
         else:
             # Time-chunk pipeline over three streams: the posterior loop is a latency chain of T x ~10 small kernels
             # (rssm.py:38-58) that leaves most CUs idle, so the encoder of chunk i+1 and the decoder of chunk i-1 run
@@ -921,6 +924,36 @@ class WorldModel(_Params):
                   out_state=out_state, embed=embed, embed_x=embed_x, action_x=action_x, reset_x=reset_x, gen=gen)
         if forward_only:
             return pk
+        # The tail of the world-model forward - decoder + MSE, reward / terminal heads, KL, the loss sums (dreamer.py:311-365) -
+        # is consumed by the world-model BACKWARD only: the imagination rollout (dreamer.py:149-157) needs the posterior
+        # features and nothing else.  With `tail` (the training step's side streams, Dreamer.training_step) it is enqueued on
+        # the world-model stream, in front of the pre-launched backward, with that stream's workspace, and the caller's stream
+        # goes from the posterior loop straight to the rollout.  Same kernels on the same operands: bit-identical
+        # (test_world_model_tail_on_side_stream_is_bit_identical).
+        use_tail = tail is not None and chunks <= 1
+        if use_tail:
+            need = ws.numel()
+            if tail.ws_wm is None or tail.ws_wm.numel() < need:
+                tail.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = tail.ws_wm
+            tail.ev_fork.record(torch.cuda.current_stream())
+            tail.s_wm.wait_event(tail.ev_fork)
+            pk['tail'] = tail
+        with (torch.cuda.stream(tail.s_wm) if use_tail else contextlib.nullcontext()):
+            return self._forward_tail(pk, obs, c, dec, dec_p, dec_acts, loss_image, ws, mbuf, chunks, image, action, reset,
+                                      enc_acts, rssm_acts)
+
+    def _forward_tail(self, pk, obs, c, dec, dec_p, dec_acts, loss_image, ws, mbuf, chunks, image, action, reset, enc_acts,
+                      rssm_acts):
+        shp, T, B, I, feat, post, prior, idx = (pk[k] for k in ('shp', 'T', 'B', 'I', 'feat', 'post', 'prior', 'idx'))
+        lib = H.lib()
+        N, NE, dev = T * B * I, T * B, feat.device
+        D_, F_ = c.deter_dim, self.features_dim
+        gauss = not c.stoch_discrete
+        Z = c.stoch_dim * (c.stoch_discrete or 1)
+        if chunks <= 1:
+            H.call('dm_conv_decoder_mse_fwd', ctypes.byref(shp), H.fptr(feat), F_, H.ptr(image), ctypes.byref(dec_p),
+                   H.fptr(dec_acts), H.fptr(loss_image), None, H.ptr(ws), ws.numel(), H.stream())
 
         reward_t = obs['reward'].float().contiguous()
         terminal_t = obs['terminal'].float().contiguous()
@@ -1204,7 +1237,7 @@ class WorldModel(_Params):
         return metrics, tensors, idx
 
     def training_step(self, obs, in_state, iwae_samples=1, do_open_loop=False, do_image_pred=False, forward_only=False,
-                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None, _internal=False):
+                      u_post=None, forced_idx=None, imag_horizon=1, u_pred=None, mbuf=None, _internal=False, _tail=None):
         """dreamer.py:297-396. Returns (loss, features (T,B,1,F), states, out_state, metrics, tensors)."""
         I = int(iwae_samples)
         if do_open_loop and torch.is_grad_enabled():
@@ -1215,8 +1248,10 @@ class WorldModel(_Params):
             feats, out_state = self.forward(obs, in_state)
             return torch.tensor(0.0), feats, None, out_state, {}, {}
         pk = self._forward(obs, in_state, u_post, forced_idx, imag_horizon=imag_horizon, open_loop=do_open_loop, mbuf=mbuf,
-                           iwae=I)
+                           iwae=I, tail=None if (do_open_loop or do_image_pred) else _tail)
         loss = _WMStep.apply(self, pk, *self._param_order())
+        if pk.get('tail') is not None:        # everything the forward's tail produced is final once the caller's stream has
+            pk['tail'].ev_tail.record(pk['tail'].s_wm)      # waited for this event (Dreamer.training_step does, before returning)
         D_ = self.deter_dim
         # the feature matrix lives in the step arena (overwritten by the next step): callers get their own copy, except
         # Dreamer.training_step, which consumes it before returning (_internal)
@@ -1419,6 +1454,8 @@ class Dreamer(nn.Module):
                 m.precision = int(self.amp)
         self._overlap = None
         self.overlap_backward = True      # pre-launch the three backward passes on side streams (see _Overlap)
+        # the world-model forward's tail (decoder, heads, losses) on the world-model stream: WorldModel._forward (A/B: DM_WM_TAIL=0)
+        self.wm_tail_on_side = os.environ.get('DM_WM_TAIL', '1') != '0'
 
     # ---- optimizers (dreamer.py:60-87)
     def param_groups(self):
@@ -1695,10 +1732,17 @@ class Dreamer(nn.Module):
         # every loss / metric scalar of this step lands in ONE device buffer (METRIC_SLOTS)
         mbuf = torch.zeros(METRIC_BUF_FLOATS, device=obs['action'].device)
         self.metric_buffer = mbuf
+        tail = None
+        dev0 = obs['action'].device
+        if (self.overlap_backward and torch.is_grad_enabled() and self.wm_tail_on_side and dev0.type == 'cuda'
+                and not torch.cuda.is_current_stream_capturing()):
+            if self._overlap is None or self._overlap.s_wm.device != dev0:
+                self._overlap = _Overlap(dev0)
+            tail = self._overlap
         loss_model, features, states, out_state, metrics, tensors = \
             self.wm.training_step(obs, in_state, iwae_samples=iwae_samples, do_open_loop=do_open_loop,
                                   do_image_pred=do_image_pred, u_post=u_post, forced_idx=forced_idx,
-                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf, _internal=True)
+                                  imag_horizon=imag_horizon, u_pred=noise.get('u_pred'), mbuf=mbuf, _internal=True, _tail=tail)
         pk = self.wm._last_pack
         ov = None
         if not (self.overlap_backward and torch.is_grad_enabled()):
@@ -1718,7 +1762,8 @@ class Dreamer(nn.Module):
             need = pk['ws'].numel()
             if ov.ws_wm is None or ov.ws_wm.numel() < need:
                 ov.ws_wm = torch.empty(need, dtype=torch.uint8, device=dev)
-            ov.ev_wm_fwd.record(torch.cuda.current_stream())
+            # (with the forward's tail already on s_wm the backward simply follows it in stream order)
+            ov.ev_wm_fwd.record(ov.s_wm if pk.get('tail') is not None else torch.cuda.current_stream())
             pk['pre'] = ov.submit(ov.s_wm, ov.ev_wm_fwd, lambda: _prelaunched(self.wm, lambda: self.wm._backward(
                 pk, ov.ws_wm, scratch=gens.get(id(self.wm), True), defer_wgrad=True)))
         metrics, tensors = dict(metrics), tensors.copy()          # LazyTensors.copy(): image_rec stays a thunk
@@ -1783,6 +1828,8 @@ class Dreamer(nn.Module):
                                      terminal_pred=t2.mean, image_pred=image_dream.view(T, B, *image_dream.shape[-3:]),
                                      **t_ac2)
                 self.last_extras.update(dream_log_act_idx=dpk2['act_idx'].clone())
+        if pk.get('tail') is not None:      # losses, metrics and tensors of the world model were written on the world-model stream
+            torch.cuda.current_stream().wait_event(pk['tail'].ev_tail)
         if self.probe_gradients:      # dreamer.py:183-186
             losses = (loss_model + loss_probe, loss_actor, loss_critic)
         else:

@@ -58,8 +58,10 @@ def submit(self, stream, wait_event, fn):
 
     def fn2():
         t = time.perf_counter() - T0[0]
+        e_s = torch.cuda.Event(enable_timing=True)
+        e_s.record(torch.cuda.current_stream())        # completes when the stream has passed the job's wait_event: the GPU-side start
         r = fn()
-        log.append((t, f'job {label} start (submitted {1e3 * t_sub:.2f})', None))
+        log.append((t, f'job {label} start (submitted {1e3 * t_sub:.2f})', e_s))
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         log.append((time.perf_counter() - T0[0], f'job {label} enqueued', e))

@@ -1237,6 +1237,50 @@ def test_early_head_window_is_bit_identical(hip):
             assert torch.equal(a[2], b[2]), f'step {s}: parameters differ'
 
 
+@pytest.mark.parametrize('amp,extra', [(False, {}), (True, {}), (False, dict(iwae_samples=3)), (False, dict(aux_critic=True))])
+def test_world_model_tail_on_side_stream_is_bit_identical(hip, amp, extra):
+    """The tail of the world-model forward (decoder + MSE, reward / terminal heads, KL, the loss sums, the auxiliary critic) is
+    enqueued on the world-model stream in front of the pre-launched backward, with that stream's workspace, while the caller's
+    stream goes from the posterior loop straight to the rollout (WorldModel._forward, Dreamer.wm_tail_on_side).  Same kernels
+    on the same operands: every loss, metric, logged tensor, gradient and updated parameter equals the run with the tail on the
+    caller's stream, bit for bit - fp32 and bf16, with IWAE samples, with the auxiliary critic."""
+    oconf = O.tiny_conf(amp=amp, **extra)
+    params = O.make_params(oconf, seed=7)
+    runs = []
+    for tail in (True, False):
+        model = _build(oconf, params)
+        model.wm_tail_on_side = tail
+        opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
+        st = model.init_state(oconf.batch_size * oconf.iwae_samples)
+        hist = []
+        for s in range(3):
+            obs = _to_dev(O.preprocess(O.synthetic_batch(oconf, seed=90 + s, first=(s == 0)), oconf))
+            torch.manual_seed(95 + s)              # the samplers' uniforms come from torch's generator: same draws in both runs
+            losses, st2, metrics, tensors, _ = model.training_step(obs, st)
+            assert (model.wm._last_pack.get('tail') is not None) == tail
+            for opt in opts:
+                opt.zero_grad()
+            for loss in losses:
+                loss.backward()
+            model.grad_clip(oconf.grad_clip, oconf.grad_clip_ac)
+            grads = torch.cat([o.flat_grad for o in opts]).clone()
+            for opt in opts:
+                opt.step()
+            st = tuple(x.clone() for x in st2)
+            hist.append(([float(x) for x in losses], {k: float(v) for k, v in metrics.items()},
+                         {k: v.detach().float().cpu() for k, v in tensors.items()}, grads.cpu(),
+                         torch.cat([o.flat_param for o in opts]).cpu()))
+        runs.append(hist)
+    for s, (a, b) in enumerate(zip(*runs)):
+        assert a[0] == b[0], (s, a[0], b[0])
+        assert a[1] == b[1], (s, {k: (a[1][k], b[1][k]) for k in a[1] if a[1][k] != b[1][k]})
+        assert a[2].keys() == b[2].keys()
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), f'step {s}: tensor {k} differs'
+        assert torch.equal(a[3], b[3]), f'step {s}: gradients differ'
+        assert torch.equal(a[4], b[4]), f'step {s}: parameters differ'
+
+
 @pytest.mark.parametrize('fixture', ['atari_literal', 'atari_native'])
 def test_training_step_matches_reference_at_atari_literal(hip, fixture):
     """BASELINE.json configs[1] at FULL size against the slim golden written by the real reference
