@@ -1,7 +1,7 @@
 """How far does the host run ahead of the GPU inside one gradient step (diagnostic)?  For a few steady-state steps: the
 host time at marked points of the step and the GPU time at which an event recorded at that point completes, on one clock
 (both relative to a synchronised origin), plus every C-ABI call that took the host more than 0.5 ms and the start/end of the
-launcher thread's jobs.  usage: python scripts/host_lead.py [f32|bf16] [steps=4]"""
+launcher thread's jobs.  usage: python scripts/host_lead.py [f32|bf16] [steps=4] [batch columns=50]"""
 import os
 import sys
 import time
@@ -15,9 +15,10 @@ from pydreamer_amd import models as M
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cols = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
-conf = config.atari_literal(amp=(dtype == 'bf16'))
+conf = config.atari_literal(amp=(dtype == 'bf16'), **({'batch_size': cols} if cols else {}))
 torch.manual_seed(0)
 model = M.Dreamer(conf).to(dev)
 opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
