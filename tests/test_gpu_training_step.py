@@ -687,6 +687,24 @@ def test_training_step_continuous_actor_vs_oracle(hip):
             _check_pair(r, oconf)
 
 
+@pytest.mark.parametrize('stoch,classes', [(40, 32), (64, 32), (33, 8)])
+def test_training_step_wide_stoch_vs_oracle(hip, stoch, classes):
+    """stoch_dim > 32 (the reference's larger configurations, e.g. 96 x 32 with deter 2048): the fragment-major gather +
+    LayerNorm form of z_mlp (`ln_z`, csrc/rssm.hip) and the lane-per-latent samplers are built for <= 32 latents per row, so these
+    shapes must take the generic kernels - every loss, metric and per-parameter gradient of two consecutive steps against the
+    oracle, with the persistent posterior kernel allowed and refused."""
+    from pydreamer_amd import hip as H
+    oconf = O.tiny_conf(stoch_dim=stoch, stoch_discrete=classes)
+    keep = H.lib().dm_rssm_lds_enable(-1)
+    try:
+        for lds in (1, 0):
+            H.lib().dm_rssm_lds_enable(lds)
+            for r in _run_pair(oconf, 2):
+                _check_pair(r, oconf)
+    finally:
+        H.lib().dm_rssm_lds_enable(keep)
+
+
 @pytest.mark.parametrize('layers,deter', [(2, 64), (4, 96)])
 def test_training_step_gru_cell_stack_vs_oracle(hip, layers, deter):
     """GRUCellStack with several layers (rnn.py:40-67) against the oracle: every loss, metric and per-parameter gradient
