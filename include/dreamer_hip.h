@@ -426,7 +426,7 @@ int dm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* clip_coef, void* stream);
 int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* critic_target <- critic, a2c.py:151-152 */
-/* Row threshold from which the 400-wide MLP heads run their whole forward as ONE launch (csrc/mlp_chain.hip; default 1024,
+/* Row threshold from which the 400-wide MLP heads run their whole forward as ONE launch (csrc/mlp_chain.hip; default 256,
  * below it the per-layer launches are faster).  rows >= 1 sets it; returns the previous value (rows < 1: query only). */
 int dm_mlp_chain_min_rows(int rows);
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).

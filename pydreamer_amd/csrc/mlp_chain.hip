@@ -1,7 +1,8 @@
 // Whole-MLP forward in ONE launch for the 400-wide heads at small and mid row counts (common.py:37-65; a2c.py:37-39;
 // decoders.py:257-319):   [Linear -> LayerNorm(eps) -> ELU] x L  ->  Linear(out_dim <= 32)
 //
-// Where it runs (rows >= dm_mlp_chain_min_rows, default 1024, below the row-panel threshold): the actor inside the
+// Where it runs (rows >= dm_mlp_chain_min_rows, default 256 - round 5: 1024 before; at the 350 / 650 rows of the 8- / 4-way shards the
+// one launch beats the 13 dependent per-layer launches by 0.1 ms per step - below the row-panel threshold): the actor inside the
 // imagination rollout (M = T*B = 2500 rows per horizon step, dreamer.py:188-216) and the reward / terminal heads over the
 // T*B posterior features.  There the per-layer form costs 3 launches per layer (GEMM + split-K reduce or LayerNorm) on
 // N = 400-wide products that the tiled GEMM runs at 30-55 TF/s: 13 dependent launches for the actor, 15 times per step.
@@ -450,7 +451,7 @@ static const int g_chain_off = getenv("DM_MLP_NO_CHAIN") ? 1 : 0;       // A/B s
 // weight stream's latency), so the launch pays once the per-layer form's ~13 launches on the same rows cost more: from
 // ~1000 rows up (2500-row rollout step: 137 vs 167 us); at a 350-row shard the per-layer products, which spread over all
 // CUs by split-K, take 95 us.  DM_CHAIN_MIN_ROWS overrides.
-static int g_chain_min_rows = getenv("DM_CHAIN_MIN_ROWS") ? atoi(getenv("DM_CHAIN_MIN_ROWS")) : 1024;
+static int g_chain_min_rows = getenv("DM_CHAIN_MIN_ROWS") ? atoi(getenv("DM_CHAIN_MIN_ROWS")) : 256;
 extern "C" int dm_mlp_chain_min_rows(int rows) {       // rows >= 1: set; returns the previous value
   const int prev = g_chain_min_rows;
   if (rows >= 1) g_chain_min_rows = rows;

@@ -113,7 +113,7 @@ def test_mlp_head_sparse_trailing_columns(hip, rows, dense, S, C, out_dim):
     """dm_mlp_head_fwd_sparse (layer 0 = dense columns on the matrix pipe + the one-hot latent columns as a sum of weight
     rows) equals dm_mlp_head_fwd on feature rows [h | one-hot z] - output, saved pre-activations and statistics, so the
     unchanged dm_mlp_head_bwd gives the same gradients - and stays EXACT for arbitrary (dense, scaled, all-zero) trailing
-    columns; fp64 reference; bf16 operands too.  Rows >= 16 384: the row-panel kernels; 1 024 <= rows < 16 384: the whole-MLP
+    columns; fp64 reference; bf16 operands too.  Rows >= 16 384: the row-panel kernels; 256 <= rows < 16 384: the whole-MLP
     kernel (weights packed for the dense columns only, the addend joins the layer-0 pre-activation before the LayerNorm)."""
     from pydreamer_amd.models import MLP
     torch.manual_seed(11)
@@ -206,7 +206,7 @@ def test_mlp_head_chain_fwd_bwd(hip, rows, in_dim, out_dim, layers):
     what the per-layer backward expects (gradients checked through dm_mlp_head_bwd); the acts-free call gives identical
     outputs; DM_MLP_NO_CHAIN=1 is the A/B switch back to GEMM + LayerNorm launches."""
     from pydreamer_amd.models import MLP
-    prev = hip.lib().dm_mlp_chain_min_rows(1)            # the production threshold is 1024 rows
+    prev = hip.lib().dm_mlp_chain_min_rows(1)            # the production threshold is 256 rows
     try:
         _chain_case(rows, in_dim, out_dim, layers)
     finally:
