@@ -221,12 +221,15 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--ring', type=int, default=8)
+    ap.add_argument('--reps', type=int, default=3, help='the timed region of exactly --steps steps (barrier + synchronise on both sides) is repeated this '
+                    'many times back to back; `value` / `ms_per_step` are the MEDIAN region (max over ranks each), min / max are printed beside it')
     ap.add_argument('--prof-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pmc-json', default='',
                     help='per-kernel HBM traffic from two rocprofv3 PMC passes of THIS command (scripts/pmc_traffic.py); it carries a '
                          'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
     ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
+    ap.add_argument('--emulate-rank', type=int, default=0, help='with --emulate-world N: which rank''s shard (uneven splits: 50 columns over 8 ranks are 7,7,6,6,6,6,6,6)')
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
@@ -242,7 +245,9 @@ def main():
     ap.add_argument('--shape-table', default='', help='write the per-shape GEMM table of the profiled pass to this file (diagnostic)')
     args = ap.parse_args()
     if not args.pmc_json:       # the committed counter summary of the same command (fp32 / bf16 step), if its fingerprint matches the tree
-        args.pmc_json = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_bf16.json' if args.dtype == 'bf16' else 'r05_pmc_traffic.json')
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic' + ('_bf16' if args.dtype == 'bf16' else '') + '.json')))
+        args.pmc_json = cands[-1] if cands else os.path.join(ROOT, 'profiles', 'none.json')      # the newest round's; refused below if its fingerprint is stale
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -289,7 +294,7 @@ def main():
     B = gconf.batch_size
     lo, hi = DP.shard_bounds(B, world, rank)
     if args.emulate_world > 1 and world == 1:
-        lo, hi = DP.shard_bounds(B, args.emulate_world, 0)
+        lo, hi = DP.shard_bounds(B, args.emulate_world, args.emulate_rank)
     conf = make_conf(batch_size=hi - lo, amp=(args.dtype == 'bf16'))
     # algorithmic TFLOP per grad step (2 MAC, dense as the reference executes, backward = 2x forward)
     alg_tflop = {'atari-literal': 2.76, 'atari-native': 2.00, 'dmc': 4.83}[args.workload]
@@ -319,34 +324,48 @@ def main():
     main_prio = os.environ.get('DM_MAIN_PRIO')            # experiment switch: run the caller's stream at another priority
     if main_prio is not None:
         torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(main_prio)))
+    main_res = int(os.environ.get('DM_MAIN_RESERVE_CUS', '0'))    # experiment: the caller's stream without the first k CUs of every 32
+    if main_res > 0:
+        torch.cuda.set_stream(hip.cu_masked_stream([0xFFFFFFFF ^ ((1 << main_res) - 1)] * 8, dev))
     for i in range(args.warmup):
         step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        metrics = step(args.warmup + i)
-    t_enqueued = time.perf_counter() - t0               # host done enqueuing; the GPU may still be running
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    rank_ms = [1e3 * elapsed / args.steps]
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        per_rank = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(per_rank, t)
-        rank_ms = [1e3 * float(x.item()) / args.steps for x in per_rank]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the timed region: EXACTLY --steps steps between barrier + synchronise, max over ranks; repeated --reps times back to back
+    # (state, optimizer moments and replay ring carry on), the median region is the reported one
+    regions, t_enq = [], []
+    n_done = args.warmup
+    for rep in range(max(1, args.reps)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            metrics = step(n_done + i)
+        t_enq.append(time.perf_counter() - t0)          # host done enqueuing; the GPU may still be running
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        n_done += args.steps
+        per = [el]
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            per_rank = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(per_rank, t)
+            per = [float(x.item()) for x in per_rank]
+        regions.append(per)
+    order = sorted(range(len(regions)), key=lambda r: max(regions[r]))
+    mid = order[len(order) // 2]                        # the median region (by its max over ranks)
+    elapsed = max(regions[mid])
+    t_enqueued = t_enq[mid]
+    rank_ms = [1e3 * x / args.steps for x in regions[mid]]
+    region_ms = [1e3 * max(r) / args.steps for r in regions]
     loss_model = float(metrics['loss_model'])
     # What the host needs to ENQUEUE a step when nothing holds it back: three more steps right after the synchronise (empty
     # queues).  `host_enqueue_ms_per_step` above is taken over the timed region, where the runtime's queue back-pressure
     # makes the launching threads wait for the GPU once they are a few steps ahead - it tracks the GPU, not the host's cost.
     th = time.perf_counter()
     for i in range(3):
-        step(args.warmup + args.steps + i)
+        step(n_done + i)
     host_free_ms = 1e3 * (time.perf_counter() - th) / 3
     torch.cuda.synchronize()
     dist_info = None
@@ -444,7 +463,7 @@ def main():
             model.join_optimizers()
         torch.cuda.synchronize()
         for i in range(args.prof_steps):
-            step(args.warmup + args.steps + i, eager=True)   # per-launch events need real launches, not a replay
+            step(n_done + 3 + i, eager=True)   # per-launch events need real launches, not a replay
         torch.cuda.synchronize()
         if args.shape_table:        # per-shape table of the profiled pass (diagnostic, stderr / file)
             cap = 8192 * args.prof_steps
@@ -543,6 +562,7 @@ def main():
             traffic_note = f'no PMC file ({type(e).__name__})' 
         roof = dict(bound='mfma', achieved=dom['tflops'], peak=peak, unit='TFLOP/s', frac=dom['tflops'] / peak, traffic=traffic,
                     traffic_unit=traffic_note,
+                    pmc_fingerprint_matches=(traffic is not None) if args.workload == 'atari-literal' else None,
                     # not observed by THIS run: read back from the committed counter passes of the same command (fingerprint-checked)
                     traffic_source=('committed profile ' + os.path.relpath(args.pmc_json, ROOT)) if traffic is not None else None,
                     algorithmic_bytes_per_launch=dom.get('alg_bytes_per_launch'),
@@ -568,7 +588,8 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         line = dict(metric=METRIC, value=args.steps / elapsed, unit='grad-steps/s', n_gpus=world, steps=args.steps,
-                    warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='strong', vs_baseline=None,
+                    warmup=args.warmup, ms_per_step=ms, ms_per_step_min=min(region_ms), ms_per_step_median=ms,
+                    ms_per_step_max=max(region_ms), timed_regions=len(region_ms), ms_per_step_regions=region_ms, higher_is_better=True, scaling='strong', vs_baseline=None,
                     dtype='f32' if args.dtype == 'f32' else 'bf16 (MFMA operands; fp32 accumulate, fp32 storage and non-GEMM math)', data='synthetic',
                     config=dict(workload={'atari-literal': 'atari-literal: defaults+atari, batch_size 50, batch_length 50, imag_horizon 15, '
                                          'deter_dim 600, stoch 32x32, hidden 1000, cnn_depth 48, action_dim 18, ',

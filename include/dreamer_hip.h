@@ -70,7 +70,7 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 11 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 12 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
@@ -79,7 +79,8 @@ int dm_version(void);                 /* ABI version, currently 11 (v2: LayerNor
                                          v10: dm_gemm_dma_enable added; the dm_chain_graph_ family (hipGraph replay of the launch chains: GPU-neutral in three rounds of
                                          measurement) and the persistent BPTT kernel with its switch dm_rssm_lds_bwd_enable - slower inside the step at every shard size - removed;
                                          dm_prof_end reports 44 kinds;
-                                         v11: dm_dec_l4_bwd_direct_enable added */
+                                         v11: dm_dec_l4_bwd_direct_enable added;
+                                         v12: dm_rssm_lds_status_ack / dm_rssm_lds_gave_up; the native exchange step dm_rccl_* / dm_allreduce_grads */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */
@@ -148,13 +149,17 @@ int dm_dec_l4_bwd_direct_enable(int on);
  * never exceeds the CU count) and the spin loops are bounded; DM_RSSM_LDS_COOP=1 launches cooperatively instead (measured slower: it drains
  * the other streams around the kernel).
  * dm_rssm_lds_status: non-zero once such a kernel has given up in a spin loop (that step's outputs are invalid; every later call
- * takes the launch chain).  Dreamer.check_device_status() / packed_metrics_host() raise on it.
+ * takes the launch chain).  dm_rssm_lds_status_ack: the same word, read AND cleared - the give-up is reported once
+ * (Dreamer.check_device_status() / packed_metrics_host() raise on it) while the kernel stays switched off for the life of the
+ * process (dm_rssm_lds_gave_up: the acknowledged status), so a trainer can restore a checkpoint and continue on the launch chain.
  * dm_rssm_lds_prof: 16 sums of clock ticks (100 MHz) of its workgroup 0, one per phase / sub-phase, since the last reset (diagnostic). */
 int dm_rssm_lds_enable(int on);
 int dm_bptt_fold_enable(int on);        /* launch schedule of the BPTT loop: the two LayerNorm+ELU backward stages of a step folded into the products
                                             that consume them, dx W = rstd (g W - mean(g) colsum(W) - mean(g xhat) xhat W), so those products start
                                             with their operand loads instead of a row reduction.  ON by default (DM_BPTT_FOLD=0); -1 queries. */
 int dm_rssm_lds_status(void);
+int dm_rssm_lds_status_ack(void);
+int dm_rssm_lds_gave_up(void);
 int dm_rssm_lds_prof(unsigned long long* out16, int reset);
 
 /* y = ELU(LayerNorm(x; gamma, beta, eps)) row-wise; stats[r] = {mean, rstd}. (common.py:44-49, rssm.py:105-115) */
@@ -443,6 +448,25 @@ int dm_prof_end(double* out, int nkinds);
 int dm_prof_rows(double* rows, int max_rows);
 /* y = a*x + b*y */
 int dm_axpby(int64_t n, float a, const float* x, float b, float* y, void* stream);
+
+/* ---- the data-parallel exchange step, native (csrc/comm.hip; SURVEY 8(b) dm_allreduce_grads, 8(e)) ------------------------
+ * The reference is single-process (no counterpart); pydreamer_amd/dist.py shards the batch axis and SUM-all-reduces each
+ * optimizer group's flat fp32 gradient buffer before grad_clip (dreamer.py:73-87 then sees the global-batch gradient).
+ * RCCL is bound with dlopen at first use (no link-time dependency; the instance torch already holds is preferred).
+ *   dm_rccl_available()                1 when librccl could be bound, else 0 (never fails)
+ *   dm_rccl_version()                  ncclGetVersion's code, 0 when unavailable
+ *   dm_rccl_unique_id(id128)           rank 0: the 128-byte id of a new communicator (the host carries it to the other ranks)
+ *   dm_rccl_comm_init(&comm, n, id, r) collective over the n ranks; the communicator is bound to the CURRENT device
+ *   dm_allreduce_grads(buf, n, comm, stream)   buf[0..n) <- sum over ranks, in place, fp32, enqueued on `stream`; never
+ *                                      synchronises.  One communicator per optimizer group: a group's collective is ordered by
+ *                                      its stream alone (right behind the backward pass that filled the buffer).
+ *   dm_rccl_comm_destroy(comm) */
+int dm_rccl_available(void);
+int dm_rccl_version(void);
+int dm_rccl_unique_id(void* id128);
+int dm_rccl_comm_init(void** comm, int nranks, const void* id128, int rank);
+int dm_rccl_comm_destroy(void* comm);
+int dm_allreduce_grads(void* buf, size_t n, void* comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,7 @@ class MultinomialPatch:
 
 def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames=1, slim=False):
     """slim: full-size configs - inputs are NOT stored (tests regenerate them from the same seeds through
-    oracle.synthetic_batch / make_noise), tensors are reduced to checksums, latent indices of the dream to 2 steps + sums."""
+    oracle.synthetic_batch / make_noise), tensors are reduced to checksums."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     sys.path.insert(0, REF)
@@ -180,11 +180,11 @@ def run(name, sections, overrides, steps=2, full_grads=(), save_image_rec_frames
         out[pre + 'out_state_z'] = new_state[1].numpy()
         out[pre + 'idx_post'] = post_idx.numpy().astype(np.uint8)
         out[pre + 'idx_act'] = act_idx.numpy().astype(np.uint8)
+        # the FULL (H, M, S) latent index tensor of the imagination, slim fixtures included (1.2 MB of u8 at Atari-literal,
+        # rssm.py:177-179): a test can then name the first step / group at which a trajectory left the reference's
+        out[pre + 'idx_lat'] = lat_idx.numpy().astype(np.uint8)
         if slim:
-            out[pre + 'idx_lat'] = lat_idx[:2].numpy().astype(np.uint8)
             out[pre + 'idx_lat_rowsum'] = lat_idx.sum(-1).numpy().astype(np.uint16)     # (H, M): sum of the 32 indices
-        else:
-            out[pre + 'idx_lat'] = lat_idx.numpy().astype(np.uint8)
         out[pre + 'grad_norms'] = np.array([float(g.double().norm()) for g in grads.values()])
         out[pre + 'grad_names'] = np.array(list(grads.keys()))
         out[pre + 'grad_proj'] = np.array([O.grad_probe(g, i) for i, g in enumerate(grads.values())])     # (P, 2): directions

@@ -7,6 +7,7 @@
 
 int dm_fail(int code, const char* fmt, ...);
 
+#define DM_MAX_DEVICES 16      // per-device once-flags (function attributes are per device)
 #define DM_LAUNCH_CHECK()                                                                      \
   do {                                                                                         \
     hipError_t e__ = hipGetLastError();                                                        \

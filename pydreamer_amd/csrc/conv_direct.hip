@@ -286,11 +286,13 @@ int dm_dec_l4_fwd_launch(int frames, int d, const float* x, const float* w, cons
   const size_t lds = (size_t)DEC_ROWS * DEC_COLS * (d + 4) * sizeof(float);       // 70.7 KB at d = 48: above the 64 KB default
 #define DM_DEC_L4(D_)                                                                                                  \
   if (d == D_) {                                                                                                       \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
+    static bool attr_set[DM_MAX_DEVICES] = {false};      /* per device, like l4_raise_lds below */                  \
+    int dev_ = 0;                                                                                                      \
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= DM_MAX_DEVICES) return dm_fail(DM_E_DEVICE, "dec_l4_fwd: hipGetDevice"); \
+    if (!attr_set[dev_]) {                                                                                             \
       if (hipFuncSetAttribute((const void*)dec_l4_fwd_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
         return dm_fail(DM_E_HIP, "dec_l4_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                \
-      attr_set = true;                                                                                                 \
+      attr_set[dev_] = true;                                                                                           \
     }                                                                                                                  \
     hipLaunchKernelGGL((dec_l4_fwd_kernel<D_>), dim3(frames * 4), dim3(256), lds, st, frames, x, w4, bias, out);         \
   }
@@ -491,11 +493,13 @@ static int dec_l4_wgrad_blocks(int frames) { return frames > 512 ? 512 : frames;
 size_t dm_dec_l4_wgrad_part_floats(int frames, int d) { return (size_t)dec_l4_wgrad_blocks(frames) * 4 * d * L4_K; }
 
 template <typename K>
-static int l4_raise_lds(K kern, size_t lds, bool* done) {
-  if (!*done) {
+static int l4_raise_lds(K kern, size_t lds, bool* done) {      // done: one flag per device (the attribute is per device)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DM_MAX_DEVICES) return dm_fail(DM_E_DEVICE, "dec_l4 backward: hipGetDevice failed / device %d", dev);
+  if (!done[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return dm_fail(DM_E_HIP, "dec_l4 backward: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    *done = true;
+    done[dev] = true;
   }
   return DM_OK;
 }
@@ -512,8 +516,8 @@ int dm_dec_l4_dgrad_launch(int frames, int d, const float* G4, const float* w, f
   const size_t lds = (size_t)64 * L4_RS_D * sizeof(float);
 #define DM_L4_DG(CB_)                                                                                                \
   if (CB == CB_) {                                                                                                   \
-    static bool attr_set = false;                                                                                    \
-    DM_TRY(l4_raise_lds(dec_l4_dgrad_kernel<CB_, L4_RS_D>, lds, &attr_set));                                         \
+    static bool attr_set[DM_MAX_DEVICES] = {false};                                                                  \
+    DM_TRY(l4_raise_lds(dec_l4_dgrad_kernel<CB_, L4_RS_D>, lds, attr_set));                                         \
     hipLaunchKernelGGL((dec_l4_dgrad_kernel<CB_, L4_RS_D>), dim3(frames), dim3(256), lds, st, frames, d, G4, wp, x3, dx, dx_h); \
   }
   DM_L4_DG(1) DM_L4_DG(2) DM_L4_DG(3) DM_L4_DG(4)
@@ -532,8 +536,8 @@ int dm_dec_l4_wgrad_launch(int frames, int d, const float* G4, const float* x3, 
   const size_t lds = (size_t)64 * L4_RS_W * sizeof(float);
 #define DM_L4_WG(IB_)                                                                                                \
   if (IB == IB_) {                                                                                                   \
-    static bool attr_set = false;                                                                                    \
-    DM_TRY(l4_raise_lds(dec_l4_wgrad_kernel<IB_, L4_RS_W>, lds, &attr_set));                                         \
+    static bool attr_set[DM_MAX_DEVICES] = {false};                                                                  \
+    DM_TRY(l4_raise_lds(dec_l4_wgrad_kernel<IB_, L4_RS_W>, lds, attr_set));                                         \
     hipLaunchKernelGGL((dec_l4_wgrad_kernel<IB_, L4_RS_W>), dim3(blocks), dim3(256), lds, st, frames, d, G4, x3, part); \
   }
   DM_L4_WG(1) DM_L4_WG(2) DM_L4_WG(3) DM_L4_WG(4)

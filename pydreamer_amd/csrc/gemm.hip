@@ -26,6 +26,7 @@
 #include <math.h>
 #include <type_traits>
 #include <mutex>
+#include <atomic>
 
 
 struct GemmKArgs {
@@ -1166,11 +1167,18 @@ extern "C" int dm_gemm_dma_enable(int on) {
 }
 template <void (*KERN)(const GemmKArgs)>
 static int dma_launch(int lds_bytes, const GemmKArgs& a, dim3 grid, hipStream_t stream) {
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [&]() { attr_rc = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
-  if (attr_rc != hipSuccess) return dm_fail(DM_E_HIP, "gemm: hipFuncSetAttribute(%d B of LDS): %s", lds_bytes, hipGetErrorString(attr_rc));
+  // the attribute belongs to the CURRENT DEVICE's function object: one flag per device (a process that touches a second GPU -
+  // single-process multi-device tests - would otherwise launch the 48-72 KiB rings there without it)
+  static std::atomic<int> done[DM_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DM_MAX_DEVICES) return dm_fail(DM_E_DEVICE, "gemm: hipGetDevice failed / device %d", dev);
+  if (!done[dev].load(std::memory_order_acquire)) {
+    hipError_t rc = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (rc != hipSuccess) return dm_fail(DM_E_HIP, "gemm: hipFuncSetAttribute(%d B of LDS): %s", lds_bytes, hipGetErrorString(rc));
+    done[dev].store(1, std::memory_order_release);
+  }
   hipLaunchKernelGGL(KERN, grid, dim3(256), (size_t)lds_bytes, stream, a);
+  DM_LAUNCH_CHECK();
   return DM_OK;
 }
 template <int BM, int BN, int WGM, int WGN>

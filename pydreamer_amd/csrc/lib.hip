@@ -16,7 +16,7 @@ int dm_fail(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int dm_version(void) { return 11; }
+extern "C" int dm_version(void) { return 12; }
 extern "C" const char* dm_last_error(void) { return g_err; }
 
 extern "C" int dm_device_check(void) {
@@ -67,7 +67,18 @@ static int side_init_locked() {
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   const char* pe = getenv("DM_WGRAD_SIDE_PRIO");
   const int prio = pe ? atoi(pe) : least;               // lowest priority: the chains' small kernels dispatch first
-  hipError_t e = hipStreamCreateWithPriority(&g_side_stream, hipStreamNonBlocking, prio);
+  // DM_WGRAD_SIDE_RESERVE_CUS=k (experiment): the side stream without the first k CUs of every 32 (hipExtStreamCreateWithCUMask),
+  // so the deferred weight-gradient products never occupy the CUs the BPTT chain's small kernels are dispatched to
+  const char* re = getenv("DM_WGRAD_SIDE_RESERVE_CUS");
+  const int res = re ? atoi(re) : 0;
+  hipError_t e;
+  if (res > 0 && res < 32) {
+    uint32_t mask[8];
+    for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu ^ ((1u << res) - 1u);
+    e = hipExtStreamCreateWithCUMask(&g_side_stream, 8, mask);
+  } else {
+    e = hipStreamCreateWithPriority(&g_side_stream, hipStreamNonBlocking, prio);
+  }
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&g_side_fork_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g_side_done_ev, hipEventDisableTiming);
   if (e != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side: %s", hipGetErrorString(e));

@@ -448,9 +448,11 @@ __global__ void __launch_bounds__(256) mlp_chain_pack_kernel(const ChainPackArgs
 // ---------------------------------------------------------------- host side ---------------------
 static const int g_chain_off = getenv("DM_MLP_NO_CHAIN") ? 1 : 0;       // A/B switch: keep the per-layer launches
 // A row block takes ~135 us however many there are (one CU walks all 1.13 M MACs per row: 66 us of MFMA issue plus the
-// weight stream's latency), so the launch pays once the per-layer form's ~13 launches on the same rows cost more: from
-// ~1000 rows up (2500-row rollout step: 137 vs 167 us); at a 350-row shard the per-layer products, which spread over all
-// CUs by split-K, take 95 us.  DM_CHAIN_MIN_ROWS overrides.
+// weight stream's latency).  Alone, the per-layer form's ~13 launches win below ~1000 rows (350 rows: 95 us of kernels,
+// spread over all CUs by split-K); INSIDE the step their 12 dependent-launch gaps cost more than that: measured in round 5
+// at the 350 / 650 rows of the 8- / 4-way shards, one launch beats the 13 by 0.1 ms per step; round 6 measured the 300 rows
+// of a 6-column shard (ranks 2-7 of an 8-way split; `bench.py --emulate-world 8 --emulate-rank 7`, profiles/r06_chain_rows.txt).
+// The default sits just below that smallest measured size.  DM_CHAIN_MIN_ROWS / dm_mlp_chain_min_rows override.
 static int g_chain_min_rows = getenv("DM_CHAIN_MIN_ROWS") ? atoi(getenv("DM_CHAIN_MIN_ROWS")) : 256;
 extern "C" int dm_mlp_chain_min_rows(int rows) {       // rows >= 1: set; returns the previous value
   const int prev = g_chain_min_rows;

@@ -900,6 +900,18 @@ extern "C" int dm_rssm_lds_enable(int on) {
 }
 // Sticky: non-zero once a persistent kernel of this process has given up inside a spin loop (its outputs are garbage).
 extern "C" int dm_rssm_lds_status(void) { return g_host_err ? (int)*(volatile unsigned*)g_host_err : 0; }
+// Acknowledge a give-up: returns the status word and clears it, so the error is REPORTED once (Dreamer.check_device_status), while
+// the persistent kernel stays switched off for the life of the process (g_gave_up: every later call runs the launch chain).
+static int g_gave_up = 0;
+extern "C" int dm_rssm_lds_status_ack(void) {
+  const int st = dm_rssm_lds_status();
+  if (st != 0) {
+    g_gave_up = st;
+    *(volatile unsigned*)g_host_err = 0u;
+  }
+  return st;
+}
+extern "C" int dm_rssm_lds_gave_up(void) { return g_gave_up; }
 
 // Above 32 rows the launch chain is the faster posterior loop since its LayerNorm stages are done once per row instead of once
 // per consuming workgroup (rssm.hip ln_z, gemm_skinny.hip row-split strips): T = 50, B = 50 2.15 vs 2.8-2.9 ms alone, the
@@ -909,7 +921,7 @@ static const int g_rssm_lds_max_b = getenv("DM_RSSM_LDS_MAX_B") ? atoi(getenv("D
 bool dm_rssm_lds_ok(int B, int D, int Hd, int S, int C) {
   RlPlan p;
   // (once a persistent kernel has given up - dm_rssm_lds_status - every later call takes the launch chain instead of failing)
-  return g_rssm_lds && dm_rssm_lds_status() == 0 && (B <= g_rssm_lds_max_b || g_rssm_lds >= 2) && rl_plan(B, D, Hd, S, C, &p) &&
+  return g_rssm_lds && dm_rssm_lds_status() == 0 && g_gave_up == 0 && (B <= g_rssm_lds_max_b || g_rssm_lds >= 2) && rl_plan(B, D, Hd, S, C, &p) &&
          rl_device_ok(p.G, p.lds_bytes) && rl_fwd_ready(p.rl);
 }
 size_t dm_rssm_lds_ws_floats(int B, int D, int Hd, int S, int C, int steps) {
@@ -932,7 +944,7 @@ extern "C" int dm_rssm_lds_prof(unsigned long long* out16, int reset) {
 int dm_rssm_lds_launch(const DmRssmLds& q, hipStream_t st) {
   RlPlan p;
   if (!rl_plan(q.B, q.D, q.Hd, q.S, q.C, &p) || !rl_device_ok(p.G, p.lds_bytes)) return dm_fail(DM_E_SHAPE, "rssm_lds: shape does not qualify");
-  DM_REQUIRE(dm_rssm_lds_status() == 0, DM_E_HIP, "rssm_lds: an earlier persistent posterior kernel gave up in a spin loop");
+  DM_REQUIRE(dm_rssm_lds_status() == 0 && g_gave_up == 0, DM_E_HIP, "rssm_lds: an earlier persistent posterior kernel gave up in a spin loop");
   const int steps = q.t_end - q.t_begin;
   if (steps <= 0) return DM_OK;
   RlArgs a;

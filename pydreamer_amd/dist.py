@@ -24,8 +24,39 @@ def shard_obs(obs, world, rank):
     return {k: v[:, lo:hi].contiguous() for k, v in obs.items()}, (lo, hi)
 
 
-def attach(optimizers, local_batch, global_batch, group=None, model=None):
+class _NativeWork:
+    """What FusedAdamW keeps of an early all-reduce issued through the native entry point: the collective sits on the stream
+    the backward pass ran on, and loss.backward() joins that stream anyway - nothing to wait for on the host."""
+
+    def wait(self):
+        return True
+
+
+def _native_comms(optimizers, group):
+    """One RCCL communicator per optimizer group (csrc/comm.hip): rank 0 draws the ids, the job's torch.distributed group
+    carries them (any backend), every rank joins - collective, in optimizer order."""
+    import ctypes
+    from . import hip as H
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    comms = []
+    for _ in optimizers:
+        ids = [None]
+        if rank == 0:
+            buf = (ctypes.c_char * 128)()
+            H.call('dm_rccl_unique_id', buf)
+            ids = [bytes(buf)]
+        dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        comm = ctypes.c_void_p()
+        H.call('dm_rccl_comm_init', ctypes.byref(comm), world, ctypes.c_char_p(ids[0]), rank)
+        comms.append(comm)
+    return comms
+
+
+def attach(optimizers, local_batch, global_batch, group=None, model=None, native=None):
     """Enable gradient all-reduce inside FusedAdamW.clip_grad_norm for every optimizer group.
+    native (default: the environment's DM_DP_NATIVE=1): issue the collectives through the library's own entry point
+    dm_allreduce_grads (include/dreamer_hip.h) on one RCCL communicator PER GROUP instead of torch.distributed - a group's
+    all-reduce is then ordered by the stream it is enqueued on and drain() is not needed.  GPU tensors + RCCL only.
     model (a pydreamer_amd Dreamer whose init_optimizers() produced `optimizers`): the B_r/B weight is FOLDED into the scale
     argument every backward entry point already takes (models.WorldModel / ActorCritic.grad_weight), so the rank's gradient
     buffers come out of the backward kernels already weighted and no extra pass over the 92 MB buffer runs per step; without
@@ -39,9 +70,14 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None):
         model.ac.grad_weight = w
         folded = {id(model._opt[k]) for k in ('wm', 'actor', 'critic')}
     global _attached
-    for opt in optimizers:
+    import os
+    if native is None:
+        native = os.environ.get('DM_DP_NATIVE', '0') == '1'
+    comms = _native_comms(optimizers, group) if native else [None] * len(optimizers)
+    for opt, comm in zip(optimizers, comms):
         opt.dp = (group, w)
         opt.dp_folded = id(opt) in folded
+        opt.dp_comm = comm
     _attached = True
 
 
@@ -87,11 +123,24 @@ def allreduce_scratch_async(opt):
     if opt.dp is None:
         return
     group = _weight(opt, opt.scratch)
+    if getattr(opt, 'dp_comm', None) is not None:
+        _native_allreduce(opt, opt.scratch)
+        opt.early_reduce = _NativeWork()
+        return
     opt.early_reduce = dist.all_reduce(opt.scratch, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def _native_allreduce(opt, buf):
+    """dm_allreduce_grads on the CURRENT stream (include/dreamer_hip.h; the group's own communicator)."""
+    from . import hip as H
+    H.call('dm_allreduce_grads', H.fptr(buf), buf.numel(), opt.dp_comm, H.stream())
 
 
 def allreduce_grads(opt):
     """grad <- sum_r (B_r/B) grad_r, in place on the flat buffer (one collective per optimizer group)."""
+    if getattr(opt, 'dp_comm', None) is not None:      # own communicator: ordered by the stream, no cross-group issue order to keep
+        _weight(opt, opt.flat_grad)
+        return _native_allreduce(opt, opt.flat_grad)
     drain()
     group = _weight(opt, opt.flat_grad)
     dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=group)

@@ -109,6 +109,12 @@ _SIGNATURES = {
     'dm_device_check': (c_int, []),
     'dm_workspace_bytes': (c_size_t, [POINTER(dm_shape)]),
     'dm_stream_create_cu_mask': (c_int, [_P, c_int, POINTER(c_void_p)]),
+    'dm_rccl_available': (c_int, []),
+    'dm_rccl_version': (c_int, []),
+    'dm_rccl_unique_id': (c_int, [_P]),
+    'dm_rccl_comm_init': (c_int, [POINTER(c_void_p), c_int, _P, c_int]),
+    'dm_rccl_comm_destroy': (c_int, [_P]),
+    'dm_allreduce_grads': (c_int, [_P, c_size_t, _P, _P]),
     'dm_stream_destroy': (c_int, [_P]),
     'dm_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int,
                             _P, c_size_t, _P]),
@@ -188,6 +194,8 @@ _SIGNATURES = {
     'dm_rssm_lds_enable': (c_int, [c_int]),
     'dm_bptt_fold_enable': (c_int, [c_int]),
     'dm_rssm_lds_status': (c_int, []),
+    'dm_rssm_lds_status_ack': (c_int, []),
+    'dm_rssm_lds_gave_up': (c_int, []),
     'dm_rssm_lds_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),
     'dm_wgrad_side_join': (c_int, [_P]),
@@ -197,7 +205,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 11     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 12     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():

@@ -477,7 +477,14 @@ class _Overlap:
         # the latency-bound chain gets the high-priority queue: its 40-110-workgroup kernels must be dispatched ahead of
         # the thousands of queued GEMM workgroups of the concurrent work, or the chain just slows down
         self.s_wm = torch.cuda.Stream(device, priority=int(os.environ.get('DM_WM_PRIO', '-1')))
-        self.s_ac = torch.cuda.Stream(device, priority=int(os.environ.get('DM_AC_PRIO', '0')))
+        # DM_AC_RESERVE_CUS=k (experiment): the actor-critic stream is created through
+        # hipExtStreamCreateWithCUMask WITHOUT the first k CUs of every 32, so the world-model stream's latency chain always finds
+        # k CUs per XCD free of this stream's full-chip products - no additional stream, s_wm stays unmasked
+        res = int(os.environ.get('DM_AC_RESERVE_CUS', '0'))
+        if res > 0:
+            self.s_ac = H.cu_masked_stream([0xFFFFFFFF ^ ((1 << res) - 1)] * 8, device)
+        else:
+            self.s_ac = torch.cuda.Stream(device, priority=int(os.environ.get('DM_AC_PRIO', '0')))
         self.ev_wm_fwd = torch.cuda.Event()
         self.ev_fwd = torch.cuda.Event()
         self.ev_fork, self.ev_tail = torch.cuda.Event(), torch.cuda.Event()      # the world-model forward's tail on s_wm (WorldModel._forward)
@@ -1546,15 +1553,18 @@ class Dreamer(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def check_device_status(self):
-        """Raises if a persistent posterior kernel of this process has given up in a spin loop (csrc/rssm_lds.hip: it needs every
-        workgroup resident at once; a second process on the GPU can starve it).  The flag is host-visible memory the kernel
+        """Raises - ONCE - if a persistent posterior kernel of this process has given up in a spin loop (csrc/rssm_lds.hip: it needs
+        every workgroup resident at once; a second process on the GPU can starve it).  The flag is host-visible memory the kernel
         writes, so this costs nothing; it is meaningful behind a device synchronisation - packed_metrics_host() and the
-        trainer's logging sync are where it is called.  After a give-up the library falls back to the launch chain for every
-        later call (dm_rssm_lds_ok), but the step that gave up produced garbage and must not be trusted."""
-        st = H.lib().dm_rssm_lds_status()
+        trainer's logging sync are where it is called.  The call ACKNOWLEDGES the flag (dm_rssm_lds_status_ack): the step that
+        gave up produced garbage and must not be trusted, so the trainer restores its last checkpoint and goes on IN THIS
+        PROCESS - the library keeps the persistent kernel switched off from then on (dm_rssm_lds_gave_up) and every later call
+        runs the launch chain, and later logging calls do not raise again."""
+        st = H.lib().dm_rssm_lds_status_ack()
         if st != 0:
             raise RuntimeError(f'a persistent RSSM kernel gave up in a spin loop (status {st}): the outputs of that training step '
-                               'are invalid - restore the last checkpoint; later steps run the launch chain')
+                               'are invalid - restore the last checkpoint; later steps of this process run the launch chain '
+                               '(the persistent kernel stays off) and this error is not raised again')
 
     def packed_metrics(self):
         """(names, buffer, idx): every loss / metric scalar of the last training_step() (+ the gradient norms once grad_clip()
@@ -1829,7 +1839,15 @@ class Dreamer(nn.Module):
                                      **t_ac2)
                 self.last_extras.update(dream_log_act_idx=dpk2['act_idx'].clone())
         if pk.get('tail') is not None:      # losses, metrics and tensors of the world model were written on the world-model stream
-            torch.cuda.current_stream().wait_event(pk['tail'].ev_tail)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pk['tail'].ev_tail)
+            # ... and ALLOCATED from that stream's pool: what leaves training_step() is read on the caller's stream from here on, so the
+            # caching allocator must not hand such a block to the next s_wm allocation while a caller-stream read is still queued
+            # (the actor-critic outputs are guarded the same way)
+            leaving = [loss_model, pk.get('dec_acts')] + [v for v in dict.values(pk['tensors']) if torch.is_tensor(v)]
+            for t in leaving:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
         if self.probe_gradients:      # dreamer.py:183-186
             losses = (loss_model + loss_probe, loss_actor, loss_critic)
         else:

@@ -258,6 +258,12 @@ class SequentialReplay:
             out = {} if out is None else out
             for k, v in first.items():
                 out[k] = np.empty((self.batch_length, self.batch_size) + v.shape[1:], v.dtype)
+            if 'terminal' not in out:      # the first file predates `terminal` but another piece of this batch carries it: same
+                for pieces in plans:       # column as ReplayFeed lays out (zeros for the files without it, _copy)
+                    src = next((ep.fields['terminal'] for ep, _, _ in pieces if 'terminal' in ep.fields), None)
+                    if src is not None:
+                        out['terminal'] = np.empty((self.batch_length, self.batch_size) + src.shape[1:], src.dtype)
+                        break
         for b, pieces in enumerate(plans):
             self._copy(pieces, out, b)
         return out
@@ -310,7 +316,6 @@ class ReplayFeed:
         T, B = replay.batch_length, replay.batch_size
         # `terminal` always has a column: an episode without the field contributes zeros (SequentialReplay._copy), so a
         # repository that mixes files with and without it still yields the flags of those that carry them
-        self._has_terminal = True
         self._small = {k: np.empty((T, B) + probe[k].shape[1:], probe[k].dtype)
                        for k in ('action', 'action_next', 'reward') if k in probe}
         self._small['terminal'] = np.empty((T, B), probe['terminal'].dtype if 'terminal' in probe else np.float32)
@@ -339,10 +344,7 @@ class ReplayFeed:
         self.replay.fill(raw)
         self._actions(raw['action'], slot['action'])
         self._actions(raw['action_next'], slot['action_next'])
-        if self._has_terminal:
-            slot['terminal'][...] = raw['terminal']
-        else:
-            slot['terminal'][...] = 0.0
+        slot['terminal'][...] = raw['terminal']
         r = raw['reward'].astype(np.float32)
         if self.clip_rewards == 'tanh':
             r = np.tanh(r)

@@ -6,7 +6,7 @@ tail -4 $O/t.txt
 for rep in 1 2; do
   for v in 1 0; do
     for cfg in "--dtype f32" "--dtype bf16" "--dtype f32 --emulate-world 8" "--dtype f32 --emulate-world 2"; do
-      DM_WM_TAIL=$v timeout 300 python bench.py $cfg --steps 30 --warmup 8 --no-cpu-baseline --no-h2d-leg --prof-steps 0 2>/dev/null | python -c "
+      DM_WM_TAIL=$v timeout 300 python bench.py --reps 1 $cfg --steps 30 --warmup 8 --no-cpu-baseline --no-h2d-leg --prof-steps 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); print('tail $v  $cfg ', round(d['ms_per_step'],3), 'ms')"
     done

@@ -10,7 +10,7 @@ REPO=$PWD
 SHA=$(python bench.py --csrc-sha)
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/profh_$C -o p -- python $REPO/bench.py --dtype bf16 --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/pmch_$C.json 2> $OUT/pmch_$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/profh_$C -o p -- python $REPO/bench.py --reps 1 --dtype bf16 --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/pmch_$C.json 2> $OUT/pmch_$C.err
 done
 python $REPO/scripts/pmc_traffic.py $(find /tmp/profh_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/profh_WRITE_SIZE -name "*counter_collection.csv" | head -1) 3 $SHA > $OUT/${TAG}_pmc_traffic_bf16.json
 cd $REPO

@@ -21,15 +21,15 @@ REPO=$PWD
 SHA=$(python bench.py --csrc-sha)
 cd /tmp
 if has core; then
-$RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/ks_bench.json 2> $OUT/ks.err
+$RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o t -- python $REPO/bench.py --reps 1 --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/ks_bench.json 2> $OUT/ks.err
 cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python $REPO/scripts/trace_timeline.py $(find /tmp/prof_ks -name "*kernel_trace.csv" | head -1) 2 > $OUT/${TAG}_timeline.txt 2>&1
 # the same workload on ONE stream (--no-overlap): per-kernel durations undisturbed by concurrent streams - the file the bench line's
 # roofline.achieved (HIP events in a single-stream pass) must agree with
-$RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks_serial -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --no-overlap > $OUT/ks_serial_bench.json 2> $OUT/ks_serial.err
+$RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks_serial -o t -- python $REPO/bench.py --reps 1 --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --no-overlap > $OUT/ks_serial_bench.json 2> $OUT/ks_serial.err
 cp $(find /tmp/prof_ks_serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_serial.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  $RP --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  $RP --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o p -- python $REPO/bench.py --reps 1 --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-h2d-leg --prof-steps 0 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 python $REPO/scripts/pmc_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/prof_WRITE_SIZE -name "*counter_collection.csv" | head -1) 3 $SHA > $OUT/${TAG}_pmc_traffic.json
 cd $REPO
@@ -38,16 +38,16 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 fi
 cd $REPO
 if has configs; then
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
-for W in 2 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
-python bench.py --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --pipeline --dtype bf16 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50_bf16.json 2>/dev/null
+python bench.py --reps 1 --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world 8 > $OUT/${TAG}_bench_shard7of50.json 2>/dev/null
+for W in 2 4; do python bench.py --reps 1 --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 --pipeline --emulate-world $W > $OUT/${TAG}_bench_shard_world$W.json 2>/dev/null; done
+python bench.py --reps 1 --steps 20 --warmup 5 --no-cpu-baseline --workload atari-native > $OUT/${TAG}_bench_atari_native.json 2>/dev/null
+python bench.py --reps 1 --steps 10 --warmup 4 --no-cpu-baseline --workload dmc --dtype bf16 > $OUT/${TAG}_bench_dmc_bf16.json 2>/dev/null
+python bench.py --reps 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --pipeline --dtype bf16 --emulate-world 8 > $OUT/${TAG}_bench_shard7of50_bf16.json 2>/dev/null
 bash scripts/collect_pmc_bf16.sh $TAG > $OUT/collect_bf16.log 2>&1      # bf16 step: its own counter passes, then the bf16 bench line
 DM_BF16_NO_TWINS=1 python bench.py --dtype bf16 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent > $OUT/${TAG}_bench_bf16_fp32_storage.json 2>/dev/null
-python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
+python bench.py --reps 1 --steps 10 --warmup 4 --no-cpu-baseline --no-h2d-leg --pmc-json /nonexistent --shape-table $OUT/${TAG}_gemm_shapes.txt > /dev/null 2>&1
 # kernel statistics of the 7-column shard (the rollout / posterior / BPTT chains at 350 rows: DESIGN 6)
-cd /tmp; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks_shard -o t -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --emulate-world 8 --no-overlap > /dev/null 2> $OUT/ks_shard.err
+cd /tmp; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_ks_shard -o t -- python $REPO/bench.py --reps 1 --steps 8 --warmup 3 --no-cpu-baseline --no-h2d-leg --prof-steps 0 --emulate-world 8 --no-overlap > /dev/null 2> $OUT/ks_shard.err
 cp $(find /tmp/prof_ks_shard -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_shard7of50_serial.csv; cd $REPO
 # per-queue timelines of one step (which stream is busy when), fp32 and bf16
 bash scripts/gpu_trace.sh f32 $TAG > /dev/null 2>&1; cp $OUT/queues_f32.txt $OUT/${TAG}_queues_f32.txt

@@ -131,7 +131,7 @@ def test_bench_multi_rank_code_path_smoke(hip):
     if torch.cuda.device_count() < 2:
         env['DM_BENCH_ONE_DEVICE'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--reps', '1', '--steps', '3', '--warmup', '1',
            '--prof-steps', '1']
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -173,7 +173,7 @@ def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
     width), every rank holds BIT-IDENTICAL parameters after 2 steps, the loss of the global batch (sum_r B_r/B loss_r) and the
     parameters equal the 1-rank run on the same global batch (the replay ring and the sampler uniforms are drawn in the global
     layout and sliced) up to fp32 summation order."""
-    flags = ('--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
+    flags = ('--reps', '1', '--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
     ndev = torch.cuda.device_count()
     d8 = _run_bench(8, {'DM_BENCH_ONE_DEVICE': '1'} if ndev < 8 else {}, *flags)
     d1 = _run_bench(1, {}, *flags)
@@ -207,7 +207,7 @@ def test_default_deployment_over_rccl_on_real_gpus(hip, world):
     ndev = torch.cuda.device_count()
     if ndev < world:
         pytest.skip(f'needs {world} GPUs for one process per GPU over RCCL; this box has {ndev}')
-    flags = ('--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
+    flags = ('--reps', '1', '--steps', '2', '--warmup', '0', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2')
     dn = _run_bench(world, {}, *flags)
     d1 = _run_bench(1, {}, *flags)
     dd = dn['distributed']
@@ -222,3 +222,43 @@ def test_default_deployment_over_rccl_on_real_gpus(hip, world):
     c8, c1 = dd['param_checksum_rank0'], d1['param_checksum']
     for i in range(4):
         assert abs(c8[i] - c1[i]) <= 2e-5 * c1[4 + i] + 1e-6, (i, c8, c1)
+
+
+def test_native_rccl_entry_points_one_rank():
+    """The native exchange step (include/dreamer_hip.h dm_rccl_* / dm_allreduce_grads, csrc/comm.hip) on real hardware as far as a
+    1-GPU box can take it: RCCL is bound with dlopen, a ONE-rank communicator is created on the current device, and the in-place
+    SUM all-reduce of two flat fp32 buffers - enqueued on two different non-default streams, one communicator each, as
+    dist.attach(native=True) lays them out per optimizer group - leaves the data unchanged (the sum over one rank) and ordered
+    behind the kernel that wrote the buffer on that stream.  N > 1 needs N GPUs (RCCL refuses two ranks on one device)."""
+    import ctypes
+    from pydreamer_amd import hip as H
+    lib = H.lib()
+    if not lib.dm_rccl_available():
+        pytest.skip('librccl is not loadable on this box')
+    assert lib.dm_rccl_version() > 20000
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    comms, streams, bufs, refs = [], [], [], []
+    for i in range(2):
+        idb = (ctypes.c_char * 128)()
+        H.call('dm_rccl_unique_id', idb)
+        comm = ctypes.c_void_p()
+        H.call('dm_rccl_comm_init', ctypes.byref(comm), 1, ctypes.c_char_p(bytes(idb)), 0)
+        assert comm.value
+        comms.append(comm)
+        streams.append(torch.cuda.Stream(dev))
+    for i, (comm, st) in enumerate(zip(comms, streams)):
+        with torch.cuda.stream(st):
+            x = torch.randn(1_000_003 + i, device=dev)
+            y = x * 3.0 + 1.0                      # the producer on this stream; the collective must see its result
+            H.call('dm_allreduce_grads', H.fptr(y), y.numel(), comm, H.stream())
+            z = y * 0.5                             # ... and the consumer the collective's
+            bufs.append(z)
+            refs.append((x * 3.0 + 1.0) * 0.5)
+    torch.cuda.synchronize()
+    for z, r in zip(bufs, refs):
+        assert torch.equal(z, r)
+    with pytest.raises(H.DreamerHipError):
+        H.call('dm_allreduce_grads', None, 4, comms[0], None)
+    for comm in comms:
+        H.call('dm_rccl_comm_destroy', comm)

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dreamer_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr)))
     lib = hip.lib()
-    assert lib.dm_version() == hip.DM_ABI_VERSION == 11
+    assert lib.dm_version() == hip.DM_ABI_VERSION == 12
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(hip.exported_symbols()) == declared, set(declared) ^ set(hip.exported_symbols())
@@ -239,7 +239,10 @@ def test_runtime_switch_defaults():
         assert lib.dm_bf16_twins_enable(-1) == 1
         assert lib.dm_rssm_lds_enable(-1) == 1
         assert lib.dm_bptt_fold_enable(-1) == 1 or os.environ.get('DM_BPTT_FOLD')
-    assert lib.dm_rssm_lds_status() == 0
+    assert lib.dm_rssm_lds_status() == 0 and lib.dm_rssm_lds_status_ack() == 0 and lib.dm_rssm_lds_gave_up() == 0
+    assert lib.dm_rccl_available() in (0, 1)          # the native exchange step binds RCCL with dlopen: no link-time dependency
+    if lib.dm_rccl_available():
+        assert lib.dm_rccl_version() > 20000
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
     assert lib.dm_gemm_dma_enable(-1) == 1 and lib.dm_gemm_dma_enable(0) == 0 and lib.dm_gemm_dma_enable(1) == 1
     assert lib.dm_dec_l4_bwd_direct_enable(-1) == 1 and lib.dm_dec_l4_bwd_direct_enable(0) == 0 and lib.dm_dec_l4_bwd_direct_enable(1) == 1
