@@ -36,6 +36,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CH_NBLK = 25;                    // hidden = 400
 constexpr int CH_N = CH_NBLK * 16;
 constexpr int CH_LD = CH_N + 4;                // LDS row stride (floats): rows stay 16-byte aligned
+#ifndef CH_PRE
+#define CH_PRE 0
+#endif
 constexpr int CH_WB = 7;                       // column blocks per wave (wave 0: 0..6; waves 1..3: 6 real blocks + a dummy)
 
 struct ChainArgs {
@@ -71,144 +74,156 @@ __device__ __forceinline__ float chain_red16(float v) {
   return v;
 }
 
-// operands of one pair of 16-k groups.  k past K: the address is clamped into the row and the ACTIVATION fragment is
-// zeroed when it is consumed (K is a multiple of 4, so a 16-byte fragment is valid or not as a whole).
-struct ChainFrag {
-  float4 a[2];
-  float4 b[CH_WB][2];
-};
-// Weight fragments are buffer loads: one descriptor per layer (wave-uniform), the block's byte offset in the scalar
-// offset, and ONE 32-bit vector offset per half shared by the 7 loads (per-load 64-bit vector addresses made the register
-// allocator recycle in-flight load destinations as address temporaries, which put an s_waitcnt vmcnt(0) at the top of
-// the loop and serialised the pipeline).
+// ---- the operand ring (round 6) ------------------------------------------------------------------------------------------
+// What bounds the kernel was measured in round 6 (profiles/r06_mlp_chain_anatomy.txt: weight loads only 72 us, MFMAs only 93 us,
+// neither 44 us, both 100 us per 16-row block): ~49 us of MFMA issue and ~44 us of layer epilogues, barriers and exposed
+// latencies - the weight stream hides under the MFMAs.  So (a) the loop keeps its operands in a ring of small UNITS - fp32: one
+// 16-k group (a lane's four k of A and of the wave's 7 weight blocks: 8 x 16 bytes), four units deep; a unit's loads go out
+// right behind the MFMAs that consumed its slot and have three units of MFMAs (2 700 cycles) to land - in 128 registers instead
+// of three whole pairs in 192: the kernel fits 256 registers and TWO workgroups share a CU, so one block's epilogue runs under
+// the other's MFMAs (the 938-block calls of the late head window ran one block per CU, every epilogue exposed); (b) the next
+// layer's first weight units are requested BEFORE the epilogue of the current layer; (c) the epilogue's barriers wait for LDS
+// traffic only (__syncthreads also drains the global stores of the saved activations, ~2 us each) and there are three per
+// layer instead of four.  Same k -> MFMA order as before (results equal the round-5 kernel's up to the compiler's fma
+// contraction choices in the epilogue).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 chain_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-// PACKED: 0 = row-major weights, 1 = fragment-major fp32, 2 = fragment-major bf16 (a lane's 8 operand values of a pair in
-// ONE 16-byte load, already rounded: half the stream and no conversion in the loop)
-template <bool FIRST, int PACKED>
-__device__ __forceinline__ void chain_load(ChainFrag& f, const float* A, const float* ybuf, __amdgpu_buffer_rsrc_t W,
-                                           unsigned wblk, int K, int pair, int l15, int q, int last) {
-  if (PACKED == 2) {
-    const int np = (K + 31) >> 5;
+__device__ __forceinline__ void chain_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One unit of operands.  UK = 16: fp32 product, one 16-k group (b[i] = the lane's 4 k of weight block i).  UK = 32: bf16
+// product, one pair of 16-k groups = ONE v_mfma_f32_16x16x32_bf16 per block; PACKED 2: b[i] = the lane's 8 bf16 of block i in
+// one 16-byte load, else b[i] / b2[i] = its two fp32 fragments (rounded in registers).
+template <int UK, int PACKED>
+struct ChainUnit {
+  float4 a[UK / 16];
+  float4 b[CH_WB];
+  float4 b2[(UK == 32 && PACKED != 2) ? CH_WB : 1];
+};
+// Weight fragments are buffer loads: one descriptor per layer (wave-uniform), the block's byte offset in the scalar
+// offset, and ONE 32-bit vector offset shared by the 7 loads (per-load 64-bit vector addresses made the register
+// allocator recycle in-flight load destinations as address temporaries, which put an s_waitcnt vmcnt(0) at the top of
+// the loop and serialised the pipeline).  PACKED: 0 = row-major weights (wblk = byte offset of the wave's first block),
+// 1 = fragment-major fp32, 2 = fragment-major bf16 (wblk = first block of the wave; K-edge zeros are in the packed copy).
+template <int UK, int PACKED>
+__device__ __forceinline__ void chain_load_b(ChainUnit<UK, PACKED>& f, __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int u,
+                                             int l15, int q, int last) {
+  const int np = (K + 31) >> 5;
+  if constexpr (PACKED == 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int k = pair * 32 + h * 16 + 4 * q;
+    for (int h = 0; h < UK / 16; ++h) {
+      int k = u * UK + h * 16 + 4 * q;
       k = k < K ? k : K - 4;
-      f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+      const unsigned off = (unsigned)(l15 * K + k) * 4u;
+#pragma unroll
+      for (int i = 0; i < CH_WB; ++i) {
+        const unsigned soff = wblk + (unsigned)(i == CH_WB - 1 ? last : i) * 16u * (unsigned)K * 4u;       // wave-uniform bytes
+        if (h == 0) f.b[i] = chain_bload(W, off, soff);
+        else if constexpr (UK == 32) f.b2[i] = chain_bload(W, off, soff);
+      }
     }
+  } else {
     const unsigned voff = (unsigned)(q * 16 + l15) * 16u;
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i) {
       const unsigned blk = wblk + (unsigned)(i == CH_WB - 1 ? last : i);
-      f.b[i][0] = chain_bload(W, voff, (blk * (unsigned)np + (unsigned)pair) * 1024u);
+      if constexpr (PACKED == 2) f.b[i] = chain_bload(W, voff, (blk * (unsigned)np + (unsigned)u) * 1024u);
+      else if constexpr (UK == 16) f.b[i] = chain_bload(W, voff, (blk * (unsigned)(2 * np) + (unsigned)u) * 1024u);
+      else {
+        f.b[i] = chain_bload(W, voff, ((blk * (unsigned)np + (unsigned)u) * 2u) * 1024u);
+        f.b2[i] = chain_bload(W, voff, ((blk * (unsigned)np + (unsigned)u) * 2u + 1u) * 1024u);
+      }
     }
-    return;
-  }
-  if (PACKED == 1) {      // wblk = first block of the wave; K-edge zeros are in the packed copy
-    const int np = (K + 31) >> 5;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int k = pair * 32 + h * 16 + 4 * q;
-      k = k < K ? k : K - 4;
-      f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
-    }
-    const unsigned voff = (unsigned)(q * 16 + l15) * 16u;
-#pragma unroll
-    for (int i = 0; i < CH_WB; ++i) {
-      const unsigned blk = wblk + (unsigned)(i == CH_WB - 1 ? last : i);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) f.b[i][h] = chain_bload(W, voff, ((blk * (unsigned)np + (unsigned)pair) * 2u + (unsigned)h) * 1024u);
-    }
-    return;
-  }
-  unsigned off[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    int k = pair * 32 + h * 16 + 4 * q;
-    k = k < K ? k : K - 4;
-    off[h] = (unsigned)(l15 * K + k) * 4u;
-    f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
-  }
-#pragma unroll
-  for (int i = 0; i < CH_WB; ++i) {
-    const unsigned soff = wblk + (unsigned)(i == CH_WB - 1 ? last : i) * 16u * (unsigned)K * 4u;       // wave-uniform bytes
-#pragma unroll
-    for (int h = 0; h < 2; ++h) f.b[i][h] = chain_bload(W, off[h], soff);
   }
 }
-// BF (dm_mlp_params.precision = 1, conf.amp): the pair's 32 k are ONE v_mfma_f32_16x16x32_bf16 per block - a lane's two
-// fragments (k = 32p + 4q.. and 32p + 16 + 4q..) are its 8 operand values, rounded to bf16 (RNE) in registers; A and B use
+// k past K: the address is clamped into the row and the ACTIVATION fragment is zeroed when it is consumed (K is a multiple
+// of 4, so a 16-byte fragment is valid or not as a whole).
+template <bool FIRST, int UK, int PACKED>
+__device__ __forceinline__ void chain_load_a(ChainUnit<UK, PACKED>& f, const float* A, const float* ybuf, int K, int u, int l15, int q) {
+#pragma unroll
+  for (int h = 0; h < UK / 16; ++h) {
+    int k = u * UK + h * 16 + 4 * q;
+    k = k < K ? k : K - 4;
+    f.a[h] = FIRST ? *reinterpret_cast<const float4*>(A + k) : *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
+  }
+}
+// BF (dm_mlp_params.precision = 1, conf.amp): the unit's 32 k are ONE v_mfma_f32_16x16x32_bf16 per block - a lane's two
+// fragments (k = 32u + 4q.. and 32u + 16 + 4q..) are its 8 operand values, rounded to bf16 (RNE) in registers; A and B use
 // the same k order, which is all the product needs.
 __device__ __forceinline__ bf16x8 chain_bf8(float4 lo, float4 hi) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const u4 v = {dm_pack_bf16x2(lo.x, lo.y), dm_pack_bf16x2(lo.z, lo.w), dm_pack_bf16x2(hi.x, hi.y), dm_pack_bf16x2(hi.z, hi.w)};
   return __builtin_bit_cast(bf16x8, v);
 }
-template <bool BF, int PACKED>
-__device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainFrag& f, int K, int pair, int q) {
-  if (BF) {
-    const bool v0 = pair * 32 + 4 * q < K, v1 = pair * 32 + 16 + 4 * q < K;
+template <int UK, int PACKED>
+__device__ __forceinline__ void chain_mfma(f32x4 (&acc)[CH_WB], const ChainUnit<UK, PACKED>& f, int K, int u, int q) {
+  if constexpr (UK == 32) {
+    const bool v0 = u * 32 + 4 * q < K, v1 = u * 32 + 16 + 4 * q < K;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const bf16x8 a8 = chain_bf8(v0 ? f.a[0] : z, v1 ? f.a[1] : z);
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i) {
-      const bf16x8 b8 = PACKED == 2 ? __builtin_bit_cast(bf16x8, f.b[i][0]) : chain_bf8(f.b[i][0], f.b[i][1]);
+      bf16x8 b8;
+      if constexpr (PACKED == 2) b8 = __builtin_bit_cast(bf16x8, f.b[i]);
+      else b8 = chain_bf8(f.b[i], f.b2[i]);
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
     }
     return;
+  } else {
+  const bool valid = u * 16 + 4 * q < K;
+  const float aj[4] = {valid ? f.a[0].x : 0.f, valid ? f.a[0].y : 0.f, valid ? f.a[0].z : 0.f, valid ? f.a[0].w : 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < CH_WB; ++i) {
+      const float4 bb = f.b[i];
+      const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bv, acc[i], 0, 0, 0);
+    }
   }
+}
+
+// One layer's k-loop over the ring.  `pre`: the weight parts of units 0 .. DEPTH-1 are already in flight (requested in front of
+// the previous layer's epilogue): only their activation parts are fetched here.
+template <bool FIRST, int UK, int PACKED, int DEPTH>
+__device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], ChainUnit<UK, PACKED> (&f)[DEPTH], bool pre, const float* A,
+                                            const float* ybuf, __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
+  const int nu = (K + UK - 1) / UK;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const bool valid = pair * 32 + h * 16 + 4 * q < K;
-    const float aj[4] = {valid ? f.a[h].x : 0.f, valid ? f.a[h].y : 0.f, valid ? f.a[h].z : 0.f, valid ? f.a[h].w : 0.f};
+  for (int d = 0; d < DEPTH; ++d) {
+    const int u = d < nu ? d : 0;
+    if (!pre) chain_load_b<UK, PACKED>(f[d], W, wblk, K, u, l15, q, last);
+    chain_load_a<FIRST, UK, PACKED>(f[d], A, ybuf, K, u, l15, q);
+  }
+  for (int u0 = 0; u0 < nu; u0 += DEPTH) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < CH_WB; ++i) {
-        const float4 bb = f.b[i][h];
-        const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[j], bv, acc[i], 0, 0, 0);
+    for (int d = 0; d < DEPTH; ++d) {
+      const int u = u0 + d;
+      if (u >= nu) break;
+      __builtin_amdgcn_sched_barrier(0);
+      chain_mfma<UK, PACKED>(acc, f[d], K, u, q);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + DEPTH < nu) {                             // the slot just consumed takes the unit DEPTH ahead
+        chain_load_b<UK, PACKED>(f[d], W, wblk, K, u + DEPTH, l15, q, last);
+        chain_load_a<FIRST, UK, PACKED>(f[d], A, ybuf, K, u + DEPTH, l15, q);
       }
+    }
   }
 }
 
-// A: this lane's activation row (layer 0, global); W: this lane's weight row of the wave's first block.
-template <bool FIRST, bool BF, int PACKED>
-__device__ __forceinline__ void chain_layer(f32x4 (&acc)[CH_WB], const float* A, const float* ybuf,
-                                            __amdgpu_buffer_rsrc_t W, unsigned wblk, int K, int l15, int q, int last) {
-  const int np = (K + 31) >> 5;
-  ChainFrag f0, f1, f2;
-  chain_load<FIRST, PACKED>(f0, A, ybuf, W, wblk, K, 0, l15, q, last);
-  chain_load<FIRST, PACKED>(f1, A, ybuf, W, wblk, K, 1 < np ? 1 : 0, l15, q, last);
-  for (int p = 0; p < np; p += 3) {
-    chain_load<FIRST, PACKED>(f2, A, ybuf, W, wblk, K, p + 2 < np ? p + 2 : 0, l15, q, last);
-    __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF, PACKED>(acc, f0, K, p, q);
-    if (p + 1 >= np) break;
-    chain_load<FIRST, PACKED>(f0, A, ybuf, W, wblk, K, p + 3 < np ? p + 3 : 0, l15, q, last);
-    __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF, PACKED>(acc, f1, K, p + 1, q);
-    if (p + 2 >= np) break;
-    chain_load<FIRST, PACKED>(f1, A, ybuf, W, wblk, K, p + 4 < np ? p + 4 : 0, l15, q, last);
-    __builtin_amdgcn_sched_barrier(0);
-    chain_mfma<BF, PACKED>(acc, f2, K, p + 2, q);
-  }
-}
-
-template <bool BF>
-__global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g) {
-  __shared__ __attribute__((aligned(16))) float ybuf[16 * CH_LD];      // the next layer's input block
-  __shared__ float red[4][16];                                         // per-wave row partials
-  __shared__ float outp[4][16][32];                                    // per-wave output-layer partials
+template <bool BF, int PACKED>
+__device__ __forceinline__ void chain_body(const ChainArgs& g, float* ybuf, float (*red)[4][16], float (*outp)[16][32]) {
+  constexpr int UK = BF ? 32 : 16;
+  constexpr int DEPTH = BF ? (PACKED == 2 ? 3 : 2) : 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // tell the compiler it is wave-uniform
   const int l15 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * 16;
   const int nb0 = wave == 0 ? 0 : 1 + 6 * wave;          // first block of this wave: 0, 7, 13, 19
   const int cnt = wave == 0 ? 7 : 6;                     // real blocks; block index cnt.. are dummies (clamped, ignored)
+  const int last = cnt == CH_WB ? CH_WB - 1 : 0;
   // layer 0 reads its activation rows from global memory; rows past the end re-read the last row (never written back)
   const int arow = m0 + l15 < g.rows ? m0 + l15 : g.rows - 1;
   const float* A0 = g.x + (size_t)arow * g.ldx;
@@ -218,6 +233,13 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
 #pragma unroll
   for (int r = 0; r < 4; ++r) rok[r] = rbase + r < g.rows;
   const float inv_n = 1.0f / (float)CH_N;
+  // 32-bit element offsets of this lane's four output rows (a wave-uniform base pointer + one VGPR offset per access: 64-bit
+  // per-lane pointers were hoisted above the k-loop and spilled)
+  int roff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) roff[r] = (rok[r] ? rbase + r : g.rows - 1) * CH_N + nb0 * 16 + l15;
+  ChainUnit<UK, PACKED> f[DEPTH];
+  bool pre = false;
 
   for (int l = 0; l < g.layers; ++l) {
     f32x4 acc[CH_WB];
@@ -226,42 +248,49 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
     const int K = l == 0 ? g.k0 : CH_N;
     // all waves walk 7 blocks (wave 0 sets the pace anyway); the 7th of waves 1..3 is a dummy that re-reads the wave's
     // first block and is ignored below
-    const bool packed = g.wp[l] != nullptr;
     const int npr = (K + 31) >> 5;
-    const __amdgpu_buffer_rsrc_t Wl = packed
+    const __amdgpu_buffer_rsrc_t Wl = PACKED
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp[l]), 0, CH_NBLK * npr * (BF ? 1024 : 2048), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w[l]), 0, CH_N * K * 4, 0x00020000);
-    const unsigned wblk = packed ? (unsigned)nb0 : (unsigned)(nb0 * 16) * (unsigned)K * 4u;
-    const int last = cnt == CH_WB ? CH_WB - 1 : 0;
+    const unsigned wblk = PACKED ? (unsigned)nb0 : (unsigned)(nb0 * 16) * (unsigned)K * 4u;
     // the epilogue's per-column parameters, fetched BEFORE the k-loop (dependent global round trips after it cost ~2 us
     // each on a workgroup that has nothing else to run)
     float pbi[CH_WB], pga[CH_WB], pbe[CH_WB];
     {
       const float* bias = g.b[l];
+#pragma unroll
+      for (int i = 0; i < CH_WB; ++i) pbi[i] = bias ? bias[(nb0 + (i < cnt ? i : 0)) * 16 + l15] : 0.f;
+    }
+    if (l == 0) chain_layer<true, UK, PACKED, DEPTH>(acc, f, pre, A0, nullptr, Wl, wblk, K, l15, q, last);
+    else chain_layer<false, UK, PACKED, DEPTH>(acc, f, pre, nullptr, ybuf, Wl, wblk, K, l15, q, last);
+    // the next layer's first weight units, requested in front of this layer's epilogue (fragment-major copies only: one
+    // descriptor per layer, K = 400 for every layer but the first)
+    pre = false;
+    if (PACKED && CH_PRE && l + 1 < g.layers) {
+      constexpr int KN = CH_N, NPN = (KN + 31) >> 5;
+      const __amdgpu_buffer_rsrc_t Wn =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp[l + 1]), 0, CH_NBLK * NPN * (BF ? 1024 : 2048), 0x00020000);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) chain_load_b<UK, PACKED>(f[d], Wn, (unsigned)nb0, KN, d, l15, q, last);
+      pre = true;
+    }
+    {      // the LayerNorm's gain / bias columns: requested here, consumed behind the two statistics barriers (round 6: held
+           // across the k-loop they cost 14 registers of the 256 that let two workgroups share a CU)
       const float* gam = g.gamma[l];
       const float* bet = g.beta[l];
 #pragma unroll
       for (int i = 0; i < CH_WB; ++i) {
         const int c = (nb0 + (i < cnt ? i : 0)) * 16 + l15;
-        pbi[i] = bias ? bias[c] : 0.f;
         pga[i] = gam[c];
         pbe[i] = bet[c];
       }
     }
-    if (packed) {      // packed copies are bf16 when the kernel multiplies in bf16 (host: dm_mlp_chain_pack_launch)
-      if (l == 0) chain_layer<true, BF, BF ? 2 : 1>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-      else chain_layer<false, BF, BF ? 2 : 1>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
-    } else {
-      if (l == 0) chain_layer<true, BF, 0>(acc, A0, nullptr, Wl, wblk, K, l15, q, last);
-      else chain_layer<false, BF, 0>(acc, nullptr, ybuf, Wl, wblk, K, l15, q, last);
-    }
     if (l == 0 && g.add0) {      // the sparse tail's contribution (28 more values: loaded here, not held across the k-loop)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* ar = g.add0 + (size_t)(rok[r] ? rbase + r : g.rows - 1) * CH_N + nb0 * 16 + l15;
 #pragma unroll
         for (int i = 0; i < CH_WB; ++i)
-          if (i < cnt) acc[i][r] += ar[i * 16];
+          if (i < cnt) acc[i][r] += g.add0[roff[r] + i * 16];
       }
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -278,13 +307,13 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float t = chain_red16(s[r]);
-      if (l15 == 0) red[wave][4 * q + r] = t;
+      if (l15 == 0) red[0][wave][4 * q + r] = t;
     }
-    __syncthreads();                                     // also: every wave is done reading ybuf
+    chain_lds_barrier();                                 // also: every wave is done reading ybuf
     float mean[4], rstd[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      mean[r] = ((red[0][4 * q + r] + red[1][4 * q + r]) + (red[2][4 * q + r] + red[3][4 * q + r])) * inv_n;
+      mean[r] = ((red[0][0][4 * q + r] + red[0][1][4 * q + r]) + (red[0][2][4 * q + r] + red[0][3][4 * q + r])) * inv_n;
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < CH_WB; ++i)
@@ -295,29 +324,27 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
           ss[r] += d * d;
         }
       }
-    __syncthreads();                                     // red is re-used
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {                        // (its own array: red[0] is still being read by slower waves)
       const float t = chain_red16(ss[r]);
-      if (l15 == 0) red[wave][4 * q + r] = t;
+      if (l15 == 0) red[1][wave][4 * q + r] = t;
     }
-    __syncthreads();
+    chain_lds_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      rstd[r] = 1.0f / sqrtf(((red[0][4 * q + r] + red[1][4 * q + r]) + (red[2][4 * q + r] + red[3][4 * q + r])) * inv_n + g.eps);
+      rstd[r] = 1.0f / sqrtf(((red[1][0][4 * q + r] + red[1][1][4 * q + r]) + (red[1][2][4 * q + r] + red[1][3][4 * q + r])) * inv_n + g.eps);
     if (g.stats[l] && wave == 0 && l15 == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (rok[r]) { g.stats[l][2 * (size_t)(rbase + r)] = mean[r]; g.stats[l][2 * (size_t)(rbase + r) + 1] = rstd[r]; }
+        if (rok[r]) { g.stats[l][2 * (rbase + r)] = mean[r]; g.stats[l][2 * (rbase + r) + 1] = rstd[r]; }
     }
     if (g.xpre[l]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (rok[r]) {
-          float* xr = g.xpre[l] + (size_t)(rbase + r) * CH_N + nb0 * 16 + l15;
 #pragma unroll
           for (int i = 0; i < CH_WB; ++i)
-            if (i < cnt) xr[i * 16] = acc[i][r];
+            if (i < cnt) g.xpre[l][roff[r] + i * 16] = acc[i][r];
         }
     }
 #pragma unroll
@@ -331,10 +358,9 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (rok[r]) {
-          float* yr = g.y[l] + (size_t)(rbase + r) * CH_N + nb0 * 16 + l15;
 #pragma unroll
           for (int i = 0; i < CH_WB; ++i)
-            if (i < cnt) yr[i * 16] = acc[i][r];
+            if (i < cnt) g.y[l][roff[r] + i * 16] = acc[i][r];
         }
     }
     // the post-activation block goes to LDS: the next layer's (or the output layer's) A operand
@@ -344,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
 #pragma unroll
         for (int r = 0; r < 4; ++r) ybuf[(4 * q + r) * CH_LD + (nb0 + i) * 16 + l15] = acc[i][r];
       }
-    __syncthreads();
+    chain_lds_barrier();
   }
 
   // The MLP's output layer out = y Wout^T + bout (out_dim <= 32) as one more product: two 16-column blocks (output rows past
@@ -359,8 +385,8 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int k = (g0 + (i < gn ? i : 0)) * 16 + 4 * q;
-      w0[i] = *reinterpret_cast<const float4*>(wout + (size_t)o0 * CH_N + k);
-      w1[i] = *reinterpret_cast<const float4*>(wout + (size_t)o1 * CH_N + k);
+      w0[i] = *reinterpret_cast<const float4*>(wout + (o0 * CH_N + k));
+      w1[i] = *reinterpret_cast<const float4*>(wout + (o1 * CH_N + k));
       wa[i] = *reinterpret_cast<const float4*>(ybuf + l15 * CH_LD + k);
     }
     f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -381,14 +407,29 @@ __global__ void __launch_bounds__(256, 1) mlp_chain_fwd_kernel(const ChainArgs g
       outp[wave][4 * q + r][l15] = c0[r];
       outp[wave][4 * q + r][16 + l15] = c1[r];
     }
-    __syncthreads();
+    chain_lds_barrier();
     for (int e = tid; e < 16 * g.out_dim; e += 256) {
       const int r = e / g.out_dim, o = e % g.out_dim;
       if (m0 + r < g.rows)
-        g.out[(size_t)(m0 + r) * g.ldout + o] = ((outp[0][r][o] + outp[1][r][o]) + (outp[2][r][o] + outp[3][r][o])) +
+        g.out[(m0 + r) * g.ldout + o] = ((outp[0][r][o] + outp[1][r][o]) + (outp[2][r][o] + outp[3][r][o])) +
                                                 (bout ? bout[o] : 0.f);
     }
   }
+}
+
+// EXCL: the launch is ONE round (a block per CU at most) on a latency chain - the rollout's actor, 15 times per step - and must
+// not share its SIMDs: measured (profiles/r06_mlp_chain_anatomy.txt), a 256-register build that lets other streams' waves
+// co-reside runs 15 % faster alone and makes the step SLOWER (fp32 33.15 -> 33.6 ms, 7-column shard 9.22 -> 9.94 ms): the
+// round-5 kernel's 465 registers had kept every other wave off its SIMDs.  The EXCL build claims the accumulator file up to
+// a255 (one dead write), so a wave owns its SIMD again; the multi-round launches (the 938-block head windows) take the shared
+// build, where a second block's MFMAs cover the first one's epilogue.
+template <bool BF, int PACKED, bool EXCL>
+__global__ void __launch_bounds__(256, (PACKED && !EXCL) ? 2 : 1) mlp_chain_fwd_kernel(const ChainArgs g) {      // (the row-major A/B form keeps one block per CU)
+  __shared__ __attribute__((aligned(16))) float ybuf[16 * CH_LD];      // the next layer's input block
+  __shared__ float red[2][4][16];                                      // per-wave row partials: [0] sums, [1] centred squares
+  __shared__ float outp[4][16][32];                                    // per-wave output-layer partials
+  if constexpr (EXCL) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  chain_body<BF, PACKED>(g, ybuf, red, outp);
 }
 
 // fragment-major copy of the hidden-layer weights, all layers in one launch: one thread per destination 16-byte group
@@ -543,8 +584,24 @@ int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const
   const int slot = dm_prof_slot_begin(22, 2.0 * rows * macs,
                                       4.0 * ((double)rows * in_dim + macs + (double)rows * out_dim +
                                              (xpre ? 2.0 * rows * CH_N * layers : 0.0)), st);
-  if (dm_cur_precision()) hipLaunchKernelGGL(mlp_chain_fwd_kernel<true>, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(mlp_chain_fwd_kernel<false>, dim3((unsigned)dm_cdiv(rows, 16)), dim3(256), 0, st, a);
+  // packed copies are bf16 when the kernel multiplies in bf16 (dm_mlp_chain_pack_launch); all layers or none are packed
+  const dim3 grid((unsigned)dm_cdiv(rows, 16)), blk(256);
+  const bool packed = a.wp[0] != nullptr;
+  static const int excl_env = getenv("DM_CHAIN_EXCL") ? atoi(getenv("DM_CHAIN_EXCL")) : 1;      // A/B switch: 0 = the shared build everywhere
+  const bool excl = excl_env && grid.x <= 256;
+#define DM_CHAIN_LAUNCH(BF_, PK_)                                                                        \
+  do {                                                                                                   \
+    if (excl) hipLaunchKernelGGL((mlp_chain_fwd_kernel<BF_, PK_, true>), grid, blk, 0, st, a);          \
+    else hipLaunchKernelGGL((mlp_chain_fwd_kernel<BF_, PK_, false>), grid, blk, 0, st, a);              \
+  } while (0)
+  if (dm_cur_precision()) {
+    if (packed) DM_CHAIN_LAUNCH(true, 2);
+    else DM_CHAIN_LAUNCH(true, 0);
+  } else {
+    if (packed) DM_CHAIN_LAUNCH(false, 1);
+    else DM_CHAIN_LAUNCH(false, 0);
+  }
+#undef DM_CHAIN_LAUNCH
   dm_prof_slot_end(slot, st);
   DM_LAUNCH_CHECK();
   return DM_OK;

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdreamer_hip.so')
+LIB_PATH = os.environ.get('DM_LIB_PATH') or os.path.join(_HERE, 'libdreamer_hip.so')      # (DM_LIB_PATH: A/B of two builds on one box)
 
 DM_MAX_MLP_LAYERS = 8
 DM_GEMM_ACCUM = 1
