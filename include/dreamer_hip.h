@@ -434,6 +434,9 @@ int dm_copy_params(float* dst, const float* src, int64_t n, void* stream);   /* 
 /* Row threshold from which the 400-wide MLP heads run their whole forward as ONE launch (csrc/mlp_chain.hip; default 256,
  * below it the per-layer launches are faster).  rows >= 1 sets it; returns the previous value (rows < 1: query only). */
 int dm_mlp_chain_min_rows(int rows);
+/* The imagination rollout's one-hot action draw (dreamer.py:198-200) rides in the output stage of the whole-MLP actor kernel
+ * (1, default) or runs as its own sampler launch (0); same rule and operation order: bit-identical draws.  -1 queries. */
+int dm_rollout_fuse_act_enable(int on);
 /* Optional per-launch timing of the GEMM kernel with HIP events on the launch stream (bench.py's roofline line).
  * dm_prof_begin arms up to max_launches slots; dm_prof_end synchronises on the events, fills
  * out[kind*4+{0,1,2,3}] = {launches, algorithmic flops (2MNK), milliseconds, algorithmic bytes 4(MK+NK+MN)} for

@@ -291,10 +291,19 @@ int dm_dec_l4_wgrad_launch(int frames, int d, const float* G4, const float* x3, 
 // fused MLP (mlp.hip)
 // chain_wpack (optional): fragment-major weights already packed by the caller (dm_mlp_chain_pack_launch) for the whole-MLP
 // kernel; null: packed here, per call, into the workspace
+// chain_sample (with chain_wpack, out_dim <= 32): the one-hot categorical draw of the output row (dreamer.py:198-200: the
+// rollout's action sampler) rides in the whole-MLP kernel's output stage - same rule and operation order as
+// dm_sample_onehot_launch(rows, 1, out_dim, out, ...), so the drawn indices are bit-identical to the stand-alone sampler's
+struct DmChainSample {
+  const float* u;        // one uniform per row
+  float* onehot;         // rows x out_dim (ldo floats per row)
+  int ldo;
+  int32_t* idx;          // optional
+};
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
                       void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack = nullptr, int sparse_cols = 0,
-                      const float* chain_add0 = nullptr);
+                      const float* chain_add0 = nullptr, const DmChainSample* chain_sample = nullptr);
 // chain_add0 (with chain_wpack packed for k0 = in_dim - sparse_cols): the caller already has the sparse columns' contribution
 // (the imagination rollout knows the latent's indices and gathers it, rssm.hip)
 // sparse_cols > 0: the LAST sparse_cols columns of x are mostly zero (one-hot latent groups); the row-panel path then
@@ -326,7 +335,7 @@ size_t dm_mlp_chain_pack_floats(int in_dim, int layers);
 int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, float* wpack, hipStream_t st, int k0 = 0);
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
                             float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
-                            hipStream_t st, int k0 = 0, const float* add0 = nullptr);
+                            hipStream_t st, int k0 = 0, const float* add0 = nullptr, const DmChainSample* sample = nullptr);
 bool dm_mlp_chain_sparse_ok(int in_dim, int sparse_cols);      // the sparse-tail layer 0 applies (fp32 calls, aligned split)
 
 int dm_prof_slot_begin(int kind, double flops, double bytes, hipStream_t st);      // gemm.hip: per-launch HIP-event timing

@@ -48,7 +48,7 @@ extern "C" size_t dm_mlp_ws_floats(int rows, int hidden, int layers) {
 int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim, const float* x, int ldx,
                       const dm_mlp_params* p, float* acts, int acts_total_rows, int acts_row_off, float* out, int ldout,
                       void* ws, size_t ws_bytes, hipStream_t st, const float* chain_wpack, int sparse_cols,
-                      const float* chain_add0) {
+                      const float* chain_add0, const DmChainSample* chain_sample) {
   DM_REQUIRE(layers >= 1 && layers <= DM_MAX_MLP_LAYERS, DM_E_SHAPE, "mlp: layers=%d", layers);
   DM_REQUIRE(sparse_cols >= 0 && sparse_cols < in_dim, DM_E_SHAPE, "mlp: sparse_cols=%d of in_dim=%d", sparse_cols, in_dim);
   DM_REQUIRE(ws_bytes >= DM_SPLITK_FLOATS * sizeof(float), DM_E_WORKSPACE, "mlp_fwd: workspace too small");
@@ -110,8 +110,9 @@ int dm_mlp_fwd_launch(int rows, int in_dim, int hidden, int layers, int out_dim,
       }
     }
     return dm_mlp_chain_fwd_launch(rows, in_dim, layers, out_dim, x, ldx, p, acts ? a.xpre : nullptr,
-                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, wpack, st, k0, add0);
+                                   acts ? a.stats : nullptr, acts ? a.y : nullptr, out, ldout, wpack, st, k0, add0, chain_sample);
   }
+  DM_REQUIRE(!chain_sample, DM_E_SHAPE, "mlp_fwd: the fused sampler rides in the whole-MLP kernel only (rows %d)", rows);
   if (panel) {
     const bool fuse_out = out_dim <= 32;
     // bf16 operands: one bf16 copy of the hidden-layer weights per call (the panels then stream half the bytes, unconverted)

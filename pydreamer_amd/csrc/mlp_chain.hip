@@ -64,6 +64,8 @@ struct ChainArgs {
   // LayerNorm.  k0 = in_dim, add0 = null: the plain product.
   int k0;
   const float* add0;
+  // fused one-hot sampler of the output row (DmChainSample, common.h); samp_u null: none
+  const float* samp_u; float* samp_onehot; int samp_ld; int32_t* samp_idx;
 };
 
 __device__ __forceinline__ float chain_red16(float v) {
@@ -414,6 +416,30 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, float* ybuf, floa
         g.out[(m0 + r) * g.ldout + o] = ((outp[0][r][o] + outp[1][r][o]) + (outp[2][r][o] + outp[3][r][o])) +
                                                 (bout ? bout[o] : 0.f);
     }
+    // The categorical draw of the row (the rollout's action, dreamer.py:198-200), one lane per row: the logits are re-made from
+    // the LDS partials by the expression above (the same float), then the shared rule in the operation order of
+    // sample_onehot_kernel (elementwise.hip): max, sequential sum of exp, sequential cdf, idx = #{cdf_k <= u cdf_last}.
+    if (g.samp_u && tid < 16 && m0 + tid < g.rows) {
+      const int r = tid, C = g.out_dim, row = m0 + tid;
+      auto logit = [&](int k) { return ((outp[0][r][k] + outp[1][r][k]) + (outp[2][r][k] + outp[3][r][k])) + (bout ? bout[k] : 0.f); };
+      float mx = logit(0);
+      for (int k = 1; k < C; ++k) mx = fmaxf(mx, logit(k));
+      float sum = 0.f;
+      for (int k = 0; k < C; ++k) sum += expf(logit(k) - mx);
+      float total_p = 0.f;
+      for (int k = 0; k < C; ++k) total_p += expf(logit(k) - mx) / sum;
+      const float target = g.samp_u[row] * total_p;
+      float cdf = 0.f;
+      int idx = 0;
+      for (int k = 0; k < C; ++k) {
+        cdf += expf(logit(k) - mx) / sum;
+        idx += (cdf <= target) ? 1 : 0;
+      }
+      if (idx > C - 1) idx = C - 1;
+      float* o = g.samp_onehot + (size_t)row * g.samp_ld;
+      for (int k = 0; k < C; ++k) o[k] = (k == idx) ? 1.f : 0.f;
+      if (g.samp_idx) g.samp_idx[row] = idx;
+    }
   }
 }
 
@@ -558,8 +584,12 @@ int dm_mlp_chain_pack_launch(int in_dim, int layers, const dm_mlp_params* p, flo
 // wpack: fragment-major weights from dm_mlp_chain_pack_launch (null: the kernel gathers from the row-major weights).
 int dm_mlp_chain_fwd_launch(int rows, int in_dim, int layers, int out_dim, const float* x, int ldx, const dm_mlp_params* p,
                             float* const* xpre, float* const* stats, float* const* y, float* out, int ldout, const float* wpack,
-                            hipStream_t st, int k0, const float* add0) {
+                            hipStream_t st, int k0, const float* add0, const DmChainSample* sample) {
   ChainArgs a = {};
+  if (sample) {
+    DM_REQUIRE(sample->u && sample->onehot && sample->ldo >= out_dim, DM_E_NULL, "mlp_chain: fused sampler arguments");
+    a.samp_u = sample->u; a.samp_onehot = sample->onehot; a.samp_ld = sample->ldo; a.samp_idx = sample->idx;
+  }
   if (k0 == 0) k0 = in_dim;
   DM_REQUIRE(k0 == in_dim || (add0 && wpack && !g_chain_nopack && k0 >= 4 && k0 < in_dim && (k0 & 3) == 0), DM_E_SHAPE,
              "mlp_chain: a sparse-tail layer 0 (k0=%d of %d) needs its addend and weights packed for k0", k0, in_dim);

@@ -798,6 +798,13 @@ struct DmRolloutMarks {
   }
 };
 
+static int g_rollout_fuse_act = getenv("DM_ROLLOUT_NO_FUSE_ACT") ? 0 : 1;
+// 1 / 0: the rollout's one-hot action draw in the output stage of the whole-MLP actor kernel / as its own launch; -1 queries.
+extern "C" int dm_rollout_fuse_act_enable(int on) {
+  if (on >= 0) g_rollout_fuse_act = on ? 1 : 0;
+  return g_rollout_fuse_act;
+}
+
 extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, const dm_rssm_params* P,
                                 const dm_mlp_params* actor, const float* u_act, const float* u_prior, float* feats,
                                 float* actions, int32_t* act_idx, float* actor_acts, float* actor_logits, void* ws,
@@ -923,12 +930,18 @@ extern "C" int dm_dream_rollout(const dm_shape* s, int M, const float* start, co
                                     actor_add0, Hm, nullptr, nullptr, nullptr, 0.f, nullptr, 0, st));
     }
     const int asp = actor_add0 ? Z : 0;
+    int32_t* ai = act_idx ? act_idx + (size_t)i * M : aidx;       // the sampled action's index (scratch if the caller wants none)
+    // one-hot actors on the whole-MLP kernel: the action draw rides in that kernel's output stage (round 6; DM_ROLLOUT_NO_FUSE_ACT=1
+    // keeps the stand-alone sampler launch - same rule, same operation order, bit-identical draws)
+    const bool fuse_act = adist == 0 && actor_wpack && g_rollout_fuse_act;
+    const DmChainSample samp = {u_act + (size_t)i * M, act, A, ai};
     if (actor_acts)
       DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, actor_acts, H * M, i * M, logits, AO, sk, skb, st, actor_wpack, asp,
-                               actor_add0));
-    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack, asp, actor_add0));
-    int32_t* ai = act_idx ? act_idx + (size_t)i * M : aidx;       // the sampled action's index (scratch if the caller wants none)
-    if (adist == 0)
+                               actor_add0, fuse_act ? &samp : nullptr));
+    else DM_TRY(dm_mlp_fwd_launch(M, F, Hm, L, AO, cur, F, actor, macts, M, 0, logits, AO, sk, skb, st, actor_wpack, asp, actor_add0,
+                                  fuse_act ? &samp : nullptr));
+    if (fuse_act) {
+    } else if (adist == 0)
       DM_TRY(dm_sample_onehot_launch(M, 1, A, logits, A, u_act + (size_t)i * M, nullptr, act, A, ai, nullptr, nullptr, st));
     else
       DM_TRY(dm_sample_continuous_launch(adist, M, A, logits, u_act + (size_t)i * M * A, act, st));

@@ -188,6 +188,7 @@ _SIGNATURES = {
     'dm_prof_end': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_prof_rows': (c_int, [POINTER(ctypes.c_double), c_int]),
     'dm_mlp_chain_min_rows': (c_int, [c_int]),
+    'dm_rollout_fuse_act_enable': (c_int, [c_int]),
     'dm_bf16_twins_enable': (c_int, [c_int]),
     'dm_gemm_dma_enable': (c_int, [c_int]),
     'dm_dec_l4_bwd_direct_enable': (c_int, [c_int]),

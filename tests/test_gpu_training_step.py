@@ -949,6 +949,36 @@ def test_dream_rollout_vs_oracle(hip):
     _close(th.mean, to, 1e-4, 1e-5, 'dream terminals')
 
 
+def test_dream_rollout_action_draw_in_the_actor_kernel(hip):
+    """Round 6: with a one-hot actor on the whole-MLP kernel (>= 256 imagined rows) the action draw of every rollout step
+    (dreamer.py:198-200) happens in that kernel's output stage instead of a sampler launch.  Same rule, same operation order:
+    the whole rollout - action indices, latents, features - is BIT-IDENTICAL to the run with the stand-alone sampler
+    (dm_rollout_fuse_act_enable), and the action indices equal the oracle's."""
+    from pydreamer_amd import hip as H
+    oconf = O.tiny_conf()
+    params = O.make_params(oconf, seed=3)
+    model = _build(oconf, params)
+    M, Hh = 300, 4
+    g = torch.Generator().manual_seed(9)
+    h = torch.tanh(torch.randn(M, oconf.deter_dim, generator=g))
+    z = F.one_hot(torch.randint(0, oconf.stoch_discrete, (M, oconf.stoch_dim), generator=g), oconf.stoch_discrete).float().reshape(M, -1)
+    u_act, u_prior = torch.rand(Hh, M, generator=g), torch.rand(Hh, M, oconf.stoch_dim, generator=g)
+    fo, ao, ro, to, xo = O.dream({k: v for k, v in params.items()}, oconf, (h, z), Hh, u_act, u_prior)
+    runs = []
+    keep = H.lib().dm_rollout_fuse_act_enable(-1)
+    try:
+        for on in (1, 0):
+            assert H.lib().dm_rollout_fuse_act_enable(on) == on
+            fh, ah, rh, th = model.dream((h.to(DEV), z.to(DEV)), Hh, u_act=u_act.to(DEV), u_prior=u_prior.to(DEV))
+            runs.append((fh.clone(), ah.clone(), rh.mean.clone(), th.mean.clone()))
+    finally:
+        H.lib().dm_rollout_fuse_act_enable(keep)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1].cpu(), ao), 'action draws differ from the oracle'
+    _close(runs[0][0], fo, 0, 2e-5, 'dream features')
+
+
 @pytest.mark.parametrize('B,T', [(6, 4), (7, 4), (50, 4), (50, 10), (7, 10)])
 def test_rssm_sequence_fwd_bwd_vs_oracle(hip, B, T):
     """dm_rssm_sequence_fwd / dm_rssm_sequence_bwd stand-alone through the C-ABI at the Atari-literal cell width (deter 600,
