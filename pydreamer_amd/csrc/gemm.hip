@@ -51,6 +51,7 @@ struct GemmKArgs {
   int tiles_m;
   int n_tiles, n_items;
   int tiles_n, n_fast;
+  int n_groups;               // > 1: the fast tile dimension is cut into this many column groups (gemm_decode)
   int a_vec, b_vec;
   unsigned short* Ch;         // optional bf16 twin of C (same ldc), written with the final value
   int use_dma;                // host-side: this launch takes gemm_dma_kernel (not read by the kernels)
@@ -224,12 +225,37 @@ __device__ __forceinline__ GemmItem gemm_decode(const GemmKArgs& g, int id) {
   it.split = item / g.n_tiles;
   // the index of the dimension with FEWER tiles runs fastest: the tiles that re-read one panel of the big operand
   // (activation rows for M >> N, patch rows for weight gradients) are then neighbours in the same XCD's chunk
-  if (g.n_fast) {
-    it.n0 = (tile % g.tiles_n) * BN;
-    it.m0 = (tile / g.tiles_n) * BM;
+  // Round 6: with n_groups > 1 the fast dimension is cut into that many groups, each walked completely (slow index inside a
+  // group, fast index inside the group's width) before the next one.  An XCD's contiguous chunk of the item list then covers a
+  // 2-D block of tiles - about (n_tiles / 8) / width rows of the slow operand x one group's width of the fast one - instead of a
+  // few slow rows x ALL fast panels: eight private L2s fetch ~25 % fewer operand bytes on the 2 500 x 1 800 rollout products
+  // (the eight L2s do not share lines, and a kernel boundary invalidates them: what one XCD's tiles need, that XCD fetches).
+  // Same tiles, same arithmetic per tile: results are bit-identical for every grouping.
+  const int F = g.n_fast ? g.tiles_n : g.tiles_m;
+  int fast, slow;
+  if (g.n_groups > 1) {
+    const int S = g.n_fast ? g.tiles_m : g.tiles_n;
+    const int w = F / g.n_groups, rem = F % g.n_groups;
+    int base = 0, f0 = 0, wg = w + (rem > 0 ? 1 : 0);
+    for (int gi = 0; gi < g.n_groups - 1; ++gi) {
+      const int cnt = S * wg;
+      if (tile < base + cnt) break;
+      base += cnt; f0 += wg;
+      wg = w + (gi + 1 < rem ? 1 : 0);
+    }
+    const int local = tile - base;
+    fast = f0 + local % wg;
+    slow = local / wg;
   } else {
-    it.m0 = (tile % g.tiles_m) * BM;
-    it.n0 = (tile / g.tiles_m) * BN;
+    fast = tile % F;
+    slow = tile / F;
+  }
+  if (g.n_fast) {
+    it.n0 = fast * BN;
+    it.m0 = slow * BM;
+  } else {
+    it.m0 = fast * BM;
+    it.n0 = slow * BN;
   }
   it.kbeg = it.split * g.k_per_split;
   it.kend = min(g.K, it.kbeg + g.k_per_split);
@@ -1498,6 +1524,26 @@ int dm_gemm_launch(const DmGemm& q, void* ws, size_t ws_bytes, hipStream_t strea
   a.tiles_n = tiles_n;
   a.n_fast = tiles_n <= tiles_m ? 1 : 0;
   a.n_items = (int)(tiles * nsplit);
+  {      // column groups of the fast dimension (gemm_decode): the grouping that minimises the operand rows one XCD's chunk touches
+    static const int grp_env = getenv("DM_GEMM_XCD_GROUPS") ? atoi(getenv("DM_GEMM_XCD_GROUPS")) : 0;      // 0 auto, 1 off, 2 / 4 forced
+    const int F = a.n_fast ? tiles_n : tiles_m, S = a.n_fast ? tiles_m : tiles_n;
+    const int bf = a.n_fast ? BN : BM, bs = a.n_fast ? BM : BN;
+    int best_g = 1;
+    if (nsplit == 1 && tiles >= 64 && !q.c_tab) {
+      double best = -1.0;
+      for (int G = 1; G <= 4; G *= 2) {
+        if (grp_env > 1 && G != grp_env) continue;
+        if (F / G < 2) break;
+        const double width = (double)F / G;
+        double srows = ((double)tiles / 8.0) / width;
+        if (srows > S) srows = S;
+        if (srows < 1.0) srows = 1.0;
+        const double cost = srows * bs + width * bf;
+        if (best < 0 || cost < best * 0.95) { best = cost; best_g = G; }      // (a new grouping has to win by 5 %)
+      }
+    }
+    a.n_groups = grp_env == 1 ? 1 : best_g;
+  }
   const int tc = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 ? 2 : (BN == 96 ? 3 : 4));
   dim3 grid((unsigned)a.n_items);
   const int gather = q.a_maj ? 1 : (q.b_maj ? 2 : 0);
