@@ -80,7 +80,8 @@ int dm_version(void);                 /* ABI version, currently 12 (v2: LayerNor
                                          measurement) and the persistent BPTT kernel with its switch dm_rssm_lds_bwd_enable - slower inside the step at every shard size - removed;
                                          dm_prof_end reports 44 kinds;
                                          v11: dm_dec_l4_bwd_direct_enable added;
-                                         v12: dm_rssm_lds_status_ack / dm_rssm_lds_gave_up; the native exchange step dm_rccl_* / dm_allreduce_grads */
+                                         v12: dm_rssm_lds_status_ack / dm_rssm_lds_gave_up; the native exchange step dm_rccl_* / dm_allreduce_grads;
+                                              dm_rollout_fuse_act_enable */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */

@@ -10,7 +10,7 @@
 # timelines; lab = the tile-kernel laboratory, SQ counters, tile sweep, persistent-kernel phase clocks (code-specific: re-run when
 # csrc/gemm.hip or csrc/rssm_lds.hip changed).  Every profiler run is bounded by `timeout`.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 PARTS=${PARTS:-core configs lab}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 RP="timeout 600 rocprofv3"
