@@ -244,6 +244,8 @@ def test_runtime_switch_defaults():
     if lib.dm_rccl_available():
         assert lib.dm_rccl_version() > 20000
     assert lib.dm_bf16_twins_enable(0) == 0 and lib.dm_bf16_twins_enable(1) == 1
+    if not os.environ.get('DM_ROLLOUT_NO_FUSE_ACT'):      # round 6: the rollout's action draw rides in the actor kernel by default
+        assert lib.dm_rollout_fuse_act_enable(-1) == 1 and lib.dm_rollout_fuse_act_enable(0) == 0 and lib.dm_rollout_fuse_act_enable(1) == 1
     assert lib.dm_gemm_dma_enable(-1) == 1 and lib.dm_gemm_dma_enable(0) == 0 and lib.dm_gemm_dma_enable(1) == 1
     assert lib.dm_dec_l4_bwd_direct_enable(-1) == 1 and lib.dm_dec_l4_bwd_direct_enable(0) == 0 and lib.dm_dec_l4_bwd_direct_enable(1) == 1
 
