@@ -230,6 +230,9 @@ def main():
                          'fingerprint of the kernel sources and is refused (traffic = null) when that differs from the tree')
     ap.add_argument('--emulate-world', type=int, default=0, help='diagnostic only: run rank 0''s batch shard of an N-rank job on one GPU without the all-reduce (per-rank compute time at N GPUs); the line is marked invalid as a metric')
     ap.add_argument('--emulate-rank', type=int, default=0, help='with --emulate-world N: which rank''s shard (uneven splits: 50 columns over 8 ranks are 7,7,6,6,6,6,6,6)')
+    ap.add_argument('--force-dp', action='store_true', help='diagnostic on a 1-GPU box: a ONE-rank nccl (= RCCL) group, the data-parallel code path switched on - '
+                    'every optimizer group is all-reduced (over one rank) exactly where an N-rank job does it; DM_DP_NATIVE=1 selects the library\'s own '
+                    'dm_allreduce_grads.  What the collectives and their stream cost the step, without a second GPU; the line is marked invalid as a metric')
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric); bf16 = configs[2]: '
                     'conf.amp, GEMM operands in bf16 with fp32 accumulation and storage')
     ap.add_argument('--no-overlap', action='store_true', help='run all backward passes on one stream (A/B switch)')
@@ -271,6 +274,10 @@ def main():
         dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
         if not one_device and (dist.get_backend() != 'nccl' or dist.get_world_size() != args.gpus):
             raise SystemExit(f'--gpus {args.gpus}: expected {args.gpus} ranks over nccl (= RCCL), got {dist.get_world_size()} over {dist.get_backend()}')
+    elif args.force_dp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1)
 
     from pydreamer_amd import config, hip
     from pydreamer_amd import dist as DP
@@ -303,7 +310,7 @@ def main():
     model.overlap_backward = not args.no_overlap
     model.pipeline_ac_optimizer = bool(args.pipeline) and not (args.no_pipeline or args.no_overlap)
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-    DP.attach(opts, hi - lo, B, model=model)           # the B_r/B weight rides in the backward kernels' scale arguments
+    DP.attach(opts, hi - lo, B, model=model, force=args.force_dp)      # the B_r/B weight rides in the backward kernels' scale arguments
     ring = make_ring(conf, B, lo, hi, args.ring, dev, 1234)      # the global batch, this rank's columns
     noise = GlobalNoise(conf, B, lo, hi, dev, 777)     # global-layout sampler uniforms, the rank's columns sliced out
     state = {'s': model.init_state(hi - lo)}
@@ -602,6 +609,8 @@ def main():
                                 parallelism=f'dp{world} (batch-sharded {[DP.shard_bounds(B, world, r)[1] - DP.shard_bounds(B, world, r)[0] for r in range(world)]})',
                                 algorithmic_tflop_per_step=alg_tflop),
                     **({'INVALID_diagnostic_emulated_world': args.emulate_world} if args.emulate_world > 1 else {}),
+                    **({'INVALID_diagnostic_forced_one_rank_dp': 'native dm_allreduce_grads' if os.environ.get('DM_DP_NATIVE') == '1' else 'torch.distributed nccl'}
+                       if args.force_dp else {}),
                     **({'INVALID_smoke_all_ranks_on_one_device': True} if one_device else {}),
                     loss_model_last=loss_model,
                     param_checksum=[float(o.flat_param.double().sum()) for o in opts] + [float(o.flat_param.double().abs().sum()) for o in opts],
@@ -614,7 +623,7 @@ def main():
                     **({} if args.dtype == 'f32' else {'note_dtype': 'BASELINE configs[2] (mixed precision); the headline metric is the f32 line'}),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

@@ -39,7 +39,10 @@ def _native_comms(optimizers, group):
     from . import hip as H
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     comms = []
-    for _ in optimizers:
+    for i, _ in enumerate(optimizers):
+        if i > 0 and _os.environ.get('DM_DP_NATIVE_ONE_COMM') == '1':      # experiment: one communicator for every group
+            comms.append(comms[0])
+            continue
         ids = [None]
         if rank == 0:
             buf = (ctypes.c_char * 128)()
@@ -52,7 +55,7 @@ def _native_comms(optimizers, group):
     return comms
 
 
-def attach(optimizers, local_batch, global_batch, group=None, model=None, native=None):
+def attach(optimizers, local_batch, global_batch, group=None, model=None, native=None, force=False):
     """Enable gradient all-reduce inside FusedAdamW.clip_grad_norm for every optimizer group.
     native (default: the environment's DM_DP_NATIVE=1): issue the collectives through the library's own entry point
     dm_allreduce_grads (include/dreamer_hip.h) on one RCCL communicator PER GROUP instead of torch.distributed - a group's
@@ -61,8 +64,8 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None, native
     argument every backward entry point already takes (models.WorldModel / ActorCritic.grad_weight), so the rank's gradient
     buffers come out of the backward kernels already weighted and no extra pass over the 92 MB buffer runs per step; without
     it (or for a group fed by autograd, the 1-element probe group) the buffer is multiplied before the collective."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return      # (force: a ONE-rank group still issues its collectives - bench.py --force-dp measures their cost on a 1-GPU box)
     w = float(local_batch) / float(global_batch)
     folded = set()
     if model is not None and getattr(model, '_opt', None) is not None:
@@ -74,6 +77,9 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None, native
     if native is None:
         native = os.environ.get('DM_DP_NATIVE', '0') == '1'
     comms = _native_comms(optimizers, group) if native else [None] * len(optimizers)
+    if native and _os.environ.get('DM_DP_NATIVE_IDLE') == '1':      # experiment: the communicators exist, the collectives go through torch
+        globals()['_idle_comms'] = comms
+        comms = [None] * len(optimizers)
     for opt, comm in zip(optimizers, comms):
         opt.dp = (group, w)
         opt.dp_folded = id(opt) in folded
@@ -81,6 +87,14 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None, native
     _attached = True
 
 
+import os as _os
+# Round 6 measured the collectives of a ONE-rank RCCL group on a 1-GPU box (bench.py --force-dp, profiles/r06_force_dp.txt): the
+# EARLY all-reduce - issued from the launcher thread right behind a pre-launched backward, on torch's communication stream,
+# overlapped with the actor / critic backward - costs the step +7 ... +12.6 ms (fp32 33.2 -> 45.8 ms, 7-column shard 9.3 -> 16.2 ms)
+# although a one-rank collective moves no data: the communication stream is a fifth busy stream.  The LATE form -
+# every group reduced inside grad_clip(), when the step's streams have drained - costs +0.15 ms (shard) ... +1.0 ms (50 columns).
+# Default: late.  DM_DP_EARLY=1 restores the overlapped form for a fabric where the transfer itself is the larger cost.
+_EARLY = _os.environ.get('DM_DP_EARLY', '0') == '1'
 _inflight = []      # futures of launcher-thread jobs that may issue collectives (models._Overlap.submit)
 _attached = False   # set by attach(): only then can a launcher job issue a collective, and only then does drain() ever run
 
@@ -120,7 +134,7 @@ def allreduce_scratch_async(opt):
     "issued as soon as each backward finishes (wm first, overlapped with actor/critic backward)"): starts the SUM all-reduce
     of the group's (B_r/B-weighted) buffer; the handle is waited for in loss.backward() (FusedAdamW.adopt_scratch), so
     grad_clip() finds the global-batch gradient already in place."""
-    if opt.dp is None:
+    if opt.dp is None or not _EARLY:
         return
     group = _weight(opt, opt.scratch)
     if getattr(opt, 'dp_comm', None) is not None:

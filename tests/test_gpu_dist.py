@@ -44,7 +44,7 @@ def _one_step(model, conf, opts, obs, noise, steps=2):
     return out
 
 
-def _worker(rank, world, port, overlap, fold, out):
+def _worker(rank, world, port, overlap, fold, out, early=False):
     import torch.distributed as dist
     from oracle import dreamer_oracle as O
     from pydreamer_amd import config
@@ -71,6 +71,7 @@ def _worker(rank, world, port, overlap, fold, out):
         model = model.to(dev)
         model.overlap_backward = overlap
         opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
+        DP._EARLY = early       # the all-reduce behind each pre-launched backward (overlapped) instead of inside grad_clip (round 6: the default is late)
         DP.attach(opts, hi - lo, B, model=model if fold else None)    # fold: B_r/B inside the backward kernels' scales
         assert opts[0].dp is not None and opts[0].dp_folded == fold and not opts[1].dp_folded
         shard, _ = DP.shard_obs(obs, world, rank)
@@ -82,8 +83,8 @@ def _worker(rank, world, port, overlap, fold, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap,fold', [(True, True), (False, True), (True, False)])
-def test_two_rank_step_equals_one_rank(hip, overlap, fold):
+@pytest.mark.parametrize('overlap,fold,early', [(True, True, False), (False, True, False), (True, False, False), (True, True, True)])
+def test_two_rank_step_equals_one_rank(hip, overlap, fold, early):
     import torch.multiprocessing as mp
     from oracle import dreamer_oracle as O
     from pydreamer_amd import config
@@ -91,7 +92,7 @@ def test_two_rank_step_equals_one_rank(hip, overlap, fold):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), overlap, fold, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), overlap, fold, out, early), nprocs=world, join=True)
     res = dict(out)
     assert set(res) == {0, 1}
     # the single-process run of the whole batch
