@@ -1,7 +1,7 @@
 """-m gpu: the data-parallel step through the REAL optimizer path (FusedAdamW + pydreamer_amd.dist), two ranks.
 
 With >= 2 visible GPUs the ranks run one per GPU over RCCL ("nccl"); on a 1-GPU box both ranks share cuda:0 and talk
-over gloo (which all-reduces CUDA tensors through host staging) - the same FusedAdamW.clip_grad_norm / early
+over gloo (which all-reduces CUDA tensors through host staging) - the same FusedAdamW.clip_grad_norm / (late or early)
 all-reduce code runs either way.  Bars: posterior indices of every shard bit-identical to the matching
 columns of the 1-rank run (uniforms are sliced from the global layout); parameters after clip + AdamW within 1e-5."""
 import os
@@ -169,7 +169,7 @@ def _run_bench(world, extra_env, *flags):
 def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
     """BASELINE configs[3] as far as one GPU can show it: bench.py --gpus 8 at the FULL Atari-literal dimensions, one process
     per rank as the driver launches it.  On a box with < 8 GPUs all ranks share cuda:0 and talk over gloo
-    (DM_BENCH_ONE_DEVICE=1; same FusedAdamW / early all-reduce / B_r/B-folded backward code as over RCCL).  Checks
+    (DM_BENCH_ONE_DEVICE=1; same FusedAdamW / all-reduce-in-grad_clip / B_r/B-folded backward code as over RCCL).  Checks
     (SURVEY 8(e)): the 50 columns are dealt 7/7/6/6/6/6/6/6 (the 6-column shard shape of ranks 2-7 executes here at full
     width), every rank holds BIT-IDENTICAL parameters after 2 steps, the loss of the global batch (sum_r B_r/B loss_r) and the
     parameters equal the 1-rank run on the same global batch (the replay ring and the sampler uniforms are drawn in the global
@@ -197,7 +197,7 @@ def test_eight_rank_job_at_atari_literal_equals_one_rank(hip):
 
 @pytest.mark.parametrize('world', [2, 4, 8])
 def test_default_deployment_over_rccl_on_real_gpus(hip, world):
-    """The deployment every real shard runs - one process per GPU over RCCL ("nccl"), data-parallel FusedAdamW with the early
+    """The deployment every real shard runs - one process per GPU over RCCL ("nccl"), data-parallel FusedAdamW with the (round 6: late, inside grad_clip; DM_DP_EARLY=1: early)
     all-reduce and the B_r/B weight folded into the backward kernels, the pipelined actor / critic optimizer, AND the persistent
     posterior kernel ON (its default for <= 32-column shards: 25/25, 13/13/12/12, 7/7/6/6/6/6/6/6 of the 50 columns) - at the
     full Atari-literal size, through bench.py as the driver launches it.  Needs `world` GPUs: two trainers cannot share one
