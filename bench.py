@@ -376,7 +376,7 @@ def main():
     host_free_ms = 1e3 * (time.perf_counter() - th) / 3
     torch.cuda.synchronize()
     dist_info = None
-    if world > 1:
+    if world > 1 or args.force_dp:      # (--force-dp: the same record over a ONE-rank RCCL group)
         # per-rank numbers (before the MAX) and the stand-alone cost of the step's all-reduces on this fabric
         mine = torch.tensor([1e3 * t_enqueued / args.steps], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]

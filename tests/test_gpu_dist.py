@@ -263,3 +263,29 @@ def test_native_rccl_entry_points_one_rank():
         H.call('dm_allreduce_grads', None, 4, comms[0], None)
     for comm in comms:
         H.call('dm_rccl_comm_destroy', comm)
+
+
+def test_default_shard_deployment_over_one_rank_rccl(hip):
+    """What a 1-GPU box can run of the real deployment (round 6): `bench.py --force-dp --emulate-world 8 --pipeline` - rank 0's
+    7-column shard of an 8-way split at the FULL Atari-literal size, the data-parallel code path switched on over a ONE-rank RCCL
+    ("nccl") group: B_r/B folded into the backward kernels, every optimizer group all-reduced by RCCL inside grad_clip (the
+    round-6 default), the pipelined actor / critic optimizer AND the persistent posterior kernel on.  Until this round RCCL had
+    executed zero times.  Asserted: the backend is nccl, the persistent kernel ran and did not give up, the loss is finite and
+    the line is marked as the diagnostic it is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--force-dp', '--emulate-world', '8', '--pipeline', '--reps', '1',
+           '--steps', '3', '--warmup', '1', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['INVALID_diagnostic_forced_one_rank_dp'] == 'torch.distributed nccl' and d['INVALID_diagnostic_emulated_world'] == 8
+    di = d['distributed']
+    assert di['backend'] == 'nccl' and di['world_size'] == 1 and di['rccl_version']
+    assert di['persistent_posterior_kernel_ran'] == [True] and di['rssm_lds_status'] == [0]
+    assert di['replicas_identical'] and np.isfinite(d['loss_model_last']) and d['loss_model_last'] > 0
+    assert all(v['ms'] >= 0 for v in di['allreduce_standalone'].values())
