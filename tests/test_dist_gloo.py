@@ -100,6 +100,10 @@ def _native_worker(rank, world, port, B, out):
         assert [o.dp_comm.value for o in opts] == [1001, 1002, 1003], 'one communicator per group, ids in optimizer order'
         # early (stream-ordered) form for group 0, plain form for the others; no launcher future is tracked and drain() is not
         # reached (the stub's single gloo group still wants one issue order, RCCL's per-group communicators would not)
+        DP._EARLY = False                                    # the product default (round 6): no early all-reduce, nothing is issued
+        DP.allreduce_scratch_async(opts[0])
+        assert getattr(opts[0], 'early_reduce', None) is None and calls.count('dm_allreduce_grads') == 0
+        DP._EARLY = True                                     # DM_DP_EARLY=1: the overlapped form
         DP.allreduce_scratch_async(opts[0])
         assert isinstance(opts[0].early_reduce, DP._NativeWork) and opts[0].early_reduce.wait()
         DP._inflight.append('poison: allreduce_grads must not drain on the native path')
