@@ -277,7 +277,9 @@ def main():
     elif args.force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=0, world_size=1)
+        # (DM_BENCH_FORCE_BACKEND=gloo: the control plane over gloo, so that with DM_DP_NATIVE=1 the library's communicators are the
+        #  only RCCL communicators of the process)
+        dist.init_process_group(os.environ.get('DM_BENCH_FORCE_BACKEND', 'nccl'), rank=0, world_size=1)
 
     from pydreamer_amd import config, hip
     from pydreamer_amd import dist as DP
@@ -310,7 +312,12 @@ def main():
     model.overlap_backward = not args.no_overlap
     model.pipeline_ac_optimizer = bool(args.pipeline) and not (args.no_pipeline or args.no_overlap)
     opts = model.init_optimizers(conf.adam_lr, conf.adam_lr_actor, conf.adam_lr_critic, conf.adam_eps)
-    DP.attach(opts, hi - lo, B, model=model, force=args.force_dp)      # the B_r/B weight rides in the backward kernels' scale arguments
+    if os.environ.get('DM_BENCH_DP_IDLE') == '1' and args.force_dp:
+        # experiment: the process group exists and has run one collective (its communicator and stream are there), but the step issues none
+        dist.all_reduce(torch.zeros(8, device=dev))
+        torch.cuda.synchronize()
+    else:
+        DP.attach(opts, hi - lo, B, model=model, force=args.force_dp)      # the B_r/B weight rides in the backward kernels' scale arguments
     ring = make_ring(conf, B, lo, hi, args.ring, dev, 1234)      # the global batch, this rank's columns
     noise = GlobalNoise(conf, B, lo, hi, dev, 777)     # global-layout sampler uniforms, the rank's columns sliced out
     state = {'s': model.init_state(hi - lo)}

@@ -102,6 +102,7 @@ int dm_stream_destroy(void* stream);
  * Unarmed (the default for every direct caller) everything is enqueued on the caller's stream.  Results are bit-identical
  * either way (same kernels, same arguments).  No reference counterpart (autograd orders these itself). */
 int dm_wgrad_side_arm(int on);
+int dm_wgrad_side_touch(void);          /* create the side stream now and give it one command: it then holds its hardware queue before later streams ask for one */
 int dm_wgrad_side_join(void* stream);
 
 /* ---------------------------------------------------------------- primitives ------------------- */

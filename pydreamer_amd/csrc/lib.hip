@@ -95,6 +95,18 @@ extern "C" int dm_wgrad_side_arm(int on) {
   return DM_OK;
 }
 
+// Creates the side stream NOW and gives it one command, so that it holds its hardware queue before anything else (a communicator's
+// internal streams, torch's communication stream) asks for one: round 6 measured that the order in which streams first get work
+// decides which of them end up sharing a hardware queue (profiles/r06_force_dp.txt, runs C / G / H).
+extern "C" int dm_wgrad_side_touch(void) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  DM_TRY(side_init_locked());
+  static float* pad = nullptr;
+  if (!pad && hipMalloc(reinterpret_cast<void**>(&pad), 256) != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side_touch: hipMalloc failed");
+  if (hipMemsetAsync(pad, 0, 256, g_side_stream) != hipSuccess) return dm_fail(DM_E_HIP, "wgrad_side_touch: memset failed");
+  return DM_OK;
+}
+
 hipStream_t dm_wgrad_side_stream(hipStream_t st) { return tl_side_armed && g_side_stream ? g_side_stream : st; }
 
 int dm_wgrad_side_fork(hipStream_t st, hipStream_t sw) {

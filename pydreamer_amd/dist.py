@@ -24,6 +24,20 @@ def shard_obs(obs, world, rank):
     return {k: v[:, lo:hi].contiguous() for k, v in obs.items()}, (lo, hi)
 
 
+class _LazyComms:
+    """The optimizer groups' RCCL communicators (csrc/comm.hip), created at first use - by whichever thread gets there first."""
+
+    def __init__(self, optimizers, group):
+        import threading
+        self.optimizers, self.group, self.comms, self.lock = list(optimizers), group, None, threading.Lock()
+
+    def get(self, i):
+        with self.lock:
+            if self.comms is None:
+                self.comms = _native_comms(self.optimizers, self.group)
+        return self.comms[i]
+
+
 class _NativeWork:
     """What FusedAdamW keeps of an early all-reduce issued through the native entry point: the collective sits on the stream
     the backward pass ran on, and loss.backward() joins that stream anyway - nothing to wait for on the host."""
@@ -68,6 +82,8 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None, native
         return      # (force: a ONE-rank group still issues its collectives - bench.py --force-dp measures their cost on a 1-GPU box)
     w = float(local_batch) / float(global_batch)
     folded = set()
+    if model is not None and hasattr(model, 'prepare_streams'):
+        model.prepare_streams()      # the step's streams take their hardware queues before any communicator is built (models.Dreamer.prepare_streams)
     if model is not None and getattr(model, '_opt', None) is not None:
         model.wm.grad_weight = w
         model.ac.grad_weight = w
@@ -76,24 +92,28 @@ def attach(optimizers, local_batch, global_batch, group=None, model=None, native
     import os
     if native is None:
         native = os.environ.get('DM_DP_NATIVE', '0') == '1'
-    comms = _native_comms(optimizers, group) if native else [None] * len(optimizers)
-    if native and _os.environ.get('DM_DP_NATIVE_IDLE') == '1':      # experiment: the communicators exist, the collectives go through torch
-        globals()['_idle_comms'] = comms
-        comms = [None] * len(optimizers)
-    for opt, comm in zip(optimizers, comms):
+    # native: the communicators are created LAZILY, at the first all-reduce (like torch creates its own): round 6 measured that a
+    # communicator created BEFORE the model's side streams exist costs the step +13 ms (profiles/r06_force_dp.txt, run G) - RCCL's
+    # internal streams then take the hardware queues first and the step's busy streams end up sharing one.  Every rank reaches
+    # its first all-reduce at the same point of the program, so the collective creation stays matched.
+    lazy = _LazyComms(optimizers, group) if native else None
+    for i, opt in enumerate(optimizers):
         opt.dp = (group, w)
         opt.dp_folded = id(opt) in folded
-        opt.dp_comm = comm
+        opt.dp_comm = (lazy, i) if native else None
     _attached = True
 
 
 import os as _os
-# Round 6 measured the collectives of a ONE-rank RCCL group on a 1-GPU box (bench.py --force-dp, profiles/r06_force_dp.txt): the
-# EARLY all-reduce - issued from the launcher thread right behind a pre-launched backward, on torch's communication stream,
-# overlapped with the actor / critic backward - costs the step +7 ... +12.6 ms (fp32 33.2 -> 45.8 ms, 7-column shard 9.3 -> 16.2 ms)
-# although a one-rank collective moves no data: the communication stream is a fifth busy stream.  The LATE form -
-# every group reduced inside grad_clip(), when the step's streams have drained - costs +0.15 ms (shard) ... +1.0 ms (50 columns).
-# Default: late.  DM_DP_EARLY=1 restores the overlapped form for a fabric where the transfer itself is the larger cost.
+# Round 6 measured the collectives of a ONE-rank RCCL group on a 1-GPU box (bench.py --force-dp, profiles/r06_force_dp.txt):
+#  * torch's EARLY all-reduce - issued from the launcher thread right behind a pre-launched backward, overlapped with the actor /
+#    critic backward - runs on torch's communication stream, a FIFTH busy stream where the runtime has four hardware queues by
+#    default: +5 ... +12 ms per step although a one-rank collective moves no data (GPU_MAX_HW_QUEUES=8: +0.1 ... +0.4 ms);
+#  * the LATE form - every group reduced inside grad_clip(), when the step's streams have drained - costs +0.03 ... +0.06 ms;
+#  * the library's own all-reduce (native=True / DM_DP_NATIVE=1) is enqueued on the backward's own stream - no fifth stream - and is
+#    free in both forms, but has only ever run with one rank.
+# Default: torch, late.  DM_DP_EARLY=1 selects the overlapped form (with DM_DP_NATIVE=1, or with GPU_MAX_HW_QUEUES=8 in the
+# environment) for a fabric where the transfer itself is the larger cost.
 _EARLY = _os.environ.get('DM_DP_EARLY', '0') == '1'
 _inflight = []      # futures of launcher-thread jobs that may issue collectives (models._Overlap.submit)
 _attached = False   # set by attach(): only then can a launcher job issue a collective, and only then does drain() ever run
@@ -147,7 +167,8 @@ def allreduce_scratch_async(opt):
 def _native_allreduce(opt, buf):
     """dm_allreduce_grads on the CURRENT stream (include/dreamer_hip.h; the group's own communicator)."""
     from . import hip as H
-    H.call('dm_allreduce_grads', H.fptr(buf), buf.numel(), opt.dp_comm, H.stream())
+    lazy, i = opt.dp_comm
+    H.call('dm_allreduce_grads', H.fptr(buf), buf.numel(), lazy.get(i), H.stream())
 
 
 def allreduce_grads(opt):

@@ -199,6 +199,7 @@ _SIGNATURES = {
     'dm_rssm_lds_gave_up': (c_int, []),
     'dm_rssm_lds_prof': (c_int, [_P, c_int]),
     'dm_wgrad_side_arm': (c_int, [c_int]),
+    'dm_wgrad_side_touch': (c_int, []),
     'dm_wgrad_side_join': (c_int, [_P]),
     'dm_dream_rollout_marks': (c_int, [c_int, POINTER(c_int), POINTER(c_void_p)]),
     'dm_mlp_head_fwd_rows': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, POINTER(dm_mlp_params), _P, _P, _P,

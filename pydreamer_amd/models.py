@@ -459,7 +459,24 @@ def _prelaunched(owner, fn):
 
 
 _HEADS_EARLY = os.environ.get('DM_HEADS_EARLY', '1') != '0'    # A/B switch: 0 runs the heads over the imagined states behind the rollout only
+_WGRAD_SIDE_DP = os.environ.get('DM_WGRAD_SIDE_DP', '1') != '0'    # A/B switch: 0 = no side stream under data parallelism (rounds 3-5)
 _WGRAD_SIDE = os.environ.get('DM_WGRAD_SIDE', '1') != '0'      # A/B switch: 0 keeps every weight gradient on the caller's stream
+
+
+def _warn_if_communicator_exists():
+    """The step's streams are about to be created: has torch's default process group built its RCCL communicator already?"""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != 'nccl':
+            return
+        be = dist.distributed_c10d._get_default_group()._get_backend(torch.device('cuda'))
+        if be._is_initialized():
+            import warnings
+            warnings.warn('pydreamer_amd: an RCCL communicator exists before the model\'s streams were created - every training step '
+                          'will be slower by 10-20 ms (hardware-queue assignment order; profiles/r06_force_dp.txt).  Build the model and '
+                          'call init_optimizers() / prepare_streams() before the first collective.', RuntimeWarning, stacklevel=3)
+    except Exception:       # a diagnostic only: private torch API
+        pass
 
 
 class _Overlap:
@@ -493,6 +510,17 @@ class _Overlap:
         with torch.cuda.device(device):
             self.ev_mark.record()          # (torch creates the HIP event at the first record; the library needs its handle)
             self.ev_heads.record()
+        # Every stream of the step gets one command NOW (round 6): a HIP stream takes its hardware queue when it first gets work, and
+        # which streams later SHARE a queue depends on that order - a communicator created before these streams had run anything
+        # cost the step +13 ms, an early all-reduce whose communicator appeared mid-step +6 ms (profiles/r06_force_dp.txt).
+        if os.environ.get('DM_STREAM_PREBIND', '1') != '0':
+            with torch.cuda.device(device):
+                for st in (self.s_wm, self.s_ac):
+                    with torch.cuda.stream(st):
+                        torch.zeros(64, device=device)
+                if _WGRAD_SIDE:
+                    H.call('dm_wgrad_side_touch')
+                torch.cuda.synchronize(device)
         self.ws_wm = None
         self.ws_ac = None
         # The HIP runtime needs ~6 us of host time per kernel launch and a step is ~1800 launches; at small per-GPU
@@ -1119,10 +1147,10 @@ class WorldModel(_Params):
         # low-priority side stream, where they run beside the BPTT loop (a 50-row latency chain that leaves most CUs idle); they
         # read gradient buffers in the workspace of THEIR call, so each call gets its own (include/dreamer_hip.h
         # dm_wgrad_side_arm).  The encoder backward is not deferred (it is the tail: there is nothing left to hide behind).
-        # (measured: no gain on a 7-column shard.  Not under data parallelism: ROCm multiplexes streams onto 4 hardware queues by
-        #  default, a rank already runs caller + two backward streams + the communication stream + RCCL's own, and a parked
-        #  stream stalls whatever shares its queue - see replay.DeviceRing._produce; unmeasured there, so left as it was)
-        dp_on = getattr(getattr(self, '_fused', None), 'dp', None) is not None
+        # (measured: no gain on a 7-column shard, -1.1 ms at 25 columns.  Rounds 3-5 switched it off under data parallelism, unmeasured;
+        #  round 6 measured it over a one-rank RCCL group: off costs +0.9 ... +1.2 ms at 25 / 50 columns, on costs nothing beside the
+        #  late all-reduce or the library's own - profiles/r06_force_dp.txt run K.  DM_WGRAD_SIDE_DP=0 restores the old behaviour.)
+        dp_on = getattr(getattr(self, '_fused', None), 'dp', None) is not None and not _WGRAD_SIDE_DP
         side = defer_wgrad and _WGRAD_SIDE and B * I >= 16 and not dp_on and not torch.cuda.is_current_stream_capturing()
         ws_dec = ws_enc = ws
         if side:
@@ -1479,9 +1507,27 @@ class Dreamer(nn.Module):
                          critic=FusedAdamW(groups['critic'], lr=lr_critic or lr, eps=eps))
         # the backward passes write straight into these optimizers' gradient buffers (see _flat_views)
         self.wm._fused, self.ac.actor._fused, self.ac.critic._fused = self._opt['wm'], self._opt['actor'], self._opt['critic']
+        self.prepare_streams()
         if self.probe_gradients:      # dreamer.py:67-71: three optimizers; the probe head's parameters belong to none of them
             return self._opt['wm'], self._opt['actor'], self._opt['critic']
         return self._opt['wm'], self._opt['probe'], self._opt['actor'], self._opt['critic']
+
+    def prepare_streams(self, device=None):
+        """Creates the step's side streams and gives each its hardware queue NOW (_Overlap.__init__).  Called by init_optimizers()
+        and by dist.attach(model=...); a data-parallel trainer must reach one of them BEFORE its first collective (a barrier and a
+        parameter broadcast count): a communicator that exists before these streams have run anything slowed every later step by
+        +11 ... +19 ms in round 6's measurement (profiles/r06_force_dp.txt, run J) - the process warns when it sees that order.
+        No-op on the CPU, when the streams exist already, and inside a graph capture."""
+        if device is None:
+            device = next(self.parameters()).device
+        device = torch.device(device)
+        if device.type != 'cuda' or not self.overlap_backward or torch.cuda.is_current_stream_capturing():
+            return
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self._overlap is None or self._overlap.s_wm.device != device:
+            _warn_if_communicator_exists()
+            self._overlap = _Overlap(device)
 
     def grad_clip(self, grad_clip, grad_clip_ac=None):
         if getattr(self, '_opt', None) is None:

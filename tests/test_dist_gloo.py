@@ -97,7 +97,7 @@ def _native_worker(rank, world, port, B, out):
         for o in opts:
             o.scratch = o.flat_grad
         DP.attach(opts, hi - lo, B, native=True)
-        assert [o.dp_comm.value for o in opts] == [1001, 1002, 1003], 'one communicator per group, ids in optimizer order'
+        assert calls == [], 'the communicators are created lazily, at the first all-reduce'
         # early (stream-ordered) form for group 0, plain form for the others; no launcher future is tracked and drain() is not
         # reached (the stub's single gloo group still wants one issue order, RCCL's per-group communicators would not)
         DP._EARLY = False                                    # the product default (round 6): no early all-reduce, nothing is issued
@@ -112,6 +112,7 @@ def _native_worker(rank, world, port, B, out):
         assert DP._inflight == ['poison: allreduce_grads must not drain on the native path']
         DP._inflight.clear()
         assert calls.count('dm_allreduce_grads') == 3 and calls.count('dm_rccl_comm_init') == 3
+        assert [o.dp_comm[0].get(o.dp_comm[1]).value for o in opts] == [1001, 1002, 1003], 'one communicator per group, ids in optimizer order'
         out[rank] = [float((o.flat_grad - pc.mean(0)).abs().max()) for o, pc in zip(opts, per_col)]
     finally:
         H.call, H.fptr, H.stream = keep

@@ -289,3 +289,66 @@ def test_default_shard_deployment_over_one_rank_rccl(hip):
     assert di['persistent_posterior_kernel_ran'] == [True] and di['rssm_lds_status'] == [0]
     assert di['replicas_identical'] and np.isfinite(d['loss_model_last']) and d['loss_model_last'] > 0
     assert all(v['ms'] >= 0 for v in di['allreduce_standalone'].values())
+
+
+def test_native_overlapped_allreduce_equals_late_torch_one_rank(hip):
+    """The library's own exchange step in its OVERLAPPED form (DM_DP_NATIVE=1 DM_DP_EARLY=1: dm_allreduce_grads enqueued right
+    behind each pre-launched backward on that backward's stream, one communicator per optimizer group, created at the first
+    all-reduce) against the product default (torch.distributed, inside grad_clip) on the 7-column shard over a ONE-rank RCCL
+    group: a sum over one rank is the identity, so after the same steps the parameter checksums must be EQUAL to the bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for name, extra in (('late', {}), ('native_early', dict(DM_DP_NATIVE='1', DM_DP_EARLY='1'))):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), **extra)
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--force-dp', '--emulate-world', '8', '--reps', '1',
+               '--steps', '3', '--warmup', '1', '--prof-steps', '0', '--no-cpu-baseline', '--no-h2d-leg', '--ring', '2']
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert lines['native_early']['INVALID_diagnostic_forced_one_rank_dp'] == 'native dm_allreduce_grads'
+    a, b = (lines[k]['distributed']['param_checksum_rank0'] for k in ('late', 'native_early'))
+    assert a == b, (a, b)
+    assert lines['late']['loss_model_last'] == lines['native_early']['loss_model_last']
+
+
+_ORDER_SCRIPT = r'''
+import sys, warnings
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import dreamer_oracle as O
+from pydreamer_amd import config
+from pydreamer_amd.models import Dreamer
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1)
+if sys.argv[2] == 'collective_first':
+    dist.all_reduce(torch.zeros(4, device=dev))
+    torch.cuda.synchronize()
+c = O.tiny_conf(batch_size=5, batch_length=4, imag_horizon=3)
+conf = config.load_config('defaults', 'atari', **{k: getattr(c, k) for k in vars(c)})
+model = Dreamer(conf).to(dev)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    model.init_optimizers(1e-4, 1e-4, 1e-4, 1e-5)
+assert model._overlap is not None, 'init_optimizers() creates the streams'
+print('WARNED' if any('RCCL communicator exists' in str(x.message) for x in w) else 'QUIET')
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('order,expect', [('collective_first', 'WARNED'), ('model_first', 'QUIET')])
+def test_stream_creation_order_against_the_first_collective(hip, order, expect):
+    """Round 6 measured that a communicator built BEFORE the step's streams hold their hardware queues slows every later step by
+    10-20 ms (profiles/r06_force_dp.txt): init_optimizers() therefore creates and binds the streams at once (prepare_streams), and
+    a process that ran a collective before that is told so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, '-c', _ORDER_SCRIPT, root, order], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    marks = [l for l in r.stdout.splitlines() if l in ('WARNED', 'QUIET')]      # (RCCL prints its banner on stdout as well)
+    assert marks == [expect], (r.stdout[-500:], r.stderr[-1500:])
