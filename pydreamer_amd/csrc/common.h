@@ -8,6 +8,13 @@
 int dm_fail(int code, const char* fmt, ...);
 
 #define DM_MAX_DEVICES 16      // per-device once-flags (function attributes are per device)
+
+// Wave priority of the latency-chain kernels (experiment, round 6): s_setprio raises a wave's instruction-issue priority on its SIMD
+// over the co-resident waves of other streams' throughput kernels.  0 = leave the hardware default (compile-time: -DDM_CHAIN_SETPRIO=n).
+#ifndef DM_CHAIN_SETPRIO
+#define DM_CHAIN_SETPRIO 0
+#endif
+#define DM_CHAIN_PRIO() do { if (DM_CHAIN_SETPRIO > 0) __builtin_amdgcn_s_setprio(DM_CHAIN_SETPRIO); } while (0)
 #define DM_LAUNCH_CHECK()                                                                      \
   do {                                                                                         \
     hipError_t e__ = hipGetLastError();                                                        \

@@ -452,10 +452,16 @@ __device__ __forceinline__ void skinny_strip(const SkinnyArgs& g, int strip, int
   }
 }
 
+// DM_SKINNY_LDS_PAD (floats, compile-time experiment of round 6): LDS claimed beyond what the strip needs, so that no workgroup of
+// the LDS-DMA tile kernels (48 KB each) fits on a CU beside a strip - does a chain kernel run faster with the CU to itself?
+#ifndef DM_SKINNY_LDS_PAD
+#define DM_SKINNY_LDS_PAD 0
+#endif
 template <int BL, int NRB, int MODE, int EPI = 0>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_kernel(const SkinnyArgs g) {
-  __shared__ float part[SK_WAVES * 64 * 16];
+  __shared__ float part[SK_WAVES * 64 * 16 + DM_SKINNY_LDS_PAD];
   __shared__ SkinnyShared sh;
+  DM_CHAIN_PRIO();
   skinny_strip<BL, NRB, 1, MODE, EPI, MODE == 2 ? 2 : 4>(g, blockIdx.x, blockIdx.y * (16 * NRB), part, &sh, nullptr);   // grid.y = (16 NRB)-row chunks of M
 }
 // Posterior / prior head with the sampler in the epilogue: LayerNorm+ELU prologue, 32-wide strips (one categorical group
@@ -465,6 +471,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_sample_kernel(const
   __shared__ float part[SK_WAVES * 64 * 32];
   __shared__ SkinnyShared sh;
   __shared__ float tile[64 * 33];
+  DM_CHAIN_PRIO();
   skinny_strip<0, NRB, 2, 1, 1, 2>(g, blockIdx.x, blockIdx.y * (16 * NRB), part, &sh, tile);      // grid.y = (16 NRB)-row chunks of M
 }
 // Two independent products in ONE launch (the loops are bound by the number of launches, ~5 us of GPU time and ~6 us of
@@ -476,8 +483,9 @@ struct SkinnyPairArgs { SkinnyArgs g[2]; int nb0, nb; };      // nb = strips of 
 // NCB1 = 2: the second product in 32-wide strips (softmax-backward epilogue: a strip is one categorical group)
 template <int NRB, int MODE0, int MODE1, int NCB1 = 1>
 __global__ void __launch_bounds__(SK_WAVES * 64) skinny_gemm_pair_kernel(const SkinnyPairArgs a) {
-  __shared__ float part[SK_WAVES * 64 * 16 * NCB1];
+  __shared__ float part[SK_WAVES * 64 * 16 * NCB1 + (NCB1 == 1 ? DM_SKINNY_LDS_PAD : 0)];
   __shared__ SkinnyShared sh;
+  DM_CHAIN_PRIO();
   const int b = blockIdx.x % a.nb, m0 = (blockIdx.x / a.nb) * (16 * NRB);
   if (b < a.nb0) skinny_strip<0, NRB, 1, MODE0, 0, MODE0 == 2 ? 2 : 4>(a.g[0], b, m0, part, &sh, nullptr);
   else skinny_strip<0, NRB, NCB1, MODE1, 0, (MODE1 == 2 || NCB1 == 2) ? 2 : 4>(a.g[1], b - a.nb0, m0, part, &sh, nullptr);

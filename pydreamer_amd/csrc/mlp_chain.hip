@@ -455,6 +455,7 @@ __global__ void __launch_bounds__(256, (PACKED && !EXCL) ? 2 : 1) mlp_chain_fwd_
   __shared__ float red[2][4][16];                                      // per-wave row partials: [0] sums, [1] centred squares
   __shared__ float outp[4][16][32];                                    // per-wave output-layer partials
   if constexpr (EXCL) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  DM_CHAIN_PRIO();
   chain_body<BF, PACKED>(g, ybuf, red, outp);
 }
 
