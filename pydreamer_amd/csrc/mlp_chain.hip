@@ -449,12 +449,19 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, float* ybuf, floa
 // round-5 kernel's 465 registers had kept every other wave off its SIMDs.  The EXCL build claims the accumulator file up to
 // a255 (one dead write), so a wave owns its SIMD again; the multi-round launches (the 938-block head windows) take the shared
 // build, where a second block's MFMAs cover the first one's epilogue.
+// (DM_CHAIN_EXCL_AGPR, compile-time: the highest accumulator register the exclusive build claims.  255 = the whole file, nobody fits
+//  beside the wave; 127 / 191 leave room for one 128- / 96-register wave of another kernel - measured, profiles/r06_chain_exclusivity.txt)
+#ifndef DM_CHAIN_EXCL_AGPR
+#define DM_CHAIN_EXCL_AGPR 255
+#endif
+#define DM_STR2(x) #x
+#define DM_STR(x) DM_STR2(x)
 template <bool BF, int PACKED, bool EXCL>
 __global__ void __launch_bounds__(256, (PACKED && !EXCL) ? 2 : 1) mlp_chain_fwd_kernel(const ChainArgs g) {      // (the row-major A/B form keeps one block per CU)
   __shared__ __attribute__((aligned(16))) float ybuf[16 * CH_LD];      // the next layer's input block
   __shared__ float red[2][4][16];                                      // per-wave row partials: [0] sums, [1] centred squares
   __shared__ float outp[4][16][32];                                    // per-wave output-layer partials
-  if constexpr (EXCL) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  if constexpr (EXCL) asm volatile("v_accvgpr_write_b32 a" DM_STR(DM_CHAIN_EXCL_AGPR) ", 0" ::: "a" DM_STR(DM_CHAIN_EXCL_AGPR));
   DM_CHAIN_PRIO();
   chain_body<BF, PACKED>(g, ybuf, red, outp);
 }
