@@ -672,6 +672,18 @@ def test_training_step_tiny_two_steps_vs_oracle(hip):
         _check_pair(r, oconf)
 
 
+@pytest.mark.parametrize('B,T,Hh', [(1, 2, 1), (1, 5, 4), (16, 2, 2), (17, 3, 2), (32, 2, 2), (33, 2, 2), (51, 5, 2), (64, 4, 2), (65, 4, 3)])
+def test_training_step_at_dispatch_boundaries_vs_oracle(hip, B, T, Hh):
+    """Batch / sequence sizes on both sides of every row threshold the host and the library dispatch on: one batch column and the
+    shortest sequence with a transition (B = 1, T = 2, H = 1); 16 / 17 and 32 / 33 rows (strip heights of the <= 64-row products,
+    the persistent posterior kernel's <= 32-row limit); 64 / 65 rows (strip kernels vs tile kernels in the T loops); T x B = 255 /
+    256 / 260 imagination rows (launch chain vs whole-MLP kernel).  Two consecutive trainer iterations each, every loss, metric,
+    sampled index, per-parameter gradient and post-AdamW parameter against the oracle."""
+    oconf = O.tiny_conf(batch_size=B, batch_length=T, imag_horizon=Hh)
+    for r in _run_pair(oconf, 2, seed=B + T):
+        _check_pair(r, oconf)
+
+
 def test_training_step_teacher_forced_vs_oracle(hip):
     """Posterior indices forced to the oracle's: isolates float parity from sampler decisions."""
     oconf = O.tiny_conf(batch_size=4, batch_length=6, kl_balance=0.5)     # also covers the plain-KL branch (dreamer.py:334-335)
