@@ -591,7 +591,7 @@ def test_rssm_lds_kernel_with_a_busy_chip(hip):
         assert torch.equal(a, b), what
 
 
-def _run_pair(oconf, steps, forced=False, seed=0):
+def _run_pair(oconf, steps, forced=False, seed=0, mutate=None):
     """One or more full trainer iterations (train.py:165-198) on the oracle (CPU) and the HIP model (GPU)."""
     params = O.make_params(oconf, seed=seed)
     ora = O.OracleDreamer(oconf, params)
@@ -603,6 +603,8 @@ def _run_pair(oconf, steps, forced=False, seed=0):
     out = []
     for s in range(steps):
         raw = O.synthetic_batch(oconf, seed=1234 + s, first=(s == 0))
+        if mutate is not None:
+            mutate(raw, s)
         noise = O.make_noise(oconf, seed=777 + s)
         obs = O.preprocess(raw, oconf)
         lo, st_o2, mo, to, xo = ora.training_step(obs, st_o, noise)
@@ -681,6 +683,36 @@ def test_training_step_at_dispatch_boundaries_vs_oracle(hip, B, T, Hh):
     sampled index, per-parameter gradient and post-AdamW parameter against the oracle."""
     oconf = O.tiny_conf(batch_size=B, batch_length=T, imag_horizon=Hh)
     for r in _run_pair(oconf, 2, seed=B + T):
+        _check_pair(r, oconf)
+
+
+def _all_reset(raw, s):
+    raw['reset'][:] = True
+
+
+def _no_reset(raw, s):
+    raw['reset'][:] = False
+
+
+def _all_terminal(raw, s):
+    raw['terminal'][:] = 1.0
+    raw['reward'][:] = 1.0
+
+
+def _extreme_frames(raw, s):
+    raw['image_u8'][:] = 255 if s == 0 else 0
+    raw['reward'][:] = -1.0
+    raw['action_idx'][:] = raw['action_idx'].max()
+
+
+@pytest.mark.parametrize('mutate', [_all_reset, _no_reset, _all_terminal, _extreme_frames], ids=lambda f: f.__name__.strip('_'))
+def test_training_step_on_degenerate_batches_vs_oracle(hip, mutate):
+    """Replay batches at the corners of what preprocessing can hand over (preprocessing.py:135-150): every row reset at every step
+    (the recurrent state is zeroed before each cell, rssm.py:117-119), no reset at all (two iterations: the second starts from the
+    carried state), every step terminal with reward 1, saturated frames (all 255, then all 0) with one repeated action and reward
+    -1.  Two trainer iterations each against the oracle, all of _check_pair's bars."""
+    oconf = O.tiny_conf(batch_size=4, batch_length=6, imag_horizon=3)
+    for r in _run_pair(oconf, 2, seed=11, mutate=mutate):
         _check_pair(r, oconf)
 
 
