@@ -70,7 +70,7 @@ typedef struct dm_shape {
 #define DM_FLAG_GRU_MASK (3 << DM_FLAG_GRU_SHIFT)
 
 /* ---------------------------------------------------------------- library ---------------------- */
-int dm_version(void);                 /* ABI version, currently 12 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
+int dm_version(void);                 /* ABI version, currently 13 (v2: LayerNorm-GRU slots; v3: per-call precision; v4: GRUCellStack layer slots;
                                          v5: dm_kl_sampled_gauss_*, dm_chain_graph_*, dm_fp32_mode - additions only;
                                          v6: LayerNorm slots of GRUCellStack layers 1..3, dm_rssm_params grows to 58;
                                          v7: dm_wgrad_side_arm / _join, dm_dream_rollout_marks, dm_mlp_head_fwd_rows - additions only;
@@ -81,7 +81,8 @@ int dm_version(void);                 /* ABI version, currently 12 (v2: LayerNor
                                          dm_prof_end reports 44 kinds;
                                          v11: dm_dec_l4_bwd_direct_enable added;
                                          v12: dm_rssm_lds_status_ack / dm_rssm_lds_gave_up; the native exchange step dm_rccl_* / dm_allreduce_grads;
-                                              dm_rollout_fuse_act_enable */
+                                              dm_rollout_fuse_act_enable;
+                                         v13: dm_wgrad_side_touch added */
 const char* dm_last_error(void);      /* thread-local message of the last failing call */
 int dm_device_check(void);            /* DM_OK iff the current HIP device is gfx950 */
 size_t dm_workspace_bytes(const dm_shape* shp);   /* scratch needed by any call below for this shape */

@@ -207,7 +207,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-DM_ABI_VERSION = 12     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
+DM_ABI_VERSION = 13     # include/dreamer_hip.h dm_version(): the struct layouts above (dm_rssm_params: 58 slots) belong to this one
 
 
 def lib():
