@@ -210,8 +210,18 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(int n, int chunks, in
   const int col = blockIdx.x * 32 + cx;
   for (int q = 0; q < nq; ++q) {
     float s = 0.f;
-    if (col < n)
-      for (int c = cy; c < chunks; c += 8) s += partial[((size_t)c * nq + q) * n + col];
+    if (col < n) {
+      // four loads in flight per thread, added in the SAME order as the plain loop (625 chunks of a 40 000-row head were 78 dependent
+      // load + add rounds: 11 us for a 400-column sum)
+      const float* p = partial + (size_t)q * n + col;
+      const size_t st = (size_t)nq * n;
+      int c = cy;
+      for (; c + 24 < chunks; c += 32) {
+        const float v0 = p[(size_t)c * st], v1 = p[(size_t)(c + 8) * st], v2 = p[(size_t)(c + 16) * st], v3 = p[(size_t)(c + 24) * st];
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; c < chunks; c += 8) s += p[(size_t)c * st];
+    }
     red[cy][cx] = s;
     __syncthreads();
     if (cy == 0 && col < n) {
