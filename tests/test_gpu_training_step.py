@@ -1373,14 +1373,19 @@ def test_world_model_tail_on_side_stream_is_bit_identical(hip, amp, extra):
         assert torch.equal(a[4], b[4]), f'step {s}: parameters differ'
 
 
-def test_forty_trainer_iterations_on_a_fixed_batch_learn_like_the_oracle(hip):
+@pytest.mark.parametrize('extra', [dict(), dict(target_interval=10), dict(actor_dist='tanh_normal', action_dim=4, entropy=1.0e-4),
+                                   dict(stoch_discrete=0, stoch_dim=16), dict(gru_type='gru_layernorm', gru_layers=2, deter_dim=64),
+                                   dict(aux_critic=True, target_interval_aux=7, target_interval=9)],
+                         ids=['default', 'target_refresh', 'continuous_actor', 'gaussian_latents', 'layernorm_gru_stack', 'aux_critic'])
+def test_forty_trainer_iterations_on_a_fixed_batch_learn_like_the_oracle(hip, extra):
     """The whole trainer section (train.py:165-198: training_step, zero_grad, four backward passes, grad_clip, four AdamW steps) run
     FORTY times on one fixed batch from the same initial parameters, on the oracle (CPU, torch.optim.AdamW) and on this build
     (flat-buffer AdamW, side streams, buffer-swap gradient hand-over in its steady state): the world-model loss must FALL on both
-    (522 -> 482 on the oracle) and the two trajectories must stay together - parameters that have gone through 40 optimizer steps of
+    (522 -> 482 on the oracle; variants: critic-target refreshes inside the window, a continuous actor, Gaussian latents, a two-layer
+    LayerNorm GRU stack, the auxiliary critic with its own target interval) and the two trajectories must stay together - parameters that have gone through 40 optimizer steps of
     this build give the loss the reference's arithmetic gives, to 1e-4 relative at every step (measured on MI355X: worst gap 2.4e-7,
     522.278 -> 482.429 on both)."""
-    oconf = O.tiny_conf(adam_lr=1e-3, adam_lr_actor=3e-4, adam_lr_critic=3e-4)
+    oconf = O.tiny_conf(adam_lr=1e-3, adam_lr_actor=3e-4, adam_lr_critic=3e-4, **extra)
     params = O.make_params(oconf, seed=3)
     ora = O.OracleDreamer(oconf, params)
     ora.init_optimizers()
@@ -1388,8 +1393,9 @@ def test_forty_trainer_iterations_on_a_fixed_batch_learn_like_the_oracle(hip):
     opts = model.init_optimizers(oconf.adam_lr, oconf.adam_lr_actor, oconf.adam_lr_critic, oconf.adam_eps)
     obs = O.preprocess(O.synthetic_batch(oconf, seed=1234, first=True), oconf)
     obs_d = _to_dev(obs)
+    n_iter = 40 if not extra else 20          # (the variants run half the window: ~0.7 s per iteration on the box, mostly host)
     traj_o, traj_h, worst = [], [], 0.0
-    for s in range(40):
+    for s in range(n_iter):
         noise = O.make_noise(oconf, seed=777 + s)
         lo, _, mo, _, _ = ora.training_step(obs, ora.init_state(oconf.batch_size), noise)
         ora.backward_clip_step(lo)
@@ -1408,8 +1414,8 @@ def test_forty_trainer_iterations_on_a_fixed_batch_learn_like_the_oracle(hip):
         traj_o.append(b)
         traj_h.append(a)
     print(f'fixed-batch training: oracle {traj_o[0]:.3f} -> {traj_o[-1]:.3f}, build {traj_h[0]:.3f} -> {traj_h[-1]:.3f}, worst relative gap {worst:.2e}')
-    assert traj_h[-1] < 0.95 * traj_h[0] and traj_o[-1] < 0.95 * traj_o[0]
-    assert all(traj_h[i + 5] < traj_h[i] for i in range(0, 35, 5)), traj_h      # falling over every 5-step window
+    assert traj_h[-1] < (0.95 if n_iter == 40 else 0.985) * traj_h[0] and traj_o[-1] < (0.95 if n_iter == 40 else 0.985) * traj_o[0]
+    assert all(traj_h[i + 5] < traj_h[i] for i in range(0, n_iter - 5, 5)), traj_h      # falling over every 5-step window
     # the replicas after 40 steps: parameters of the two implementations, group by group
     sd = model.state_dict()
     for k, v in ora.p.items():
