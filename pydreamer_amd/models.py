@@ -519,7 +519,10 @@ class _Overlap:
                     with torch.cuda.stream(st):
                         torch.zeros(64, device=device)
                 if _WGRAD_SIDE:
-                    H.call('dm_wgrad_side_touch')
+                    try:
+                        H.call('dm_wgrad_side_touch')
+                    except H.DreamerHipError:       # an optimisation only (the library owns ONE side stream, on the device that used it first)
+                        pass
                 torch.cuda.synchronize(device)
         self.ws_wm = None
         self.ws_ac = None
